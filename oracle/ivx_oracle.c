@@ -1,0 +1,490 @@
+/*
+ * ivx_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, single-threaded restatement of the reference algorithms on the
+ * InVesalius voxel hot path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product
+ * (invesalius3_amd/) never does and has no CPU fallback.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the reference checkout).  The reference's native crate (Rust/PyO3) cannot
+ * be built in this environment (no cargo/rustc) and VTK / scikit-image are not
+ * installed, so:
+ *   - floodfill / fill-holes: pinned by the reference's own golden vectors
+ *     (tests/test_segmentation_tools.py:17-134) -> tests/test_oracle_golden.py
+ *   - MIDA / LMIP / contour-MIP: the reference has no tests -> restatement
+ *     cross-checked by hand-worked rays ("parity unpinned" upstream)
+ *   - marching cubes: reference = vtkContourFilter (VTK 9.3, not vendored) ->
+ *     "parity unpinned" for triangle topology; vertex positions follow the
+ *     documented linear interpolation on grid edges.
+ *   - watershed_ift: pinned against the live scipy.ndimage.watershed_ift.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off, see oracle/Makefile)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MC_TABLE_QUAL static const
+#include "../include/ivx_mc_tables.h"
+
+#define ORC_OK 0
+#define ORC_EINVAL (-1)
+#define ORC_ERANGE (-2)  /* seed out of bounds (reference: Rust index panic) */
+#define ORC_ENOMEM (-3)
+#define ORC_EDOM (-4)    /* NumCast failure (reference: unwrap() panic) */
+
+enum { DT_U8 = 0, DT_I16 = 1, DT_F64 = 2, DT_U16 = 3 };
+
+static inline double ld(int dt, const char *p) {
+    switch (dt) {
+    case DT_U8: return (double)*(const uint8_t *)p;
+    case DT_I16: return (double)*(const int16_t *)p;
+    case DT_U16: return (double)*(const uint16_t *)p;
+    default: return *(const double *)p;
+    }
+}
+static inline void st(int dt, char *p, double v) {
+    switch (dt) {
+    case DT_U8: *(uint8_t *)p = (uint8_t)v; break;
+    case DT_I16: *(int16_t *)p = (int16_t)v; break;
+    case DT_U16: *(uint16_t *)p = (uint16_t)v; break;
+    default: *(double *)p = v; break;
+    }
+}
+#define AT(base, s, z, y, x) ((base) + (z) * (s)[0] + (y) * (s)[1] + (x) * (s)[2])
+
+typedef struct { int64_t x, y, z; } vox_t;
+typedef struct { vox_t *v; size_t n, cap; } stack_t;
+static int push(stack_t *s, int64_t x, int64_t y, int64_t z) {
+    if (s->n == s->cap) {
+        size_t nc = s->cap ? s->cap * 2 : 1024;
+        vox_t *nv = (vox_t *)realloc(s->v, nc * sizeof(vox_t));
+        if (!nv) return -1;
+        s->v = nv; s->cap = nc;
+    }
+    s->v[s->n].x = x; s->v[s->n].y = y; s->v[s->n].z = z; s->n++;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------
+ * generic_floodfill_threshold            invesalius_rs/src/floodfill.rs:96-166
+ * generic_floodfill_threshold_inplace    invesalius_rs/src/floodfill.rs:168-237
+ * Seeds are (x,y,z) and index data[z,y,x] (:121-122). A seed is accepted iff
+ * its value is in [t0,t1]; LIFO (pop_back); for every strct[kk,jj,ii] != 0
+ * neighbour (centre offset = dim/2) in bounds: if barrier != fill and value in
+ * range -> barrier = fill, push.  `inplace`: barrier array == data array and
+ * fill is written in data's dtype.
+ * ---------------------------------------------------------------------- */
+static int flood_generic(int dt, char *data, const int64_t shape[3], const int64_t ds[3],
+                         const int64_t *seeds, int64_t nseeds, double t0, double t1, double fill,
+                         const uint8_t *strct, const int64_t ss[3], uint8_t *out,
+                         const int64_t os[3], int inplace) {
+    const int64_t dz = shape[0], dy = shape[1], dx = shape[2];
+    const int64_t odz = ss[0], ody = ss[1], odx = ss[2];
+    const int64_t oz = odz / 2, oy = ody / 2, ox = odx / 2;
+    stack_t s = {0, 0, 0};
+    for (int64_t n = 0; n < nseeds; n++) {
+        int64_t i = seeds[3 * n], j = seeds[3 * n + 1], k = seeds[3 * n + 2];
+        if (i < 0 || j < 0 || k < 0 || i >= dx || j >= dy || k >= dz) { free(s.v); return ORC_ERANGE; }
+        double v = ld(dt, AT(data, ds, k, j, i));
+        if (v >= t0 && v <= t1) {
+            if (push(&s, i, j, k)) { free(s.v); return ORC_ENOMEM; }
+            if (inplace) st(dt, AT(data, ds, k, j, i), fill);
+            else *(uint8_t *)AT((char *)out, os, k, j, i) = (uint8_t)fill;
+        }
+    }
+    while (s.n) {
+        vox_t p = s.v[--s.n];
+        if (inplace) st(dt, AT(data, ds, p.z, p.y, p.x), fill);
+        else *(uint8_t *)AT((char *)out, os, p.z, p.y, p.x) = (uint8_t)fill;
+        for (int64_t kk = 0; kk < odz; kk++) {
+            int64_t zo = p.z + kk - oz;
+            if (zo < 0 || zo >= dz) continue;
+            for (int64_t jj = 0; jj < ody; jj++) {
+                int64_t yo = p.y + jj - oy;
+                if (yo < 0 || yo >= dy) continue;
+                for (int64_t ii = 0; ii < odx; ii++) {
+                    if (!strct[(kk * ody + jj) * odx + ii]) continue;
+                    int64_t xo = p.x + ii - ox;
+                    if (xo < 0 || xo >= dx) continue;
+                    double v = ld(dt, AT(data, ds, zo, yo, xo));
+                    int blocked = inplace ? (v == fill)
+                                          : (*(uint8_t *)AT((char *)out, os, zo, yo, xo) == (uint8_t)fill);
+                    if (!blocked && v >= t0 && v <= t1) {
+                        if (inplace) st(dt, AT(data, ds, zo, yo, xo), fill);
+                        else *(uint8_t *)AT((char *)out, os, zo, yo, xo) = (uint8_t)fill;
+                        if (push(&s, xo, yo, zo)) { free(s.v); return ORC_ENOMEM; }
+                    }
+                }
+            }
+        }
+    }
+    free(s.v);
+    return ORC_OK;
+}
+
+int orc_floodfill_threshold(int dt, const void *data, const int64_t shape[3], const int64_t ds[3],
+                            const int64_t *seeds, int64_t nseeds, double t0, double t1, int fill,
+                            const uint8_t *strct, const int64_t ss[3], uint8_t *out, const int64_t os[3]) {
+    return flood_generic(dt, (char *)data, shape, ds, seeds, nseeds, t0, t1, (double)fill, strct, ss, out, os, 0);
+}
+int orc_floodfill_threshold_inplace(int dt, void *data, const int64_t shape[3], const int64_t ds[3],
+                                    const int64_t *seeds, int64_t nseeds, double t0, double t1, double fill,
+                                    const uint8_t *strct, const int64_t ss[3]) {
+    return flood_generic(dt, (char *)data, shape, ds, seeds, nseeds, t0, t1, fill, strct, ss, 0, ds, 1);
+}
+
+/* floodfill_internal                        invesalius_rs/src/floodfill.rs:5-49
+ * 6-neighbour FIFO flood of data == v; the seed is filled unconditionally. */
+int orc_floodfill(int dt, const void *data_, const int64_t shape[3], const int64_t ds[3], int64_t i,
+                  int64_t j, int64_t k, double v, int fill, uint8_t *out, const int64_t os[3]) {
+    const char *data = (const char *)data_;
+    const int64_t d = shape[0], h = shape[1], w = shape[2];
+    if (i < 0 || j < 0 || k < 0 || i >= w || j >= h || k >= d) return ORC_ERANGE;
+    stack_t q = {0, 0, 0};
+    size_t head = 0;
+    if (push(&q, i, j, k)) return ORC_ENOMEM;
+    *(uint8_t *)AT((char *)out, os, k, j, i) = (uint8_t)fill;
+    static const int off[6][3] = {{0, 0, 1}, {0, 0, -1}, {0, 1, 0}, {0, -1, 0}, {1, 0, 0}, {-1, 0, 0}};
+    while (head < q.n) {
+        vox_t p = q.v[head++];
+        for (int n = 0; n < 6; n++) {
+            int64_t x = p.x + off[n][0], y = p.y + off[n][1], z = p.z + off[n][2];
+            if (x < 0 || y < 0 || z < 0 || x >= w || y >= h || z >= d) continue;
+            uint8_t *o = (uint8_t *)AT((char *)out, os, z, y, x);
+            if (ld(dt, AT(data, ds, z, y, x)) == v && *o != (uint8_t)fill) {
+                *o = (uint8_t)fill;
+                if (push(&q, x, y, z)) { free(q.v); return ORC_ENOMEM; }
+            }
+        }
+    }
+    free(q.v);
+    return ORC_OK;
+}
+
+/* floodfill_auto_threshold                invesalius_rs/src/floodfill_py.rs:12-85
+ * i16 only; 6-neighbour FIFO; the admissible range is recomputed from the
+ * value of the voxel being expanded: [ceil(v(1-p)), floor(v(1+p))] as i16
+ * (Rust `as i16` saturates). */
+static int16_t sat_i16(float f) {
+    if (f != f) return 0;
+    if (f <= -32768.0f) return -32768;
+    if (f >= 32767.0f) return 32767;
+    return (int16_t)f;
+}
+int orc_floodfill_auto_threshold(const int16_t *data_, const int64_t shape[3], const int64_t ds[3],
+                                 const int64_t *seeds, int64_t nseeds, float p, int fill, uint8_t *out,
+                                 const int64_t os[3]) {
+    const char *data = (const char *)data_;
+    const int64_t d = shape[0], h = shape[1], w = shape[2];
+    stack_t q = {0, 0, 0};
+    size_t head = 0;
+    for (int64_t n = 0; n < nseeds; n++) {
+        int64_t i = seeds[3 * n], j = seeds[3 * n + 1], k = seeds[3 * n + 2];
+        if (i < 0 || j < 0 || k < 0 || i >= w || j >= h || k >= d) { free(q.v); return ORC_ERANGE; }
+        if (push(&q, i, j, k)) { free(q.v); return ORC_ENOMEM; }
+        *(uint8_t *)AT((char *)out, os, k, j, i) = (uint8_t)fill;
+    }
+    static const int off[6][3] = {{0, 0, 1}, {0, 0, -1}, {0, 1, 0}, {0, -1, 0}, {1, 0, 0}, {-1, 0, 0}};
+    while (head < q.n) {
+        vox_t c = q.v[head++];
+        float val = (float)*(const int16_t *)AT(data, ds, c.z, c.y, c.x);
+        int16_t t0 = sat_i16(ceilf(val * (1.0f - p)));
+        int16_t t1 = sat_i16(floorf(val * (1.0f + p)));
+        for (int n = 0; n < 6; n++) {
+            int64_t x = c.x + off[n][0], y = c.y + off[n][1], z = c.z + off[n][2];
+            if (x < 0 || y < 0 || z < 0 || x >= w || y >= h || z >= d) continue;
+            uint8_t *o = (uint8_t *)AT((char *)out, os, z, y, x);
+            if (*o == (uint8_t)fill) continue;
+            int16_t nv = *(const int16_t *)AT(data, ds, z, y, x);
+            if (nv >= t0 && nv <= t1) {
+                *o = (uint8_t)fill;
+                if (push(&q, x, y, z)) { free(q.v); return ORC_ENOMEM; }
+            }
+        }
+    }
+    free(q.v);
+    return ORC_OK;
+}
+
+/* fill_holes_automatically_internal         invesalius_rs/src/floodfill.rs:51-94
+ * returns 1 if modified, 0 if not, <0 on error.  Faithful quirk:
+ * label 0 is relabelled too when its size <= max_size. */
+int orc_fill_holes(uint8_t *mask, const int64_t shape[3], const int64_t ms[3], const uint32_t *labels_,
+                   const int64_t ls[3], uint32_t nlabels, uint32_t max_size) {
+    const char *labels = (const char *)labels_;
+    uint32_t *sizes = (uint32_t *)calloc((size_t)nlabels + 1, sizeof(uint32_t));
+    if (!sizes) return ORC_ENOMEM;
+    for (int64_t z = 0; z < shape[0]; z++)
+        for (int64_t y = 0; y < shape[1]; y++)
+            for (int64_t x = 0; x < shape[2]; x++) {
+                uint32_t l = *(const uint32_t *)AT(labels, ls, z, y, x);
+                if (l > nlabels) { free(sizes); return ORC_ERANGE; }
+                sizes[l]++;
+            }
+    int modified = 0;
+    for (uint32_t l = 0; l <= nlabels; l++)
+        if (sizes[l] > 0 && sizes[l] <= max_size) { modified = 1; break; }
+    if (modified)
+        for (int64_t z = 0; z < shape[0]; z++)
+            for (int64_t y = 0; y < shape[1]; y++)
+                for (int64_t x = 0; x < shape[2]; x++) {
+                    uint32_t l = *(const uint32_t *)AT(labels, ls, z, y, x);
+                    if (sizes[l] <= max_size) *(uint8_t *)AT((char *)mask, ms, z, y, x) = 254;
+                }
+    free(sizes);
+    return modified;
+}
+
+/* ------------------------------------------------------------------------
+ * Projections                                     invesalius_rs/src/mips.rs
+ * A "ray" is the lane along `axis` for output pixel (r,c):
+ *   axis 0: image[:, r, c]   axis 1: image[r, :, c]   axis 2: image[r, c, :]
+ * ---------------------------------------------------------------------- */
+static void ray_geom(int axis, const int64_t shape[3], const int64_t s[3], int64_t *nr, int64_t *nc,
+                     int64_t *len, int64_t *sr, int64_t *sc, int64_t *sl) {
+    if (axis == 0) { *nr = shape[1]; *nc = shape[2]; *len = shape[0]; *sr = s[1]; *sc = s[2]; *sl = s[0]; }
+    else if (axis == 1) { *nr = shape[0]; *nc = shape[2]; *len = shape[1]; *sr = s[0]; *sc = s[2]; *sl = s[1]; }
+    else { *nr = shape[0]; *nc = shape[1]; *len = shape[2]; *sr = s[0]; *sc = s[1]; *sl = s[2]; }
+}
+
+/* num-traits NumCast f32 -> integer: None unless MIN-1 < x < MAX+1, then trunc */
+static int numcast_f32(int dt, float v, char *dst) {
+    if (dt == DT_F64) { *(double *)dst = (double)v; return 0; }
+    if (v != v) return -1;
+    if (dt == DT_I16) { if (!(v > -32769.0f && v < 32768.0f)) return -1; *(int16_t *)dst = (int16_t)v; return 0; }
+    if (dt == DT_U8) { if (!(v > -1.0f && v < 256.0f)) return -1; *(uint8_t *)dst = (uint8_t)v; return 0; }
+    if (dt == DT_U16) { if (!(v > -1.0f && v < 65536.0f)) return -1; *(uint16_t *)dst = (uint16_t)v; return 0; }
+    return -1;
+}
+
+/* lmip                                          invesalius_rs/src/mips.rs:7-86
+ * out dtype == image dtype (the only instantiation the crate uses). */
+int orc_lmip(int dt, const void *img_, const int64_t shape[3], const int64_t s[3], int axis, double tmin,
+             double tmax, void *out_, const int64_t os[2]) {
+    const char *img = (const char *)img_;
+    char *out = (char *)out_;
+    int64_t nr, nc, len, sr, sc, sl;
+    if (axis < 0 || axis > 2) return ORC_OK; /* `_ => ()` */
+    ray_geom(axis, shape, s, &nr, &nc, &len, &sr, &sc, &sl);
+    for (int64_t r = 0; r < nr; r++)
+        for (int64_t c = 0; c < nc; c++) {
+            const char *ray = img + r * sr + c * sc;
+            double maxv = ld(dt, ray);
+            int start = maxv >= tmin && maxv <= tmax;
+            for (int64_t l = 0; l < len; l++) {
+                double v = ld(dt, ray + l * sl);
+                if (v > maxv) maxv = v;
+                else if (v < maxv && start) break;
+                if (v >= tmin && v <= tmax) start = 1;
+            }
+            st(dt, out + r * os[0] + c * os[1], maxv);
+        }
+    return ORC_OK;
+}
+
+/* get_opacity                                   invesalius_rs/src/mips.rs:88-100 */
+static inline float get_opacity(float vl, float wl, float ww) {
+    float min_value = wl - (ww / 2.0f);
+    float max_value = wl + (ww / 2.0f);
+    if (vl < min_value) return 0.0f;
+    else if (vl > max_value) return 1.0f;
+    return (vl - min_value) / (max_value - min_value);
+}
+static inline float f32min(float a, float b) { return (a != a) ? b : (b != b) ? a : (a < b ? a : b); }
+static inline float f32max(float a, float b) { return (a != a) ? b : (b != b) ? a : (a > b ? a : b); }
+
+/* mida_internal                               invesalius_rs/src/mips.rs:102-168
+ * dtype pairs (mips_py.rs:161-202): i16->i16, u8->u8, f64->u8. f32 state,
+ * evaluation order exactly as written; build with -ffp-contract=off. */
+int orc_mida(int dt, const void *img_, const int64_t shape[3], const int64_t s[3], int axis, double wl_,
+             double ww_, int odt, void *out_, const int64_t os[2]) {
+    const char *img = (const char *)img_;
+    char *out = (char *)out_;
+    if (shape[0] * shape[1] * shape[2] == 0) return ORC_EDOM; /* reduce().unwrap() on empty */
+    float img_min = 0, img_max = 0;
+    int first = 1;
+    for (int64_t z = 0; z < shape[0]; z++)
+        for (int64_t y = 0; y < shape[1]; y++)
+            for (int64_t x = 0; x < shape[2]; x++) {
+                float v = (float)ld(dt, AT(img, s, z, y, x));
+                if (first) { img_min = img_max = v; first = 0; }
+                else { img_min = f32min(img_min, v); img_max = f32max(img_max, v); }
+            }
+    const float range = img_max - img_min;
+    const float wl = (float)wl_, ww = (float)ww_;
+    int64_t nr, nc, len, sr, sc, sl;
+    ray_geom(axis > 2 ? 2 : axis, shape, s, &nr, &nc, &len, &sr, &sc, &sl);
+    int rc = ORC_OK;
+    for (int64_t r = 0; r < nr; r++)
+        for (int64_t c = 0; c < nc; c++) {
+            const char *ray = img + r * sr + c * sc;
+            float fmax = 0.0f, alpha_p = 0.0f, colour_p = 0.0f, final_colour = 0.0f;
+            for (int64_t l = 0; l < len; l++) {
+                float vl = (float)ld(dt, ray + l * sl);
+                float fpi = (1.0f / range) * (vl - img_min);
+                float dl;
+                if (fpi > fmax) { dl = fpi - fmax; fmax = fpi; } else dl = 0.0f;
+                float bt = 1.0f - dl;
+                float alpha = get_opacity(vl, wl, ww);
+                float colour = (bt * colour_p) + (1.0f - bt * alpha_p) * fpi * alpha;
+                float current_alpha = (bt * alpha_p) + (1.0f - bt * alpha_p) * alpha;
+                colour_p = colour;
+                alpha_p = current_alpha;
+                final_colour = colour;
+                if (current_alpha >= 1.0f) break;
+            }
+            if (numcast_f32(odt, range * final_colour + img_min, out + r * os[0] + c * os[1])) rc = ORC_EDOM;
+        }
+    return rc;
+}
+
+/* finite_difference (:171-195) -- the subtraction happens in T and wraps for
+ * i16/u8 in a release build; calc_fcm_intensity (:197-213). */
+static inline float fd_sub(int dt, const char *a, const char *b) {
+    switch (dt) {
+    case DT_I16: return (float)(int16_t)((uint16_t)*(const int16_t *)a - (uint16_t)*(const int16_t *)b);
+    case DT_U8: return (float)(uint8_t)(*(const uint8_t *)a - *(const uint8_t *)b);
+    default: return (float)(*(const double *)a - *(const double *)b);
+    }
+}
+static float fcm_intensity(int dt, const char *img, const int64_t shape[3], const int64_t s[3], int64_t x,
+                           int64_t y, int64_t z, float n, const float dir[3]) {
+    const int64_t sz = shape[0], sy = shape[1], sx = shape[2];
+    int64_t px = x == 0 ? 0 : x - 1, fx = x == sx - 1 ? sx - 1 : x + 1;
+    int64_t py = y == 0 ? 0 : y - 1, fy = y == sy - 1 ? sy - 1 : y + 1;
+    int64_t pz = z == 0 ? 0 : z - 1, fz = z == sz - 1 ? sz - 1 : z + 1;
+    float g0 = fd_sub(dt, AT(img, s, z, y, fx), AT(img, s, z, y, px)) / (2.0f * 1.0f);
+    float g1 = fd_sub(dt, AT(img, s, z, fy, x), AT(img, s, z, py, x)) / (2.0f * 1.0f);
+    float g2 = fd_sub(dt, AT(img, s, fz, y, x), AT(img, s, pz, y, x)) / (2.0f * 1.0f);
+    float gm = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+    if (gm == 0.0f) return 0.0f;
+    float d = g0 * dir[0] + g1 * dir[1] + g2 * dir[2];
+    float sf = powf(1.0f - fabsf(d / gm), n);
+    return gm * sf;
+}
+
+/* the FCM volume alone (tmp in fast_countour_mip_internal :237-242), dtype T */
+int orc_fcm_volume(int dt, const void *img_, const int64_t shape[3], const int64_t s[3], float n, int axis,
+                   void *tmp_) {
+    const char *img = (const char *)img_;
+    char *tmp = (char *)tmp_;
+    const int64_t isz = dt == DT_F64 ? 8 : dt == DT_I16 ? 2 : 1;
+    float dir[3] = {0, 0, 0};
+    if (axis == 0) dir[2] = 1.0f; else if (axis == 1) dir[1] = 1.0f; else if (axis == 2) dir[0] = 1.0f;
+    int rc = ORC_OK;
+    for (int64_t z = 0; z < shape[0]; z++)
+        for (int64_t y = 0; y < shape[1]; y++)
+            for (int64_t x = 0; x < shape[2]; x++) {
+                float v = fcm_intensity(dt, img, shape, s, x, y, z, n, dir);
+                if (numcast_f32(dt, v, tmp + ((z * shape[1] + y) * shape[2] + x) * isz)) rc = ORC_EDOM;
+            }
+    return rc;
+}
+
+/* fast_countour_mip_internal                  invesalius_rs/src/mips.rs:215-279 */
+int orc_fast_countour_mip(int dt, const void *img_, const int64_t shape[3], const int64_t s[3], float n,
+                          int axis, double wl, double ww, int tmip, void *out_, const int64_t os[2]) {
+    const int64_t isz = dt == DT_F64 ? 8 : dt == DT_I16 ? 2 : 1;
+    const int64_t nvox = shape[0] * shape[1] * shape[2];
+    char *tmp = (char *)malloc((size_t)(nvox > 0 ? nvox : 1) * isz);
+    if (!tmp) return ORC_ENOMEM;
+    int rc = orc_fcm_volume(dt, img_, shape, s, n, axis, tmp);
+    if (rc) { free(tmp); return rc; }
+    const int64_t ts[3] = {shape[1] * shape[2] * isz, shape[2] * isz, isz};
+    char *out = (char *)out_;
+    if (tmip == 0) {
+        int64_t nr, nc, len, sr, sc, sl;
+        if (axis < 0 || axis > 2) { free(tmp); return ORC_EINVAL; }
+        ray_geom(axis, shape, ts, &nr, &nc, &len, &sr, &sc, &sl);
+        const double lowest = dt == DT_I16 ? -32768.0 : dt == DT_U8 ? 0.0 : -1.7976931348623157e308;
+        for (int64_t r = 0; r < nr; r++)
+            for (int64_t c = 0; c < nc; c++) {
+                double acc = lowest;
+                for (int64_t l = 0; l < len; l++) {
+                    double v = ld(dt, tmp + r * sr + c * sc + l * sl);
+                    if (!(acc > v)) acc = v;
+                }
+                st(dt, out + r * os[0] + c * os[1], acc);
+            }
+    } else if (tmip == 1) {
+        if (dt == DT_U8) rc = ORC_EDOM; /* NumCast::from(700) -> u8 panics */
+        else rc = orc_lmip(dt, tmp, shape, ts, axis, 700.0, 3033.0, out, os);
+    } else if (tmip == 2) {
+        rc = orc_mida(dt, tmp, shape, ts, axis, wl, ww, dt, out, os);
+    }
+    free(tmp);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------
+ * Marching cubes == create_surface_piece's geometry
+ *   invesalius/data/surface_process.py:52-68   pad_image
+ *   invesalius/data/surface_process.py:100-186 pad -> to_vtk -> flip-Y -> contour
+ *   invesalius/data/converters.py:34-101       extent / padding conventions
+ * `a` is the piece array (mask[roi+1,1:,1:] or image[roi]), shape (nz,ny,nx).
+ * pad_xy/pad_bottom/pad_top are the paddings actually applied (0/1);
+ * vtk_pz is the z padding reported to to_vtk (== pad_bottom when
+ * fill_border_holes). Image point (i,jf,k) of the padded+flipped image has
+ * world coordinates
+ *      x = sx*(i - pad_xy),  y = sy*(jf - (NY-1-pad_xy)),  z = sz*(k + roi_start - vtk_pz)
+ * and scalar P[k][NY-1-jf][i].  Cells are visited iso-major, then k, jf, i.
+ * Vertex on an edge (low->high): t=(iso-s0)/(s1-s0) in double, position =
+ * spacing*(index+t) in double, rounded to float32.
+ * If tris == NULL only counts.  Returns number of triangles or <0.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int dt; const char *a; int64_t nz, ny, nx; const int64_t *s;
+    int pxy, pb; int64_t NZ, NY, NX; double padv;
+} mcvol_t;
+static inline double mc_at(const mcvol_t *v, int64_t k, int64_t jf, int64_t i) {
+    int64_t ja = (v->NY - 1 - jf) - v->pxy, ia = i - v->pxy, ka = k - v->pb;
+    if (ia < 0 || ia >= v->nx || ja < 0 || ja >= v->ny || ka < 0 || ka >= v->nz) return v->padv;
+    return ld(v->dt, AT(v->a, v->s, ka, ja, ia));
+}
+int64_t orc_marching_cubes(int dt, const void *a, const int64_t shape[3], const int64_t s[3], int pad_xy,
+                           int pad_bottom, int pad_top, double pad_value, int vtk_pz, int64_t roi_start,
+                           const double spacing[3], const double *iso, int niso, float *tris,
+                           int64_t max_tris) {
+    mcvol_t v;
+    v.dt = dt; v.a = (const char *)a; v.nz = shape[0]; v.ny = shape[1]; v.nx = shape[2]; v.s = s;
+    v.pxy = pad_xy ? 1 : 0; v.pb = pad_bottom ? 1 : 0;
+    v.NZ = v.nz + v.pb + (pad_top ? 1 : 0); v.NY = v.ny + 2 * v.pxy; v.NX = v.nx + 2 * v.pxy;
+    v.padv = pad_value;
+    const double sx = spacing[0], sy = spacing[1], sz = spacing[2];
+    const int64_t yoff = v.NY - 1 - v.pxy, zoff = roi_start - vtk_pz;
+    int64_t nt = 0;
+    for (int q = 0; q < niso; q++) {
+        const double value = iso[q];
+        for (int64_t k = 0; k + 1 < v.NZ; k++)
+            for (int64_t j = 0; j + 1 < v.NY; j++)
+                for (int64_t i = 0; i + 1 < v.NX; i++) {
+                    double sc[8];
+                    int idx = 0;
+                    for (int c = 0; c < 8; c++) {
+                        sc[c] = mc_at(&v, k + ((c >> 2) & 1), j + ((c >> 1) & 1), i + (c & 1));
+                        if (sc[c] >= value) idx |= 1 << c;
+                    }
+                    const int n = MC_NTRI[idx];
+                    if (!n) continue;
+                    if (tris) {
+                        if (nt + n > max_tris) return ORC_ERANGE;
+                        for (int t = 0; t < 3 * n; t++) {
+                            const int e = MC_TRI[idx][t];
+                            const int c0 = MC_EDGE_CORNERS[e][0], c1 = MC_EDGE_CORNERS[e][1];
+                            const double tt = (value - sc[c0]) / (sc[c1] - sc[c0]);
+                            double p[3] = {(double)(i + MC_EDGE_BASE[e][0] - v.pxy),
+                                           (double)(j + MC_EDGE_BASE[e][1] - yoff),
+                                           (double)(k + MC_EDGE_BASE[e][2] + zoff)};
+                            p[MC_EDGE_AXIS[e]] += tt;
+                            float *o = tris + (nt * 3 + t) * 3;
+                            o[0] = (float)(sx * p[0]); o[1] = (float)(sy * p[1]); o[2] = (float)(sz * p[2]);
+                        }
+                    }
+                    nt += n;
+                }
+    }
+    return nt;
+}

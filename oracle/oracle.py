@@ -1,0 +1,338 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+Python face of the oracle: ctypes bindings to ``oracle/libivx_oracle.so`` (the C restatement of the
+reference's Rust kernels / third-party algorithms) plus numpy restatements of the pure-numpy reference
+functions.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product package ``invesalius3_amd`` never imports it and has no CPU fallback.
+
+Reference citations are relative to the InVesalius checkout (``invesalius/...``, ``invesalius_rs/...``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+DT = {np.dtype(np.uint8): 0, np.dtype(np.int16): 1, np.dtype(np.float64): 2, np.dtype(np.uint16): 3}
+
+
+def build():
+    """Compile the C oracle in place (gcc, a second or two)."""
+    subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libivx_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.orc_marching_cubes.restype = ctypes.c_int64
+    return _LIB
+
+
+def _i64(seq):
+    return (ctypes.c_int64 * len(seq))(*[int(v) for v in seq])
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check(rc):
+    if rc == -2:
+        raise IndexError("oracle: seed/label out of bounds (reference: Rust index panic)")
+    if rc == -4:
+        raise ValueError("oracle: NumCast failure (reference: unwrap() panic)")
+    if rc < 0:
+        raise RuntimeError("oracle error %d" % rc)
+    return rc
+
+
+def _seeds(seeds):
+    s = np.ascontiguousarray(np.array([tuple(x) for x in seeds], dtype=np.int64).reshape(-1, 3))
+    return s
+
+
+# ----------------------------------------------------------------------------------------------
+# threshold                                  invesalius/data/slice_.py:1722-1769, 1225-1247
+# ----------------------------------------------------------------------------------------------
+def do_threshold_to_a_slice(slice_matrix, mask, threshold):
+    """slice_.py:1722-1737 verbatim (intended dtype uint8 stated explicitly)."""
+    thresh_min, thresh_max = threshold
+    m = ((slice_matrix >= thresh_min) & (slice_matrix <= thresh_max)) * 255
+    m[mask == 1] = 1
+    m[mask == 2] = 2
+    m[mask == 253] = 253
+    m[mask == 254] = 254
+    return m.astype("uint8")
+
+
+def do_threshold_to_all_slices(mask_matrix, target_matrix, threshold_range):
+    """slice_.py:1759-1767: slices whose flag mask[n,0,0] != 0 are skipped; flag set to 1 after."""
+    for n in range(1, mask_matrix.shape[0]):
+        if mask_matrix[n, 0, 0] == 0:
+            m = mask_matrix[n, 1:, 1:]
+            mask_matrix[n, 1:, 1:] = do_threshold_to_a_slice(target_matrix[n - 1], m, threshold_range)
+            mask_matrix[n, 0, 0] = 1
+
+
+def set_mask_threshold_volume(mask_matrix, image, threshold_range):
+    """slice_.py:1240-1247 (whole-volume SetMaskThreshold: no preserve rule, flag forced to 1)."""
+    thresh_min, thresh_max = threshold_range
+    for n, slice_ in enumerate(image):
+        m = np.ones(slice_.shape, mask_matrix.dtype)
+        m[slice_ < thresh_min] = 0
+        m[slice_ > thresh_max] = 0
+        m[m == 1] = 255
+        mask_matrix[n + 1, 1:, 1:] = m
+        mask_matrix[n + 1, 0, 0] = 1
+
+
+def set_mask_threshold_slice(slice_, threshold_range):
+    """slice_.py:1253-1256 per-slice preview."""
+    thresh_min, thresh_max = threshold_range
+    return (255 * ((slice_ >= thresh_min) & (slice_ <= thresh_max))).astype("uint8")
+
+
+# ----------------------------------------------------------------------------------------------
+# window/level LUT                          invesalius/data/imagedata_utils.py:540-564
+# np.piecewise allocates its result with the INPUT dtype, so int16 in -> int16 out with the float
+# expression truncated toward zero.
+# ----------------------------------------------------------------------------------------------
+def get_LUT_value(data, window, level):
+    shape = data.shape
+    data_ = data.ravel()
+    out = np.piecewise(
+        data_,
+        [data_ <= (level - 0.5 - (window - 1) / 2), data_ > (level - 0.5 + (window - 1) / 2)],
+        [0, window, lambda d: ((d - (level - 0.5)) / (window - 1) + 0.5) * (window)],
+    )
+    out.shape = shape
+    return out
+
+
+def get_LUT_value_255(data, window, level):
+    shape = data.shape
+    data_ = data.ravel()
+    out = np.piecewise(
+        data_,
+        [data_ <= (level - 0.5 - (window - 1) / 2), data_ > (level - 0.5 + (window - 1) / 2)],
+        [0, 255, lambda d: ((d - (level - 0.5)) / (window - 1) + 0.5) * (255)],
+    )
+    out.shape = shape
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# floodfill family                                  invesalius_rs/src/floodfill.rs
+# ----------------------------------------------------------------------------------------------
+def floodfill_threshold(data, seeds, t0, t1, fill, strct, out):
+    """generic_floodfill_threshold floodfill.rs:96-166 (wrapper semantics invesalius_rs/__init__.py:21-40)."""
+    strct = np.ascontiguousarray(strct, dtype=np.uint8)
+    if data.dtype.kind in "iu":
+        t0, t1, fill = int(t0), int(t1), int(fill)
+    s = _seeds(seeds)
+    rc = lib().orc_floodfill_threshold(
+        DT[data.dtype], _p(data), _i64(data.shape), _i64(data.strides), _p(s), ctypes.c_int64(len(s)),
+        ctypes.c_double(t0), ctypes.c_double(t1), ctypes.c_int(int(fill)), _p(strct), _i64(strct.shape),
+        _p(out), _i64(out.strides))
+    _check(rc)
+
+
+def floodfill_threshold_inplace(data, seeds, t0, t1, fill, strct):
+    """generic_floodfill_threshold_inplace floodfill.rs:168-237."""
+    strct = np.ascontiguousarray(strct, dtype=np.uint8)
+    s = _seeds(seeds)
+    rc = lib().orc_floodfill_threshold_inplace(
+        DT[data.dtype], _p(data), _i64(data.shape), _i64(data.strides), _p(s), ctypes.c_int64(len(s)),
+        ctypes.c_double(t0), ctypes.c_double(t1), ctypes.c_double(fill), _p(strct), _i64(strct.shape))
+    _check(rc)
+
+
+def floodfill(data, i, j, k, v, fill, out):
+    """floodfill_internal floodfill.rs:5-49."""
+    rc = lib().orc_floodfill(DT[data.dtype], _p(data), _i64(data.shape), _i64(data.strides),
+                             ctypes.c_int64(i), ctypes.c_int64(j), ctypes.c_int64(k), ctypes.c_double(v),
+                             ctypes.c_int(int(fill)), _p(out), _i64(out.strides))
+    _check(rc)
+
+
+def floodfill_auto_threshold(data, seeds, p, fill, out):
+    """floodfill_auto_threshold floodfill_py.rs:12-85 (i16 only)."""
+    assert data.dtype == np.int16
+    s = _seeds(seeds)
+    rc = lib().orc_floodfill_auto_threshold(_p(data), _i64(data.shape), _i64(data.strides), _p(s),
+                                            ctypes.c_int64(len(s)), ctypes.c_float(p), ctypes.c_int(int(fill)),
+                                            _p(out), _i64(out.strides))
+    _check(rc)
+
+
+def fill_holes_automatically(mask, labels, nlabels, max_size):
+    """fill_holes_automatically_internal floodfill.rs:51-94."""
+    assert mask.dtype == np.uint8 and labels.dtype == np.uint32
+    rc = lib().orc_fill_holes(_p(mask), _i64(mask.shape), _i64(mask.strides), _p(labels), _i64(labels.strides),
+                              ctypes.c_uint32(int(nlabels)), ctypes.c_uint32(int(max_size)))
+    return bool(_check(rc))
+
+
+def do_rg_confidence(image, p, bstruct, confid_mult, confid_iters):
+    """invesalius/data/styles.py:3220-3251 (compute part; LUT branch left to the caller).
+    Returns out_mask (uint8, fill=1).  Quirk Q4 kept: out_mask is NOT cleared between iterations;
+    t0/t1 are floats and the wrapper truncates them with int() for integer images."""
+    x, y, z = p
+    bool_mask = np.zeros(image.shape, dtype="bool")
+    out_mask = np.zeros(image.shape, dtype=np.uint8)
+    for k in range(int(z - 1), int(z + 2)):
+        if k < 0 or k >= bool_mask.shape[0]:
+            continue
+        for j in range(int(y - 1), int(y + 2)):
+            if j < 0 or j >= bool_mask.shape[1]:
+                continue
+            for i in range(int(x - 1), int(x + 2)):
+                if i < 0 or i >= bool_mask.shape[2]:
+                    continue
+                bool_mask[k, j, i] = True
+    for _ in range(confid_iters):
+        var = np.std(image[bool_mask])
+        mean = np.mean(image[bool_mask])
+        t0 = mean - var * confid_mult
+        t1 = mean + var * confid_mult
+        floodfill_threshold(image, ((x, y, z),), t0, t1, 1, bstruct, out_mask)
+        bool_mask[out_mask == 1] = True
+    return out_mask
+
+
+# ----------------------------------------------------------------------------------------------
+# projections                         invesalius/data/slice_.py:885-889 + invesalius_rs/src/mips.rs
+# ----------------------------------------------------------------------------------------------
+def maxip(a, axis):
+    return np.array(a).max(axis)
+
+
+def minip(a, axis):
+    return np.array(a).min(axis)
+
+
+def meanip(a, axis):
+    return np.array(a).mean(axis)
+
+
+def lmip(image, axis, tmin, tmax, out):
+    """lmip mips.rs:7-86."""
+    _check(lib().orc_lmip(DT[image.dtype], _p(image), _i64(image.shape), _i64(image.strides), int(axis),
+                          ctypes.c_double(tmin), ctypes.c_double(tmax), _p(out), _i64(out.strides)))
+
+
+def mida(image, axis, wl, ww, out):
+    """mida_internal mips.rs:102-168; dtype pairs mips_py.rs:161-202."""
+    _check(lib().orc_mida(DT[image.dtype], _p(image), _i64(image.shape), _i64(image.strides), int(axis),
+                          ctypes.c_double(int(wl)), ctypes.c_double(int(ww)), DT[out.dtype], _p(out),
+                          _i64(out.strides)))
+
+
+def fcm_volume(image, n, axis):
+    tmp = np.empty(image.shape, image.dtype)
+    _check(lib().orc_fcm_volume(DT[image.dtype], _p(image), _i64(image.shape), _i64(image.strides),
+                                ctypes.c_float(n), int(axis), _p(tmp)))
+    return tmp
+
+
+def fast_countour_mip(image, n, axis, wl, ww, tmip, out):
+    """fast_countour_mip_internal mips.rs:215-279."""
+    _check(lib().orc_fast_countour_mip(DT[image.dtype], _p(image), _i64(image.shape), _i64(image.strides),
+                                       ctypes.c_float(n), int(axis), ctypes.c_double(int(wl)),
+                                       ctypes.c_double(int(ww)), int(tmip), _p(out), _i64(out.strides)))
+
+
+# ----------------------------------------------------------------------------------------------
+# marching cubes == create_surface_piece geometry    invesalius/data/surface_process.py:71-201
+# ----------------------------------------------------------------------------------------------
+def marching_cubes(a, spacing, iso_values, roi_start=0, pad_xy=True, pad_bottom=True, pad_top=True,
+                   pad_value=0.0, vtk_pz=None):
+    """Triangle soup float32 (T,3,3) of the padded + Y-flipped piece `a` (see ivx_oracle.c)."""
+    if vtk_pz is None:
+        vtk_pz = 1 if (pad_xy and pad_bottom) else 0
+    iso = np.ascontiguousarray(iso_values, dtype=np.float64)
+    sp = np.ascontiguousarray(spacing, dtype=np.float64)
+    args = (DT[a.dtype], _p(a), _i64(a.shape), _i64(a.strides), int(bool(pad_xy)), int(bool(pad_bottom)),
+            int(bool(pad_top)), ctypes.c_double(pad_value), int(vtk_pz), ctypes.c_int64(roi_start), _p(sp),
+            _p(iso), len(iso))
+    n = _check(lib().orc_marching_cubes(*args, None, ctypes.c_int64(0)))
+    tris = np.empty((n, 3, 3), dtype=np.float32)
+    if n:
+        m = _check(lib().orc_marching_cubes(*args, _p(tris), ctypes.c_int64(n)))
+        assert m == n
+    return tris
+
+
+def create_surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
+                         fill_border_holes=True):
+    """Geometry of surface_process.py:100-186 for one piece: returns the triangle soup.
+    `mask_matrix` is the (dz+1,dy+1,dx+1) mask; `roi` a slice over z of the IMAGE."""
+    shape0 = image.shape[0] if image is not None else mask_matrix.shape[0] - 1
+    pad_bottom = roi.start == 0
+    pad_top = roi.stop >= shape0
+    if from_binary:
+        a = mask_matrix[roi.start + 1: roi.stop + 1, 1:, 1:]
+        padv, isos = 0.0, [127.0]
+    else:
+        a = image[roi]
+        padv, isos = float(np.iinfo(image.dtype).min), [float(min_value), float(max_value)]
+    if fill_border_holes:
+        return marching_cubes(a, spacing, isos, roi.start, True, pad_bottom, pad_top, padv, int(pad_bottom))
+    return marching_cubes(a, spacing, isos, roi.start, False, False, False, padv, 0)
+
+
+def write_stl_binary(path, tris):
+    """vtkSTLWriter binary layout (surface.py:1827-1829): 80 B header, u32 count, 50 B/triangle."""
+    tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 3, 3)
+    v = tris.astype(np.float64)
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.where(ln > 0, n / np.where(ln > 0, ln, 1), 0.0)
+    rec = np.zeros(len(tris), dtype=[("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+    rec["n"] = n.astype(np.float32)
+    rec["v"] = tris
+    with open(path, "wb") as f:
+        f.write(b"Visualization Toolkit generated SLA File".ljust(80))
+        f.write(np.uint32(len(tris)).tobytes())
+        f.write(rec.tobytes())
+
+
+# ----------------------------------------------------------------------------------------------
+# watershed                                  invesalius/data/watershed_process.py:19-60
+# ----------------------------------------------------------------------------------------------
+def watershed_ift(image, markers, strct):
+    """scipy.ndimage.watershed_ift restated (ni_measure.c NI_WatershedIFT); pinned vs live scipy."""
+    image = np.ascontiguousarray(image)
+    markers = np.ascontiguousarray(markers)
+    assert image.dtype in (np.uint8, np.uint16) and markers.dtype in (np.int8, np.int16)
+    s3 = np.zeros((3, 3, 3), np.uint8)
+    if image.ndim == 3:
+        s3[:] = np.asarray(strct, dtype=np.uint8)
+        shp = image.shape
+    else:
+        s3[1] = np.asarray(strct, dtype=np.uint8)
+        shp = (1,) + image.shape
+    out = np.empty_like(markers)
+    _check(lib().orc_watershed_ift(0 if image.dtype == np.uint8 else 3, _p(image), _i64(shp),
+                                   1 if markers.dtype == np.int16 else 4, _p(markers), _p(s3), _p(out)))
+    return out
+
+
+def watershed_merge(mask, tmp_mask, overwrite):
+    """styles.py:2147-2152 (3-D) / 1984-1989 (2-D) merge rule, in place on `mask`."""
+    if overwrite:
+        mask[:] = 0
+        mask[tmp_mask == 1] = 253
+    else:
+        sel = (mask == 0) | (mask == 2) | (mask == 253)
+        mask[(tmp_mask == 2) & sel] = 2
+        mask[(tmp_mask == 1) & sel] = 253
