@@ -1,0 +1,146 @@
+/*
+ * ivx.h -- C ABI of libivx.so: the MI355X (gfx950) implementation of the InVesalius dense-voxel
+ * hot path (threshold / region growing / watershed masks, MIP-family projections, marching cubes).
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain pointers, sizes and
+ * byte strides (no torch / numpy / VTK types) and returns an int status (IVX_OK or a negative
+ * IVX_E* code; ivx_last_error() gives the text).  Each declaration cites the reference interface it
+ * replaces (paths relative to the invesalius3 checkout).  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add; invesalius3_amd/ is that stub, complete.
+ *
+ * Two layers:
+ *   ivx_dev_*   operate on DEVICE pointers (dense C-order [z][y][x] arrays already resident in HBM)
+ *               on a caller-supplied HIP stream (void* == hipStream_t, NULL = default stream).
+ *               Used by the resident pipeline (bench.py, the multi-GPU slab driver).
+ *   ivx_*       operate on HOST pointers with byte strides (numpy arrays / np.memmap views such as
+ *               mask.matrix[1:,1:,1:]); they stage through HBM, run the same kernels and write the
+ *               result in place into the caller-owned output, exactly like the PyO3 functions.
+ *
+ * There is NO CPU fallback anywhere in this library: without a HIP device every compute entry
+ * point returns IVX_EHIP.
+ *
+ * Conventions (identical to the reference): arrays are [z][y][x]; seeds are (x,y,z);
+ * axis 0/1/2 = AXIAL/CORONAL/SAGITAL = reduce over z/y/x; strct is the 3x3x3 (or 1x3x3 ...) uint8
+ * structuring element from scipy.ndimage.generate_binary_structure.
+ */
+#ifndef IVX_H
+#define IVX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVX_OK 0
+#define IVX_EINVAL (-1) /* bad dtype / shape / argument        -> Python TypeError / ValueError   */
+#define IVX_ERANGE (-2) /* seed or label out of bounds          -> IndexError (Rust: index panic)  */
+#define IVX_ENOMEM (-3) /* host or device allocation failed     -> MemoryError                     */
+#define IVX_EDOM (-4)   /* NumCast failure                      -> ValueError (Rust: unwrap panic) */
+#define IVX_EHIP (-5)   /* HIP runtime error / no device        -> RuntimeError                    */
+
+/* dtype codes (image dtypes accepted by the reference's ImageTypes3 enum, invesalius_rs/src/types.rs:4-70) */
+#define IVX_U8 0
+#define IVX_I16 1
+#define IVX_F64 2
+#define IVX_U16 3
+
+/* projection ops for ivx_*mip_reduce (numpy .max/.min/.mean, invesalius/data/slice_.py:885-889) */
+#define IVX_MIP_MAX 0
+#define IVX_MIP_MIN 1
+#define IVX_MIP_MEAN 2
+
+/* ------------------------------------------------------------------------------------------------
+ * runtime
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_version(void);
+const char *ivx_last_error(void);
+int ivx_device_count(int *count);
+int ivx_set_device(int device);
+int ivx_device_synchronize(void);
+int ivx_device_name(char *buf, size_t buflen);
+int ivx_malloc(void **dptr, size_t nbytes);
+int ivx_free(void *dptr);
+int ivx_memset(void *dptr, int value, size_t nbytes, void *stream);
+int ivx_memcpy_h2d(void *dst, const void *src, size_t nbytes);
+int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes);
+int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
+int ivx_stream_create(void **stream);
+int ivx_stream_destroy(void *stream);
+int ivx_stream_synchronize(void *stream);
+/* HIP events on the stream the kernels are launched on (bench.py roofline timing) */
+int ivx_event_create(void **event);
+int ivx_event_destroy(void *event);
+int ivx_event_record(void *event, void *stream);
+int ivx_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+/* free the cached device workspaces the host-level entry points keep between calls */
+int ivx_release_workspace(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * threshold -> uint8 mask
+ *   replaces Slice.do_threshold_to_a_slice / do_threshold_to_all_slices
+ *            invesalius/data/slice_.py:1722-1737, 1739-1769            (preserve = 1)
+ *        and Slice.SetMaskThreshold whole-volume loop slice_.py:1240-1247 (preserve = 0)
+ * mask[v] = (lo <= img[v] <= hi) ? 255 : 0; with preserve, existing 1/2/253/254 are kept.
+ * skip_flags (dz bytes, may be NULL): slices with a non-zero flag are left untouched
+ * (mask.matrix[n,0,0] != 0 test, slice_.py:1761).
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_threshold_i16(const int16_t *img, int64_t dz, int64_t dy, int64_t dx, int lo, int hi,
+                          int preserve, const uint8_t *skip_flags, uint8_t *mask, void *stream);
+/* Host form.  `mask` points at the FULL (dz+1,dy+1,dx+1) matrix of invesalius/data/mask.py:422-431
+ * (flag cells in the index-0 planes); strides in bytes.  With honour_flags the per-slice flag
+ * mask[n,0,0] is tested and then set to 1 (slice_.py:1761-1767); without it every slice is
+ * processed and the flag forced to 1 (slice_.py:1240-1247). */
+int ivx_threshold_all_slices(const int16_t *img, const int64_t shape[3], const int64_t img_strides[3],
+                             int lo, int hi, int preserve, int honour_flags, uint8_t *mask,
+                             const int64_t mask_strides[3]);
+
+/* ------------------------------------------------------------------------------------------------
+ * MaxIP / MinIP / MeanIP along an axis
+ *   replaces numpy .max/.min/.mean(axis) in Slice.get_image_slice slice_.py:885-889,969-973,1056-1060
+ * out is 2-D: axis0 -> (dy,dx), axis1 -> (dz,dx), axis2 -> (dz,dy); dtype == image dtype for
+ * max/min, float64 for mean (numpy semantics).
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_mip_reduce(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, int op,
+                       void *out, void *stream);
+int ivx_mip_reduce(int dtype, const void *vol, const int64_t shape[3], const int64_t strides[3], int axis,
+                   int op, void *out, const int64_t out_strides[2]);
+
+/* ------------------------------------------------------------------------------------------------
+ * marching cubes == geometry of create_surface_piece
+ *   replaces pad_image + converters.to_vtk + vtkImageFlip + vtkContourFilter
+ *            invesalius/data/surface_process.py:52-68,100-186; invesalius/data/converters.py:34-101
+ * `a` is the piece (mask[roi+1,1:,1:] u8 or image[roi] i16), dense (nz,ny,nx).  The padding
+ * (pad_xy, pad_bottom, pad_top, pad_value) and the Y flip are folded into the addressing, never
+ * materialised.  Output: triangle soup, 9 float32 per triangle, in iso-major then (k,j,i) raster
+ * order of the padded+flipped cell grid.  Two-call protocol: count, then emit into a buffer of at
+ * least `count` triangles.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ivx_mc_params {
+    int32_t dtype;      /* IVX_U8 / IVX_I16 / IVX_U16 */
+    int32_t pad_xy;     /* 1: one pad voxel on both sides in y and x */
+    int32_t pad_bottom; /* 1: one pad slice before z=0 */
+    int32_t pad_top;    /* 1: one pad slice after the last */
+    int32_t vtk_pz;     /* z padding reported to to_vtk (== pad_bottom when fill_border_holes) */
+    int32_t niso;       /* 1 or 2 */
+    int64_t nz, ny, nx; /* piece shape */
+    int64_t roi_start;  /* first image slice of the piece */
+    double pad_value;
+    double spacing[3]; /* (sx, sy, sz) */
+    double iso[2];
+} ivx_mc_params;
+/* scratch needed by count/emit for this piece (bytes); pass a device buffer of that size */
+int ivx_dev_mc_scratch_bytes(const ivx_mc_params *p, size_t *nbytes);
+/* classify + per-row-group triangle counts + scan; *ntris (host) receives the total */
+int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch, int64_t *ntris, void *stream);
+/* emit; must follow ivx_dev_mc_count with the same params/scratch */
+int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *tris, int64_t max_tris,
+                    void *stream);
+/* Host form: strided piece in, soup out.  tris == NULL -> count only.  Returns count in *ntris. */
+int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *tris,
+                       int64_t max_tris, int64_t *ntris);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVX_H */

@@ -1,0 +1,59 @@
+// ivx_internal.h -- shared by every translation unit of libivx.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ivx.h"
+
+namespace ivx {
+
+void set_error(const char *fmt, ...);
+
+#define IVX_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            ivx::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return e__ == hipErrorOutOfMemory ? IVX_ENOMEM : IVX_EHIP;                     \
+        }                                                                                  \
+    } while (0)
+
+#define IVX_LAUNCH_CHECK() IVX_HIP(hipGetLastError())
+
+#define IVX_REQUIRE(cond, code, ...)                                                       \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            ivx::set_error(__VA_ARGS__);                                                   \
+            return (code);                                                                 \
+        }                                                                                  \
+    } while (0)
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t dtype_size(int dt) {
+    switch (dt) {
+    case IVX_U8: return 1;
+    case IVX_I16: return 2;
+    case IVX_U16: return 2;
+    case IVX_F64: return 8;
+    default: return 0;
+    }
+}
+
+// Cached device workspaces for the host-level entry points (grow-only, freed by ivx_release_workspace).
+enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_COUNT };
+int ws_get(int slot, size_t nbytes, void **dptr);
+// pinned host staging (grow-only)
+int hs_get(int slot, size_t nbytes, void **hptr);
+
+// strided host <-> dense device helpers (host side gather / scatter + one hipMemcpy)
+int upload_strided(void *dst_dev, const void *src, const int64_t shape[3], const int64_t strides[3], size_t isz,
+                   int hslot);
+int download_strided(void *dst, const int64_t shape[3], const int64_t strides[3], const void *src_dev, size_t isz,
+                     int hslot);
+int download_strided2(void *dst, const int64_t shape[2], const int64_t strides[2], const void *src_dev, size_t isz,
+                      int hslot);
+
+} // namespace ivx

@@ -1,0 +1,232 @@
+// ivx_runtime.hip -- runtime plumbing of libivx.so: errors, device memory, streams, events,
+// cached workspaces and the strided host<->dense device staging used by the host-level entry points.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "ivx_internal.h"
+
+namespace ivx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Slot {
+    void *p = nullptr;
+    size_t n = 0;
+};
+static Slot g_ws[WS_COUNT];
+static Slot g_hs[WS_COUNT];
+static std::mutex g_mu;
+
+int ws_get(int slot, size_t nbytes, void **dptr) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Slot &s = g_ws[slot];
+    if (nbytes == 0) nbytes = 16;
+    if (s.n < nbytes) {
+        if (s.p) IVX_HIP(hipFree(s.p));
+        s.p = nullptr;
+        s.n = 0;
+        size_t want = nbytes + (nbytes >> 3) + 4096; // a little slack so growing volumes do not thrash
+        IVX_HIP(hipMalloc(&s.p, want));
+        s.n = want;
+    }
+    *dptr = s.p;
+    return IVX_OK;
+}
+
+int hs_get(int slot, size_t nbytes, void **hptr) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Slot &s = g_hs[slot];
+    if (nbytes == 0) nbytes = 16;
+    if (s.n < nbytes) {
+        if (s.p) IVX_HIP(hipHostFree(s.p));
+        s.p = nullptr;
+        s.n = 0;
+        size_t want = nbytes + (nbytes >> 3) + 4096;
+        IVX_HIP(hipHostMalloc(&s.p, want, hipHostMallocDefault));
+        s.n = want;
+    }
+    *hptr = s.p;
+    return IVX_OK;
+}
+
+static inline bool dense3(const int64_t shape[3], const int64_t st[3], size_t isz) {
+    return st[2] == (int64_t)isz && st[1] == shape[2] * (int64_t)isz && st[0] == shape[1] * shape[2] * (int64_t)isz;
+}
+
+int upload_strided(void *dst_dev, const void *src, const int64_t shape[3], const int64_t st[3], size_t isz,
+                   int hslot) {
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2] * isz;
+    if (n == 0) return IVX_OK;
+    if (dense3(shape, st, isz)) {
+        IVX_HIP(hipMemcpy(dst_dev, src, n, hipMemcpyHostToDevice));
+        return IVX_OK;
+    }
+    void *h;
+    int rc = hs_get(hslot, n, &h);
+    if (rc) return rc;
+    char *d = (char *)h;
+    const char *s = (const char *)src;
+    const size_t row = (size_t)shape[2] * isz;
+    for (int64_t z = 0; z < shape[0]; z++)
+        for (int64_t y = 0; y < shape[1]; y++) {
+            const char *sp = s + z * st[0] + y * st[1];
+            char *dp = d + ((size_t)z * shape[1] + y) * row;
+            if (st[2] == (int64_t)isz) memcpy(dp, sp, row);
+            else
+                for (int64_t x = 0; x < shape[2]; x++) memcpy(dp + x * isz, sp + x * st[2], isz);
+        }
+    IVX_HIP(hipMemcpy(dst_dev, h, n, hipMemcpyHostToDevice));
+    return IVX_OK;
+}
+
+int download_strided(void *dst, const int64_t shape[3], const int64_t st[3], const void *src_dev, size_t isz,
+                     int hslot) {
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2] * isz;
+    if (n == 0) return IVX_OK;
+    if (dense3(shape, st, isz)) {
+        IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
+        return IVX_OK;
+    }
+    void *h;
+    int rc = hs_get(hslot, n, &h);
+    if (rc) return rc;
+    IVX_HIP(hipMemcpy(h, src_dev, n, hipMemcpyDeviceToHost));
+    const char *s = (const char *)h;
+    char *d = (char *)dst;
+    const size_t row = (size_t)shape[2] * isz;
+    for (int64_t z = 0; z < shape[0]; z++)
+        for (int64_t y = 0; y < shape[1]; y++) {
+            char *dp = d + z * st[0] + y * st[1];
+            const char *sp = s + ((size_t)z * shape[1] + y) * row;
+            if (st[2] == (int64_t)isz) memcpy(dp, sp, row);
+            else
+                for (int64_t x = 0; x < shape[2]; x++) memcpy(dp + x * st[2], sp + x * isz, isz);
+        }
+    return IVX_OK;
+}
+
+int download_strided2(void *dst, const int64_t shape[2], const int64_t st[2], const void *src_dev, size_t isz,
+                      int hslot) {
+    const int64_t sh3[3] = {1, shape[0], shape[1]};
+    const int64_t st3[3] = {0, st[0], st[1]};
+    if (st[1] == (int64_t)isz && st[0] == shape[1] * (int64_t)isz) {
+        const size_t n = (size_t)shape[0] * shape[1] * isz;
+        if (n) IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
+        return IVX_OK;
+    }
+    return download_strided(dst, sh3, st3, src_dev, isz, hslot);
+}
+
+} // namespace ivx
+
+using namespace ivx;
+
+extern "C" {
+
+int ivx_version(void) { return 100; }
+const char *ivx_last_error(void) { return g_err; }
+
+int ivx_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        n = 0;
+        (void)hipGetLastError();
+    }
+    *count = n;
+    return IVX_OK;
+}
+int ivx_set_device(int device) {
+    IVX_HIP(hipSetDevice(device));
+    return IVX_OK;
+}
+int ivx_device_synchronize(void) {
+    IVX_HIP(hipDeviceSynchronize());
+    return IVX_OK;
+}
+int ivx_device_name(char *buf, size_t buflen) {
+    int dev = 0;
+    IVX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    IVX_HIP(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return IVX_OK;
+}
+int ivx_malloc(void **dptr, size_t nbytes) {
+    IVX_HIP(hipMalloc(dptr, nbytes ? nbytes : 16));
+    return IVX_OK;
+}
+int ivx_free(void *dptr) {
+    if (dptr) IVX_HIP(hipFree(dptr));
+    return IVX_OK;
+}
+int ivx_memset(void *dptr, int value, size_t nbytes, void *stream) {
+    if (nbytes) IVX_HIP(hipMemsetAsync(dptr, value, nbytes, S(stream)));
+    return IVX_OK;
+}
+int ivx_memcpy_h2d(void *dst, const void *src, size_t nbytes) {
+    if (nbytes) IVX_HIP(hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice));
+    return IVX_OK;
+}
+int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes) {
+    if (nbytes) IVX_HIP(hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream) {
+    if (nbytes) IVX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, S(stream)));
+    return IVX_OK;
+}
+int ivx_stream_create(void **stream) {
+    hipStream_t s;
+    IVX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return IVX_OK;
+}
+int ivx_stream_destroy(void *stream) {
+    if (stream) IVX_HIP(hipStreamDestroy(S(stream)));
+    return IVX_OK;
+}
+int ivx_stream_synchronize(void *stream) {
+    IVX_HIP(hipStreamSynchronize(S(stream)));
+    return IVX_OK;
+}
+int ivx_event_create(void **event) {
+    hipEvent_t e;
+    IVX_HIP(hipEventCreate(&e));
+    *event = (void *)e;
+    return IVX_OK;
+}
+int ivx_event_destroy(void *event) {
+    if (event) IVX_HIP(hipEventDestroy((hipEvent_t)event));
+    return IVX_OK;
+}
+int ivx_event_record(void *event, void *stream) {
+    IVX_HIP(hipEventRecord((hipEvent_t)event, S(stream)));
+    return IVX_OK;
+}
+int ivx_event_elapsed_ms(void *start, void *stop, float *ms) {
+    IVX_HIP(hipEventSynchronize((hipEvent_t)stop));
+    IVX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return IVX_OK;
+}
+int ivx_release_workspace(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < WS_COUNT; i++) {
+        if (g_ws[i].p) (void)hipFree(g_ws[i].p);
+        g_ws[i] = Slot();
+        if (g_hs[i].p) (void)hipHostFree(g_hs[i].p);
+        g_hs[i] = Slot();
+    }
+    return IVX_OK;
+}
+
+} // extern "C"

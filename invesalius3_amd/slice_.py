@@ -1,0 +1,70 @@
+"""Threshold and slab-projection entry points of ``invesalius.data.slice_.Slice`` on the GPU.
+
+The reference methods live on the ``Slice`` singleton and read GUI state; the compute part is restated here as
+free functions with the state passed explicitly (mask matrix, image matrix, threshold range), same argument
+meaning, same in-place effects on the caller-owned ``(dz+1, dy+1, dx+1)`` uint8 mask matrix
+(invesalius/data/mask.py:422-431) including the per-slice flag cells ``matrix[n, 0, 0]``.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+PROJECTION_NORMAL, PROJECTION_MaxIP, PROJECTION_MinIP, PROJECTION_MeanIP = 0, 1, 2, 3  # invesalius/constants.py:803-806
+
+
+def _int_bounds(threshold_range):
+    """numpy compares int16 voxels with python numbers; for integer voxels `v >= lo` == `v >= ceil(lo)`."""
+    lo, hi = threshold_range
+    lo = int(math.ceil(lo))
+    hi = int(math.floor(hi))
+    lo = max(min(lo, 2 ** 31 - 1), -(2 ** 31))
+    hi = max(min(hi, 2 ** 31 - 1), -(2 ** 31))
+    return lo, hi
+
+
+def _threshold(mask_matrix, target_matrix, threshold_range, preserve, honour_flags):
+    if mask_matrix.dtype != np.uint8 or mask_matrix.ndim != 3:
+        raise TypeError("mask matrix must be a 3-D uint8 array")
+    if target_matrix.dtype != np.int16 or target_matrix.ndim != 3:
+        raise TypeError("image matrix must be a 3-D int16 array")
+    if tuple(mask_matrix.shape) != tuple(s + 1 for s in target_matrix.shape):
+        raise ValueError("mask matrix must be image shape + 1 per axis (invesalius/data/mask.py:422-431)")
+    lo, hi = _int_bounds(threshold_range)
+    L.check(L.lib().ivx_threshold_all_slices(
+        L.ptr(target_matrix), L.i64(target_matrix.shape), L.i64(target_matrix.strides), ctypes.c_int(lo),
+        ctypes.c_int(hi), ctypes.c_int(int(preserve)), ctypes.c_int(int(honour_flags)), L.ptr(mask_matrix),
+        L.i64(mask_matrix.strides)), "do_threshold_to_all_slices")
+    if hasattr(mask_matrix, "flush"):
+        mask_matrix.flush()  # slice_.py:1769
+
+
+def do_threshold_to_all_slices(mask_matrix, target_matrix, threshold_range):
+    """Slice.do_threshold_to_all_slices (invesalius/data/slice_.py:1739-1769) with do_threshold_to_a_slice
+    (:1722-1737) fused: slices whose flag ``mask_matrix[n,0,0]`` is 0 get ``255*in_range`` with existing
+    1/2/253/254 preserved, and their flag set to 1; flagged slices are left untouched."""
+    _threshold(mask_matrix, target_matrix, threshold_range, True, True)
+
+
+def set_mask_threshold(mask_matrix, image_matrix, threshold_range):
+    """Whole-volume branch of Slice.SetMaskThreshold (invesalius/data/slice_.py:1240-1247): no preserve rule,
+    every slice written, every flag forced to 1."""
+    _threshold(mask_matrix, image_matrix, threshold_range, False, False)
+
+
+def project(slab: np.ndarray, axis: int, projection: int) -> np.ndarray:
+    """MaxIP / MinIP / MeanIP of a slab: ``np.array(tmp_array).max|min|mean(axis)``
+    (invesalius/data/slice_.py:885-889, 969-973, 1056-1060)."""
+    if slab.ndim != 3:
+        raise TypeError("slab must be 3-D")
+    code = L.dtype_code(slab, (L.U8, L.I16, L.U16))
+    op = {PROJECTION_MaxIP: L.MIP_MAX, PROJECTION_MinIP: L.MIP_MIN, PROJECTION_MeanIP: L.MIP_MEAN}[projection]
+    oshape = tuple(s for i, s in enumerate(slab.shape) if i != axis)
+    out = np.empty(oshape, np.float64 if op == L.MIP_MEAN else slab.dtype)
+    L.check(L.lib().ivx_mip_reduce(code, L.ptr(slab), L.i64(slab.shape), L.i64(slab.strides), int(axis), int(op),
+                                   L.ptr(out), L.i64(out.strides)), "project")
+    return out

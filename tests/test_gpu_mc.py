@@ -1,0 +1,88 @@
+"""GPU parity: marching cubes vs the C oracle (same case table, same double->float32 rounding): the soup must be
+IDENTICAL, triangle by triangle (stronger than the 1e-5 vertex tolerance of the north star)."""
+import numpy as np
+import pytest
+
+from conftest import synth_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(gpu, ref):
+    assert gpu.shape == ref.shape
+    assert np.array_equal(gpu, ref)
+
+
+@pytest.mark.parametrize("shape,pads", [((9, 10, 11), (True, True, True)), ((4, 5, 70), (True, False, True)),
+                                        ((3, 3, 3), (False, False, False)), ((6, 64, 64), (True, True, False)),
+                                        ((2, 2, 130), (False, False, False)), ((21, 48, 56), (True, True, True))])
+def test_random_field_all_cases(ivxlib, oracle, shape, pads):
+    from invesalius3_amd import surface_process as sp
+    rng = np.random.default_rng(3)
+    a = rng.integers(-1000, 1000, shape).astype(np.int16)
+    pxy, pb, pt = pads
+    args = ((0.5, 0.75, 2.0), [0.5], 7, pxy, pb, pt, float(np.iinfo(np.int16).min), int(pxy and pb))
+    _cmp(sp.marching_cubes(a, *args), oracle.marching_cubes(a, *args))
+
+
+def test_two_iso_default_mode(ivxlib, oracle):
+    from invesalius3_amd import surface_process as sp
+    img = synth_volume((24, 40, 48), seed=21)
+    mask = np.zeros((25, 41, 49), np.uint8)
+    for roi in (slice(0, 21), slice(20, 41)):
+        g = sp.create_surface_piece(img, mask, roi, (0.4785156, 0.4785156, 2.0), 226, 3071, False)
+        r = oracle.create_surface_piece(img, mask, roi, (0.4785156, 0.4785156, 2.0), 226, 3071, False)
+        _cmp(g, r)
+        assert len(g) > 0
+
+
+def test_binary_mask_pieces_and_reference_fixture(ivxlib, oracle):
+    """tests/test_mesh_generation.py:23-37 (20^3 cube @ iso 128 -> closed surface, bounds) + piece split."""
+    from invesalius3_amd import surface_process as sp
+    m = np.zeros((20, 20, 20), np.uint8)
+    m[5:15, 5:15, 5:15] = 255
+    t = sp.marching_cubes(m, (1.0, 1.0, 1.0), [128.0], 0, False, False, False, 0.0, 0)
+    _cmp(t, oracle.marching_cubes(m, (1.0, 1.0, 1.0), [128.0], 0, False, False, False, 0.0, 0))
+    lo, hi = t.reshape(-1, 3).min(0), t.reshape(-1, 3).max(0)
+    f = 128.0 / 255.0
+    np.testing.assert_allclose([lo[0], hi[0], lo[2], hi[2]], [4 + f, 15 - f, 4 + f, 15 - f], atol=1e-6)
+    np.testing.assert_allclose([lo[1], hi[1]], [-(15 - f), -(4 + f)], atol=1e-6)
+
+    img = synth_volume((45, 32, 40), seed=22)
+    mask = np.zeros((46, 33, 41), np.uint8)
+    mask[1:, 1:, 1:] = np.where(img > -700, 255, 0)
+    g = sp.create_surface(None, mask, (1, 1, 2), 0, 0, True)
+    parts = [oracle.create_surface_piece(None, mask, slice(i * 20, i * 20 + 21), (1, 1, 2), 0, 0, True)
+             for i in range(3)]
+    _cmp(g, np.concatenate(parts))
+
+
+def test_strided_mask_view_and_empty(ivxlib, oracle):
+    from invesalius3_amd import surface_process as sp
+    mask = np.zeros((11, 21, 31), np.uint8)
+    mask[3:8, 4:15, 6:25] = 255
+    a = mask[1:, 1:, 1:]  # the non-contiguous view the reference passes around
+    _cmp(sp.marching_cubes(a, (1, 1, 1), [127.0]), oracle.marching_cubes(a, (1, 1, 1), [127.0]))
+    z = np.zeros((5, 6, 7), np.uint8)
+    assert len(sp.marching_cubes(z, (1, 1, 1), [127.0])) == 0
+    assert len(sp.marching_cubes(np.zeros((0, 6, 7), np.uint8), (1, 1, 1), [127.0])) == len(
+        oracle.marching_cubes(np.zeros((0, 6, 7), np.uint8), (1, 1, 1), [127.0]))
+
+
+def test_full_size_properties_512(ivxlib):
+    """512^3 binary mask of a ball: closed surface => signed volume ~ ball volume; vertex set invariant under
+    the 20+1-slice piece decomposition (whole-volume soup == concatenated pieces as multisets)."""
+    from invesalius3_amd import surface_process as sp
+    n = 512
+    z, y, x = np.ogrid[:n, :n, :n]
+    ball = ((z - 250.5) ** 2 + (y - 260.25) ** 2 + (x - 240.75) ** 2) <= 180.0 ** 2
+    mask = np.zeros((n + 1,) * 3, np.uint8)
+    mask[1:, 1:, 1:] = np.where(ball, 255, 0)
+    whole = sp.create_surface_piece(None, mask, slice(0, n), (1, 1, 1), 0, 0, True)
+    t = whole.astype(np.float64)
+    vol = np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() / 6.0
+    assert abs(vol / (4 / 3 * np.pi * 180.0 ** 3) - 1) < 5e-3
+    pieces = sp.create_surface(None, mask, (1, 1, 1), 0, 0, True)
+    assert len(pieces) == len(whole)
+    key = lambda a: np.sort(a.reshape(len(a), -1).view([("", np.float32)] * 9), axis=0)
+    assert np.array_equal(key(pieces), key(whole))

@@ -1,0 +1,91 @@
+"""GPU parity: threshold kernels vs the numpy restatement of slice_.py (bit-exact).  Calls go through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import synth_volume
+
+pytestmark = pytest.mark.gpu
+BONE = (226, 3071)
+
+
+def _mask_with_edits(shape, rng):
+    m = np.zeros(tuple(s + 1 for s in shape), np.uint8)
+    inner = m[1:, 1:, 1:]
+    r = rng.integers(0, 40, shape)
+    for k, v in ((1, 1), (2, 2), (3, 253), (4, 254), (5, 255), (6, 7)):
+        inner[r == k] = v
+    return m
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 10), (7, 13, 29), (33, 64, 128), (5, 16, 16), (1, 1, 1)])
+def test_do_threshold_to_all_slices_matches_reference(ivxlib, oracle, shape):
+    from invesalius3_amd import slice_
+    rng = np.random.default_rng(5)
+    img = synth_volume(shape, seed=11)
+    m_gpu = _mask_with_edits(shape, rng)
+    # some slices already thresholded/edited: flag != 0 -> must be left untouched (slice_.py:1761)
+    for n in range(1, shape[0] + 1, 3):
+        m_gpu[n, 0, 0] = 1 + (n % 2)
+    m_ref = m_gpu.copy()
+    slice_.do_threshold_to_all_slices(m_gpu, img, BONE)
+    oracle.do_threshold_to_all_slices(m_ref, img, BONE)
+    assert np.array_equal(m_gpu, m_ref)
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 10), (9, 31, 17), (16, 32, 64)])
+def test_set_mask_threshold_matches_reference(ivxlib, oracle, shape):
+    from invesalius3_amd import slice_
+    rng = np.random.default_rng(6)
+    img = synth_volume(shape, seed=12)
+    m_gpu = _mask_with_edits(shape, rng)
+    m_ref = m_gpu.copy()
+    slice_.set_mask_threshold(m_gpu, img, (-200, 500))
+    oracle.set_mask_threshold_volume(m_ref, img, (-200, 500))
+    assert np.array_equal(m_gpu, m_ref)
+
+
+def test_reference_golden_bounds(ivxlib):
+    """tests/test_bone_thresholding.py:121-185 through the GPU path: inclusive bounds 226/3071, cube [5:8]^3."""
+    from invesalius3_amd import slice_
+    vol = np.random.default_rng(2).integers(0, BONE[0] - 1, (10, 10, 10), dtype=np.int16)
+    vol[5:8, 5:8, 5:8] = (BONE[0] + BONE[1]) // 2
+    vol[0, 0, :4] = [226, 3071, 225, 3072]
+    mask = np.zeros((11, 11, 11), np.uint8)
+    slice_.do_threshold_to_all_slices(mask, vol, BONE)
+    exp = np.zeros((10, 10, 10), np.uint8)
+    exp[5:8, 5:8, 5:8] = 255
+    exp[0, 0, :2] = 255
+    assert np.array_equal(mask[1:, 1:, 1:], exp)
+    assert np.all(mask[1:, 0, 0] == 1)
+
+
+def test_noncontiguous_image_and_empty(ivxlib, oracle):
+    from invesalius3_amd import slice_
+    big = synth_volume((12, 20, 40), seed=13)
+    img = big[::2, 1:19, ::2]  # strided view
+    m_gpu = np.zeros(tuple(s + 1 for s in img.shape), np.uint8)
+    m_ref = m_gpu.copy()
+    slice_.do_threshold_to_all_slices(m_gpu, img, (-500, 100))
+    oracle.do_threshold_to_all_slices(m_ref, img, (-500, 100))
+    assert np.array_equal(m_gpu, m_ref)
+    e = np.zeros((0, 4, 4), np.int16)
+    slice_.do_threshold_to_all_slices(np.zeros((1, 5, 5), np.uint8), e, BONE)
+
+
+def test_full_size_property_512(ivxlib):
+    """BASELINE size: 512^3.  Size-independent property: mask == 255*in_range computed slice-wise by numpy on a
+    sample of slices, and idempotence (second run changes nothing)."""
+    from invesalius3_amd import slice_
+    rng = np.random.default_rng(7)
+    img = rng.integers(-1024, 3072, (512, 512, 512), dtype=np.int16)
+    mask = np.zeros((513, 513, 513), np.uint8)
+    slice_.set_mask_threshold(mask, img, BONE)
+    for z in (0, 1, 255, 510, 511):
+        exp = (255 * ((img[z] >= BONE[0]) & (img[z] <= BONE[1]))).astype(np.uint8)
+        assert np.array_equal(mask[z + 1, 1:, 1:], exp)
+    cnt = int((mask[1:, 1:, 1:] == 255).sum())
+    assert cnt == int(((img >= BONE[0]) & (img <= BONE[1])).sum())
+    before = mask.copy()
+    mask[1:, 0, 0] = 0
+    slice_.do_threshold_to_all_slices(mask, img, BONE)
+    assert np.array_equal(mask[1:, 1:, 1:], before[1:, 1:, 1:])
