@@ -140,6 +140,54 @@ int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, 
 int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *tris,
                        int64_t max_tris, int64_t *ntris);
 
+/* ------------------------------------------------------------------------------------------------
+ * seeded region growing
+ *   replaces generic_floodfill_threshold          invesalius_rs/src/floodfill.rs:96-166
+ *            generic_floodfill_threshold_inplace  invesalius_rs/src/floodfill.rs:168-237
+ *   (bindings floodfill_py.rs:137-231, wrappers invesalius_rs/__init__.py:21-54)
+ * Device form works on a bit-packed candidate / reached pair (1 bit per voxel, 64 voxels of an
+ * x-row per uint64 word, rows padded to a whole word): see DESIGN.md "region growing".
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ivx_flood_plan {
+    int64_t dz, dy, dx;
+    int64_t wx;            /* uint64 words per x-row = ceil(dx/64) */
+    uint32_t strct_bits;   /* bit (kk*9+jj*3+ii) set <=> strct[kk][jj][ii] != 0 (3x3x3, centre ignored) */
+} ivx_flood_plan;
+/* bytes of ONE bit volume (candidate or reached) for this plan */
+int ivx_flood_bits_bytes(const ivx_flood_plan *p, size_t *nbytes);
+/* scratch for the tile work-list */
+int ivx_flood_scratch_bytes(const ivx_flood_plan *p, size_t *nbytes);
+/* strct (dims 1..3 each, centre offset dim/2 as floodfill.rs:108-110) -> plan.strct_bits */
+int ivx_flood_strct_bits(const uint8_t *strct, const int64_t sshape[3], uint32_t *bits);
+/* zero `reached` and the tile work-list in `scratch` */
+int ivx_dev_flood_clear(const ivx_flood_plan *p, uint64_t *reached, void *scratch, void *stream);
+/* cand[v] = (t0 <= data[v] <= t1) && not blocked(v); barrier_mode 0: nothing blocks, 1: barrier[v] == (uint8)fill
+ * blocks (out-of-place form, floodfill.rs:154), 2: data[v] == fill blocks (in-place form, floodfill.rs:225) */
+int ivx_dev_flood_candidates(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                             const uint8_t *barrier, int barrier_mode, double fill, uint64_t *cand, void *stream);
+/* reached := seeds (x,y,z triples on the HOST) that are in [t0,t1]; such seeds are also forced into cand
+ * (a pre-filled seed still expands, floodfill.rs:121-128).  Out-of-bounds seed -> IVX_ERANGE. */
+int ivx_dev_flood_seed(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                       const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached,
+                       void *scratch, void *stream);
+/* grow `reached` inside `cand` to the fix-point; *rounds (host, may be NULL) = global rounds used */
+int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch,
+                      int *rounds, void *stream);
+/* mark every tile of the plan whose z-range touches [z0,z1) dirty (multi-GPU halo re-seeding) */
+int ivx_dev_flood_mark_slab(const ivx_flood_plan *p, void *scratch, int64_t z0, int64_t z1, void *stream);
+/* out[v] = fill where reached (uint8 out), or data[v] = fill (in-place form, dtype of data) */
+int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reached, int dtype, void *target,
+                        double fill, void *stream);
+/* number of reached voxels */
+int ivx_dev_flood_count(const ivx_flood_plan *p, const uint64_t *reached, int64_t *count, void *stream);
+int ivx_floodfill_threshold(int dtype, const void *data, const int64_t shape[3], const int64_t strides[3],
+                            const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1, int fill,
+                            const uint8_t *strct, const int64_t sshape[3], uint8_t *out,
+                            const int64_t out_strides[3]);
+int ivx_floodfill_threshold_inplace(int dtype, void *data, const int64_t shape[3], const int64_t strides[3],
+                                    const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1,
+                                    double fill, const uint8_t *strct, const int64_t sshape[3]);
+
 #ifdef __cplusplus
 }
 #endif

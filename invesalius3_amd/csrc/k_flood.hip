@@ -1,0 +1,562 @@
+// k_flood.hip -- seeded region growing (connected threshold flood) on bit planes.
+//
+// Reference semantics (bit-exact):
+//   generic_floodfill_threshold          invesalius_rs/src/floodfill.rs:96-166
+//   generic_floodfill_threshold_inplace  invesalius_rs/src/floodfill.rs:168-237
+// The reference walks a LIFO stack; the set it fills does not depend on the visiting order:
+//   filled = connected component (under `strct`) of the in-range seeds inside
+//            C = { v : t0 <= data[v] <= t1  and  barrier[v] != fill }   (+ the in-range seeds themselves),
+// so a parallel fix-point gives the same bytes.
+//
+// MI355X design (memory-bound, no MFMA):
+//   k_flood_candidates  ONE streaming pass over data (+ barrier): 2 B + 1 B read per voxel, 1 bit written.
+//                       C is 1 bit/voxel (64 voxels of an x-row per uint64): 16 MiB at 512^3, i.e. it lives in
+//                       L2 / Infinity Cache for the whole flood.
+//   k_flood_round       one workgroup per DIRTY tile of 64(x) x 16(y) x 16(z) voxels = 256 words, one lane per
+//                       word.  The reached-bits of the tile plus a one-row/one-word halo are staged in LDS
+//                       (18x18x3 words, 7.6 KiB) and iterated to the tile-local fix-point:
+//                         - 26/18/6-neighbour gather = OR of <= 9 LDS rows with +-1 bit shifts,
+//                         - propagation ALONG x inside a word is closed in O(1) with the carry trick
+//                           ((C + R) ^ C) & C  (and its bit-reversed twin), i.e. a 64-voxel run fills in one step.
+//                       A tile whose boundary changed marks exactly the neighbour tiles that can see the change
+//                       (agent-scope atomics); the host loops rounds until no tile is dirty.  Global rounds are
+//                       bounded by the number of TILES on the longest path, not voxels.
+//   k_flood_apply       reached bits -> out[v] = fill (only words with reached bits touch memory).
+#include "ivx_internal.h"
+
+typedef short short8_t __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TY = 16, TZ = 16;       // tile rows / slices (tile is one 64-voxel word wide)
+constexpr int HY = TY + 2, HZ = TZ + 2;
+constexpr int BATCH = 8;              // rounds launched between host checks
+
+struct Tiles {
+    int64_t dz, dy, dx, wx;
+    int64_t nty, ntz, ntiles;
+    uint32_t strct;
+};
+
+static int make_tiles(const ivx_flood_plan *p, Tiles *t) {
+    IVX_REQUIRE(p && p->dz >= 0 && p->dy >= 0 && p->dx >= 0, IVX_EINVAL, "flood: bad shape");
+    IVX_REQUIRE(p->wx == ivx::cdiv(p->dx, 64), IVX_EINVAL, "flood: plan.wx must be ceil(dx/64)");
+    t->dz = p->dz; t->dy = p->dy; t->dx = p->dx; t->wx = p->wx;
+    t->nty = ivx::cdiv(p->dy, TY); t->ntz = ivx::cdiv(p->dz, TZ);
+    t->ntiles = t->wx * t->nty * t->ntz;
+    t->strct = p->strct_bits & ~(1u << 13); // the centre never matters
+    IVX_REQUIRE(t->ntiles < 0x7fffffffll, IVX_EINVAL, "flood: too many tiles");
+    return IVX_OK;
+}
+
+// scratch: dirty[2][ntiles] u8 | counters[BATCH] u32 | seed staging
+constexpr size_t SEED_CHUNK = 4096;
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+struct FScratch {
+    size_t off_dirty0, off_dirty1, off_cnt, off_seeds, off_status, total;
+};
+static FScratch make_fscratch(const Tiles &t) {
+    FScratch s;
+    s.off_dirty0 = 0;
+    s.off_dirty1 = al256((size_t)t.ntiles);
+    s.off_cnt = al256(s.off_dirty1 + (size_t)t.ntiles);
+    s.off_seeds = al256(s.off_cnt + 64 * 4);
+    s.off_status = al256(s.off_seeds + SEED_CHUNK * 3 * 8);
+    s.total = al256(s.off_status + 64);
+    return s;
+}
+
+template <typename T> __device__ __forceinline__ double as_double(T v) { return (double)v; }
+
+// ---- candidates: one lane per output byte (8 voxels) ------------------------------------------------
+// BAR: 0 none, 1 uint8 barrier array (out != fill), 2 in-place (data value != fill)
+template <typename T, int BAR>
+__global__ __launch_bounds__(256) void k_flood_candidates(const T *__restrict__ data, const uint8_t *__restrict__ bar,
+                                                          Tiles t, double t0, double t1, double fill,
+                                                          uint8_t *__restrict__ cand) {
+    const int64_t bpr = t.wx * 8; // bytes per bit-row
+    const int64_t total = t.dz * t.dy * bpr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = (sizeof(T) == 2) && (t.dx % 8 == 0) && (((uintptr_t)data & 15) == 0) &&
+                     (BAR != 1 || ((uintptr_t)bar & 7) == 0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / bpr, q = i - row * bpr;
+        const int64_t x0 = q * 8;
+        unsigned m = 0;
+        if (x0 < t.dx) {
+            const int64_t base = row * t.dx + x0;
+            if (vec) { // x0+8 <= dx because dx % 8 == 0
+                const short8_t v = *reinterpret_cast<const short8_t *>(data + base);
+                unsigned long long b8 = 0;
+                if (BAR == 1) b8 = *reinterpret_cast<const unsigned long long *>(bar + base);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const double d = (double)(T)v[e];
+                    bool ok = d >= t0 && d <= t1;
+                    if (BAR == 1) ok = ok && (((b8 >> (8 * e)) & 0xff) != (unsigned long long)(uint8_t)fill);
+                    if (BAR == 2) ok = ok && d != fill;
+                    m |= ok ? (1u << e) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    if (x0 + e < t.dx) {
+                        const double d = as_double(data[base + e]);
+                        bool ok = d >= t0 && d <= t1;
+                        if (BAR == 1) ok = ok && bar[base + e] != (uint8_t)fill;
+                        if (BAR == 2) ok = ok && d != fill;
+                        m |= ok ? (1u << e) : 0u;
+                    }
+                }
+            }
+        }
+        cand[i] = (uint8_t)m;
+    }
+}
+
+// ---- seeds ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_flood_seed(const T *__restrict__ data, Tiles t, double t0, double t1, const int64_t *__restrict__ seeds,
+                             int64_t nseeds, unsigned long long *__restrict__ cand,
+                             unsigned long long *__restrict__ reached, uint8_t *__restrict__ dirty) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nseeds) return;
+    const int64_t x = seeds[3 * n], y = seeds[3 * n + 1], z = seeds[3 * n + 2];
+    const double v = as_double(data[(z * t.dy + y) * t.dx + x]);
+    if (!(v >= t0 && v <= t1)) return; // floodfill.rs:123: only in-range seeds start a flood
+    const int64_t w = (z * t.dy + y) * t.wx + (x >> 6);
+    const unsigned long long bit = 1ull << (x & 63);
+    atomicOr(&cand[w], bit); // a seed expands even when its barrier byte already equals `fill`
+    atomicOr(&reached[w], bit);
+    dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + (x >> 6)] = 1;
+}
+
+// ---- one round over the dirty tiles ---------------------------------------------------------------
+__device__ __forceinline__ unsigned long long fill_up(unsigned long long seed, unsigned long long m) {
+    return (((m + seed) ^ m) & m) | seed;
+}
+__device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed, unsigned long long m) {
+    unsigned long long f = fill_up(seed, m);
+    return __brevll(fill_up(__brevll(f), __brevll(m)));
+}
+
+__global__ __launch_bounds__(256) void k_flood_round(Tiles t, const unsigned long long *__restrict__ cand,
+                                                     unsigned long long *reached, uint8_t *dirty_cur,
+                                                     uint8_t *dirty_next, unsigned int *counter_next) {
+    __shared__ unsigned long long sR[HZ * HY * 3];
+    __shared__ unsigned int s_dirs;
+    __shared__ int s_go;
+    const int64_t tile = blockIdx.x;
+    if (threadIdx.x == 0) { // one lane consumes the flag, so no wave can see it already cleared
+        s_go = dirty_cur[tile];
+        if (s_go) dirty_cur[tile] = 0;
+        s_dirs = 0;
+    }
+    __syncthreads();
+    if (!s_go) return; // uniform per workgroup
+    const int64_t txi = tile % t.wx, r1 = tile / t.wx;
+    const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+    const int64_t z0 = tzi * TZ, y0 = tyi * TY;
+
+    // stage reached bits (+halo) in LDS; outside the volume = 0
+    for (int idx = threadIdx.x; idx < HZ * HY * 3; idx += 256) {
+        const int xx = idx % 3, rr = idx / 3;
+        const int yy = rr % HY, zz = rr / HY;
+        const int64_t z = z0 + zz - 1, y = y0 + yy - 1, w = txi + xx - 1;
+        unsigned long long v = 0;
+        if (z >= 0 && z < t.dz && y >= 0 && y < t.dy && w >= 0 && w < t.wx) {
+            // halo words may be written concurrently by the neighbouring tile's workgroup: read them past
+            // this CU's L1 (sc1) -- stale is still correct (the writer re-marks us), fresh saves a round
+            v = __hip_atomic_load(&reached[(z * t.dy + y) * t.wx + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sR[idx] = v;
+    }
+    const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> 4;
+    const int64_t z = z0 + tz, y = y0 + ty;
+    const bool inside = z < t.dz && y < t.dy;
+    const unsigned long long c = inside ? cand[(z * t.dy + y) * t.wx + txi] : 0ull;
+    __syncthreads();
+    const int me = ((tz + 1) * HY + (ty + 1)) * 3 + 1;
+    const unsigned long long r_in = sR[me];
+    unsigned long long r = r_in;
+    const uint32_t st = t.strct;
+    const bool xrun = (st >> 12 & 1) && (st >> 14 & 1); // both x neighbours of the centre row present
+    bool exhausted = true;
+    for (int it = 0; it < 1024; it++) {
+        unsigned long long nb = 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++) {
+                const uint32_t m3 = (st >> (kk * 9 + jj * 3)) & 7u;
+                if (!m3) continue; // uniform
+                // voxel p reached => p + (kk-1, jj-1, ii-1) reached; gather: source row = (z-(kk-1), y-(jj-1))
+                const int src = ((tz + 1 - (kk - 1)) * HY + (ty + 1 - (jj - 1))) * 3;
+                const unsigned long long n = sR[src + 1];
+                if (m3 & 2u) nb |= n;
+                if (m3 & 4u) nb |= (n << 1) | (sR[src] >> 63);     // ii = 2: source bit x-1
+                if (m3 & 1u) nb |= (n >> 1) | (sR[src + 2] << 63); // ii = 0: source bit x+1
+            }
+        unsigned long long nr = r | (nb & c);
+        if (xrun) nr = fill_runs(nr, c);
+        const bool changed = nr != r;
+        r = nr;
+        // everybody has read sR before anybody writes
+        if (!__syncthreads_or(changed)) {
+            exhausted = false;
+            break;
+        }
+        if (changed) sR[me] = r;
+        __syncthreads();
+    }
+    const unsigned long long chg = r ^ r_in;
+    if (chg) {
+        reached[(z * t.dy + y) * t.wx + txi] = r;
+        // which neighbour tiles can see this change?  direction d = (dz+1)*9 + (dy+1)*3 + (dx+1)
+        unsigned dirs = 0;
+        const bool zlo = tz == 0, zhi = tz == TZ - 1, ylo = ty == 0, yhi = ty == TY - 1;
+        const bool xlo = chg & 1ull, xhi = chg >> 63;
+#pragma unroll
+        for (int dzz = -1; dzz <= 1; dzz++)
+#pragma unroll
+            for (int dyy = -1; dyy <= 1; dyy++)
+#pragma unroll
+                for (int dxx = -1; dxx <= 1; dxx++) {
+                    if (!dzz && !dyy && !dxx) continue;
+                    const bool vis = (dzz == 0 || (dzz < 0 ? zlo : zhi)) && (dyy == 0 || (dyy < 0 ? ylo : yhi)) &&
+                                     (dxx == 0 || (dxx < 0 ? xlo : xhi));
+                    dirs |= vis ? (1u << ((dzz + 1) * 9 + (dyy + 1) * 3 + (dxx + 1))) : 0u;
+                }
+        if (exhausted) dirs |= 1u << 13; // iteration cap hit before the local fix-point: revisit this tile
+        if (dirs) atomicOr(&s_dirs, dirs);
+    }
+    __syncthreads();
+    if (threadIdx.x < 27 && (s_dirs >> threadIdx.x & 1u)) {
+        const int d = threadIdx.x;
+        const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
+        if (nz >= 0 && nz < t.ntz && ny >= 0 && ny < t.nty && nx >= 0 && nx < t.wx) {
+            const int64_t nt = (nz * t.nty + ny) * t.wx + nx;
+            // byte flags: use a 32-bit atomic on the containing word
+            unsigned int *wp = (unsigned int *)(dirty_next + (nt & ~(int64_t)3));
+            const unsigned int bit = 1u << (8 * (nt & 3));
+            const unsigned int old = atomicOr(wp, bit);
+            if (!(old & (0xffu << (8 * (nt & 3))))) atomicAdd(counter_next, 1u);
+        }
+    }
+}
+
+__global__ void k_flood_mark(Tiles t, int64_t tz0, int64_t tz1, uint8_t *dirty) {
+    const int64_t per = t.nty * t.wx;
+    const int64_t n = (tz1 - tz0) * per;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dirty[tz0 * per + i] = 1;
+}
+
+// ---- apply: out[v] = fill where reached ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_flood_apply(Tiles t, const uint8_t *__restrict__ reached, T *__restrict__ out,
+                                                     T fill) {
+    const int64_t bpr = t.wx * 8;
+    const int64_t total = t.dz * t.dy * bpr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const unsigned m = reached[i];
+        if (!m) continue;
+        const int64_t row = i / bpr, q = i - row * bpr;
+        T *o = out + row * t.dx + q * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (m >> e & 1u) o[e] = fill; // reached bits never exist beyond dx
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flood_count(const unsigned long long *__restrict__ bits, int64_t nwords,
+                                                     unsigned long long *__restrict__ total) {
+    unsigned long long s = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) s += __popcll(bits[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+}
+
+static inline int grid_for(int64_t n) {
+    const int64_t b = ivx::cdiv(n, 256);
+    return (int)(b < 1 ? 1 : (b < 32768 ? b : 32768));
+}
+
+template <typename T>
+static int run_candidates(const Tiles &t, const void *data, double t0, double t1, const uint8_t *bar, int bar_mode,
+                          double fill, uint8_t *cand, hipStream_t st) {
+    const int64_t total = t.dz * t.dy * t.wx * 8;
+    if (!total) return IVX_OK;
+    const int g = grid_for(total);
+    if (bar_mode == 0)
+        hipLaunchKernelGGL((k_flood_candidates<T, 0>), dim3(g), dim3(256), 0, st, (const T *)data, bar, t, t0, t1, fill, cand);
+    else if (bar_mode == 1)
+        hipLaunchKernelGGL((k_flood_candidates<T, 1>), dim3(g), dim3(256), 0, st, (const T *)data, bar, t, t0, t1, fill, cand);
+    else
+        hipLaunchKernelGGL((k_flood_candidates<T, 2>), dim3(g), dim3(256), 0, st, (const T *)data, bar, t, t0, t1, fill, cand);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+} // namespace
+
+extern "C" int ivx_flood_bits_bytes(const ivx_flood_plan *p, size_t *nbytes) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    *nbytes = al256((size_t)(t.dz * t.dy * t.wx) * 8);
+    return IVX_OK;
+}
+
+extern "C" int ivx_flood_scratch_bytes(const ivx_flood_plan *p, size_t *nbytes) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    *nbytes = make_fscratch(t).total;
+    return IVX_OK;
+}
+
+// strct (sshape dims <= 3 each, centre offset dim/2: floodfill.rs:108-110) -> 27-bit mask in 3x3x3 offset space
+extern "C" int ivx_flood_strct_bits(const uint8_t *strct, const int64_t sshape[3], uint32_t *bits) {
+    IVX_REQUIRE(strct && sshape, IVX_EINVAL, "flood: strct is NULL");
+    uint32_t b = 0;
+    for (int a = 0; a < 3; a++)
+        IVX_REQUIRE(sshape[a] >= 1 && sshape[a] <= 3, IVX_EINVAL, "flood: structuring element dims must be 1..3 (got %lld)",
+                    (long long)sshape[a]);
+    const int64_t oz = sshape[0] / 2, oy = sshape[1] / 2, ox = sshape[2] / 2;
+    for (int64_t kk = 0; kk < sshape[0]; kk++)
+        for (int64_t jj = 0; jj < sshape[1]; jj++)
+            for (int64_t ii = 0; ii < sshape[2]; ii++)
+                if (strct[(kk * sshape[1] + jj) * sshape[2] + ii]) {
+                    const int64_t dz = kk - oz + 1, dy = jj - oy + 1, dx = ii - ox + 1;
+                    b |= 1u << (dz * 9 + dy * 3 + dx);
+                }
+    *bits = b;
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_candidates(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                                        const uint8_t *barrier, int barrier_mode, double fill, uint64_t *cand,
+                                        void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    IVX_REQUIRE(barrier_mode >= 0 && barrier_mode <= 2, IVX_EINVAL, "flood: barrier_mode");
+    IVX_REQUIRE(barrier_mode != 1 || barrier, IVX_EINVAL, "flood: barrier array missing");
+    hipStream_t st = ivx::S(stream);
+    switch (dtype) {
+    case IVX_I16: return run_candidates<int16_t>(t, data, t0, t1, barrier, barrier_mode, fill, (uint8_t *)cand, st);
+    case IVX_U8: return run_candidates<uint8_t>(t, data, t0, t1, barrier, barrier_mode, fill, (uint8_t *)cand, st);
+    case IVX_U16: return run_candidates<uint16_t>(t, data, t0, t1, barrier, barrier_mode, fill, (uint8_t *)cand, st);
+    case IVX_F64: return run_candidates<double>(t, data, t0, t1, barrier, barrier_mode, fill, (uint8_t *)cand, st);
+    }
+    ivx::set_error("flood: unsupported dtype %d", dtype);
+    return IVX_EINVAL;
+}
+
+extern "C" int ivx_dev_flood_seed(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                                  const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached,
+                                  void *scratch_, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    for (int64_t n = 0; n < nseeds; n++) {
+        const int64_t x = seeds_xyz[3 * n], y = seeds_xyz[3 * n + 1], z = seeds_xyz[3 * n + 2];
+        IVX_REQUIRE(x >= 0 && y >= 0 && z >= 0 && x < t.dx && y < t.dy && z < t.dz, IVX_ERANGE,
+                    "flood: seed (%lld,%lld,%lld) outside volume (%lld,%lld,%lld) [x,y,z]", (long long)x, (long long)y,
+                    (long long)z, (long long)t.dx, (long long)t.dy, (long long)t.dz);
+    }
+    const FScratch s = make_fscratch(t);
+    char *scr = (char *)scratch_;
+    hipStream_t st = ivx::S(stream);
+    int64_t *d_seeds = (int64_t *)(scr + s.off_seeds);
+    for (int64_t b = 0; b < nseeds; b += (int64_t)SEED_CHUNK) {
+        const int64_t m = nseeds - b < (int64_t)SEED_CHUNK ? nseeds - b : (int64_t)SEED_CHUNK;
+        IVX_HIP(hipMemcpyAsync(d_seeds, seeds_xyz + 3 * b, (size_t)m * 24, hipMemcpyHostToDevice, st));
+        const int g = (int)ivx::cdiv(m, 256);
+        unsigned long long *c = (unsigned long long *)cand, *r = (unsigned long long *)reached;
+        uint8_t *dirty = (uint8_t *)(scr + s.off_dirty0);
+        switch (dtype) {
+        case IVX_I16: hipLaunchKernelGGL(k_flood_seed<int16_t>, dim3(g), dim3(256), 0, st, (const int16_t *)data, t, t0, t1, d_seeds, m, c, r, dirty); break;
+        case IVX_U8: hipLaunchKernelGGL(k_flood_seed<uint8_t>, dim3(g), dim3(256), 0, st, (const uint8_t *)data, t, t0, t1, d_seeds, m, c, r, dirty); break;
+        case IVX_U16: hipLaunchKernelGGL(k_flood_seed<uint16_t>, dim3(g), dim3(256), 0, st, (const uint16_t *)data, t, t0, t1, d_seeds, m, c, r, dirty); break;
+        case IVX_F64: hipLaunchKernelGGL(k_flood_seed<double>, dim3(g), dim3(256), 0, st, (const double *)data, t, t0, t1, d_seeds, m, c, r, dirty); break;
+        default: ivx::set_error("flood: unsupported dtype %d", dtype); return IVX_EINVAL;
+        }
+        IVX_LAUNCH_CHECK();
+        IVX_HIP(hipStreamSynchronize(st)); // d_seeds is reused by the next chunk; seeds_xyz is pageable host memory
+    }
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_clear(const ivx_flood_plan *p, uint64_t *reached, void *scratch, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    const FScratch s = make_fscratch(t);
+    IVX_HIP(hipMemsetAsync(reached, 0, (size_t)(t.dz * t.dy * t.wx) * 8, ivx::S(stream)));
+    IVX_HIP(hipMemsetAsync(scratch, 0, s.off_seeds, ivx::S(stream)));
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch_,
+                                 int *rounds, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    if (rounds) *rounds = 0;
+    if (t.ntiles == 0) return IVX_OK;
+    const FScratch s = make_fscratch(t);
+    char *scr = (char *)scratch_;
+    hipStream_t st = ivx::S(stream);
+    uint8_t *dirty[2] = {(uint8_t *)(scr + s.off_dirty0), (uint8_t *)(scr + s.off_dirty1)};
+    unsigned int *cnt = (unsigned int *)(scr + s.off_cnt);
+    int total_rounds = 0;
+    for (;;) {
+        IVX_HIP(hipMemsetAsync(cnt, 0, BATCH * 4, st));
+        for (int b = 0; b < BATCH; b++) {
+            // BATCH is even, so every batch starts with dirty[0] as the current list
+            hipLaunchKernelGGL(k_flood_round, dim3((unsigned)t.ntiles), dim3(256), 0, st, t,
+                               (const unsigned long long *)cand, (unsigned long long *)reached, dirty[b & 1],
+                               dirty[(b + 1) & 1], cnt + b);
+            IVX_LAUNCH_CHECK();
+        }
+        unsigned int h[BATCH];
+        IVX_HIP(hipMemcpyAsync(h, cnt, BATCH * 4, hipMemcpyDeviceToHost, st));
+        IVX_HIP(hipStreamSynchronize(st));
+        int used = BATCH;
+        for (int b = 0; b < BATCH; b++)
+            if (h[b] == 0) { used = b + 1; break; }
+        total_rounds += used;
+        if (h[BATCH - 1] == 0) break;
+        IVX_REQUIRE(total_rounds < (1 << 24), IVX_EHIP, "flood: did not converge");
+    }
+    if (rounds) *rounds = total_rounds;
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_mark_slab(const ivx_flood_plan *p, void *scratch_, int64_t z0, int64_t z1, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    if (z0 < 0) z0 = 0;
+    if (z1 > t.dz) z1 = t.dz;
+    if (z1 <= z0 || t.ntiles == 0) return IVX_OK;
+    const FScratch s = make_fscratch(t);
+    const int64_t tz0 = z0 / TZ, tz1 = ivx::cdiv(z1, TZ);
+    const int64_t n = (tz1 - tz0) * t.nty * t.wx;
+    hipLaunchKernelGGL(k_flood_mark, dim3((unsigned)ivx::cdiv(n, 256)), dim3(256), 0, ivx::S(stream), t, tz0, tz1,
+                       (uint8_t *)((char *)scratch_ + s.off_dirty0));
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reached, int dtype, void *target,
+                                   double fill, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    const int64_t total = t.dz * t.dy * t.wx * 8;
+    if (!total) return IVX_OK;
+    const int g = grid_for(total);
+    hipStream_t st = ivx::S(stream);
+    const uint8_t *r = (const uint8_t *)reached;
+    switch (dtype) {
+    case IVX_U8: hipLaunchKernelGGL(k_flood_apply<uint8_t>, dim3(g), dim3(256), 0, st, t, r, (uint8_t *)target, (uint8_t)fill); break;
+    case IVX_I16: hipLaunchKernelGGL(k_flood_apply<int16_t>, dim3(g), dim3(256), 0, st, t, r, (int16_t *)target, (int16_t)fill); break;
+    case IVX_U16: hipLaunchKernelGGL(k_flood_apply<uint16_t>, dim3(g), dim3(256), 0, st, t, r, (uint16_t *)target, (uint16_t)fill); break;
+    case IVX_F64: hipLaunchKernelGGL(k_flood_apply<double>, dim3(g), dim3(256), 0, st, t, r, (double *)target, fill); break;
+    default: ivx::set_error("flood: unsupported dtype %d", dtype); return IVX_EINVAL;
+    }
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_count(const ivx_flood_plan *p, const uint64_t *reached, int64_t *count, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    *count = 0;
+    const int64_t nw = t.dz * t.dy * t.wx;
+    if (!nw) return IVX_OK;
+    void *d_tot;
+    if ((rc = ivx::ws_get(ivx::WS_SMALL, 64, &d_tot))) return rc;
+    hipStream_t st = ivx::S(stream);
+    IVX_HIP(hipMemsetAsync(d_tot, 0, 8, st));
+    hipLaunchKernelGGL(k_flood_count, dim3(grid_for(nw)), dim3(256), 0, st, (const unsigned long long *)reached, nw,
+                       (unsigned long long *)d_tot);
+    IVX_LAUNCH_CHECK();
+    unsigned long long h = 0;
+    IVX_HIP(hipMemcpyAsync(&h, d_tot, 8, hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipStreamSynchronize(st));
+    *count = (int64_t)h;
+    return IVX_OK;
+}
+
+// ---- host forms -----------------------------------------------------------------------------------
+static int flood_host(int dtype, void *data, const int64_t shape[3], const int64_t strides[3], const int64_t *seeds,
+                      int64_t nseeds, double t0, double t1, double fill, const uint8_t *strct, const int64_t sshape[3],
+                      uint8_t *out, const int64_t ostrides[3], int inplace) {
+    using namespace ivx;
+    const size_t isz = dtype_size(dtype);
+    IVX_REQUIRE(isz, IVX_EINVAL, "floodfill: unsupported dtype %d", dtype);
+    ivx_flood_plan plan;
+    plan.dz = shape[0]; plan.dy = shape[1]; plan.dx = shape[2];
+    plan.wx = cdiv(shape[2], 64);
+    int rc;
+    if ((rc = ivx_flood_strct_bits(strct, sshape, &plan.strct_bits))) return rc;
+    // seed bounds are checked before anything is touched (the reference panics on an out-of-bounds seed)
+    for (int64_t n = 0; n < nseeds; n++) {
+        const int64_t x = seeds[3 * n], y = seeds[3 * n + 1], z = seeds[3 * n + 2];
+        IVX_REQUIRE(x >= 0 && y >= 0 && z >= 0 && x < shape[2] && y < shape[1] && z < shape[0], IVX_ERANGE,
+                    "floodfill: seed (%lld,%lld,%lld) outside volume", (long long)x, (long long)y, (long long)z);
+    }
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+    if (n == 0 || nseeds == 0) return IVX_OK;
+    size_t bb, sb;
+    if ((rc = ivx_flood_bits_bytes(&plan, &bb))) return rc;
+    if ((rc = ivx_flood_scratch_bytes(&plan, &sb))) return rc;
+    void *d_data, *d_out = nullptr, *d_cand, *d_reach, *d_scr;
+    if ((rc = ws_get(WS_IN, n * isz, &d_data))) return rc;
+    if ((rc = ws_get(WS_AUX0, bb, &d_cand))) return rc;
+    if ((rc = ws_get(WS_AUX1, bb, &d_reach))) return rc;
+    if ((rc = ws_get(WS_AUX2, sb, &d_scr))) return rc;
+    if ((rc = upload_strided(d_data, data, shape, strides, isz, WS_IN))) return rc;
+    if (!inplace) {
+        if ((rc = ws_get(WS_OUT, n, &d_out))) return rc;
+        if ((rc = upload_strided(d_out, out, shape, ostrides, 1, WS_OUT))) return rc;
+    }
+    if ((rc = ivx_dev_flood_clear(&plan, (uint64_t *)d_reach, d_scr, nullptr))) return rc;
+    if ((rc = ivx_dev_flood_candidates(&plan, dtype, d_data, t0, t1, (const uint8_t *)d_out, inplace ? 2 : 1, fill,
+                                       (uint64_t *)d_cand, nullptr)))
+        return rc;
+    if ((rc = ivx_dev_flood_seed(&plan, dtype, d_data, t0, t1, seeds, nseeds, (uint64_t *)d_cand, (uint64_t *)d_reach,
+                                 d_scr, nullptr)))
+        return rc;
+    if ((rc = ivx_dev_flood_run(&plan, (const uint64_t *)d_cand, (uint64_t *)d_reach, d_scr, nullptr, nullptr))) return rc;
+    if (inplace) {
+        if ((rc = ivx_dev_flood_apply(&plan, (const uint64_t *)d_reach, dtype, d_data, fill, nullptr))) return rc;
+        IVX_HIP(hipDeviceSynchronize());
+        return download_strided(data, shape, strides, d_data, isz, WS_IN);
+    }
+    if ((rc = ivx_dev_flood_apply(&plan, (const uint64_t *)d_reach, IVX_U8, d_out, fill, nullptr))) return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    return download_strided(out, shape, ostrides, d_out, 1, WS_OUT);
+}
+
+extern "C" int ivx_floodfill_threshold(int dtype, const void *data, const int64_t shape[3], const int64_t strides[3],
+                                       const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1, int fill,
+                                       const uint8_t *strct, const int64_t sshape[3], uint8_t *out,
+                                       const int64_t out_strides[3]) {
+    return flood_host(dtype, (void *)data, shape, strides, seeds_xyz, nseeds, t0, t1, (double)(uint8_t)fill, strct,
+                      sshape, out, out_strides, 0);
+}
+
+extern "C" int ivx_floodfill_threshold_inplace(int dtype, void *data, const int64_t shape[3], const int64_t strides[3],
+                                               const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1,
+                                               double fill, const uint8_t *strct, const int64_t sshape[3]) {
+    return flood_host(dtype, data, shape, strides, seeds_xyz, nseeds, t0, t1, fill, strct, sshape, nullptr, strides, 1);
+}

@@ -1,0 +1,66 @@
+"""Drop-in for the hot-path names of the reference's native module ``invesalius_rs``
+(invesalius_rs/__init__.py:11-111; PyO3 bindings invesalius_rs/src/lib.rs:22-66).
+
+Same function names, argument order and in-place effects on caller-owned numpy arrays (strided views such as
+``mask.matrix[1:, 1:, 1:]`` are accepted); the arithmetic runs in HIP kernels behind the C ABI of libivx.so.
+Errors follow SURVEY.md 8(b): dtype mismatch -> TypeError, out-of-bounds seed -> IndexError (the reference panics
+with pyo3_runtime.PanicException), NumCast failure -> ValueError.
+
+Usage in the reference tree is unchanged:   ``from invesalius3_amd import invesalius_rs as floodfill``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _seeds(seeds) -> np.ndarray:
+    tuple_seeds = [tuple(s) for s in seeds]  # invesalius_rs/__init__.py:29
+    s = np.array(tuple_seeds, dtype=np.int64).reshape(-1, 3)
+    return np.ascontiguousarray(s)
+
+
+def _strct(strct) -> np.ndarray:
+    s = np.ascontiguousarray(strct, dtype=np.uint8)  # invesalius_rs/__init__.py:31
+    if s.ndim != 3:
+        raise TypeError("strct must be 3-D")
+    return s
+
+
+def floodfill_threshold(data, seeds, t0, t1, fill, strct, out):
+    """generic_floodfill_threshold (invesalius_rs/src/floodfill.rs:96-166) through the wrapper semantics of
+    invesalius_rs/__init__.py:21-40: seeds are (x, y, z); for integer images t0/t1/fill are truncated with
+    int(); `out` (uint8, same shape) receives `fill` on the connected in-range region; voxels of `out` that
+    already hold `fill` are barriers."""
+    if data.ndim != 3 or out.ndim != 3 or tuple(data.shape) != tuple(out.shape):
+        raise TypeError("data and out must be 3-D arrays of the same shape")
+    if out.dtype != np.uint8:
+        raise TypeError("out must be uint8")
+    code = L.dtype_code(data, (L.U8, L.I16, L.F64))
+    strct_u8 = _strct(strct)
+    if data.dtype.kind in "iu":
+        t0, t1, fill = int(t0), int(t1), int(fill)
+    else:
+        t0, t1, fill = float(t0), float(t1), float(fill)
+    s = _seeds(seeds)
+    L.check(L.lib().ivx_floodfill_threshold(
+        code, L.ptr(data), L.i64(data.shape), L.i64(data.strides), L.ptr(s), ctypes.c_int64(len(s)),
+        ctypes.c_double(t0), ctypes.c_double(t1), ctypes.c_int(int(fill) & 0xFF), L.ptr(strct_u8),
+        L.i64(strct_u8.shape), L.ptr(out), L.i64(out.strides)), "floodfill_threshold")
+
+
+def floodfill_threshold_inplace(data, seeds, t0, t1, fill, strct):
+    """generic_floodfill_threshold_inplace (invesalius_rs/src/floodfill.rs:168-237; wrapper
+    invesalius_rs/__init__.py:43-54): predicate and fill on the same array (mask relabelling)."""
+    if data.ndim != 3:
+        raise TypeError("data must be 3-D")
+    code = L.dtype_code(data, (L.U8, L.I16, L.F64))
+    strct_u8 = _strct(strct)
+    s = _seeds(seeds)
+    L.check(L.lib().ivx_floodfill_threshold_inplace(
+        code, L.ptr(data), L.i64(data.shape), L.i64(data.strides), L.ptr(s), ctypes.c_int64(len(s)),
+        ctypes.c_double(t0), ctypes.c_double(t1), ctypes.c_double(fill), L.ptr(strct_u8), L.i64(strct_u8.shape)),
+        "floodfill_threshold_inplace")

@@ -1,0 +1,153 @@
+"""GPU parity: seeded region growing vs the C oracle (restatement of floodfill.rs), bit-exact."""
+import numpy as np
+import pytest
+from scipy.ndimage import generate_binary_structure
+
+from conftest import synth_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_golden_vectors(ivxlib):
+    """tests/test_segmentation_tools.py:17-102 run through the GPU path."""
+    from invesalius3_amd import invesalius_rs as floodfill
+    image = np.array([[[1, 1, 1, 5, 5], [1, 2, 2, 5, 5], [1, 2, 3, 5, 5], [1, 2, 2, 5, 5], [1, 1, 1, 5, 5]]],
+                     dtype=np.int16)
+    out_mask = np.zeros((1, 5, 5), dtype=np.uint8)
+    floodfill.floodfill_threshold(image, [[2, 2, 0]], 2, 3, 1, generate_binary_structure(3, 1), out_mask)
+    expected = np.array([[0, 0, 0, 0, 0], [0, 1, 1, 0, 0], [0, 1, 1, 0, 0], [0, 1, 1, 0, 0], [0, 0, 0, 0, 0]],
+                        dtype=np.uint8)
+    assert np.array_equal(out_mask[0], expected)
+    image = np.array([[[2, 2, 0], [0, 2, 0], [0, 0, 2]]], dtype=np.int16)
+    out8 = np.zeros((1, 3, 3), dtype=np.uint8)
+    floodfill.floodfill_threshold(image, [[0, 0, 0]], 2, 2, 1, generate_binary_structure(3, 2), out8)
+    assert np.array_equal(out8, np.array([[[1, 1, 0], [0, 1, 0], [0, 0, 1]]], dtype=np.uint8))
+    out4 = np.zeros((1, 3, 3), dtype=np.uint8)
+    floodfill.floodfill_threshold(image, [[0, 0, 0]], 2, 2, 1, generate_binary_structure(3, 1), out4)
+    assert np.array_equal(out4, np.array([[[1, 1, 0], [0, 1, 0], [0, 0, 0]]], dtype=np.uint8))
+
+
+@pytest.mark.parametrize("conn", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(24, 40, 70), (17, 33, 129), (40, 48, 64)])
+def test_random_volume_matches_oracle(ivxlib, oracle, conn, shape):
+    from invesalius3_amd import invesalius_rs as floodfill
+    img = synth_volume(shape, seed=41 + conn)
+    strct = generate_binary_structure(3, conn)
+    z, y, x = np.unravel_index(np.argmax(img), img.shape)
+    seeds = [(int(x), int(y), int(z)), (0, 0, 0), (shape[2] - 1, shape[1] - 1, shape[0] - 1)]
+    rng = np.random.default_rng(conn)
+    out_g = np.where(rng.random(shape) < 0.02, 1, 0).astype(np.uint8)  # pre-filled voxels act as barriers
+    out_g[rng.random(shape) < 0.02] = 7
+    out_r = out_g.copy()
+    t0, t1 = -800.5, 3071.9  # wrapper truncates with int() for integer data
+    floodfill.floodfill_threshold(img, seeds, t0, t1, 1, strct, out_g)
+    oracle.floodfill_threshold(img, seeds, t0, t1, 1, strct, out_r)
+    assert np.array_equal(out_g, out_r)
+    assert (out_g == 1).sum() > 1000
+
+
+def test_noise_maze_many_components(ivxlib, oracle):
+    """percolation-like noise: thin, tortuous components crossing many tiles"""
+    from invesalius3_amd import invesalius_rs as floodfill
+    rng = np.random.default_rng(5)
+    for conn, p in ((1, 0.36), (2, 0.16), (3, 0.11)):
+        img = (rng.random((40, 70, 150)) < p).astype(np.int16) * 100
+        strct = generate_binary_structure(3, conn)
+        idx = np.argwhere(img == 100)
+        seeds = [tuple(int(v) for v in idx[i][::-1]) for i in rng.integers(0, len(idx), 5)]
+        og = np.zeros(img.shape, np.uint8)
+        orf = og.copy()
+        floodfill.floodfill_threshold(img, seeds, 50, 150, 255, strct, og)
+        oracle.floodfill_threshold(img, seeds, 50, 150, 255, strct, orf)
+        assert np.array_equal(og, orf)
+
+
+def test_serpentine_worst_case(ivxlib, oracle):
+    """1-voxel-wide corridor snaking through the volume (SURVEY 8d worst case)"""
+    from invesalius3_amd import invesalius_rs as floodfill
+    dz, dy, dx = 6, 40, 130
+    img = np.zeros((dz, dy, dx), np.int16)
+    for z in range(0, dz, 2):
+        for y in range(0, dy, 2):
+            img[z, y, :] = 1
+            xs = dx - 1 if (y // 2) % 2 == 0 else 0
+            if y + 1 < dy:
+                img[z, y + 1, xs] = 1
+        if z + 1 < dz:
+            last_y = (dy - 1) // 2 * 2
+            xs = 0 if (last_y // 2) % 2 == 0 else dx - 1
+            img[z + 1, :, :] = 0
+            img[z + 1, last_y, xs] = 1
+    og = np.zeros(img.shape, np.uint8)
+    orf = og.copy()
+    s6 = generate_binary_structure(3, 1)
+    floodfill.floodfill_threshold(img, [(0, 0, 0)], 1, 1, 1, s6, og)
+    oracle.floodfill_threshold(img, [(0, 0, 0)], 1, 1, 1, s6, orf)
+    assert np.array_equal(og, orf)
+    assert og.sum() > dx * dy // 2
+
+
+def test_inplace_mask_relabel_on_strided_view(ivxlib, oracle):
+    """FloodFillMaskInteractorStyle (styles.py:2517,2534): t in [0,2] -> 254 on mask.matrix[1:,1:,1:];
+    RemoveMaskParts (styles.py:2572-2588): t in [253,255] -> 1"""
+    from invesalius3_amd import invesalius_rs as floodfill
+    img = synth_volume((20, 36, 66), seed=43)
+    mg = np.zeros((21, 37, 67), np.uint8)
+    mg[1:, 1:, 1:] = np.where(img > -850, 255, 0)
+    mr = mg.copy()
+    s = generate_binary_structure(3, 1)
+    hole = np.argwhere(mg[1:, 1:, 1:] == 0)[0][::-1]
+    floodfill.floodfill_threshold_inplace(mg[1:, 1:, 1:], [tuple(int(v) for v in hole)], 0, 2, 254, s)
+    oracle.floodfill_threshold_inplace(mr[1:, 1:, 1:], [tuple(int(v) for v in hole)], 0, 2, 254, s)
+    assert np.array_equal(mg, mr)
+    part = np.argwhere(mg[1:, 1:, 1:] == 255)[0][::-1]
+    s26 = generate_binary_structure(3, 3)
+    floodfill.floodfill_threshold_inplace(mg[1:, 1:, 1:], [tuple(int(v) for v in part)], 253, 255, 1, s26)
+    oracle.floodfill_threshold_inplace(mr[1:, 1:, 1:], [tuple(int(v) for v in part)], 253, 255, 1, s26)
+    assert np.array_equal(mg, mr)
+    assert (mg == 1).any() and (mg == 254).any()
+
+
+def test_dtypes_2d_strct_and_errors(ivxlib, oracle):
+    from invesalius3_amd import invesalius_rs as floodfill
+    rng = np.random.default_rng(8)
+    f = rng.normal(0, 1, (9, 20, 70))
+    u = (rng.random((9, 20, 70)) * 255).astype(np.uint8)
+    s2d = np.zeros((1, 3, 3), np.uint8)
+    s2d[0] = [[0, 1, 0], [1, 1, 1], [0, 1, 0]]  # 2-D structuring element (styles.py: 2-D tools)
+    for data, t0, t1 in ((f, -0.6, 2.5), (u, 60, 255)):
+        idx = np.argwhere((data >= t0) & (data <= t1))[3][::-1]
+        seed = [tuple(int(v) for v in idx)]
+        for strct in (s2d, generate_binary_structure(3, 3)):
+            og = np.zeros(data.shape, np.uint8)
+            orf = og.copy()
+            floodfill.floodfill_threshold(data, seed, t0, t1, 9, strct, og)
+            oracle.floodfill_threshold(data, seed, t0, t1, 9, strct, orf)
+            assert np.array_equal(og, orf)
+    out = np.zeros((9, 20, 70), np.uint8)
+    with pytest.raises(IndexError):
+        floodfill.floodfill_threshold(u, [(70, 0, 0)], 0, 255, 1, s2d, out)
+    with pytest.raises(TypeError):
+        floodfill.floodfill_threshold(u.astype(np.float32), [(0, 0, 0)], 0, 255, 1, s2d, out)
+    # seed out of range: nothing happens
+    floodfill.floodfill_threshold(u, [(0, 0, 0)], 256, 300, 1, s2d, out)
+    assert out.sum() == 0
+
+
+def test_full_size_512_properties(ivxlib):
+    """512^3: component of the seed equals scipy.ndimage.label's component (26-connectivity); idempotent."""
+    from scipy import ndimage
+    from invesalius3_amd import invesalius_rs as floodfill
+    n = 512
+    rng = np.random.default_rng(10)
+    small = rng.normal(0, 1, (64, 64, 64))
+    img = (ndimage.zoom(small, 8, order=1) * 1000).astype(np.int16)
+    strct = generate_binary_structure(3, 3)
+    z, y, x = np.unravel_index(np.argmax(img), img.shape)
+    out = np.zeros((n, n, n), np.uint8)
+    floodfill.floodfill_threshold(img, [(int(x), int(y), int(z))], 200, 32767, 1, strct, out)
+    lab, _ = ndimage.label(img >= 200, structure=strct)
+    assert np.array_equal(out == 1, lab == lab[z, y, x])
+    again = out.copy()
+    floodfill.floodfill_threshold(img, [(int(x), int(y), int(z))], 200, 32767, 1, strct, again)
+    assert np.array_equal(again, out)
