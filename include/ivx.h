@@ -175,6 +175,10 @@ int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *r
                       int *rounds, void *stream);
 /* mark every tile of the plan whose z-range touches [z0,z1) dirty (multi-GPU halo re-seeding) */
 int ivx_dev_flood_mark_slab(const ivx_flood_plan *p, void *scratch, int64_t z0, int64_t z1, void *stream);
+/* multi-GPU slab halo: reached[z] |= plane & cand[z] (plane = the Z-neighbour's boundary plane, dy*wx words);
+ * *changed (host) = number of words that gained bits; the tiles touching z are re-marked dirty */
+int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z,
+                           const uint64_t *plane, void *scratch, int *changed, void *stream);
 /* out[v] = fill where reached (uint8 out), or data[v] = fill (in-place form, dtype of data) */
 int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reached, int dtype, void *target,
                         double fill, void *stream);

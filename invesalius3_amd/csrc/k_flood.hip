@@ -496,6 +496,45 @@ extern "C" int ivx_dev_flood_count(const ivx_flood_plan *p, const uint64_t *reac
     return IVX_OK;
 }
 
+// ---- multi-GPU halo: OR a neighbour's reached plane into slice z; counts words that gained bits -------------
+__global__ __launch_bounds__(256) void k_flood_or_plane(unsigned long long *__restrict__ dst,
+                                                        const unsigned long long *__restrict__ src,
+                                                        const unsigned long long *__restrict__ cand, int64_t nwords,
+                                                        unsigned int *__restrict__ changed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    const unsigned long long add = src[i] & cand[i] & ~dst[i];
+    if (add) {
+        dst[i] |= add;
+        atomicAdd(changed, 1u);
+    }
+}
+
+extern "C" int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z,
+                                      const uint64_t *plane, void *scratch_, int *changed, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    IVX_REQUIRE(z >= 0 && z < t.dz, IVX_ERANGE, "flood: plane %lld outside slab", (long long)z);
+    const FScratch s = make_fscratch(t);
+    const int64_t nw = t.dy * t.wx;
+    *changed = 0;
+    if (!nw) return IVX_OK;
+    hipStream_t st = ivx::S(stream);
+    unsigned int *d_chg = (unsigned int *)((char *)scratch_ + s.off_status);
+    IVX_HIP(hipMemsetAsync(d_chg, 0, 4, st));
+    hipLaunchKernelGGL(k_flood_or_plane, dim3((unsigned)ivx::cdiv(nw, 256)), dim3(256), 0, st,
+                       (unsigned long long *)reached + z * nw, (const unsigned long long *)plane,
+                       (const unsigned long long *)cand + z * nw, nw, d_chg);
+    IVX_LAUNCH_CHECK();
+    unsigned int h = 0;
+    IVX_HIP(hipMemcpyAsync(&h, d_chg, 4, hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipStreamSynchronize(st));
+    *changed = (int)h;
+    if (h) return ivx_dev_flood_mark_slab(p, scratch_, z, z + 1, stream);
+    return IVX_OK;
+}
+
 // ---- host forms -----------------------------------------------------------------------------------
 static int flood_host(int dtype, void *data, const int64_t shape[3], const int64_t strides[3], const int64_t *seeds,
                       int64_t nseeds, double t0, double t1, double fill, const uint8_t *strct, const int64_t sshape[3],

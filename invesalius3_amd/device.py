@@ -1,0 +1,253 @@
+"""Resident-volume pipeline: upload the int16 volume once, then threshold -> region growing -> marching cubes ->
+projections all run on buffers that stay in HBM (at one GPU the PCIe staging of the host-level
+entry points dominates; the GUI data layer keeps `Slice.matrix` for the whole session, so does this class).
+
+Everything here is a thin ctypes veneer over the `ivx_dev_*` C ABI (include/ivx.h); kernels are launched on one
+HIP stream owned by the object, and `Timer` records HIP events on that same stream.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed block (freed on close / GC)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        L.check(L.lib().ivx_malloc(ctypes.byref(p), ctypes.c_size_t(max(self.nbytes, 16))), "ivx_malloc")
+        self.ptr = p
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        L.check(L.lib().ivx_memcpy_h2d(self.ptr, L.ptr(a), ctypes.c_size_t(a.nbytes)))
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        L.check(L.lib().ivx_memcpy_d2h(L.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
+        return out
+
+    def zero(self, stream=None, nbytes=None):
+        L.check(L.lib().ivx_memset(self.ptr, 0, ctypes.c_size_t(self.nbytes if nbytes is None else nbytes), stream))
+
+    def at(self, offset_bytes: int) -> ctypes.c_void_p:
+        return ctypes.c_void_p(self.ptr.value + int(offset_bytes))
+
+    def close(self):
+        if self.ptr is not None and self.ptr.value:
+            L.lib().ivx_free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Timer:
+    """HIP events on the pipeline's stream: `with t.span('name'):` accumulates milliseconds per name."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.spans = []  # (name, ev0, ev1)
+        self._pool = []
+
+    def _ev(self):
+        if self._pool:
+            return self._pool.pop()
+        e = ctypes.c_void_p()
+        L.check(L.lib().ivx_event_create(ctypes.byref(e)))
+        return e
+
+    class _Span:
+        def __init__(self, t, name):
+            self.t, self.name = t, name
+
+        def __enter__(self):
+            self.e0 = self.t._ev()
+            L.check(L.lib().ivx_event_record(self.e0, self.t.stream))
+
+        def __exit__(self, *a):
+            e1 = self.t._ev()
+            L.check(L.lib().ivx_event_record(e1, self.t.stream))
+            self.t.spans.append((self.name, self.e0, e1))
+
+    def span(self, name):
+        return Timer._Span(self, name)
+
+    def collect(self) -> dict:
+        """-> {name: [ms, ...]} and recycles the events."""
+        out = {}
+        for name, e0, e1 in self.spans:
+            ms = ctypes.c_float(0)
+            L.check(L.lib().ivx_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+            out.setdefault(name, []).append(ms.value)
+            self._pool += [e0, e1]
+        self.spans = []
+        return out
+
+
+class DeviceVolume:
+    """An int16 (dz, dy, dx) volume resident in HBM with its dense uint8 mask and the work buffers of the path."""
+
+    def __init__(self, image: np.ndarray | None = None, shape=None, spacing=(1.0, 1.0, 1.0), device: int | None = None):
+        L.require_device()
+        if device is not None:
+            L.set_device(device)
+        if image is not None:
+            if image.dtype != np.int16 or image.ndim != 3:
+                raise TypeError("image must be a 3-D int16 array")
+            shape = image.shape
+        self.shape = tuple(int(s) for s in shape)
+        self.dz, self.dy, self.dx = self.shape
+        self.n = self.dz * self.dy * self.dx
+        self.spacing = tuple(float(s) for s in spacing)
+        s = ctypes.c_void_p()
+        L.check(L.lib().ivx_stream_create(ctypes.byref(s)))
+        self.stream = s
+        self.timer = Timer(self.stream)
+        self.image = DeviceBuffer(self.n * 2)
+        self.mask = DeviceBuffer(self.n)       # dense interior of mask.matrix[1:,1:,1:]
+        self.out_mask = DeviceBuffer(self.n)   # region-growing `out` (styles.py:3190)
+        if image is not None:
+            self.image.upload(image)
+        self.mask.zero(self.stream)
+        self.out_mask.zero(self.stream)
+        # region growing bit planes + tile work-list
+        self.plan = L.FloodPlan(self.dz, self.dy, self.dx, (self.dx + 63) // 64, 0)
+        nb, ns = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        L.check(L.lib().ivx_flood_bits_bytes(ctypes.byref(self.plan), ctypes.byref(nb)))
+        L.check(L.lib().ivx_flood_scratch_bytes(ctypes.byref(self.plan), ctypes.byref(ns)))
+        self.cand = DeviceBuffer(nb.value)
+        self.reached = DeviceBuffer(nb.value)
+        self.flood_scratch = DeviceBuffer(ns.value)
+        self._mc_scratch = None
+        self._tris = None
+        self.sync()
+
+    # -- plumbing -------------------------------------------------------------------------------------
+    def sync(self):
+        L.check(L.lib().ivx_stream_synchronize(self.stream))
+
+    def close(self):
+        for b in (self.image, self.mask, self.out_mask, self.cand, self.reached, self.flood_scratch, self._mc_scratch,
+                  self._tris):
+            if b is not None:
+                b.close()
+        if self.stream is not None:
+            L.lib().ivx_stream_destroy(self.stream)
+            self.stream = None
+
+    def download_mask(self) -> np.ndarray:
+        self.sync()
+        return self.mask.download(self.shape, np.uint8)
+
+    def download_out_mask(self) -> np.ndarray:
+        self.sync()
+        return self.out_mask.download(self.shape, np.uint8)
+
+    # -- threshold (slice_.py:1240-1247 / 1722-1769) -------------------------------------------------------
+    def threshold(self, lo: int, hi: int, preserve: bool = False):
+        L.check(L.lib().ivx_dev_threshold_i16(self.image.ptr, c64(self.dz), c64(self.dy), c64(self.dx), int(lo), int(hi),
+                                              int(bool(preserve)), None, self.mask.ptr, self.stream), "threshold")
+
+    # -- region growing (floodfill.rs:96-166 on the image; styles.py:3151-3216) ----------------------------
+    def region_grow(self, seeds_xyz, t0, t1, strct, fill: int = 1, select_value: int | None = 254) -> int:
+        """floodfill_threshold(image, seeds, t0, t1, fill, strct, out_mask) followed (when select_value is not None)
+        by `mask[out_mask.astype(bool)] = select_value` (styles.py:3214).  Returns the number of global rounds."""
+        lib = L.lib()
+        s3 = np.ascontiguousarray(strct, dtype=np.uint8)
+        bits = ctypes.c_uint32(0)
+        L.check(lib.ivx_flood_strct_bits(L.ptr(s3), L.i64(s3.shape), ctypes.byref(bits)))
+        self.plan.strct_bits = bits.value
+        seeds = np.ascontiguousarray(np.array([tuple(s) for s in seeds_xyz], dtype=np.int64).reshape(-1, 3))
+        p = ctypes.byref(self.plan)
+        st = self.stream
+        t0, t1 = float(int(t0)), float(int(t1))  # wrapper int() truncation for integer images
+        L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
+        L.check(lib.ivx_dev_flood_candidates(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1),
+                                             self.out_mask.ptr, 1, ctypes.c_double(fill), self.cand.ptr, st))
+        L.check(lib.ivx_dev_flood_seed(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
+                                       c64(len(seeds)), self.cand.ptr, self.reached.ptr, self.flood_scratch.ptr, st),
+                "region_grow")
+        rounds = ctypes.c_int(0)
+        L.check(lib.ivx_dev_flood_run(p, self.cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
+                                      st), "region_grow")
+        L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
+        if select_value is not None:
+            L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.mask.ptr, ctypes.c_double(select_value), st))
+        return rounds.value
+
+    def reached_count(self) -> int:
+        n = ctypes.c_int64(0)
+        L.check(L.lib().ivx_dev_flood_count(ctypes.byref(self.plan), self.reached.ptr, ctypes.byref(n), self.stream))
+        return n.value
+
+    # -- marching cubes over the whole resident volume (surface_process.py:100-186) ------------------------
+    def _mc_params(self, from_binary, min_value, max_value, fill_border_holes=True, z0=0, z1=None, roi_start=None,
+                   pad_bottom=None, pad_top=None) -> L.McParams:
+        z1 = self.dz if z1 is None else z1
+        p = L.McParams()
+        pb = (z0 == 0) if pad_bottom is None else pad_bottom
+        pt = (z1 >= self.dz) if pad_top is None else pad_top
+        if fill_border_holes:
+            p.pad_xy, p.pad_bottom, p.pad_top, p.vtk_pz = 1, int(pb), int(pt), int(pb)
+        else:
+            p.pad_xy = p.pad_bottom = p.pad_top = p.vtk_pz = 0
+        p.nz, p.ny, p.nx = z1 - z0, self.dy, self.dx
+        p.roi_start = z0 if roi_start is None else roi_start
+        p.spacing[:] = self.spacing
+        if from_binary:
+            p.dtype, p.niso, p.pad_value = L.U8, 1, 0.0
+            p.iso[:] = [127.0, 0.0]
+        else:
+            p.dtype, p.niso, p.pad_value = L.I16, 2, float(np.iinfo(np.int16).min)
+            p.iso[:] = [float(min_value), float(max_value)]
+        return p
+
+    def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False,
+                       params: L.McParams | None = None, z0: int = 0):
+        """count + emit on the resident mask (from_binary, iso 127) or image (two iso-values).  Returns the triangle
+        count, or the (T,3,3) float32 soup when download=True."""
+        lib = L.lib()
+        p = params if params is not None else self._mc_params(from_binary, min_value, max_value, fill_border_holes)
+        nb = ctypes.c_size_t(0)
+        L.check(lib.ivx_dev_mc_scratch_bytes(ctypes.byref(p), ctypes.byref(nb)))
+        if self._mc_scratch is None or self._mc_scratch.nbytes < nb.value:
+            if self._mc_scratch is not None:
+                self._mc_scratch.close()
+            self._mc_scratch = DeviceBuffer(nb.value)
+        isz = 1 if p.dtype == L.U8 else 2
+        src = (self.mask if p.dtype == L.U8 else self.image).at(z0 * self.dy * self.dx * isz)
+        n = ctypes.c_int64(0)
+        with self.timer.span("mc_count"):
+            L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_count")
+        nt = n.value
+        if self._tris is None or self._tris.nbytes < nt * 36:
+            if self._tris is not None:
+                self._tris.close()
+            self._tris = DeviceBuffer(int(nt * 36 * 1.25) + 4096)
+        with self.timer.span("mc_emit"):
+            L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(nt), self.stream),
+                    "mc_emit")
+        if download:
+            self.sync()
+            return self._tris.download((nt, 3, 3), np.float32)
+        return nt
+
+    # -- projections ---------------------------------------------------------------------------------
+    def project(self, axis: int, op: int, out: DeviceBuffer):
+        L.check(L.lib().ivx_dev_mip_reduce(L.I16, self.image.ptr, c64(self.dz), c64(self.dy), c64(self.dx), int(axis),
+                                           int(op), out.ptr, self.stream), "project")
+
+
+def c64(v):
+    return ctypes.c_int64(int(v))

@@ -100,12 +100,13 @@ def test_inplace_mask_relabel_on_strided_view(ivxlib, oracle):
     floodfill.floodfill_threshold_inplace(mg[1:, 1:, 1:], [tuple(int(v) for v in hole)], 0, 2, 254, s)
     oracle.floodfill_threshold_inplace(mr[1:, 1:, 1:], [tuple(int(v) for v in hole)], 0, 2, 254, s)
     assert np.array_equal(mg, mr)
+    assert (mg == 254).any()
     part = np.argwhere(mg[1:, 1:, 1:] == 255)[0][::-1]
     s26 = generate_binary_structure(3, 3)
     floodfill.floodfill_threshold_inplace(mg[1:, 1:, 1:], [tuple(int(v) for v in part)], 253, 255, 1, s26)
     oracle.floodfill_threshold_inplace(mr[1:, 1:, 1:], [tuple(int(v) for v in part)], 253, 255, 1, s26)
     assert np.array_equal(mg, mr)
-    assert (mg == 1).any() and (mg == 254).any()
+    assert (mg == 1).any()
 
 
 def test_dtypes_2d_strct_and_errors(ivxlib, oracle):
