@@ -4,16 +4,22 @@
 // include/ivx_mc_tables.h shared with the CPU oracle (oracle/ivx_oracle.c orc_marching_cubes).
 //
 // MI355X design (memory-bound, no MFMA):
-//   1. k_mc_bits     one streaming pass over the voxels (2 B/voxel int16, 1 B/voxel uint8; 16-B loads per
-//                    lane) -> "inside" bit planes (scalar >= iso), 1 bit per padded grid point, both
-//                    iso-values in the same pass.  A 512^3 piece gives a 19 MB bit volume per iso: it lives in
-//                    L2 / Infinity Cache for the rest of the pipeline.
+//   1. k_mc_bits     one streaming pass over the voxels (2 B/voxel int16, 1 B/voxel uint8; one aligned 16-B load
+//                    per lane) -> "inside" bit planes (scalar >= iso), 1 bit per SOURCE voxel (64 voxels of an
+//                    x-row per uint64, the same layout the region-growing kernels use), both iso-values in the
+//                    same pass.  A 512^3 piece gives a 16 MiB bit volume per iso: it lives in L2 / Infinity
+//                    Cache for the rest of the pipeline.  The one-voxel padding and the Y flip are applied
+//                    when the words are read (funnel shift by one bit, constant pad rows), never stored.
 //   2. k_mc_count    one lane per 64-cell word: four row words (+ the carry bit of the next word) give the
 //                    active-cell mask with a handful of 64-bit ops; only active cells look up the case table.
 //                    Per-word triangle counts (u16) + per-workgroup sums.
 //   3. k_mc_scan     exclusive scan of the per-workgroup sums (u64 offsets), single workgroup.
-//   4. k_mc_emit     same traversal; wave-level prefix (DPP shuffles) + LDS across the 4 waves gives every word
-//                    its output slot; active cells gather their 8 scalars and write 9 x f32 per triangle.
+//   4. k_mc_emit     one workgroup per 256 words.  Corner words + a block scan of the counts go to LDS; then the
+//                    workgroup walks its TRIANGLES 256 at a time, one lane per triangle (binary search of the
+//                    owning word in LDS, short walk over that word's active cells), so lanes stay busy however
+//                    unevenly the surface is spread.  The 9 floats of each triangle are staged in LDS
+//                    (stride 9 dwords: conflict-free) and leave as fully coalesced dword stores: HBM sees each
+//                    output line once.
 // Output order == the oracle's (iso-major, then k, j, i raster order of cells), so parity is an array compare.
 // Vertex arithmetic is done in double and rounded once to float32, exactly like the oracle.
 #include "ivx_internal.h"
@@ -22,13 +28,14 @@
 #include "../../include/ivx_mc_tables.h"
 
 typedef short short8_t __attribute__((ext_vector_type(8)));
-typedef unsigned char uchar8_t __attribute__((ext_vector_type(8)));
+typedef unsigned char uchar16_t __attribute__((ext_vector_type(16)));
 
 namespace {
 
 struct Geom {
     int64_t nz, ny, nx;  // piece
     int64_t NZ, NY, NX;  // padded grid points
+    int64_t ws;          // uint64 words per SOURCE row = ceil(nx/64)
     int64_t WX;          // uint64 words per padded point row
     int64_t WC;          // uint64 words per cell row  (NX-1 cells)
     int64_t nrows;       // (NZ-1)*(NY-1) cell rows
@@ -46,6 +53,7 @@ static int make_geom(const ivx_mc_params *p, Geom *g) {
     g->pxy = p->pad_xy ? 1 : 0; g->pb = p->pad_bottom ? 1 : 0;
     g->NZ = p->nz + g->pb + (p->pad_top ? 1 : 0);
     g->NY = p->ny + 2 * g->pxy; g->NX = p->nx + 2 * g->pxy;
+    g->ws = ivx::cdiv(g->nx, 64);
     g->WX = ivx::cdiv(g->NX, 64);
     g->WC = g->NX > 1 ? ivx::cdiv(g->NX - 1, 64) : 0;
     g->nrows = (g->NZ > 1 && g->NY > 1) ? (g->NZ - 1) * (g->NY - 1) : 0;
@@ -56,7 +64,7 @@ static int make_geom(const ivx_mc_params *p, Geom *g) {
     return IVX_OK;
 }
 
-// scratch layout (all 256-B aligned): bits[niso][NZ*NY*WX] u64 | counts[niso][nwords] u16 |
+// scratch layout (all 256-B aligned): bits[niso][nz*ny*ws] u64 | counts[niso][nwords] u16 |
 // blocksum[niso*nblocks] u32 | blockoff[niso*nblocks+1] u64
 struct Scratch {
     size_t bits_words, nwords, nblocks;
@@ -65,11 +73,11 @@ struct Scratch {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static Scratch make_scratch(const Geom &g, int niso) {
     Scratch s;
-    s.bits_words = (size_t)(g.NZ * g.NY * g.WX);
+    s.bits_words = (size_t)(g.nz * g.ny * g.ws);
     s.nwords = (size_t)(g.nrows * g.WC);
     s.nblocks = (s.nwords + 255) / 256;
     s.off_bits = 0;
-    s.off_counts = al256(s.off_bits + (size_t)niso * s.bits_words * 8);
+    s.off_counts = al256(s.off_bits + (size_t)niso * s.bits_words * 8 + 16);
     s.off_bsum = al256(s.off_counts + (size_t)niso * s.nwords * 2);
     s.off_boff = al256(s.off_bsum + (size_t)niso * s.nblocks * 4);
     s.total = al256(s.off_boff + ((size_t)niso * s.nblocks + 1) * 8);
@@ -83,79 +91,99 @@ __device__ __forceinline__ double mc_at(const T *a, const Geom &g, int64_t k, in
     return (double)a[(ka * g.ny + ja) * g.nx + ia];
 }
 
-// ---- 1. inside-bit planes -----------------------------------------------------------------------
-// one lane per output BYTE (8 padded grid points of one row); byte b of word w <-> points 64w+8b .. +7
+// ---- 1. inside-bit planes in SOURCE coordinates -------------------------------------------------------
+// One lane per aligned 16-byte chunk of a source row: 8 voxels (2-byte types) -> 1 output byte, 16 voxels
+// (uint8) -> 2 output bytes.  Byte b of word w <-> voxels 64w+8b .. +7; bits beyond nx stay 0.
 template <typename T, int NISO>
-__global__ __launch_bounds__(256) void k_mc_bits(const T *__restrict__ a, Geom g, double iso0, double iso1,
-                                                 uint8_t *__restrict__ bits0, uint8_t *__restrict__ bits1) {
-    const int64_t bytes_per_row = g.WX * 8;
-    const int64_t total = g.NZ * g.NY * bytes_per_row;
+__global__ __launch_bounds__(256) void k_mc_bits(const T *__restrict__ a, int64_t nrows_src, int64_t nx, int64_t ws,
+                                                 double iso0, double iso1, uint8_t *__restrict__ bits0,
+                                                 uint8_t *__restrict__ bits1) {
+    constexpr int V = 16 / sizeof(T);           // voxels per lane
+    constexpr int OB = V / 8;                   // output bytes per lane
+    const int64_t cpr = ws * 64 / V;            // chunks per (word-padded) row
+    const int64_t total = nrows_src * cpr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const bool vec_rows = (g.nx % 8 == 0) && (((uintptr_t)a & 15) == 0);
+    const bool vec = (nx % V == 0) && (((uintptr_t)a & 15) == 0);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const int64_t row = t / bytes_per_row;
-        const int64_t q = t - row * bytes_per_row;
-        const int64_t k = row / g.NY, jf = row - k * g.NY;
-        const int64_t ja = (g.NY - 1 - jf) - g.pxy, ka = k - g.pb;
-        const int64_t x0 = q * 8; // first padded point of this byte
+        const int64_t row = t / cpr, q = t - row * cpr;
+        const int64_t x0 = q * V;
         unsigned m0 = 0, m1 = 0;
-        if (x0 < g.NX) {
-            const bool row_in = ja >= 0 && ja < g.ny && ka >= 0 && ka < g.nz;
-            double v[8];
-            const int64_t s0 = x0 - g.pxy; // source x of point 0
-            if (!row_in) {
+        if (x0 < nx) {
+            const T *r = a + row * nx + x0;
+            T v[V];
+            if (vec) { // x0 + V <= nx because nx % V == 0
+                if (sizeof(T) == 2) {
+                    const short8_t c = *reinterpret_cast<const short8_t *>(r);
 #pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = g.padv;
-            } else {
-                const T *r = a + (ka * g.ny + ja) * g.nx;
-                if (sizeof(T) == 2 && vec_rows && x0 + 8 <= g.nx) {
-                    // aligned 16-B chunk [x0, x0+8) of the source row; with pxy the byte covers source
-                    // [x0-1, x0+7): element -1 comes from a 2-B load (same cache line as the neighbour lane's chunk)
-                    const short8_t c = *reinterpret_cast<const short8_t *>(r + x0);
-                    if (g.pxy) {
-                        v[0] = x0 > 0 ? (double)r[x0 - 1] : g.padv;
-#pragma unroll
-                        for (int e = 1; e < 8; e++) v[e] = (double)(T)c[e - 1];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; e++) v[e] = (double)(T)c[e];
-                    }
+                    for (int e = 0; e < V; e++) v[e] = (T)c[e % 8];
                 } else {
+                    const uchar16_t c = *reinterpret_cast<const uchar16_t *>(r);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int64_t sx = s0 + e;
-                        v[e] = (sx >= 0 && sx < g.nx) ? (double)r[sx] : g.padv;
-                    }
+                    for (int e = 0; e < V; e++) v[e] = (T)c[e % 16];
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; e++) v[e] = (x0 + e < nx) ? r[e] : (T)0;
             }
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const bool valid = x0 + e < g.NX;
-                m0 |= (valid && v[e] >= iso0) ? (1u << e) : 0u;
-                if (NISO == 2) m1 |= (valid && v[e] >= iso1) ? (1u << e) : 0u;
+            for (int e = 0; e < V; e++) {
+                const bool valid = vec || (x0 + e < nx);
+                const double d = (double)v[e];
+                m0 |= (valid && d >= iso0) ? (1u << e) : 0u;
+                if (NISO == 2) m1 |= (valid && d >= iso1) ? (1u << e) : 0u;
             }
         }
-        bits0[t] = (uint8_t)m0;
-        if (NISO == 2) bits1[t] = (uint8_t)m1;
+        const int64_t ob = (row * ws * 8) + q * OB;
+        if (OB == 1) {
+            bits0[ob] = (uint8_t)m0;
+            if (NISO == 2) bits1[ob] = (uint8_t)m1;
+        } else {
+            *reinterpret_cast<uint16_t *>(bits0 + ob) = (uint16_t)m0;
+            if (NISO == 2) *reinterpret_cast<uint16_t *>(bits1 + ob) = (uint16_t)m1;
+        }
     }
 }
 
-// ---- shared traversal: the 8 corner-bit words of the 64 cells of (row, word w) ----------------------
+// ---- padded + flipped view of the source bit planes -----------------------------------------------------
+// word w of padded point row (k, jf): padded x = 64w .. 64w+63.  Pad rows / pad columns carry pbits.
+__device__ __forceinline__ uint64_t padded_word(const uint64_t *__restrict__ S, const Geom &g, int64_t k, int64_t jf,
+                                                int64_t w, uint64_t pbits) {
+    if (w >= g.WX) return 0ull;
+    const int64_t ja = (g.NY - 1 - jf) - g.pxy, ka = k - g.pb;
+    const int64_t rem = g.NX - w * 64; // padded points in this word
+    const uint64_t exist = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    if (ja < 0 || ja >= g.ny || ka < 0 || ka >= g.nz) return pbits & exist;
+    const uint64_t *row = S + (ka * g.ny + ja) * g.ws;
+    uint64_t v;
+    // bits of source x in [64w - pxy, 64w + 64 - pxy)
+    const uint64_t cur = w < g.ws ? row[w] : 0ull;
+    if (g.pxy) {
+        const uint64_t prev = (w > 0 && w - 1 < g.ws) ? row[w - 1] : 0ull;
+        v = (cur << 1) | (prev >> 63);
+    } else {
+        v = cur;
+    }
+    // positions that are padding inside an existing row: padded x < pxy or padded x >= pxy + nx
+    uint64_t src = exist;
+    if (g.pxy && w == 0) src &= ~1ull;
+    const int64_t hi = g.pxy + g.nx - w * 64; // first padded-x (relative) beyond the source
+    if (hi < 64) src &= hi <= 0 ? 0ull : ((1ull << hi) - 1ull);
+    return (v & src) | (pbits & exist & ~src);
+}
+
 struct Corner8 {
     uint64_t c[8];
     uint64_t active;
 };
 __device__ __forceinline__ Corner8 load_corners(const uint64_t *__restrict__ bits, const Geom &g, int64_t k,
-                                                int64_t j, int64_t w) {
+                                                int64_t j, int64_t w, uint64_t pbits) {
     Corner8 r;
-    const bool has_next = (w + 1) < g.WX;
 #pragma unroll
     for (int dz = 0; dz < 2; dz++)
 #pragma unroll
         for (int dy = 0; dy < 2; dy++) {
-            const uint64_t *row = bits + ((k + dz) * g.NY + (j + dy)) * g.WX;
-            const uint64_t lo = row[w];
-            const uint64_t nx = has_next ? row[w + 1] : 0ull;
+            const uint64_t lo = padded_word(bits, g, k + dz, j + dy, w, pbits);
+            const uint64_t nx = padded_word(bits, g, k + dz, j + dy, w + 1, pbits);
             r.c[4 * dz + 2 * dy] = lo;
             r.c[4 * dz + 2 * dy + 1] = (lo >> 1) | (nx << 63);
         }
@@ -170,32 +198,32 @@ __device__ __forceinline__ Corner8 load_corners(const uint64_t *__restrict__ bit
     r.active = any & ~all & valid;
     return r;
 }
-__device__ __forceinline__ int case_of(const Corner8 &r, int b) {
+__device__ __forceinline__ int case_of(const uint64_t *c, int b) {
     int idx = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) idx |= (int)((r.c[c] >> b) & 1ull) << c;
+    for (int q = 0; q < 8; q++) idx |= (int)((c[q] >> b) & 1ull) << q;
     return idx;
 }
 
 // ---- 2. count -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mc_count(const uint64_t *__restrict__ bits, Geom g, size_t nwords,
-                                                  uint16_t *__restrict__ counts, uint32_t *__restrict__ bsum) {
+                                                  uint64_t pbits, uint16_t *__restrict__ counts,
+                                                  uint32_t *__restrict__ bsum) {
     __shared__ uint32_t s_part[4];
     const size_t wid = (size_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t n = 0;
     if (wid < nwords) {
         const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
         const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
-        const Corner8 r = load_corners(bits, g, k, j, w);
+        const Corner8 r = load_corners(bits, g, k, j, w, pbits);
         uint64_t act = r.active;
         while (act) {
             const int b = __builtin_ctzll(act);
             act &= act - 1;
-            n += MC_NTRI[case_of(r, b)];
+            n += MC_NTRI[case_of(r.c, b)];
         }
         counts[wid] = (uint16_t)n;
     }
-    // workgroup sum: wave reduce + 4-entry LDS
     uint32_t s = n;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -234,16 +262,31 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
     if (threadIdx.x == 0) boff[n] = s_carry;
 }
 
-// ---- 4. emit ------------------------------------------------------------------------------------
+// ---- 4. emit: one lane per TRIANGLE ---------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const uint64_t *__restrict__ bits, Geom g,
-                                                 size_t nwords, double iso, const uint16_t *__restrict__ counts,
-                                                 const uint64_t *__restrict__ boff, uint64_t out_base,
-                                                 float *__restrict__ tris, uint64_t max_tris) {
+                                                 size_t nwords, uint64_t pbits, double iso,
+                                                 const uint16_t *__restrict__ counts,
+                                                 const uint64_t *__restrict__ boff, float *__restrict__ tris,
+                                                 uint64_t max_tris) {
+    __shared__ uint64_t s_c[8][256];   // corner words, SoA
+    __shared__ uint64_t s_act[256];
+    __shared__ uint32_t s_base[257];   // exclusive prefix of the per-word triangle counts
+    __shared__ int32_t s_k[256], s_j[256], s_w[256];
     __shared__ uint32_t s_wave[4];
-    const size_t wid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float s_out[256 * 9];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t wid = (size_t)blockIdx.x * 256 + tid;
     const uint32_t n = wid < nwords ? (uint32_t)counts[wid] : 0u;
+    if (n) {
+        const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
+        const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
+        const Corner8 r = load_corners(bits, g, k, j, w, pbits);
+#pragma unroll
+        for (int c = 0; c < 8; c++) s_c[c][tid] = r.c[c];
+        s_act[tid] = r.active;
+        s_k[tid] = (int32_t)k; s_j[tid] = (int32_t)j; s_w[tid] = (int32_t)w;
+    }
     uint32_t inc = n;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -254,58 +297,87 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const 
     __syncthreads();
     uint32_t wbase = 0;
     for (int q = 0; q < wv; q++) wbase += s_wave[q];
-    if (n == 0) return;
-    uint64_t off = out_base + boff[blockIdx.x] + wbase + (inc - n);
-    if (off + n > max_tris) return; // caller sized the buffer from the count; never write past it
+    s_base[tid] = wbase + inc - n;
+    if (tid == 255) s_base[256] = wbase + inc;
+    __syncthreads();
+    const uint32_t total = s_base[256];
+    if (total == 0) return;
+    const uint64_t gbase = boff[blockIdx.x];
+    if (gbase + total > max_tris) return; // never write past the buffer the caller sized from the count
 
-    const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
-    const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
-    const Corner8 r = load_corners(bits, g, k, j, w);
-    uint64_t act = r.active;
-    while (act) {
-        const int b = __builtin_ctzll(act);
-        act &= act - 1;
-        const int idx = case_of(r, b);
-        const int nt = MC_NTRI[idx];
-        if (!nt) continue;
-        const int64_t i = w * 64 + b;
-        double sc[8];
+    for (uint32_t c0 = 0; c0 < total; c0 += 256) {
+        const uint32_t T_ = c0 + tid;
+        if (T_ < total) {
+            // owning word: largest ww with s_base[ww] <= T_  (words with zero triangles are skipped by <=)
+            int lo = 0, hi = 256;
 #pragma unroll
-        for (int c = 0; c < 8; c++) sc[c] = mc_at(a, g, k + ((c >> 2) & 1), j + ((c >> 1) & 1), i + (c & 1));
-        float *o = tris + off * 9;
-        for (int t = 0; t < 3 * nt; t++) {
-            const int e = MC_TRI[idx][t];
-            const int c0 = MC_EDGE_CORNERS[e][0], c1 = MC_EDGE_CORNERS[e][1];
-            const double tt = (iso - sc[c0]) / (sc[c1] - sc[c0]);
-            double p0 = (double)(i + MC_EDGE_BASE[e][0] - g.pxy);
-            double p1 = (double)(j + MC_EDGE_BASE[e][1] - g.yoff);
-            double p2 = (double)(k + MC_EDGE_BASE[e][2] + g.zoff);
-            const int ax = MC_EDGE_AXIS[e];
-            if (ax == 0) p0 += tt;
-            else if (ax == 1) p1 += tt;
-            else p2 += tt;
-            o[3 * t + 0] = (float)(g.sx * p0);
-            o[3 * t + 1] = (float)(g.sy * p1);
-            o[3 * t + 2] = (float)(g.sz * p2);
+            for (int s = 0; s < 8; s++) {
+                const int mid = (lo + hi) >> 1;
+                if (s_base[mid] <= T_) lo = mid; else hi = mid;
+            }
+            const int ww = lo;
+            uint32_t rel = T_ - s_base[ww];
+            uint64_t cw[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) cw[c] = s_c[c][ww];
+            uint64_t act = s_act[ww];
+            int b = 0, idx = 0;
+            for (;;) { // walk the word's active cells until the one holding triangle `rel`
+                b = __builtin_ctzll(act);
+                idx = case_of(cw, b);
+                const uint32_t nt = MC_NTRI[idx];
+                if (rel < nt) break;
+                rel -= nt;
+                act &= act - 1;
+            }
+            const int64_t k = s_k[ww], j = s_j[ww], i = (int64_t)s_w[ww] * 64 + b;
+            float *o = s_out + tid * 9;
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                const int e = MC_TRI[idx][3 * rel + v];
+                const int c0_ = MC_EDGE_CORNERS[e][0], c1_ = MC_EDGE_CORNERS[e][1];
+                const double s0 = mc_at(a, g, k + ((c0_ >> 2) & 1), j + ((c0_ >> 1) & 1), i + (c0_ & 1));
+                const double s1 = mc_at(a, g, k + ((c1_ >> 2) & 1), j + ((c1_ >> 1) & 1), i + (c1_ & 1));
+                const double tt = (iso - s0) / (s1 - s0);
+                double p0 = (double)(i + MC_EDGE_BASE[e][0] - g.pxy);
+                double p1 = (double)(j + MC_EDGE_BASE[e][1] - g.yoff);
+                double p2 = (double)(k + MC_EDGE_BASE[e][2] + g.zoff);
+                const int ax = MC_EDGE_AXIS[e];
+                if (ax == 0) p0 += tt;
+                else if (ax == 1) p1 += tt;
+                else p2 += tt;
+                o[3 * v + 0] = (float)(g.sx * p0);
+                o[3 * v + 1] = (float)(g.sy * p1);
+                o[3 * v + 2] = (float)(g.sz * p2);
+            }
         }
-        off += nt;
+        __syncthreads();
+        const uint32_t nt_chunk = total - c0 < 256 ? total - c0 : 256;
+        float *dst = tris + (gbase + c0) * 9;
+        for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
+        __syncthreads();
     }
 }
+
+static inline uint64_t pad_bits(const ivx_mc_params *p, int q) { return p->pad_value >= p->iso[q] ? ~0ull : 0ull; }
 
 template <typename T>
 static int run_bits(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, char *scratch,
                     hipStream_t st) {
-    const int64_t total = g.NZ * g.NY * g.WX * 8;
+    constexpr int V = 16 / sizeof(T);
+    const int64_t nrows_src = g.nz * g.ny;
+    const int64_t total = nrows_src * (g.ws * 64 / V);
     if (total == 0) return IVX_OK;
     const int64_t blocks = ivx::cdiv(total, 256);
     const int grid = (int)(blocks < 32768 ? blocks : 32768);
     uint8_t *b0 = (uint8_t *)(scratch + s.off_bits);
     uint8_t *b1 = b0 + s.bits_words * 8;
     if (p->niso == 2)
-        hipLaunchKernelGGL((k_mc_bits<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)a, g, p->iso[0], p->iso[1], b0,
-                           b1);
+        hipLaunchKernelGGL((k_mc_bits<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)a, nrows_src, g.nx, g.ws,
+                           p->iso[0], p->iso[1], b0, b1);
     else
-        hipLaunchKernelGGL((k_mc_bits<T, 1>), dim3(grid), dim3(256), 0, st, (const T *)a, g, p->iso[0], 0.0, b0, b0);
+        hipLaunchKernelGGL((k_mc_bits<T, 1>), dim3(grid), dim3(256), 0, st, (const T *)a, nrows_src, g.nx, g.ws,
+                           p->iso[0], 0.0, b0, b0);
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
@@ -320,7 +392,7 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
         const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
         const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
         hipLaunchKernelGGL((k_mc_emit<T>), dim3((unsigned)s.nblocks), dim3(256), 0, st, (const T *)a, bits, g,
-                           s.nwords, p->iso[q], counts, boff + (size_t)q * s.nblocks, (uint64_t)0, tris,
+                           s.nwords, pad_bits(p, q), p->iso[q], counts, boff + (size_t)q * s.nblocks, tris,
                            (uint64_t)max_tris);
         IVX_LAUNCH_CHECK();
     }
@@ -358,8 +430,8 @@ extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scr
     for (int q = 0; q < p->niso; q++) {
         const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
         uint16_t *counts = (uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
-        hipLaunchKernelGGL(k_mc_count, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, counts,
-                           bsum + (size_t)q * s.nblocks);
+        hipLaunchKernelGGL(k_mc_count, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q),
+                           counts, bsum + (size_t)q * s.nblocks);
         IVX_LAUNCH_CHECK();
     }
     const size_t nb = s.nblocks * (size_t)p->niso;
