@@ -107,6 +107,29 @@ int ivx_mip_reduce(int dtype, const void *vol, const int64_t shape[3], const int
                    int op, void *out, const int64_t out_strides[2]);
 
 /* ------------------------------------------------------------------------------------------------
+ * MIDA, LMIP, fast contour MIP
+ *   replaces mida / lmip / fast_countour_mip of invesalius_rs/src/mips.rs:7-279
+ *   (bindings mips_py.rs:161-253, wrappers invesalius_rs/__init__.py:91-101)
+ * dtype pairs (in -> out): i16->i16, u8->u8, f64->u8 for mida; out dtype == in dtype otherwise.
+ * A NumCast failure on any output pixel returns IVX_EDOM (the reference panics).
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_minmax_f32(int dtype, const void *vol, int64_t n, float *minmax2, void *stream);
+int ivx_dev_mida(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, float wl, float ww,
+                 const float *minmax2 /* device, from ivx_dev_minmax_f32 */, int out_dtype, void *out,
+                 int *status /* device int, set to IVX_EDOM on cast failure */, void *stream);
+int ivx_dev_lmip(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, double tmin,
+                 double tmax, void *out, void *stream);
+int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
+                       void *tmp /* same dtype/shape */, int *status, void *stream);
+int ivx_mida(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
+             double wl, double ww, int out_dtype, void *out, const int64_t out_strides[2]);
+int ivx_lmip(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
+             double tmin, double tmax, void *out, const int64_t out_strides[2]);
+int ivx_fast_countour_mip(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3],
+                          float n, int axis, double wl, double ww, int tmip, void *out,
+                          const int64_t out_strides[2]);
+
+/* ------------------------------------------------------------------------------------------------
  * marching cubes == geometry of create_surface_piece
  *   replaces pad_image + converters.to_vtk + vtkImageFlip + vtkContourFilter
  *            invesalius/data/surface_process.py:52-68,100-186; invesalius/data/converters.py:34-101

@@ -1,0 +1,481 @@
+// k_rays.hip -- order-dependent slab projections: MIDA, LMIP, fast contour MIP.
+//
+// Reference semantics (bit-exact for the integer outputs; f32 state evaluated in the reference's operation order,
+// this file is compiled with -ffp-contract=off so nothing is fused):
+//   lmip                          invesalius_rs/src/mips.rs:7-86
+//   get_opacity / mida_internal   invesalius_rs/src/mips.rs:88-168   (dtype pairs: mips_py.rs:161-202)
+//   finite_difference / calc_fcm_intensity / fast_countour_mip_internal   invesalius_rs/src/mips.rs:171-279
+//
+// MI355X design (memory-bound: 2 B/voxel read once, one output pixel per ray; no MFMA):
+//   axis 0 / 1  a ray is strided in memory but ADJACENT rays are adjacent in x: lane <-> x, every step of the
+//               walk is one fully coalesced row segment per wave.
+//   axis 2      a ray is contiguous (an x-row): a wave takes 64 consecutive rows, stages a 64-row x 128-byte
+//               chunk in LDS with 16-B coalesced loads (8 lanes per row segment) and each lane then walks its own
+//               row out of LDS (row pitch 136 B: no more than 2-way bank conflicts).  The chunk loop stops as soon
+//               as every lane's ray has terminated (MIDA alpha >= 1, LMIP first fall after the threshold).
+//   k_fcm_volume  one lane per voxel, x fastest; the six clamped neighbours come through L1/L2 (each row is
+//               re-used by its two y- and two z-neighbours, so HBM still sees each voxel about once).
+#include <math.h>
+
+#include "ivx_internal.h"
+
+namespace {
+
+// ---- NumCast f32 -> T (num-traits: None unless MIN-1 < x < MAX+1, then truncation) -----------------------
+template <typename T> __device__ __forceinline__ bool numcast(float v, T *dst);
+template <> __device__ __forceinline__ bool numcast<int16_t>(float v, int16_t *dst) {
+    if (!(v > -32769.0f && v < 32768.0f)) return false;
+    *dst = (int16_t)v;
+    return true;
+}
+template <> __device__ __forceinline__ bool numcast<uint8_t>(float v, uint8_t *dst) {
+    if (!(v > -1.0f && v < 256.0f)) return false;
+    *dst = (uint8_t)v;
+    return true;
+}
+template <> __device__ __forceinline__ bool numcast<double>(float v, double *dst) {
+    *dst = (double)v;
+    return true;
+}
+
+// ---- ray functors --------------------------------------------------------------------------------------
+template <typename T> struct LmipRay { // mips.rs:24-37
+    T maxv, tmin, tmax;
+    bool start, first;
+    __device__ __forceinline__ void init(T lo, T hi) { tmin = lo; tmax = hi; first = true; start = false; maxv = (T)0; }
+    __device__ __forceinline__ bool step(T v) { // returns true when the ray is finished
+        if (first) {
+            maxv = v;
+            start = maxv >= tmin && maxv <= tmax;
+            first = false;
+        }
+        if (v > maxv) maxv = v;
+        else if (v < maxv && start) return true;
+        if (v >= tmin && v <= tmax) start = true;
+        return false;
+    }
+};
+
+struct MidaRay { // mips.rs:136-163
+    float fmax, alpha_p, colour_p, final_colour;
+    float img_min, inv_range, wl, ww;
+    __device__ __forceinline__ void init(float mn, float range, float wl_, float ww_) {
+        fmax = alpha_p = colour_p = final_colour = 0.0f;
+        img_min = mn;
+        inv_range = 1.0f / range;
+        wl = wl_;
+        ww = ww_;
+    }
+    __device__ __forceinline__ bool step(float vl) {
+        const float fpi = inv_range * (vl - img_min);
+        float dl;
+        if (fpi > fmax) {
+            dl = fpi - fmax;
+            fmax = fpi;
+        } else dl = 0.0f;
+        const float bt = 1.0f - dl;
+        // get_opacity, mips.rs:88-100
+        const float min_value = wl - (ww / 2.0f), max_value = wl + (ww / 2.0f);
+        float alpha;
+        if (vl < min_value) alpha = 0.0f;
+        else if (vl > max_value) alpha = 1.0f;
+        else alpha = (vl - min_value) / (max_value - min_value);
+        const float colour = (bt * colour_p) + (1.0f - bt * alpha_p) * fpi * alpha;
+        const float current_alpha = (bt * alpha_p) + (1.0f - bt * alpha_p) * alpha;
+        colour_p = colour;
+        alpha_p = current_alpha;
+        final_colour = colour;
+        return current_alpha >= 1.0f;
+    }
+};
+
+// ---- geometry of the three axes --------------------------------------------------------------------------
+struct RayGeom {
+    int64_t nr, nc, len; // output rows, cols, ray length
+    int64_t sr, sc, sl;  // element strides
+};
+static RayGeom ray_geom(int axis, int64_t dz, int64_t dy, int64_t dx) {
+    RayGeom g;
+    if (axis == 0) { g.nr = dy; g.nc = dx; g.len = dz; g.sr = dx; g.sc = 1; g.sl = dy * dx; }
+    else if (axis == 1) { g.nr = dz; g.nc = dx; g.len = dy; g.sr = dy * dx; g.sc = 1; g.sl = dx; }
+    else { g.nr = dz; g.nc = dy; g.len = dx; g.sr = dy * dx; g.sc = dx; g.sl = 1; }
+    return g;
+}
+
+// MODE 0 = lmip (out T), 1 = mida (out U)
+template <typename T, typename U, int MODE>
+__device__ __forceinline__ void finish(const LmipRay<T> &lr, const MidaRay &mr, float range, U *out, int *status) {
+    if (MODE == 0) {
+        *out = (U)lr.maxv;
+    } else {
+        U v = (U)0;
+        if (!numcast<U>(range * mr.final_colour + mr.img_min, &v)) atomicMin(status, IVX_EDOM);
+        *out = v;
+    }
+}
+
+// ---- axis 0 / 1: lane <-> x -------------------------------------------------------------------------------
+template <typename T, typename U, int MODE>
+__global__ __launch_bounds__(256) void k_rays_strided(const T *__restrict__ vol, RayGeom g, double p0, double p1,
+                                                      const float *__restrict__ minmax, U *__restrict__ out,
+                                                      int *__restrict__ status) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= g.nr * g.nc) return;
+    const int64_t r = pix / g.nc, c = pix - r * g.nc;
+    const T *p = vol + r * g.sr + c * g.sc;
+    LmipRay<T> lr;
+    MidaRay mr;
+    float range = 0.0f;
+    if (MODE == 0) lr.init((T)p0, (T)p1);
+    else {
+        range = minmax[1] - minmax[0];
+        mr.init(minmax[0], range, (float)p0, (float)p1);
+    }
+    bool done = false;
+    for (int64_t l0 = 0; l0 < g.len; l0 += 8) { // 8 independent loads in flight per lane, one wave vote per block
+        T v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (l0 + k < g.len) ? p[(l0 + k) * g.sl] : (T)0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (!done && l0 + k < g.len) done = MODE == 0 ? lr.step(v[k]) : mr.step((float)v[k]);
+        if (__all(done)) break; // the whole wave's rays have terminated
+    }
+    finish<T, U, MODE>(lr, mr, range, out + pix, status);
+}
+
+// ---- axis 2: wave <-> 64 rows, LDS-staged chunks -------------------------------------------------------------
+constexpr int PITCH = 136; // bytes per staged row (128 data + 8 pad)
+template <typename T, typename U, int MODE>
+__global__ __launch_bounds__(256) void k_rays_rows(const T *__restrict__ vol, int64_t nrays, int64_t len, double p0,
+                                                   double p1, const float *__restrict__ minmax, U *__restrict__ out,
+                                                   int *__restrict__ status) {
+    constexpr int CH = 128 / sizeof(T); // elements per staged row chunk
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[4][64 * PITCH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ray0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (ray0 >= nrays) return; // whole wave out of range (no block-level barriers below)
+    const int64_t ray = ray0 + lane;
+    const bool live = ray < nrays;
+    unsigned char *tile = s_tile[wv];
+    LmipRay<T> lr;
+    MidaRay mr;
+    float range = 0.0f;
+    if (MODE == 0) lr.init((T)p0, (T)p1);
+    else {
+        range = minmax[1] - minmax[0];
+        mr.init(minmax[0], range, (float)p0, (float)p1);
+    }
+    bool done = !live;
+    const bool vec_ok = ((len * sizeof(T)) % 16 == 0) && (((uintptr_t)vol & 15) == 0);
+    for (int64_t c0 = 0; c0 < len; c0 += CH) {
+        // stage rows ray0..ray0+63, elements [c0, c0+CH): 8 lanes x 16 B per row, 8 rows per pass
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int row = i * 8 + (lane >> 3), seg = lane & 7;
+            const int64_t rr = ray0 + row;
+            const int64_t e0 = c0 + seg * (16 / sizeof(T));
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (rr < nrays && e0 < len) {
+                const T *src = vol + rr * len + e0;
+                if (vec_ok && e0 + (int64_t)(16 / sizeof(T)) <= len) q = *reinterpret_cast<const uint4 *>(src);
+                else {
+                    T tmp[16 / sizeof(T)];
+#pragma unroll
+                    for (int e = 0; e < (int)(16 / sizeof(T)); e++) tmp[e] = (e0 + e < len) ? src[e] : (T)0;
+                    q = *reinterpret_cast<uint4 *>(tmp);
+                }
+            }
+            // 8-byte LDS stores (row pitch 136 is 8-aligned, not 16)
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(tile + row * PITCH + seg * 16);
+            d[0] = ((unsigned long long)q.y << 32) | q.x;
+            d[1] = ((unsigned long long)q.w << 32) | q.z;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const T *mine = reinterpret_cast<const T *>(tile + lane * PITCH);
+        const int n = (int)((len - c0) < CH ? (len - c0) : CH);
+        for (int e = 0; e < n; e++) {
+            if (!done) done = MODE == 0 ? lr.step(mine[e]) : mr.step((float)mine[e]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (__all(done)) break;
+    }
+    if (live) finish<T, U, MODE>(lr, mr, range, out + ray, status);
+}
+
+// ---- min / max of the volume as f32 (mida_internal's pre-pass, mips.rs:113-123) ------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_minmax_part(const T *__restrict__ vol, int64_t n, T *__restrict__ part) {
+    __shared__ T s_mn[4], s_mx[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    T mn = vol[0], mx = vol[0];
+    for (; i < n; i += stride) {
+        const T v = vol[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; q++) {
+            mn = s_mn[q] < mn ? s_mn[q] : mn;
+            mx = s_mx[q] > mx ? s_mx[q] : mx;
+        }
+        part[2 * blockIdx.x] = mn;
+        part[2 * blockIdx.x + 1] = mx;
+    }
+}
+template <typename T>
+__global__ void k_minmax_final(const T *__restrict__ part, int nparts, float *__restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    T mn = part[0], mx = part[1];
+    for (int i = 1; i < nparts; i++) {
+        mn = part[2 * i] < mn ? part[2 * i] : mn;
+        mx = part[2 * i + 1] > mx ? part[2 * i + 1] : mx;
+    }
+    out[0] = (float)mn; // the conversion is monotone, so min/max commute with it
+    out[1] = (float)mx;
+}
+
+// ---- contour volume (calc_fcm_intensity, mips.rs:171-213) -------------------------------------------------------
+template <typename T> __device__ __forceinline__ float fd_sub(T a, T b);
+// the subtraction happens in T and wraps in a release build
+template <> __device__ __forceinline__ float fd_sub<int16_t>(int16_t a, int16_t b) {
+    return (float)(int16_t)((uint16_t)a - (uint16_t)b);
+}
+template <> __device__ __forceinline__ float fd_sub<uint8_t>(uint8_t a, uint8_t b) { return (float)(uint8_t)(a - b); }
+template <> __device__ __forceinline__ float fd_sub<double>(double a, double b) { return (float)(a - b); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fcm_volume(const T *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
+                                                    float n, int axis, T *__restrict__ tmp, int *__restrict__ status) {
+    const int64_t total = sz * sy * sx;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t x = i % sx, r = i / sx, y = r % sy, z = r / sy;
+        const int64_t px = x == 0 ? 0 : x - 1, fx = x == sx - 1 ? sx - 1 : x + 1;
+        const int64_t py = y == 0 ? 0 : y - 1, fy = y == sy - 1 ? sy - 1 : y + 1;
+        const int64_t pz = z == 0 ? 0 : z - 1, fz = z == sz - 1 ? sz - 1 : z + 1;
+        const T *row = img + (z * sy + y) * sx;
+        const float g0 = fd_sub<T>(row[fx], row[px]) / (2.0f * 1.0f);
+        const float g1 = fd_sub<T>(img[(z * sy + fy) * sx + x], img[(z * sy + py) * sx + x]) / (2.0f * 1.0f);
+        const float g2 = fd_sub<T>(img[(fz * sy + y) * sx + x], img[(pz * sy + y) * sx + x]) / (2.0f * 1.0f);
+        const float gm = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+        float v = 0.0f;
+        if (gm != 0.0f) {
+            const float d = axis == 0 ? g2 : axis == 1 ? g1 : axis == 2 ? g0 : 0.0f; // dir = unit axis
+            const float base = 1.0f - fabsf(d / gm);
+            // f32 powf: evaluated in double and rounded once (== the correctly rounded f32 result except in
+            // astronomically rare double-rounding cases); n == 1 is exact by definition
+            const float sf = n == 1.0f ? base : (float)pow((double)base, (double)n);
+            v = gm * sf;
+        }
+        T o = (T)0;
+        if (!numcast<T>(v, &o)) atomicMin(status, IVX_EDOM);
+        tmp[i] = o;
+    }
+}
+
+template <typename T, typename U, int MODE>
+static int launch_rays(const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, double p0, double p1,
+                       const float *minmax, void *out, int *status, hipStream_t st) {
+    const RayGeom g = ray_geom(axis, dz, dy, dx);
+    const int64_t npix = g.nr * g.nc;
+    if (npix == 0) return IVX_OK;
+    if (axis == 2) {
+        hipLaunchKernelGGL((k_rays_rows<T, U, MODE>), dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st,
+                           (const T *)vol, npix, g.len, p0, p1, minmax, (U *)out, status);
+    } else {
+        hipLaunchKernelGGL((k_rays_strided<T, U, MODE>), dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st,
+                           (const T *)vol, g, p0, p1, minmax, (U *)out, status);
+    }
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+template <typename T> static int run_minmax(const void *vol, int64_t n, float *out, hipStream_t st) {
+    void *part;
+    const int nb = (int)(ivx::cdiv(n, 256) < 2048 ? ivx::cdiv(n, 256) : 2048);
+    int rc = ivx::ws_get(ivx::WS_AUX3, (size_t)nb * 2 * sizeof(T) + 64, &part);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_minmax_part<T>, dim3(nb), dim3(256), 0, st, (const T *)vol, n, (T *)part);
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_minmax_final<T>, dim3(1), dim3(64), 0, st, (const T *)part, nb, out);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+} // namespace
+
+extern "C" int ivx_dev_minmax_f32(int dtype, const void *vol, int64_t n, float *minmax2, void *stream) {
+    IVX_REQUIRE(n > 0, IVX_EDOM, "minmax: empty volume (the reference unwraps a None)");
+    hipStream_t st = ivx::S(stream);
+    switch (dtype) {
+    case IVX_I16: return run_minmax<int16_t>(vol, n, minmax2, st);
+    case IVX_U8: return run_minmax<uint8_t>(vol, n, minmax2, st);
+    case IVX_F64: return run_minmax<double>(vol, n, minmax2, st);
+    }
+    ivx::set_error("minmax: unsupported dtype %d", dtype);
+    return IVX_EINVAL;
+}
+
+extern "C" int ivx_dev_mida(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, float wl, float ww,
+                            const float *minmax2, int out_dtype, void *out, int *status, void *stream) {
+    hipStream_t st = ivx::S(stream);
+    if (axis > 2 || axis < 0) axis = 2; // `_ => image.slice(s![r, c, ..])`, mips.rs:131
+    if (dtype == IVX_I16 && out_dtype == IVX_I16)
+        return launch_rays<int16_t, int16_t, 1>(vol, dz, dy, dx, axis, wl, ww, minmax2, out, status, st);
+    if (dtype == IVX_U8 && out_dtype == IVX_U8)
+        return launch_rays<uint8_t, uint8_t, 1>(vol, dz, dy, dx, axis, wl, ww, minmax2, out, status, st);
+    if (dtype == IVX_F64 && out_dtype == IVX_U8)
+        return launch_rays<double, uint8_t, 1>(vol, dz, dy, dx, axis, wl, ww, minmax2, out, status, st);
+    if (dtype == IVX_F64 && out_dtype == IVX_F64) // only reached from fast_countour_mip (tmp f64 -> out f64)
+        return launch_rays<double, double, 1>(vol, dz, dy, dx, axis, wl, ww, minmax2, out, status, st);
+    ivx::set_error("mida: Invalid image or output type (in %d, out %d)", dtype, out_dtype);
+    return IVX_EINVAL;
+}
+
+extern "C" int ivx_dev_lmip(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, double tmin,
+                            double tmax, void *out, void *stream) {
+    hipStream_t st = ivx::S(stream);
+    if (axis < 0 || axis > 2) return IVX_OK; // `_ => ()`, mips.rs:84
+    switch (dtype) {
+    case IVX_I16: return launch_rays<int16_t, int16_t, 0>(vol, dz, dy, dx, axis, tmin, tmax, nullptr, out, nullptr, st);
+    case IVX_U8: return launch_rays<uint8_t, uint8_t, 0>(vol, dz, dy, dx, axis, tmin, tmax, nullptr, out, nullptr, st);
+    case IVX_F64: return launch_rays<double, double, 0>(vol, dz, dy, dx, axis, tmin, tmax, nullptr, out, nullptr, st);
+    }
+    ivx::set_error("lmip: unsupported dtype %d", dtype);
+    return IVX_EINVAL;
+}
+
+extern "C" int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
+                                  void *tmp, int *status, void *stream) {
+    hipStream_t st = ivx::S(stream);
+    const int64_t total = dz * dy * dx;
+    if (!total) return IVX_OK;
+    const int64_t blocks = ivx::cdiv(total, 256);
+    const int grid = (int)(blocks < 65536 ? blocks : 65536);
+    switch (dtype) {
+    case IVX_I16: hipLaunchKernelGGL(k_fcm_volume<int16_t>, dim3(grid), dim3(256), 0, st, (const int16_t *)vol, dz, dy, dx, n, axis, (int16_t *)tmp, status); break;
+    case IVX_U8: hipLaunchKernelGGL(k_fcm_volume<uint8_t>, dim3(grid), dim3(256), 0, st, (const uint8_t *)vol, dz, dy, dx, n, axis, (uint8_t *)tmp, status); break;
+    case IVX_F64: hipLaunchKernelGGL(k_fcm_volume<double>, dim3(grid), dim3(256), 0, st, (const double *)vol, dz, dy, dx, n, axis, (double *)tmp, status); break;
+    default: ivx::set_error("fcm: unsupported dtype %d", dtype); return IVX_EINVAL;
+    }
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+// ---- host forms -----------------------------------------------------------------------------------------------
+namespace {
+struct HostRay {
+    void *d_in, *d_out, *d_small;
+    int64_t osh[2];
+    size_t isz;
+};
+static int host_prep(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
+                     size_t osz, HostRay *h) {
+    using namespace ivx;
+    h->isz = dtype_size(dtype);
+    IVX_REQUIRE(dtype == IVX_I16 || dtype == IVX_U8 || dtype == IVX_F64, IVX_EINVAL, "Invalid image or output type");
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+    const int a = (axis < 0 || axis > 2) ? 2 : axis;
+    if (a == 0) { h->osh[0] = shape[1]; h->osh[1] = shape[2]; }
+    else if (a == 1) { h->osh[0] = shape[0]; h->osh[1] = shape[2]; }
+    else { h->osh[0] = shape[0]; h->osh[1] = shape[1]; }
+    int rc;
+    if ((rc = ws_get(WS_IN, n * h->isz, &h->d_in))) return rc;
+    if ((rc = ws_get(WS_OUT, (size_t)h->osh[0] * h->osh[1] * osz, &h->d_out))) return rc;
+    if ((rc = ws_get(WS_SMALL, 256, &h->d_small))) return rc;
+    IVX_HIP(hipMemset(h->d_small, 0, 256));
+    return upload_strided(h->d_in, img, shape, strides, h->isz, WS_IN);
+}
+static int host_status(const HostRay &h) {
+    int st = 0;
+    IVX_HIP(hipMemcpy(&st, (char *)h.d_small + 64, 4, hipMemcpyDeviceToHost));
+    IVX_REQUIRE(st == 0, IVX_EDOM, "NumCast failure: a projected value does not fit the output dtype (the reference panics)");
+    return IVX_OK;
+}
+} // namespace
+
+extern "C" int ivx_mida(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
+                        double wl, double ww, int out_dtype, void *out, const int64_t out_strides[2]) {
+    using namespace ivx;
+    IVX_REQUIRE((dtype == IVX_I16 && out_dtype == IVX_I16) || (dtype == IVX_U8 && out_dtype == IVX_U8) ||
+                    (dtype == IVX_F64 && out_dtype == IVX_U8),
+                IVX_EINVAL, "Invalid image or output type");
+    IVX_REQUIRE(shape[0] * shape[1] * shape[2] > 0, IVX_EDOM, "mida: empty image (the reference unwraps a None)");
+    HostRay h;
+    int rc = host_prep(dtype, img, shape, strides, axis, dtype_size(out_dtype), &h);
+    if (rc) return rc;
+    float *mm = (float *)h.d_small;
+    int *status = (int *)((char *)h.d_small + 64);
+    if ((rc = ivx_dev_minmax_f32(dtype, h.d_in, shape[0] * shape[1] * shape[2], mm, nullptr))) return rc;
+    if ((rc = ivx_dev_mida(dtype, h.d_in, shape[0], shape[1], shape[2], axis, (float)wl, (float)ww, mm, out_dtype,
+                           h.d_out, status, nullptr)))
+        return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    if ((rc = download_strided2(out, h.osh, out_strides, h.d_out, dtype_size(out_dtype), WS_OUT))) return rc;
+    return host_status(h);
+}
+
+extern "C" int ivx_lmip(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
+                        double tmin, double tmax, void *out, const int64_t out_strides[2]) {
+    using namespace ivx;
+    if (axis < 0 || axis > 2) return IVX_OK;
+    if (shape[0] * shape[1] * shape[2] == 0) return IVX_OK;
+    HostRay h;
+    int rc = host_prep(dtype, img, shape, strides, axis, dtype_size(dtype), &h);
+    if (rc) return rc;
+    if ((rc = ivx_dev_lmip(dtype, h.d_in, shape[0], shape[1], shape[2], axis, tmin, tmax, h.d_out, nullptr))) return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    return download_strided2(out, h.osh, out_strides, h.d_out, h.isz, WS_OUT);
+}
+
+extern "C" int ivx_fast_countour_mip(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3],
+                                     float n, int axis, double wl, double ww, int tmip, void *out,
+                                     const int64_t out_strides[2]) {
+    using namespace ivx;
+    const int64_t nvox = shape[0] * shape[1] * shape[2];
+    HostRay h;
+    int rc = host_prep(dtype, img, shape, strides, axis, dtype_size(dtype), &h);
+    if (rc) return rc;
+    if (nvox == 0) return tmip == 2 ? IVX_EDOM : IVX_OK;
+    void *d_tmp;
+    if ((rc = ws_get(WS_AUX0, (size_t)nvox * h.isz, &d_tmp))) return rc;
+    float *mm = (float *)h.d_small;
+    int *status = (int *)((char *)h.d_small + 64);
+    if ((rc = ivx_dev_fcm_volume(dtype, h.d_in, shape[0], shape[1], shape[2], n, axis, d_tmp, status, nullptr))) return rc;
+    if ((rc = host_status(h))) return rc; // the reference panics while building tmp, before any projection
+    if (tmip == 0) {
+        IVX_REQUIRE(axis >= 0 && axis <= 2, IVX_EINVAL, "fast_countour_mip: axis %d", axis);
+        if (dtype == IVX_F64) {
+            // fold_axis max over f64: same as LMIP with an unreachable threshold window is NOT equivalent; use the
+            // ray kernel in LMIP mode with start never set: tmin > tmax
+            rc = ivx_dev_lmip(dtype, d_tmp, shape[0], shape[1], shape[2], axis, 1.0, -1.0, h.d_out, nullptr);
+        } else {
+            rc = ivx_dev_mip_reduce(dtype, d_tmp, shape[0], shape[1], shape[2], axis, IVX_MIP_MAX, h.d_out, nullptr);
+        }
+        if (rc) return rc;
+    } else if (tmip == 1) {
+        IVX_REQUIRE(dtype != IVX_U8, IVX_EDOM, "fast_countour_mip: NumCast::from(700) does not fit uint8 (the reference panics)");
+        if ((rc = ivx_dev_lmip(dtype, d_tmp, shape[0], shape[1], shape[2], axis, 700.0, 3033.0, h.d_out, nullptr))) return rc;
+    } else if (tmip == 2) {
+        if ((rc = ivx_dev_minmax_f32(dtype, d_tmp, nvox, mm, nullptr))) return rc;
+        if ((rc = ivx_dev_mida(dtype, d_tmp, shape[0], shape[1], shape[2], axis, (float)wl, (float)ww, mm, dtype, h.d_out,
+                               status, nullptr)))
+            return rc;
+    } else {
+        return IVX_OK; // `_ => ()`: out untouched
+    }
+    IVX_HIP(hipDeviceSynchronize());
+    if ((rc = host_status(h))) return rc;
+    return download_strided2(out, h.osh, out_strides, h.d_out, h.isz, WS_OUT);
+}

@@ -64,3 +64,63 @@ def floodfill_threshold_inplace(data, seeds, t0, t1, fill, strct):
         code, L.ptr(data), L.i64(data.shape), L.i64(data.strides), L.ptr(s), ctypes.c_int64(len(s)),
         ctypes.c_double(t0), ctypes.c_double(t1), ctypes.c_double(fill), L.ptr(strct_u8), L.i64(strct_u8.shape)),
         "floodfill_threshold_inplace")
+
+
+def _proj_out_shape(image, axis):
+    a = 2 if axis not in (0, 1, 2) else axis
+    return tuple(d for i, d in enumerate(image.shape) if i != a)
+
+
+def _fits(v, dtype, name):
+    """`wl.extract::<i16>()` / `::<u8>()` (mips_py.rs:172-184): a Python int outside the image dtype is an
+    OverflowError in the reference."""
+    if dtype.kind in "iu":
+        info = np.iinfo(dtype)
+        if not info.min <= int(v) <= info.max:
+            raise OverflowError("%s=%r out of range for %s" % (name, v, dtype))
+        return int(v)
+    return float(v)
+
+
+def mida(image: np.ndarray, axis: int, wl: int, ww: int, out: np.ndarray):
+    """mida (invesalius_rs/__init__.py:91-95 -> mips_py.rs:161-202 -> mida_internal mips.rs:102-168).
+    dtype pairs: int16->int16, uint8->uint8, float64->uint8."""
+    if image.ndim != 3 or out.ndim != 2:
+        raise TypeError("Invalid image or output type")
+    pairs = {(np.dtype(np.int16), np.dtype(np.int16)), (np.dtype(np.uint8), np.dtype(np.uint8)),
+             (np.dtype(np.float64), np.dtype(np.uint8))}
+    if (image.dtype, out.dtype) not in pairs:
+        raise TypeError("Invalid image or output type")
+    if tuple(out.shape) != _proj_out_shape(image, axis):
+        raise ValueError("out has the wrong shape")
+    wl, ww = _fits(int(wl), image.dtype, "wl"), _fits(int(ww), image.dtype, "ww")
+    L.check(L.lib().ivx_mida(L.DT[image.dtype], L.ptr(image), L.i64(image.shape), L.i64(image.strides), int(axis),
+                             ctypes.c_double(wl), ctypes.c_double(ww), L.DT[out.dtype], L.ptr(out),
+                             L.i64(out.strides)), "mida")
+
+
+def lmip(image: np.ndarray, axis: int, tmin, tmax, out: np.ndarray):
+    """lmip (invesalius_rs/src/mips.rs:7-86).  The reference calls it (slice_.py:892,980,1063) but never exports it
+    (invesalius_rs/__init__.py:83 is commented out -> AttributeError); exported here."""
+    if image.ndim != 3 or out.ndim != 2 or image.dtype != out.dtype:
+        raise TypeError("Invalid image or output type")
+    code = L.dtype_code(image, (L.U8, L.I16, L.F64))
+    if axis in (0, 1, 2) and tuple(out.shape) != _proj_out_shape(image, axis):
+        raise ValueError("out has the wrong shape")
+    tmin, tmax = _fits(tmin, image.dtype, "tmin"), _fits(tmax, image.dtype, "tmax")
+    L.check(L.lib().ivx_lmip(code, L.ptr(image), L.i64(image.shape), L.i64(image.strides), int(axis),
+                             ctypes.c_double(tmin), ctypes.c_double(tmax), L.ptr(out), L.i64(out.strides)), "lmip")
+
+
+def fast_countour_mip(image: np.ndarray, n: float, axis: int, wl: int, ww: int, tmip: int, out: np.ndarray):
+    """fast_countour_mip (invesalius_rs/__init__.py:98-101 -> mips_py.rs:204-253 -> mips.rs:215-279).
+    tmip 0 = MIP, 1 = LMIP(700, 3033), 2 = MIDA of the contour volume; out dtype == image dtype."""
+    if image.ndim != 3 or out.ndim != 2 or image.dtype != out.dtype:
+        raise TypeError("Invalid image or output type")
+    code = L.dtype_code(image, (L.U8, L.I16, L.F64))
+    if tuple(out.shape) != _proj_out_shape(image, axis):
+        raise ValueError("out has the wrong shape")
+    wl, ww = _fits(int(wl), image.dtype, "wl"), _fits(int(ww), image.dtype, "ww")
+    L.check(L.lib().ivx_fast_countour_mip(code, L.ptr(image), L.i64(image.shape), L.i64(image.strides),
+                                          ctypes.c_float(n), int(axis), ctypes.c_double(wl), ctypes.c_double(ww),
+                                          int(tmip), L.ptr(out), L.i64(out.strides)), "fast_countour_mip")

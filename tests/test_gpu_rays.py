@@ -1,0 +1,131 @@
+"""GPU parity: MIDA / LMIP / fast contour MIP vs the C oracle (restatement of invesalius_rs/src/mips.rs).
+Integer outputs must be bit-exact; float64 contour outputs within 1e-5 relative (f32 pow: see k_rays.hip)."""
+import numpy as np
+import pytest
+
+from conftest import synth_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def _out(img, axis, dtype=None):
+    shp = tuple(d for i, d in enumerate(img.shape) if i != axis)
+    return np.zeros(shp, dtype or img.dtype)
+
+
+@pytest.mark.parametrize("shape", [(20, 24, 40), (7, 13, 29), (66, 70, 130), (3, 64, 64)])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_mida_i16(ivxlib, oracle, shape, axis):
+    from invesalius3_amd import invesalius_rs as mips
+    img = synth_volume(shape, seed=51)
+    for wl, ww in ((300, 300), (40, 400), (-600, 1500)):  # slice_.py:898-900 passes window_level twice (quirk Q1)
+        g, r = _out(img, axis), _out(img, axis)
+        mips.mida(img, axis, wl, ww, g)
+        oracle.mida(img, axis, wl, ww, r)
+        assert np.array_equal(g, r)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_mida_u8_and_f64(ivxlib, oracle, axis):
+    from invesalius3_amd import invesalius_rs as mips
+    img = synth_volume((18, 30, 70), seed=52)
+    u = ((img.astype(np.int32) + 1024) // 17).clip(0, 255).astype(np.uint8)
+    g, r = _out(u, axis), _out(u, axis)
+    mips.mida(u, axis, 60, 80, g)
+    oracle.mida(u, axis, 60, 80, r)
+    assert np.array_equal(g, r)
+    f = (u.astype(np.float64) * 0.9 + 3.0)  # f64 image -> u8 output (mips_py.rs:184-194)
+    g, r = _out(f, axis, np.uint8), _out(f, axis, np.uint8)
+    mips.mida(f, axis, 60, 80, g)
+    oracle.mida(f, axis, 60, 80, r)
+    assert np.array_equal(g, r)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_lmip(ivxlib, oracle, axis):
+    from invesalius3_amd import invesalius_rs as mips
+    img = synth_volume((33, 45, 150), seed=53)
+    for tmin, tmax in ((-200, 500), (700, 3033), (5000, 6000)):
+        g, r = _out(img, axis), _out(img, axis)
+        mips.lmip(img, axis, tmin, tmax, g)
+        oracle.lmip(img, axis, tmin, tmax, r)
+        assert np.array_equal(g, r)
+    sl = img[4:20, 3:40, ::2]  # strided slab
+    g, r = _out(sl, axis), _out(sl, axis)
+    mips.lmip(sl, axis, -300, 300, g)
+    oracle.lmip(np.ascontiguousarray(sl), axis, -300, 300, r)
+    assert np.array_equal(g, r)
+
+
+@pytest.mark.parametrize("tmip", [0, 1, 2])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_fast_countour_mip_i16(ivxlib, oracle, axis, tmip):
+    from invesalius3_amd import invesalius_rs as mips
+    img = synth_volume((24, 40, 72), seed=54)
+    g, r = _out(img, axis), _out(img, axis)
+    mips.fast_countour_mip(img, 1.0, axis, 300, 300, tmip, g)  # border size 1.0: pow exact
+    oracle.fast_countour_mip(img, 1.0, axis, 300, 300, tmip, r)
+    assert np.array_equal(g, r)
+    assert g.any()
+
+
+def test_fcm_volume_other_exponents(ivxlib, oracle):
+    """n != 1: f32 powf on the GPU is pow in double rounded once; glibc powf may differ by 1 ulp before the
+    truncating cast, so allow at most 1 LSB on a vanishing fraction of pixels."""
+    from invesalius3_amd import invesalius_rs as mips
+    img = synth_volume((20, 36, 64), seed=55)
+    for n in (0.5, 2.0, 3.3):
+        for axis in range(3):
+            g, r = _out(img, axis), _out(img, axis)
+            mips.fast_countour_mip(img, n, axis, 300, 300, 0, g)
+            oracle.fast_countour_mip(img, n, axis, 300, 300, 0, r)
+            d = np.abs(g.astype(np.int32) - r.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_fcm_u8_f64_and_errors(ivxlib, oracle):
+    from invesalius3_amd import invesalius_rs as mips
+    img = synth_volume((12, 20, 66), seed=56)
+    u = ((img.astype(np.int32) + 1024) // 17).clip(0, 255).astype(np.uint8)
+    for tmip in (0, 2):
+        g, r = _out(u, 1), _out(u, 1)
+        mips.fast_countour_mip(u, 1.0, 1, 100, 100, tmip, g)
+        oracle.fast_countour_mip(u, 1.0, 1, 100, 100, tmip, r)
+        assert np.array_equal(g, r)
+    with pytest.raises(ValueError):  # NumCast::from(700) into u8 panics in the reference
+        mips.fast_countour_mip(u, 1.0, 1, 100, 100, 1, _out(u, 1))
+    f = img.astype(np.float64) * 0.37
+    g, r = _out(f, 2), _out(f, 2)
+    mips.fast_countour_mip(f, 1.0, 2, 100.0, 50.0, 0, g)
+    oracle.fast_countour_mip(f, 1.0, 2, 100.0, 50.0, 0, r)
+    np.testing.assert_allclose(g, r, rtol=1e-6)
+    with pytest.raises(TypeError):
+        mips.mida(img, 0, 1, 1, np.zeros((20, 66), np.uint8))
+    with pytest.raises(OverflowError):
+        mips.mida(img, 0, 40000, 1, _out(img, 0))
+    # steep gradient: contour intensity exceeds int16 -> the reference panics on NumCast -> ValueError
+    steep = np.zeros((4, 4, 8), np.int16)
+    steep[:, :, ::2] = 32767
+    steep[:, :, 1::2] = -32768
+    steep[:, ::2, :] = 0
+    with pytest.raises(ValueError):
+        oracle.fast_countour_mip(steep, 1.0, 0, 1, 1, 0, _out(steep, 0))
+    with pytest.raises(ValueError):
+        mips.fast_countour_mip(steep, 1.0, 0, 1, 1, 0, _out(steep, 0))
+
+
+def test_full_size_512_mida_properties(ivxlib):
+    """512^3: MIDA of a volume whose every ray is constant equals that constant (alpha-composite of a flat ray);
+    MIDA output is bounded by the ray's min/max."""
+    from invesalius3_amd import invesalius_rs as mips
+    rng = np.random.default_rng(12)
+    plane = rng.integers(-1000, 2000, (512, 512), dtype=np.int16)
+    vol = np.broadcast_to(plane, (512, 512, 512)).copy()
+    out = np.zeros((512, 512), np.int16)
+    mips.mida(vol, 0, 300, 600, out)
+    assert np.all(np.abs(out.astype(np.int32) - plane) <= 1)
+    vol2 = rng.integers(-1024, 3072, (512, 512, 512), dtype=np.int16)
+    for axis in range(3):
+        o = np.zeros((512, 512), np.int16)
+        mips.mida(vol2, axis, 500, 800, o)
+        assert np.all(o <= vol2.max(axis)) and np.all(o >= vol2.min())
