@@ -215,6 +215,50 @@ int ivx_floodfill_threshold_inplace(int dtype, void *data, const int64_t shape[3
                                     const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1,
                                     double fill, const uint8_t *strct, const int64_t sshape[3]);
 
+/* ------------------------------------------------------------------------------------------------
+ * fill small holes
+ *   replaces fill_holes_automatically_internal invesalius_rs/src/floodfill.rs:51-94
+ *   (labels come from scipy.ndimage.label on the host, invesalius/data/mask.py:529-531)
+ * *modified = 1 when any label had 0 < size <= max_size (then voxels whose label size <= max_size -> 254,
+ * label 0 included: faithful quirk).  A label > nlabels is IVX_ERANGE (the reference panics).
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_fill_holes(uint8_t *mask, const uint32_t *labels, int64_t n, uint32_t nlabels, uint32_t max_size,
+                       uint32_t *sizes /* device, nlabels+1 */, int *status2 /* device: [0] modified, [1] error */,
+                       void *stream);
+int ivx_fill_holes_automatically(uint8_t *mask, const int64_t shape[3], const int64_t mask_strides[3],
+                                 const uint32_t *labels, const int64_t label_strides[3], uint32_t nlabels,
+                                 uint32_t max_size, int *modified);
+
+/* ------------------------------------------------------------------------------------------------
+ * watershed pre- and post-processing (the deterministic parts of do_watershed,
+ * invesalius/data/watershed_process.py:19-60)
+ *   ivx_dev_lut_u16        get_LUT_value / get_LUT_value_255 (imagedata_utils.py:540-564): np.piecewise on an
+ *                          int16 array -> int16 (float64 expression truncated toward zero) -> .astype(uint16)
+ *   ivx_dev_shift_min_u16  (image - image.min()).astype("uint16")   (watershed_process.py:47,55)
+ *   ivx_dev_morph_gradient_u16  scipy.ndimage.morphological_gradient(size) == max - min filter, mode="reflect"
+ *   ivx_dev_watershed_merge     merge rule of styles.py:2147-2152: tmp (labels 0/1/2) into mask
+ *   ivx_watershed_prepare  host form: LUT or min-shift, then optional gradient, -> the uint16 cost image
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_lut_u16(const int16_t *img, int64_t n, double window, double level, int top255, uint16_t *out,
+                    void *stream);
+int ivx_dev_shift_min_u16(const int16_t *img, int64_t n, int imin, uint16_t *out, void *stream);
+int ivx_dev_morph_gradient_u16(const uint16_t *in, int64_t dz, int64_t dy, int64_t dx, int size, uint16_t *out,
+                               void *stream);
+int ivx_dev_watershed_merge(uint8_t *mask, const uint8_t *tmp, int64_t n, int overwrite, void *stream);
+int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int use_ww_wl,
+                          double window, double level, int gradient_size, uint16_t *out);
+int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mask_strides[3], const uint8_t *tmp,
+                        const int64_t tmp_strides[3], int overwrite);
+
+/* ------------------------------------------------------------------------------------------------
+ * confidence-connected region growing support (do_rg_confidence, invesalius/data/styles.py:3220-3251):
+ * exact integer count / sum / sum-of-squares of image[sel != 0]; dst[v] = 1 where src[v] == value.
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_masked_stats_i16(const int16_t *img, const uint8_t *sel, int64_t n, int64_t out3[3], void *stream);
+int ivx_dev_or_equal_u8(uint8_t *dst, const uint8_t *src, int64_t n, int value, void *stream);
+/* dst[v] = fill where src[v] == value  (mask[out_mask.astype(bool)] = 254, styles.py:3214,3249) */
+int ivx_dev_flood_apply_where(uint8_t *dst, const uint8_t *src, int64_t n, int value, int fill, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

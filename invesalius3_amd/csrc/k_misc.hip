@@ -1,0 +1,322 @@
+// k_misc.hip -- the small streaming kernels around the segmentation tools.
+//
+//   fill_holes        fill_holes_automatically_internal           invesalius_rs/src/floodfill.rs:51-94
+//   lut_u16           get_LUT_value(...).astype("uint16")         invesalius/data/imagedata_utils.py:555-564,
+//                                                                 invesalius/data/watershed_process.py:34,42
+//   shift_min_u16     (image - image.min()).astype("uint16")      invesalius/data/watershed_process.py:47,55
+//   morph_gradient    scipy.ndimage.morphological_gradient(size)  invesalius/data/watershed_process.py:36-38,49-51
+//                     == maximum_filter - minimum_filter, mode="reflect", uint16
+//   watershed_merge   styles.py:2147-2152 (3-D) / 1984-1989 (2-D)
+//   masked_stats      np.mean / np.std over image[bool_mask]      invesalius/data/styles.py:3237-3238
+//
+// All are HBM streaming passes (bytes per voxel in DESIGN.md section 3); no LDS tiling is needed except for the
+// gradient, whose 27 taps are served by L1/L2 (each row is re-read by its y/z neighbours while still cached).
+#include "ivx_internal.h"
+
+namespace {
+
+static inline int grid_for(int64_t n, int per_thread = 1) {
+    const int64_t b = ivx::cdiv(ivx::cdiv(n, per_thread), 256);
+    return (int)(b < 1 ? 1 : (b < 65536 ? b : 65536));
+}
+
+// ---- fill holes ---------------------------------------------------------------------------------------------
+// histogram of u32 labels.  Neighbouring voxels mostly share a label (background, big regions), so a wave first
+// checks whether all its lanes hold the same label and then issues ONE atomic for the whole wave.
+__global__ __launch_bounds__(256) void k_label_hist(const uint32_t *__restrict__ labels, int64_t n, uint32_t nlabels,
+                                                    uint32_t *__restrict__ sizes, int *__restrict__ status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        bool live = i < n;
+        const uint32_t l = live ? labels[i] : 0xffffffffu;
+        if (live && l > nlabels) {
+            atomicMin(status, IVX_ERANGE); // the reference indexes sizes[label]: out-of-bounds panic
+            live = false;
+        }
+        if (!__ballot(live)) continue; // wave-uniform
+        const uint32_t first = __shfl(l, __builtin_ctzll(__ballot(live)), 64);
+        const unsigned long long same = __ballot(live && l == first);
+        const unsigned long long livem = __ballot(live);
+        if (same == livem) {
+            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(livem)) atomicAdd(&sizes[first], (uint32_t)__popcll(livem));
+        } else if (live) {
+            atomicAdd(&sizes[l], 1u);
+        }
+    }
+}
+__global__ void k_any_small(const uint32_t *__restrict__ sizes, uint32_t nlabels, uint32_t max_size, int *__restrict__ modified) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= (int64_t)nlabels && sizes[i] > 0 && sizes[i] <= max_size) *modified = 1; // benign race: all write 1
+}
+__global__ __launch_bounds__(256) void k_fill_small(uint8_t *__restrict__ mask, const uint32_t *__restrict__ labels,
+                                                    int64_t n, const uint32_t *__restrict__ sizes, uint32_t max_size,
+                                                    const int *__restrict__ modified) {
+    if (!*modified) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (sizes[labels[i]] <= max_size) mask[i] = 254; // includes label 0 when it is small (faithful quirk Q5)
+}
+
+// ---- window / level LUT -------------------------------------------------------------------------------------
+// np.piecewise on an int16 array: result dtype int16, the float64 expression is truncated toward zero.
+__global__ __launch_bounds__(256) void k_lut_u16(const int16_t *__restrict__ img, int64_t n, double window, double level,
+                                                 double top, uint16_t *__restrict__ out) {
+    const double lo = level - 0.5 - (window - 1.0) / 2.0;
+    const double hi = level - 0.5 + (window - 1.0) / 2.0;
+    const int16_t topv = (int16_t)top;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double d = (double)img[i];
+        int16_t r;
+        if (d <= lo) r = 0;
+        else if (d > hi) r = topv;
+        else r = (int16_t)(((d - (level - 0.5)) / (window - 1.0) + 0.5) * top);
+        out[i] = (uint16_t)r; // .astype("uint16")
+    }
+}
+__global__ __launch_bounds__(256) void k_shift_min_u16(const int16_t *__restrict__ img, int64_t n, int imin,
+                                                       uint16_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint16_t m = (uint16_t)(int16_t)imin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (uint16_t)((uint16_t)img[i] - m); // int16 wrap-around then .astype("uint16") == mod 2^16
+}
+
+// ---- morphological gradient, cubic flat footprint of odd `size`, mode="reflect" --------------------------------
+__device__ __forceinline__ int64_t reflect(int64_t i, int64_t n) { // d c b a | a b c d | d c b a
+    if (n == 1) return 0;
+    const int64_t p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_morph_gradient(const T *__restrict__ in, int64_t dz, int64_t dy, int64_t dx, int r,
+                                                        T *__restrict__ out) {
+    const int64_t total = dz * dy * dx;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t x = i % dx, q = i / dx, y = q % dy, z = q / dy;
+        T mx = in[i], mn = in[i];
+        for (int c = -r; c <= r; c++) {
+            const int64_t zz = reflect(z + c, dz);
+            for (int b = -r; b <= r; b++) {
+                const int64_t yy = reflect(y + b, dy);
+                const T *row = in + (zz * dy + yy) * dx;
+                for (int a = -r; a <= r; a++) {
+                    const T v = row[reflect(x + a, dx)];
+                    mx = v > mx ? v : mx;
+                    mn = v < mn ? v : mn;
+                }
+            }
+        }
+        out[i] = (T)(mx - mn);
+    }
+}
+
+// ---- watershed merge -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ws_merge(uint8_t *__restrict__ mask, const uint8_t *__restrict__ tmp, int64_t n,
+                                                  int overwrite) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint8_t t = tmp[i];
+        uint8_t m = mask[i];
+        if (overwrite) m = t == 1 ? 253 : 0;
+        else {
+            const bool sel = m == 0 || m == 2 || m == 253;
+            if (t == 2 && sel) m = 2;
+            if (t == 1 && sel) m = 253;
+        }
+        mask[i] = m;
+    }
+}
+
+// ---- masked statistics: count, sum, sum of squares as exact integers ---------------------------------------------
+__global__ __launch_bounds__(256) void k_masked_stats(const int16_t *__restrict__ img, const uint8_t *__restrict__ sel,
+                                                      int64_t n, unsigned long long *__restrict__ acc) {
+    long long cnt = 0, s = 0, s2 = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (sel[i]) {
+            const long long v = img[i];
+            cnt++;
+            s += v;
+            s2 += v * v;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, 64);
+        s += __shfl_xor(s, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&acc[0], (unsigned long long)cnt);
+        atomicAdd(&acc[1], (unsigned long long)s); // two's complement: wraps back to the signed sum
+        atomicAdd(&acc[2], (unsigned long long)s2);
+    }
+}
+__global__ __launch_bounds__(256) void k_set_where(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t n,
+                                                   int value, int fill) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (src[i] == (uint8_t)value) dst[i] = (uint8_t)fill;
+}
+__global__ __launch_bounds__(256) void k_or_eq(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t n, int value) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (src[i] == (uint8_t)value) dst[i] = 1;
+}
+
+} // namespace
+
+extern "C" int ivx_dev_fill_holes(uint8_t *mask, const uint32_t *labels, int64_t n, uint32_t nlabels, uint32_t max_size,
+                                  uint32_t *sizes, int *status2 /* device: [0] modified, [1] error */, void *stream) {
+    hipStream_t st = ivx::S(stream);
+    IVX_HIP(hipMemsetAsync(sizes, 0, ((size_t)nlabels + 1) * 4, st));
+    IVX_HIP(hipMemsetAsync(status2, 0, 8, st));
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_label_hist, dim3(grid_for(n, 4)), dim3(256), 0, st, labels, n, nlabels, sizes, status2 + 1);
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_any_small, dim3((unsigned)ivx::cdiv((int64_t)nlabels + 1, 256)), dim3(256), 0, st, sizes, nlabels,
+                       max_size, status2);
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fill_small, dim3(grid_for(n, 4)), dim3(256), 0, st, mask, labels, n, sizes, max_size, status2);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+extern "C" int ivx_fill_holes_automatically(uint8_t *mask, const int64_t shape[3], const int64_t mst[3],
+                                            const uint32_t *labels, const int64_t lst[3], uint32_t nlabels,
+                                            uint32_t max_size, int *modified) {
+    using namespace ivx;
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+    *modified = 0;
+    void *d_mask, *d_lab, *d_sizes, *d_stat;
+    int rc;
+    if ((rc = ws_get(WS_OUT, n, &d_mask))) return rc;
+    if ((rc = ws_get(WS_IN, n * 4, &d_lab))) return rc;
+    if ((rc = ws_get(WS_AUX0, ((size_t)nlabels + 1) * 4, &d_sizes))) return rc;
+    if ((rc = ws_get(WS_SMALL, 256, &d_stat))) return rc;
+    if ((rc = upload_strided(d_mask, mask, shape, mst, 1, WS_OUT))) return rc;
+    if ((rc = upload_strided(d_lab, labels, shape, lst, 4, WS_IN))) return rc;
+    if ((rc = ivx_dev_fill_holes((uint8_t *)d_mask, (const uint32_t *)d_lab, (int64_t)n, nlabels, max_size,
+                                 (uint32_t *)d_sizes, (int *)d_stat, nullptr)))
+        return rc;
+    int h[2] = {0, 0};
+    IVX_HIP(hipMemcpy(h, d_stat, 8, hipMemcpyDeviceToHost));
+    IVX_REQUIRE(h[1] == 0, IVX_ERANGE, "fill_holes: a label exceeds nlabels (the reference panics on sizes[label])");
+    *modified = h[0];
+    if (h[0]) return download_strided(mask, shape, mst, d_mask, 1, WS_OUT);
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_lut_u16(const int16_t *img, int64_t n, double window, double level, int top255, uint16_t *out,
+                               void *stream) {
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_lut_u16, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), img, n, window, level,
+                       top255 ? 255.0 : window, out);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+extern "C" int ivx_dev_shift_min_u16(const int16_t *img, int64_t n, int imin, uint16_t *out, void *stream) {
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_shift_min_u16, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), img, n, imin, out);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+extern "C" int ivx_dev_morph_gradient_u16(const uint16_t *in, int64_t dz, int64_t dy, int64_t dx, int size, uint16_t *out,
+                                          void *stream) {
+    IVX_REQUIRE(size >= 1 && (size & 1), IVX_EINVAL, "morphological_gradient: only odd footprint sizes are supported (got %d)", size);
+    const int64_t n = dz * dy * dx;
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_morph_gradient<uint16_t>, dim3(grid_for(n)), dim3(256), 0, ivx::S(stream), in, dz, dy, dx, size / 2, out);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+extern "C" int ivx_dev_watershed_merge(uint8_t *mask, const uint8_t *tmp, int64_t n, int overwrite, void *stream) {
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_ws_merge, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), mask, tmp, n, overwrite);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+extern "C" int ivx_dev_masked_stats_i16(const int16_t *img, const uint8_t *sel, int64_t n, int64_t out3[3], void *stream) {
+    void *d_acc;
+    int rc = ivx::ws_get(ivx::WS_SMALL, 256, &d_acc);
+    if (rc) return rc;
+    hipStream_t st = ivx::S(stream);
+    unsigned long long *acc = (unsigned long long *)((char *)d_acc + 128);
+    IVX_HIP(hipMemsetAsync(acc, 0, 24, st));
+    if (n) {
+        hipLaunchKernelGGL(k_masked_stats, dim3(grid_for(n, 8)), dim3(256), 0, st, img, sel, n, acc);
+        IVX_LAUNCH_CHECK();
+    }
+    IVX_HIP(hipMemcpyAsync(out3, acc, 24, hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipStreamSynchronize(st));
+    return IVX_OK;
+}
+extern "C" int ivx_dev_or_equal_u8(uint8_t *dst, const uint8_t *src, int64_t n, int value, void *stream) {
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_or_eq, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), dst, src, n, value);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_apply_where(uint8_t *dst, const uint8_t *src, int64_t n, int value, int fill, void *stream) {
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_set_where, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), dst, src, n, value, fill);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+// host forms used by the watershed_process mirror ---------------------------------------------------------------------
+extern "C" int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int use_ww_wl,
+                                     double window, double level, int gradient_size /* 0 = none */, uint16_t *out) {
+    using namespace ivx;
+    const int64_t n = shape[0] * shape[1] * shape[2];
+    if (n == 0) return IVX_OK;
+    void *d_img, *d_a, *d_b;
+    int rc;
+    if ((rc = ws_get(WS_IN, (size_t)n * 2, &d_img))) return rc;
+    if ((rc = ws_get(WS_AUX0, (size_t)n * 2, &d_a))) return rc;
+    if ((rc = upload_strided(d_img, img, shape, strides, 2, WS_IN))) return rc;
+    if (use_ww_wl) {
+        if ((rc = ivx_dev_lut_u16((const int16_t *)d_img, n, window, level, 0, (uint16_t *)d_a, nullptr))) return rc;
+    } else {
+        float *mm;
+        void *d_small;
+        if ((rc = ws_get(WS_SMALL, 256, &d_small))) return rc;
+        mm = (float *)d_small;
+        if ((rc = ivx_dev_minmax_f32(IVX_I16, d_img, n, mm, nullptr))) return rc;
+        float h[2];
+        IVX_HIP(hipMemcpy(h, mm, 8, hipMemcpyDeviceToHost));
+        if ((rc = ivx_dev_shift_min_u16((const int16_t *)d_img, n, (int)h[0], (uint16_t *)d_a, nullptr))) return rc;
+    }
+    void *res = d_a;
+    if (gradient_size > 0) {
+        if ((rc = ws_get(WS_AUX1, (size_t)n * 2, &d_b))) return rc;
+        if ((rc = ivx_dev_morph_gradient_u16((const uint16_t *)d_a, shape[0], shape[1], shape[2], gradient_size,
+                                             (uint16_t *)d_b, nullptr)))
+            return rc;
+        res = d_b;
+    }
+    IVX_HIP(hipDeviceSynchronize());
+    IVX_HIP(hipMemcpy(out, res, (size_t)n * 2, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+
+extern "C" int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mst[3], const uint8_t *tmp,
+                                   const int64_t tst[3], int overwrite) {
+    using namespace ivx;
+    const int64_t n = shape[0] * shape[1] * shape[2];
+    if (n == 0) return IVX_OK;
+    void *d_m, *d_t;
+    int rc;
+    if ((rc = ws_get(WS_OUT, (size_t)n, &d_m))) return rc;
+    if ((rc = ws_get(WS_IN, (size_t)n, &d_t))) return rc;
+    if ((rc = upload_strided(d_m, mask, shape, mst, 1, WS_OUT))) return rc;
+    if ((rc = upload_strided(d_t, tmp, shape, tst, 1, WS_IN))) return rc;
+    if ((rc = ivx_dev_watershed_merge((uint8_t *)d_m, (const uint8_t *)d_t, n, overwrite, nullptr))) return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    return download_strided(mask, shape, mst, d_m, 1, WS_OUT);
+}

@@ -186,6 +186,36 @@ class DeviceVolume:
             L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.mask.ptr, ctypes.c_double(select_value), st))
         return rounds.value
 
+    def region_grow_confidence(self, seed_xyz, strct, confid_mult=2.5, confid_iters=3, select_value=254):
+        """do_rg_confidence (invesalius/data/styles.py:3220-3251): `confid_iters` rounds of
+        mean +- confid_mult * std over the grown region -> floodfill_threshold into the SAME out_mask (never cleared:
+        SURVEY quirk Q4).  Statistics are exact integer sums on the GPU; mean/std are formed in float64 on the host
+        (std = sqrt(E[x^2] - mean^2): differs from numpy's two-pass value by rounding only, far below the int()
+        truncation the wrapper applies to t0/t1)."""
+        lib = L.lib()
+        x, y, z = (int(v) for v in seed_xyz)
+        sel = np.zeros(self.shape, np.uint8)
+        sel[max(z - 1, 0):z + 2, max(y - 1, 0):y + 2, max(x - 1, 0):x + 2] = 1  # styles.py:3226-3235
+        d_sel = DeviceBuffer(self.n)
+        d_sel.upload(sel)
+        rounds = 0
+        for _ in range(int(confid_iters)):
+            acc = (ctypes.c_int64 * 3)()
+            L.check(lib.ivx_dev_masked_stats_i16(self.image.ptr, d_sel.ptr, c64(self.n), acc, self.stream))
+            cnt, s1, s2 = int(acc[0]), int(acc[1]), int(acc[2])
+            mean = s1 / cnt
+            var = max(s2 / cnt - mean * mean, 0.0)
+            std = float(np.sqrt(var))
+            t0, t1 = mean - std * confid_mult, mean + std * confid_mult
+            rounds += self.region_grow([(x, y, z)], t0, t1, strct, fill=1, select_value=None)
+            L.check(lib.ivx_dev_or_equal_u8(d_sel.ptr, self.out_mask.ptr, c64(self.n), 1, self.stream))
+        if select_value is not None:
+            L.check(lib.ivx_dev_flood_apply_where(self.mask.ptr, self.out_mask.ptr, c64(self.n), 1, int(select_value),
+                                                  self.stream))
+        self.sync()
+        d_sel.close()
+        return rounds
+
     def reached_count(self) -> int:
         n = ctypes.c_int64(0)
         L.check(L.lib().ivx_dev_flood_count(ctypes.byref(self.plan), self.reached.ptr, ctypes.byref(n), self.stream))

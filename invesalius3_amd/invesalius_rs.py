@@ -124,3 +124,18 @@ def fast_countour_mip(image: np.ndarray, n: float, axis: int, wl: int, ww: int, 
     L.check(L.lib().ivx_fast_countour_mip(code, L.ptr(image), L.i64(image.shape), L.i64(image.strides),
                                           ctypes.c_float(n), int(axis), ctypes.c_double(wl), ctypes.c_double(ww),
                                           int(tmip), L.ptr(out), L.i64(out.strides)), "fast_countour_mip")
+
+
+def fill_holes_automatically(mask: np.ndarray, labels: np.ndarray, nlabels: int, max_size: int) -> bool:
+    """fill_holes_automatically (floodfill_py.rs:233-249 -> floodfill.rs:51-94): voxels whose uint32 label has
+    0 < size <= max_size become 254 in `mask` (in place); returns whether anything was modified."""
+    if mask.dtype != np.uint8 or labels.dtype != np.uint32:
+        raise TypeError("mask must be uint8 and labels uint32")
+    if mask.ndim != 3 or tuple(mask.shape) != tuple(labels.shape):
+        raise TypeError("mask and labels must be 3-D arrays of the same shape")
+    modified = ctypes.c_int(0)
+    L.check(L.lib().ivx_fill_holes_automatically(
+        L.ptr(mask), L.i64(mask.shape), L.i64(mask.strides), L.ptr(labels), L.i64(labels.strides),
+        ctypes.c_uint32(int(nlabels)), ctypes.c_uint32(int(max_size)), ctypes.byref(modified)),
+        "fill_holes_automatically")
+    return bool(modified.value)

@@ -1,0 +1,149 @@
+"""GPU parity: fill holes, window/level LUT, min-shift, morphological gradient, watershed merge, confidence region
+growing and the resident DeviceVolume pipeline -- against numpy / scipy / the C oracle, bit-exact."""
+import numpy as np
+import pytest
+from scipy import ndimage
+from scipy.ndimage import generate_binary_structure
+
+from conftest import synth_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fill_holes_reference_fixture(ivxlib):
+    """tests/test_segmentation_tools.py:105-134 through the GPU path."""
+    from invesalius3_amd import invesalius_rs as floodfill
+    mask_2d = np.ones((7, 7), dtype=np.uint8)
+    mask_2d[3, 3] = 0
+    mask = mask_2d[np.newaxis, ...].copy()
+    labels_2d, _ = ndimage.label(mask_2d == 0, structure=np.ones((3, 3), dtype=np.uint8), output=np.uint32)
+    labels = labels_2d[np.newaxis, ...]
+    ret = floodfill.fill_holes_automatically(mask, labels, int(labels.max()), 1)
+    expected = np.ones((1, 7, 7), dtype=np.uint8)
+    expected[0, 3, 3] = 254
+    assert ret and np.array_equal(mask, expected)
+
+
+@pytest.mark.parametrize("max_size", [0, 3, 50, 10 ** 9])
+def test_fill_holes_matches_oracle(ivxlib, oracle, max_size):
+    """Mask.fill_holes_auto (mask.py:519-562): label the background, fill the small components."""
+    from invesalius3_amd import invesalius_rs as floodfill
+    img = synth_volume((30, 50, 70), seed=61)
+    big = np.zeros((31, 51, 71), np.uint8)
+    big[1:, 1:, 1:] = np.where(img > -820, 255, 0)
+    mg = big.copy()
+    mr = big.copy()
+    labels, nlabels = ndimage.label(big[1:, 1:, 1:] < 127, structure=generate_binary_structure(3, 1), output=np.uint32)
+    rg = floodfill.fill_holes_automatically(mg[1:, 1:, 1:], labels, nlabels, max_size)
+    rr = oracle.fill_holes_automatically(mr[1:, 1:, 1:], labels, nlabels, max_size)
+    assert rg == rr
+    assert np.array_equal(mg, mr)
+    with pytest.raises(IndexError):
+        floodfill.fill_holes_automatically(mg[1:, 1:, 1:], labels, max(int(nlabels) - 1, 0), 5)
+
+
+@pytest.mark.parametrize("ww,wl", [(400, 300), (2000, 500), (255, 127), (80.5, 40.25)])
+def test_lut_and_minshift_cost_images(ivxlib, oracle, ww, wl):
+    from invesalius3_amd import watershed_process as wp
+    img = synth_volume((12, 33, 47), seed=62)
+    exp = oracle.get_LUT_value(img, ww, wl).astype("uint16")  # watershed_process.py:34
+    assert np.array_equal(wp.cost_image(img, True, wl, ww), exp)
+    exp2 = (img - img.min()).astype("uint16")  # watershed_process.py:47
+    assert np.array_equal(wp.cost_image(img, False, wl, ww), exp2)
+    sl = img[5]  # 2-D variant (styles.py:1926-2000)
+    assert np.array_equal(wp.cost_image(sl, True, wl, ww), oracle.get_LUT_value(sl, ww, wl).astype("uint16"))
+
+
+@pytest.mark.parametrize("size", [1, 3, 5])
+def test_morphological_gradient_matches_scipy(ivxlib, oracle, size):
+    from invesalius3_amd import watershed_process as wp
+    img = synth_volume((9, 21, 40), seed=63)
+    lut = oracle.get_LUT_value(img, 600, 200).astype("uint16")
+    exp = ndimage.morphological_gradient(lut, size)  # watershed_process.py:36-38
+    assert exp.dtype == np.uint16
+    assert np.array_equal(wp.cost_image(img, True, 200, 600, size), exp)
+    exp2 = ndimage.morphological_gradient((img - img.min()).astype("uint16"), size)
+    assert np.array_equal(wp.cost_image(img, False, 0, 0, size), exp2)
+    if size == 3:
+        sl = img[4]
+        assert np.array_equal(wp.cost_image(sl, False, 0, 0, 3), ndimage.morphological_gradient((sl - sl.min()).astype("uint16"), 3))
+
+
+@pytest.mark.parametrize("overwrite", [False, True])
+def test_watershed_merge_rule(ivxlib, oracle, overwrite):
+    from invesalius3_amd import watershed_process as wp
+    rng = np.random.default_rng(64)
+    big = rng.choice(np.array([0, 1, 2, 253, 254, 255, 7], np.uint8), (11, 21, 31))
+    tmp = rng.integers(0, 3, (10, 20, 30)).astype(np.uint8)
+    mg, mr = big.copy(), big.copy()
+    wp.merge(mg[1:, 1:, 1:], tmp, overwrite)
+    oracle.watershed_merge(mr[1:, 1:, 1:], tmp, overwrite)
+    assert np.array_equal(mg, mr)
+
+
+def test_do_watershed_ift_pipeline_matches_reference_calls(ivxlib, tmp_path):
+    """tests/test_segmentation_tools.py:170-213 analogue for the IFT branch: same memmap + queue protocol; the
+    GPU-made cost image feeds the same scipy call, so the labels equal the reference pipeline's."""
+    import queue
+    from invesalius3_amd import watershed_process as wp
+    image = np.zeros((5, 5, 5), dtype=np.int16)
+    image[2, 2, 2] = 100
+    image[1:4, 1:4, 1:4] += 50
+    markers = np.zeros((5, 5, 5), dtype=np.uint8)
+    markers[2, 2, 2] = 1
+    markers[0, 0, 0] = 2
+    tfile = str(tmp_path / "ws.dat")
+    np.memmap(tfile, shape=image.shape, dtype="uint8", mode="w+").flush()
+    q = queue.Queue()
+    bstruct = generate_binary_structure(3, 1)
+    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", 3, False, 0, 0, q)
+    assert q.get() == 1
+    got = np.array(np.memmap(tfile, shape=image.shape, dtype="uint8", mode="r"))
+    exp = ndimage.watershed_ift((image - image.min()).astype("uint16"), markers.astype("int8"), bstruct)
+    assert np.array_equal(got, exp.astype(np.uint8))
+    assert (got == 1).sum() == 27 and (got == 2).sum() == 98  # SURVEY 8c golden counts
+
+
+def test_device_volume_pipeline_matches_oracle(ivxlib, oracle):
+    """resident pipeline == host pipeline == oracle: threshold -> 26-conn region grow -> select -> MC"""
+    from invesalius3_amd.device import DeviceVolume
+    img = synth_volume((40, 64, 96), seed=65)
+    strct = generate_binary_structure(3, 3)
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    seed = (int(x), int(y), int(z))
+    vol = DeviceVolume(img, spacing=(0.5, 0.5, 2.0))
+    vol.threshold(-700, 3071)
+    vol.region_grow([seed], -700, 3071, strct, fill=1, select_value=254)
+    tri = vol.marching_cubes(from_binary=True, download=True)
+    m_ref = np.zeros((41, 65, 97), np.uint8)
+    oracle.set_mask_threshold_volume(m_ref, img, (-700, 3071))
+    out_ref = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold(img, [seed], -700, 3071, 1, strct, out_ref)
+    m_ref[1:, 1:, 1:][out_ref.astype(bool)] = 254
+    assert np.array_equal(vol.download_out_mask(), out_ref)
+    assert np.array_equal(vol.download_mask(), m_ref[1:, 1:, 1:])
+    assert vol.reached_count() == int(out_ref.sum())
+    tri_ref = oracle.create_surface_piece(None, m_ref, slice(0, 40), (0.5, 0.5, 2.0), 0, 0, True)
+    assert tri.shape == tri_ref.shape and np.array_equal(tri, tri_ref)
+    # two-iso "Default" mode on the resident image
+    tri2 = vol.marching_cubes(from_binary=False, min_value=-700, max_value=3071, download=True)
+    tri2_ref = oracle.create_surface_piece(img, m_ref, slice(0, 40), (0.5, 0.5, 2.0), -700, 3071, False)
+    assert np.array_equal(tri2, tri2_ref)
+    vol.close()
+
+
+def test_confidence_region_growing_matches_oracle(ivxlib, oracle):
+    """do_rg_confidence (styles.py:3220-3251) incl. quirk Q4 (out_mask never cleared between iterations)"""
+    from invesalius3_amd.device import DeviceVolume
+    img = synth_volume((32, 48, 80), seed=66)
+    strct = generate_binary_structure(3, 2)
+    for pick in (np.argmax(img), img.size // 2 + 1234):
+        z, y, x = np.unravel_index(int(pick), img.shape)
+        vol = DeviceVolume(img)
+        vol.region_grow_confidence((int(x), int(y), int(z)), strct, 2.5, 3, select_value=254)
+        ref = oracle.do_rg_confidence(img, (int(x), int(y), int(z)), strct, 2.5, 3)
+        assert np.array_equal(vol.download_out_mask(), ref)
+        exp_mask = np.zeros(img.shape, np.uint8)
+        exp_mask[ref.astype(bool)] = 254
+        assert np.array_equal(vol.download_mask(), exp_mask)
+        vol.close()
