@@ -113,7 +113,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_slab = os.environ.get("IVX_FORCE_SLAB") == "1"  # exercise the sharded path (torch + RCCL) at world 1
+    if world > 1 or force_slab:
         import torch
         import torch.distributed as dist  # RCCL
 
@@ -126,15 +127,15 @@ def main():
     from invesalius3_amd.device import DeviceVolume
 
     L.require_device()
-    L.set_device(local_rank if world > 1 else 0)
+    L.set_device(local_rank if dist is not None else 0)
     n = args.size
     shape = (n, n, n)
     img = synth_v512(shape, z_offset=rank * n, z_total=world * n)
     z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
-    seed = (int(x), int(y), int(z))
+    seed = (int(x), int(y), int(z) + rank * n)  # global (x, y, z): every rank seeds the brightest voxel of its slab
     strct = generate_binary_structure(3, 3)
 
-    if world > 1:
+    if dist is not None:
         from invesalius3_amd.parallel import SlabVolume
 
         vol = SlabVolume(img, rank, world, dist)

@@ -242,11 +242,11 @@ int ivx_fill_holes_automatically(uint8_t *mask, const int64_t shape[3], const in
 int ivx_dev_lut_u16(const int16_t *img, int64_t n, double window, double level, int top255, uint16_t *out,
                     void *stream);
 int ivx_dev_shift_min_u16(const int16_t *img, int64_t n, int imin, uint16_t *out, void *stream);
-int ivx_dev_morph_gradient_u16(const uint16_t *in, int64_t dz, int64_t dy, int64_t dx, int size, uint16_t *out,
-                               void *stream);
+int ivx_dev_morph_gradient_u16(const uint16_t *in, int64_t dz, int64_t dy, int64_t dx, const int size[3],
+                               uint16_t *out, void *stream);
 int ivx_dev_watershed_merge(uint8_t *mask, const uint8_t *tmp, int64_t n, int overwrite, void *stream);
 int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int use_ww_wl,
-                          double window, double level, int gradient_size, uint16_t *out);
+                          double window, double level, const int gradient_size[3] /* NULL = none */, uint16_t *out);
 int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mask_strides[3], const uint8_t *tmp,
                         const int64_t tmp_strides[3], int overwrite);
 

@@ -92,19 +92,19 @@ __device__ __forceinline__ int64_t reflect(int64_t i, int64_t n) { // d c b a | 
     return i < n ? i : p - 1 - i;
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_morph_gradient(const T *__restrict__ in, int64_t dz, int64_t dy, int64_t dx, int r,
-                                                        T *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_morph_gradient(const T *__restrict__ in, int64_t dz, int64_t dy, int64_t dx, int rz,
+                                                        int ry, int rx, T *__restrict__ out) {
     const int64_t total = dz * dy * dx;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t x = i % dx, q = i / dx, y = q % dy, z = q / dy;
         T mx = in[i], mn = in[i];
-        for (int c = -r; c <= r; c++) {
+        for (int c = -rz; c <= rz; c++) {
             const int64_t zz = reflect(z + c, dz);
-            for (int b = -r; b <= r; b++) {
+            for (int b = -ry; b <= ry; b++) {
                 const int64_t yy = reflect(y + b, dy);
                 const T *row = in + (zz * dy + yy) * dx;
-                for (int a = -r; a <= r; a++) {
+                for (int a = -rx; a <= rx; a++) {
                     const T v = row[reflect(x + a, dx)];
                     mx = v > mx ? v : mx;
                     mn = v < mn ? v : mn;
@@ -225,12 +225,14 @@ extern "C" int ivx_dev_shift_min_u16(const int16_t *img, int64_t n, int imin, ui
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
-extern "C" int ivx_dev_morph_gradient_u16(const uint16_t *in, int64_t dz, int64_t dy, int64_t dx, int size, uint16_t *out,
-                                          void *stream) {
-    IVX_REQUIRE(size >= 1 && (size & 1), IVX_EINVAL, "morphological_gradient: only odd footprint sizes are supported (got %d)", size);
+extern "C" int ivx_dev_morph_gradient_u16(const uint16_t *in, int64_t dz, int64_t dy, int64_t dx, const int size[3],
+                                          uint16_t *out, void *stream) {
+    for (int a = 0; a < 3; a++)
+        IVX_REQUIRE(size[a] >= 1 && (size[a] & 1), IVX_EINVAL,
+                    "morphological_gradient: only odd footprint sizes are supported (got %d)", size[a]);
     const int64_t n = dz * dy * dx;
     if (n == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_morph_gradient<uint16_t>, dim3(grid_for(n)), dim3(256), 0, ivx::S(stream), in, dz, dy, dx, size / 2, out);
+    hipLaunchKernelGGL(k_morph_gradient<uint16_t>, dim3(grid_for(n)), dim3(256), 0, ivx::S(stream), in, dz, dy, dx, size[0] / 2, size[1] / 2, size[2] / 2, out);
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
@@ -271,7 +273,8 @@ extern "C" int ivx_dev_flood_apply_where(uint8_t *dst, const uint8_t *src, int64
 
 // host forms used by the watershed_process mirror ---------------------------------------------------------------------
 extern "C" int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int use_ww_wl,
-                                     double window, double level, int gradient_size /* 0 = none */, uint16_t *out) {
+                                     double window, double level, const int gradient_size[3] /* NULL = none */,
+                                     uint16_t *out) {
     using namespace ivx;
     const int64_t n = shape[0] * shape[1] * shape[2];
     if (n == 0) return IVX_OK;
@@ -293,7 +296,7 @@ extern "C" int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3],
         if ((rc = ivx_dev_shift_min_u16((const int16_t *)d_img, n, (int)h[0], (uint16_t *)d_a, nullptr))) return rc;
     }
     void *res = d_a;
-    if (gradient_size > 0) {
+    if (gradient_size) {
         if ((rc = ws_get(WS_AUX1, (size_t)n * 2, &d_b))) return rc;
         if ((rc = ivx_dev_morph_gradient_u16((const uint16_t *)d_a, shape[0], shape[1], shape[2], gradient_size,
                                              (uint16_t *)d_b, nullptr)))

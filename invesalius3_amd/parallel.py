@@ -1,0 +1,224 @@
+"""Z-slab sharding of the voxel path across GPUs: one process per GPU, RCCL (torch.distributed "nccl") between
+Z-neighbours only.
+
+The decomposition is the reference's own (SurfaceManager.AddNewActor, invesalius/data/surface.py:1362-1380: Z pieces
+plus ONE overlap slice, concatenated):
+
+* threshold            no communication (each rank thresholds its slab and its halo slices).
+* marching cubes       rank g contours the cell layers between its slices and needs ONE slice of rank g+1 (its top
+                       halo); pad_bottom only on rank 0, pad_top only on the last rank; soup = concatenation.
+* region growing       local fix-point -> send the two interior boundary REACHED bit planes to the Z-neighbours ->
+                       OR the received planes into the halo slices -> all-reduce(sum) of "words that gained bits"
+                       -> repeat until 0.  Monotone, so it converges to exactly the single-GPU component.
+
+The orchestration (`slab_region_grow`, `slab_layout`, `slab_mc_args`) is backend-agnostic: the GPU backend is
+`SlabVolume` below; tests/test_parallel_gloo.py drives the same functions with a numpy backend over gloo
+(world_size 2) and checks them against the single-volume oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class SlabLayout:
+    rank: int
+    world: int
+    nz: int          # interior slices owned by this rank
+    hb: int          # 1 if a bottom halo slice (copy of rank-1's last slice) is stored
+    ht: int          # 1 if a top halo slice (copy of rank+1's first slice) is stored
+    z_global0: int   # global index of the first interior slice
+
+    @property
+    def local_dz(self) -> int:
+        return self.nz + self.hb + self.ht
+
+    @property
+    def first_interior(self) -> int:
+        return self.hb
+
+    @property
+    def last_interior(self) -> int:
+        return self.hb + self.nz - 1
+
+
+def slab_layout(rank: int, world: int, nz: int) -> SlabLayout:
+    """Equal slabs of `nz` slices (weak scaling); halo slices towards existing neighbours only."""
+    return SlabLayout(rank, world, nz, 1 if rank > 0 else 0, 1 if rank < world - 1 else 0, rank * nz)
+
+
+def slab_mc_args(lay: SlabLayout, fill_border_holes: bool = True) -> dict:
+    """Marching-cubes piece of this rank in the conventions of create_surface_piece (surface_process.py:96-103):
+    roi = [z_global0, z_global0 + nz + 1) clipped to the volume, i.e. interior slices + the top halo slice."""
+    return dict(z0=lay.hb, z1=lay.hb + lay.nz + lay.ht, roi_start=lay.z_global0,
+                pad_bottom=(lay.rank == 0) and fill_border_holes,
+                pad_top=(lay.rank == lay.world - 1) and fill_border_holes)
+
+
+def local_seeds(lay: SlabLayout, seeds_xyz_global):
+    """Global (x, y, z) seeds -> local coordinates of the seeds that fall inside this rank's stored slices."""
+    out = []
+    for x, y, z in seeds_xyz_global:
+        zl = int(z) - lay.z_global0 + lay.hb
+        if 0 <= zl < lay.local_dz:
+            out.append((int(x), int(y), zl))
+    return out
+
+
+class TorchComm:
+    """Neighbour exchange + scalar all-reduce over torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, dist, rank: int, world: int, device="cpu"):
+        import torch
+
+        self.dist, self.rank, self.world, self.device, self.torch = dist, rank, world, device, torch
+
+    def exchange(self, to_down, to_up):
+        """Send `to_down` to rank-1 and `to_up` to rank+1; returns (from_down, from_up) (None at the ends)."""
+        torch, dist = self.torch, self.dist
+        ops, from_down, from_up = [], None, None
+        if self.rank > 0:
+            from_down = torch.empty_like(to_down)
+            ops += [dist.P2POp(dist.isend, to_down, self.rank - 1), dist.P2POp(dist.irecv, from_down, self.rank - 1)]
+        if self.rank < self.world - 1:
+            from_up = torch.empty_like(to_up)
+            ops += [dist.P2POp(dist.isend, to_up, self.rank + 1), dist.P2POp(dist.irecv, from_up, self.rank + 1)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if self.device != "cpu":
+                torch.cuda.current_stream().synchronize()
+        return from_down, from_up
+
+    def allreduce_sum(self, value: int) -> int:
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+
+def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
+    """Iterate local fix-point + halo exchange to the global fix-point.  `backend` provides
+    flood_run(), export_plane(z) -> tensor, or_plane(z, tensor) -> int (words/voxels that gained bits).
+    Returns the number of exchange rounds."""
+    rounds = 0
+    while True:
+        backend.flood_run()
+        down = backend.export_plane(lay.first_interior) if lay.hb else None
+        up = backend.export_plane(lay.last_interior) if lay.ht else None
+        from_down, from_up = comm.exchange(down, up)
+        changed = 0
+        if from_down is not None:
+            changed += backend.or_plane(0, from_down)
+        if from_up is not None:
+            changed += backend.or_plane(lay.local_dz - 1, from_up)
+        rounds += 1
+        if comm.allreduce_sum(changed) == 0:
+            return rounds
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU backend
+# ---------------------------------------------------------------------------------------------------------------
+def _make_slab_volume():
+    from . import _lib as L
+    from .device import DeviceVolume, c64
+
+    class SlabVolume(DeviceVolume):
+        """This rank's Z-slab (+ halo slices) resident in HBM.  Same call surface as DeviceVolume; region growing and
+        marching cubes are the sharded versions."""
+
+        def __init__(self, image_slab: np.ndarray, rank: int, world: int, dist, spacing=(1.0, 1.0, 1.0)):
+            import torch
+
+            self.lay = slab_layout(rank, world, image_slab.shape[0])
+            self.comm = TorchComm(dist, rank, world, device="cuda")
+            self._torch = torch
+            # one-time halo exchange of the IMAGE (static input): my first slice goes down, my last slice goes up
+            down = torch.from_numpy(np.ascontiguousarray(image_slab[0])).cuda()
+            up = torch.from_numpy(np.ascontiguousarray(image_slab[-1])).cuda()
+            from_down, from_up = self.comm.exchange(down, up)
+            parts = []
+            if self.lay.hb:
+                parts.append(from_down.cpu().numpy()[None])
+            parts.append(image_slab)
+            if self.lay.ht:
+                parts.append(from_up.cpu().numpy()[None])
+            local = np.concatenate(parts) if len(parts) > 1 else image_slab
+            super().__init__(np.ascontiguousarray(local), spacing=spacing, device=torch.cuda.current_device())
+            self.plane_words = self.dy * self.plan.wx
+            self._send = [torch.empty(self.plane_words, dtype=torch.int64, device="cuda") for _ in range(2)]
+
+        # -- backend protocol of slab_region_grow ---------------------------------------------------------------
+        def flood_run(self):
+            r = ctypes.c_int(0)
+            L.check(L.lib().ivx_dev_flood_run(ctypes.byref(self.plan), self.cand.ptr, self.reached.ptr,
+                                              self.flood_scratch.ptr, ctypes.byref(r), self.stream), "flood_run")
+            self._rounds += r.value
+
+        def export_plane(self, z: int):
+            t = self._send[0 if z == self.lay.first_interior else 1]
+            L.check(L.lib().ivx_memcpy_d2d(ctypes.c_void_p(t.data_ptr()), self.reached.at(z * self.plane_words * 8),
+                                           ctypes.c_size_t(self.plane_words * 8), self.stream))
+            self.sync()  # the plane must be complete before RCCL (torch's stream) reads it
+            return t
+
+        def or_plane(self, z: int, tensor) -> int:
+            chg = ctypes.c_int(0)
+            L.check(L.lib().ivx_dev_flood_or_plane(ctypes.byref(self.plan), self.cand.ptr, self.reached.ptr, c64(z),
+                                                   ctypes.c_void_p(tensor.data_ptr()), self.flood_scratch.ptr,
+                                                   ctypes.byref(chg), self.stream), "flood_or_plane")
+            return chg.value
+
+        # -- sharded operations ----------------------------------------------------------------------------------
+        def region_grow(self, seeds_xyz_global, t0, t1, strct, fill: int = 1, select_value=254) -> int:
+            """Seeds are GLOBAL (x, y, z); z counts slices of the whole (world * nz)-slice volume."""
+            lib = L.lib()
+            s3 = np.ascontiguousarray(strct, dtype=np.uint8)
+            bits = ctypes.c_uint32(0)
+            L.check(lib.ivx_flood_strct_bits(L.ptr(s3), L.i64(s3.shape), ctypes.byref(bits)))
+            self.plan.strct_bits = bits.value
+            p, st = ctypes.byref(self.plan), self.stream
+            t0, t1 = float(int(t0)), float(int(t1))
+            L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
+            L.check(lib.ivx_dev_flood_candidates(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1),
+                                                 self.out_mask.ptr, 1, ctypes.c_double(fill), self.cand.ptr, st))
+            loc = local_seeds(self.lay, seeds_xyz_global)
+            if loc:
+                seeds = np.ascontiguousarray(np.array(loc, dtype=np.int64).reshape(-1, 3))
+                L.check(lib.ivx_dev_flood_seed(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1),
+                                               L.ptr(seeds), c64(len(seeds)), self.cand.ptr, self.reached.ptr,
+                                               self.flood_scratch.ptr, st), "region_grow")
+            self._rounds = 0
+            slab_region_grow(self, self.comm, self.lay)
+            L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
+            if select_value is not None:
+                L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.mask.ptr, ctypes.c_double(select_value), st))
+            return self._rounds
+
+        def reached_count(self) -> int:
+            """Reached voxels of the INTERIOR slices only (halo slices belong to the neighbours)."""
+            sub = L.FloodPlan(self.lay.nz, self.dy, self.dx, self.plan.wx, self.plan.strct_bits)
+            n = ctypes.c_int64(0)
+            L.check(L.lib().ivx_dev_flood_count(ctypes.byref(sub), self.reached.at(self.lay.hb * self.plane_words * 8),
+                                                ctypes.byref(n), self.stream))
+            return n.value
+
+        def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
+            a = slab_mc_args(self.lay, fill_border_holes)
+            p = self._mc_params(from_binary, min_value, max_value, fill_border_holes, z0=a["z0"], z1=a["z1"],
+                                roi_start=a["roi_start"], pad_bottom=a["pad_bottom"], pad_top=a["pad_top"])
+            return super().marching_cubes(from_binary, min_value, max_value, fill_border_holes, download, params=p,
+                                          z0=a["z0"])
+
+    return SlabVolume
+
+
+def __getattr__(name):  # SlabVolume needs libivx + a device; build the class lazily so the CPU tests can import us
+    if name == "SlabVolume":
+        cls = _make_slab_volume()
+        globals()["SlabVolume"] = cls
+        return cls
+    raise AttributeError(name)

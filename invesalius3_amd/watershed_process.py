@@ -20,7 +20,7 @@ import numpy as np
 from . import _lib as L
 
 
-def cost_image(image: np.ndarray, use_ww_wl: bool, wl, ww, gradient_size: int = 0) -> np.ndarray:
+def cost_image(image: np.ndarray, use_ww_wl: bool, wl, ww, gradient_size=0) -> np.ndarray:
     """uint16 flood input: ``get_LUT_value(image, ww, wl).astype("uint16")`` or
     ``(image - image.min()).astype("uint16")`` (watershed_process.py:34,42,47,55), then optionally
     ``ndimage.morphological_gradient(tmp, gradient_size)`` (watershed_process.py:36-38,49-51)."""
@@ -28,8 +28,15 @@ def cost_image(image: np.ndarray, use_ww_wl: bool, wl, ww, gradient_size: int = 
         raise TypeError("image must be a 2-D or 3-D int16 array")
     img3 = image if image.ndim == 3 else image[np.newaxis]
     out = np.empty(img3.shape, np.uint16)
+    gs = None
+    if gradient_size:  # int -> same size on every axis of the input (scipy semantics); tuple -> per axis
+        sz = tuple(int(v) for v in gradient_size) if np.ndim(gradient_size) else (int(gradient_size),) * image.ndim
+        if len(sz) != image.ndim:
+            raise RuntimeError("size must have one entry per image axis")
+        sz = (1,) * (3 - len(sz)) + sz
+        gs = (ctypes.c_int * 3)(*sz)
     L.check(L.lib().ivx_watershed_prepare(L.ptr(img3), L.i64(img3.shape), L.i64(img3.strides), int(bool(use_ww_wl)),
-                                          ctypes.c_double(float(ww)), ctypes.c_double(float(wl)), int(gradient_size),
+                                          ctypes.c_double(float(ww)), ctypes.c_double(float(wl)), gs,
                                           L.ptr(out)), "watershed cost image")
     return out.reshape(image.shape)
 

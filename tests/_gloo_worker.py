@@ -1,0 +1,79 @@
+"""Worker for tests/test_parallel_gloo.py: one rank of a world_size-N gloo job running the slab orchestration of
+invesalius3_amd.parallel with a numpy/oracle backend (test infrastructure; the GPU backend is SlabVolume)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class NumpyBackend:
+    """bool-array stand-in for the bit-plane kernels: flood_run = binary propagation inside `cand`."""
+
+    def __init__(self, cand, reached, strct):
+        self.cand, self.reached, self.strct = cand, reached, strct
+
+    def flood_run(self):
+        from scipy import ndimage
+        if self.reached.any():
+            self.reached = ndimage.binary_propagation(self.reached, structure=self.strct, mask=self.cand)
+
+    def export_plane(self, z):
+        import torch
+        return torch.from_numpy(self.reached[z].astype(np.uint8).copy())
+
+    def or_plane(self, z, tensor):
+        add = tensor.numpy().astype(bool) & self.cand[z] & ~self.reached[z]
+        self.reached[z] |= add
+        return int(add.sum())
+
+
+def main():
+    import torch.distributed as dist
+    from scipy.ndimage import generate_binary_structure
+
+    from conftest import synth_volume
+    from invesalius3_amd import parallel as par
+    from oracle import oracle as orc
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    outdir, nz, conn = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = synth_volume((world * nz, 40, 70), seed=77)  # every rank can rebuild the whole volume (test only)
+    t0, t1 = -850, 3071
+    lay = par.slab_layout(rank, world, nz)
+    lo = lay.z_global0 - lay.hb
+    local = full[lo: lo + lay.local_dz]
+    strct = generate_binary_structure(3, conn)
+    z, y, x = np.unravel_index(int(np.argmax(full)), full.shape)
+    seeds = [(int(x), int(y), int(z)), (0, 0, 0)]
+    cand = (local >= t0) & (local <= t1)
+    reached = np.zeros_like(cand)
+    for sx, sy, sz in par.local_seeds(lay, seeds):
+        if cand[sz, sy, sx]:
+            reached[sz, sy, sx] = True
+    be = NumpyBackend(cand, reached, strct)
+    comm = par.TorchComm(dist, rank, world, device="cpu")
+    rounds = par.slab_region_grow(be, comm, lay)
+    interior = be.reached[lay.first_interior: lay.last_interior + 1]
+    np.save(os.path.join(outdir, "reached_%d.npy" % rank), interior)
+    # halo consistency: my halo slices must equal the neighbours' interior boundary slices (checked by the parent)
+    np.save(os.path.join(outdir, "halo_%d.npy" % rank), np.stack([be.reached[0], be.reached[-1]]))
+    # marching cubes piece of this rank on the thresholded + selected mask
+    mask_local = np.where(cand, 255, 0).astype(np.uint8)
+    mask_local[be.reached] = 254
+    a = par.slab_mc_args(lay)
+    piece = mask_local[a["z0"]: a["z1"]]
+    tris = orc.marching_cubes(piece, (0.5, 0.5, 2.0), [127.0], a["roi_start"], True, a["pad_bottom"], a["pad_top"], 0.0,
+                              int(a["pad_bottom"]))
+    np.save(os.path.join(outdir, "tris_%d.npy" % rank), tris)
+    np.save(os.path.join(outdir, "rounds_%d.npy" % rank), np.array([rounds]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

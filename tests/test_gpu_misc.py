@@ -64,6 +64,8 @@ def test_morphological_gradient_matches_scipy(ivxlib, oracle, size):
     assert np.array_equal(wp.cost_image(img, True, 200, 600, size), exp)
     exp2 = ndimage.morphological_gradient((img - img.min()).astype("uint16"), size)
     assert np.array_equal(wp.cost_image(img, False, 0, 0, size), exp2)
+    aniso = (1, 3, 5)
+    assert np.array_equal(wp.cost_image(img, True, 200, 600, aniso), ndimage.morphological_gradient(lut, aniso))
     if size == 3:
         sl = img[4]
         assert np.array_equal(wp.cost_image(sl, False, 0, 0, 3), ndimage.morphological_gradient((sl - sl.min()).astype("uint16"), 3))
@@ -87,16 +89,15 @@ def test_do_watershed_ift_pipeline_matches_reference_calls(ivxlib, tmp_path):
     import queue
     from invesalius3_amd import watershed_process as wp
     image = np.zeros((5, 5, 5), dtype=np.int16)
-    image[2, 2, 2] = 100
-    image[1:4, 1:4, 1:4] += 50
-    markers = np.zeros((5, 5, 5), dtype=np.uint8)
+    image[1:4, 1:4, 1:4] = 100
+    markers = np.zeros((5, 5, 5), dtype=np.int16)
     markers[2, 2, 2] = 1
     markers[0, 0, 0] = 2
     tfile = str(tmp_path / "ws.dat")
     np.memmap(tfile, shape=image.shape, dtype="uint8", mode="w+").flush()
     q = queue.Queue()
     bstruct = generate_binary_structure(3, 1)
-    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", 3, False, 0, 0, q)
+    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), False, 0, 0, q)
     assert q.get() == 1
     got = np.array(np.memmap(tfile, shape=image.shape, dtype="uint8", mode="r"))
     exp = ndimage.watershed_ift((image - image.min()).astype("uint16"), markers.astype("int8"), bstruct)
