@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output for the bench: per-kernel average duration (kernel_stats.csv) joined with per-launch
+FETCH_SIZE / WRITE_SIZE from two separate --pmc passes (counter_collection.csv).
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports exactly half the bytes of a wide coalesced streaming read, so the corrected read traffic is 2 x FETCH_SIZE
+(upper bound for narrow accesses); WRITE_SIZE is taken as is (uncalibrated).
+usage: summarize_pmc.py <dir> [<out.md>]
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(k_[a-z0-9_]+|__amd_rocclr_[A-Za-z]+)", name)
+    base = m.group(1) if m else name[:40]
+    t = re.search(r"<([^>]*)>", name)
+    return base + ("<" + t.group(1).replace("unsigned char", "u8").replace("short", "i16").replace("(anonymous namespace)::", "") + ">" if t else "")
+
+
+def counters(path):
+    acc = defaultdict(list)
+    try:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    except FileNotFoundError:
+        pass
+    return acc
+
+
+def main():
+    d = sys.argv[1]
+    stats = {}
+    with open(d + "/kt_kernel_stats.csv") as f:
+        for r in csv.DictReader(f):
+            stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]), float(r["Percentage"]))
+    fe, wr = counters(d + "/fetch_counter_collection.csv"), counters(d + "/write_counter_collection.csv")
+    lines = ["| kernel | calls | avg us | % time | FETCH_SIZE KiB/launch | read MB/launch (2x corrected) | WRITE_SIZE KiB/launch | write MB/launch |",
+             "|---|---|---|---|---|---|---|---|"]
+    for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
+        f_ = sum(fe[k]) / len(fe[k]) if fe.get(k) else float("nan")
+        w_ = sum(wr[k]) / len(wr[k]) if wr.get(k) else float("nan")
+        lines.append("| %s | %d | %.1f | %.2f | %.0f | %.1f | %.0f | %.1f |" % (k, calls, avg / 1e3, pct, f_, 2 * f_ * 1024 / 1e6, w_, w_ * 1024 / 1e6))
+    out = "\n".join(lines)
+    print(out)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(out + "\n")
+
+
+if __name__ == "__main__":
+    main()
