@@ -56,4 +56,10 @@ int download_strided(void *dst, const int64_t shape[3], const int64_t strides[3]
 int download_strided2(void *dst, const int64_t shape[2], const int64_t strides[2], const void *src_dev, size_t isz,
                       int hslot);
 
+// GPU -> host mailbox in pinned, host-coherent memory: a 1-thread kernel copies up to 32 dwords and then stores a
+// sequence number; the host spins on the sequence word instead of paying a stream synchronisation round trip
+// (~5 us instead of ~40 us).  Falls back to hipStreamSynchronize if the word does not arrive in time.
+int mailbox_publish(const void *dsrc, int ndwords, hipStream_t st, uint32_t *seq_out);
+int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords);
+
 } // namespace ivx

@@ -126,6 +126,53 @@ int download_strided2(void *dst, const int64_t shape[2], const int64_t st[2], co
     return download_strided(dst, sh3, st3, src_dev, isz, hslot);
 }
 
+// ---- mailbox ------------------------------------------------------------------------------------------------
+static uint32_t *g_mb = nullptr; // pinned host memory, 64 dwords per slot x 64 slots (ring)
+static uint32_t g_mb_seq = 0;
+
+__global__ void k_mailbox_publish(const uint32_t *__restrict__ src, int n, uint32_t *mb, uint32_t seq) {
+    if (threadIdx.x || blockIdx.x) return;
+    for (int i = 0; i < n; i++) mb[i] = src[i];
+    __threadfence_system();
+    __hip_atomic_store(&mb[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int mailbox_publish(const void *dsrc, int ndwords, hipStream_t st, uint32_t *seq_out) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_mb) {
+            void *p = nullptr;
+            IVX_HIP(hipHostMalloc(&p, 64 * 64 * 4, hipHostMallocMapped | hipHostMallocCoherent));
+            memset(p, 0, 64 * 64 * 4);
+            g_mb = (uint32_t *)p;
+        }
+        *seq_out = ++g_mb_seq;
+        if (*seq_out == 0) *seq_out = ++g_mb_seq;
+    }
+    IVX_REQUIRE(ndwords >= 0 && ndwords <= 32, IVX_EINVAL, "mailbox: too many words");
+    uint32_t *slot = g_mb + (size_t)(*seq_out & 63u) * 64;
+    hipLaunchKernelGGL(k_mailbox_publish, dim3(1), dim3(64), 0, st, (const uint32_t *)dsrc, ndwords, slot, *seq_out);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords) {
+    volatile uint32_t *slot = g_mb + (size_t)(seq & 63u) * 64;
+    bool ok = false;
+    for (long spins = 0; spins < 20000000L; spins++) { // ~ a few hundred ms worst case, then the safe path
+        if (__atomic_load_n(&slot[63], __ATOMIC_ACQUIRE) == seq) { ok = true; break; }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (!ok) {
+        IVX_HIP(hipStreamSynchronize(st));
+        IVX_REQUIRE(__atomic_load_n(&slot[63], __ATOMIC_ACQUIRE) == seq, IVX_EHIP, "mailbox: GPU never published sequence %u", seq);
+    }
+    for (int i = 0; i < ndwords; i++) out[i] = slot[i];
+    return IVX_OK;
+}
+
 } // namespace ivx
 
 using namespace ivx;

@@ -148,6 +148,26 @@ __global__ void k_flood_seed(const T *__restrict__ data, Tiles t, double t0, dou
     dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + (x >> 6)] = 1;
 }
 
+struct SeedPack {
+    int64_t xyz[16][3];
+    int n;
+};
+template <typename T>
+__global__ void k_flood_seed_args(const T *__restrict__ data, Tiles t, double t0, double t1, SeedPack sp,
+                                  unsigned long long *__restrict__ cand, unsigned long long *__restrict__ reached,
+                                  uint8_t *__restrict__ dirty) {
+    const int n = threadIdx.x;
+    if (n >= sp.n) return;
+    const int64_t x = sp.xyz[n][0], y = sp.xyz[n][1], z = sp.xyz[n][2];
+    const double v = as_double(data[(z * t.dy + y) * t.dx + x]);
+    if (!(v >= t0 && v <= t1)) return;
+    const int64_t w = (z * t.dy + y) * t.wx + (x >> 6);
+    const unsigned long long bit = 1ull << (x & 63);
+    atomicOr(&cand[w], bit);
+    atomicOr(&reached[w], bit);
+    dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + (x >> 6)] = 1;
+}
+
 // ---- one round over the dirty tiles ---------------------------------------------------------------
 __device__ __forceinline__ unsigned long long fill_up(unsigned long long seed, unsigned long long m) {
     return (((m + seed) ^ m) & m) | seed;
@@ -157,49 +177,60 @@ __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed,
     return __brevll(fill_up(__brevll(f), __brevll(m)));
 }
 
-__global__ __launch_bounds__(256) void k_flood_round(Tiles t, const unsigned long long *__restrict__ cand,
-                                                     unsigned long long *reached, uint8_t *dirty_cur,
-                                                     uint8_t *dirty_next, unsigned int *counter_next) {
-    __shared__ unsigned long long sR[HZ * HY * 3];
-    __shared__ unsigned int s_dirs;
-    __shared__ int s_go;
-    const int64_t tile = blockIdx.x;
-    if (threadIdx.x == 0) { // one lane consumes the flag, so no wave can see it already cleared
-        s_go = dirty_cur[tile];
-        if (s_go) dirty_cur[tile] = 0;
-        s_dirs = 0;
-    }
-    __syncthreads();
-    if (!s_go) return; // uniform per workgroup
+// Tile update shared by the per-round kernel and the persistent frontier.
+// LDS holds, for the 18x18 rows of the tile + halo: sN = the row's word, sD = the row's word dilated by one voxel
+// along x including the carry bits of the x-neighbour words (so a full 3-wide strct row costs ONE LDS read), and the
+// two carry bits themselves (generic structuring elements).  The local fix-point is a chaotic relaxation: reached
+// bits only ever get OR'ed in, so a lane may read a neighbour's word while it is being rewritten -- any mix of old
+// and new bits is a valid intermediate state -- and ONE barrier per iteration (the termination vote) is enough.
+// ATOMIC: stage / publish with agent-scope atomics (needed when other workgroups update neighbours concurrently
+// AND no kernel boundary follows, i.e. in the persistent frontier).
+struct TileLds {
+    unsigned long long sN[HZ * HY];
+    unsigned long long sD[HZ * HY];
+    unsigned char sCL[HZ * HY], sCR[HZ * HY];
+    unsigned int dirs;
+};
+
+template <bool ATOMIC>
+__device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long long *__restrict__ cand,
+                                            unsigned long long *reached, int64_t tile, TileLds &L) {
     const int64_t txi = tile % t.wx, r1 = tile / t.wx;
     const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
     const int64_t z0 = tzi * TZ, y0 = tyi * TY;
-
-    // stage reached bits (+halo) in LDS; outside the volume = 0
-    for (int idx = threadIdx.x; idx < HZ * HY * 3; idx += 256) {
-        const int xx = idx % 3, rr = idx / 3;
-        const int yy = rr % HY, zz = rr / HY;
-        const int64_t z = z0 + zz - 1, y = y0 + yy - 1, w = txi + xx - 1;
-        unsigned long long v = 0;
-        if (z >= 0 && z < t.dz && y >= 0 && y < t.dy && w >= 0 && w < t.wx) {
-            // halo words may be written concurrently by the neighbouring tile's workgroup: read them past
-            // this CU's L1 (sc1) -- stale is still correct (the writer re-marks us), fresh saves a round
-            v = __hip_atomic_load(&reached[(z * t.dy + y) * t.wx + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // stage: lane idx <-> halo row idx (324 rows, 2 passes); 3 words per row, loads issued back to back
+    for (int idx = threadIdx.x; idx < HZ * HY; idx += 256) {
+        const int yy = idx % HY, zz = idx / HY;
+        const int64_t z = z0 + zz - 1, y = y0 + yy - 1;
+        unsigned long long w3[3] = {0ull, 0ull, 0ull};
+        if (z >= 0 && z < t.dz && y >= 0 && y < t.dy) {
+            unsigned long long *row = reached + (z * t.dy + y) * t.wx;
+#pragma unroll
+            for (int xx = 0; xx < 3; xx++) {
+                const int64_t w = txi + xx - 1;
+                if (w >= 0 && w < t.wx)
+                    w3[xx] = ATOMIC ? __hip_atomic_load(row + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : row[w];
+            }
         }
-        sR[idx] = v;
+        const unsigned long long cl = w3[0] >> 63, cr = w3[2] & 1ull;
+        L.sN[idx] = w3[1];
+        L.sD[idx] = w3[1] | (w3[1] << 1) | (w3[1] >> 1) | cl | (cr << 63);
+        L.sCL[idx] = (unsigned char)cl;
+        L.sCR[idx] = (unsigned char)cr;
     }
     const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> 4;
     const int64_t z = z0 + tz, y = y0 + ty;
     const bool inside = z < t.dz && y < t.dy;
     const unsigned long long c = inside ? cand[(z * t.dy + y) * t.wx + txi] : 0ull;
     __syncthreads();
-    const int me = ((tz + 1) * HY + (ty + 1)) * 3 + 1;
-    const unsigned long long r_in = sR[me];
+    const int me = (tz + 1) * HY + (ty + 1);
+    const unsigned long long r_in = L.sN[me];
+    const unsigned long long mycl = L.sCL[me], mycr = L.sCR[me];
     unsigned long long r = r_in;
     const uint32_t st = t.strct;
     const bool xrun = (st >> 12 & 1) && (st >> 14 & 1); // both x neighbours of the centre row present
     bool exhausted = true;
-    for (int it = 0; it < 1024; it++) {
+    for (int it = 0; it < 2048; it++) {
         unsigned long long nb = 0;
 #pragma unroll
         for (int kk = 0; kk < 3; kk++)
@@ -208,27 +239,32 @@ __global__ __launch_bounds__(256) void k_flood_round(Tiles t, const unsigned lon
                 const uint32_t m3 = (st >> (kk * 9 + jj * 3)) & 7u;
                 if (!m3) continue; // uniform
                 // voxel p reached => p + (kk-1, jj-1, ii-1) reached; gather: source row = (z-(kk-1), y-(jj-1))
-                const int src = ((tz + 1 - (kk - 1)) * HY + (ty + 1 - (jj - 1))) * 3;
-                const unsigned long long n = sR[src + 1];
-                if (m3 & 2u) nb |= n;
-                if (m3 & 4u) nb |= (n << 1) | (sR[src] >> 63);     // ii = 2: source bit x-1
-                if (m3 & 1u) nb |= (n >> 1) | (sR[src + 2] << 63); // ii = 0: source bit x+1
+                const int src = (tz + 1 - (kk - 1)) * HY + (ty + 1 - (jj - 1));
+                if (m3 == 7u) nb |= L.sD[src];
+                else {
+                    const unsigned long long n = L.sN[src];
+                    if (m3 & 2u) nb |= n;
+                    if (m3 & 4u) nb |= (n << 1) | (unsigned long long)L.sCL[src];        // ii = 2: source bit x-1
+                    if (m3 & 1u) nb |= (n >> 1) | ((unsigned long long)L.sCR[src] << 63); // ii = 0: source bit x+1
+                }
             }
         unsigned long long nr = r | (nb & c);
         if (xrun) nr = fill_runs(nr, c);
         const bool changed = nr != r;
-        r = nr;
-        // everybody has read sR before anybody writes
+        if (changed) {
+            r = nr;
+            L.sN[me] = r;
+            L.sD[me] = r | (r << 1) | (r >> 1) | mycl | (mycr << 63);
+        }
         if (!__syncthreads_or(changed)) {
             exhausted = false;
             break;
         }
-        if (changed) sR[me] = r;
-        __syncthreads();
     }
     const unsigned long long chg = r ^ r_in;
     if (chg) {
-        reached[(z * t.dy + y) * t.wx + txi] = r;
+        if (ATOMIC) atomicOr(&reached[(z * t.dy + y) * t.wx + txi], r); // monotone publish: bits are never lost
+        else reached[(z * t.dy + y) * t.wx + txi] = r;
         // which neighbour tiles can see this change?  direction d = (dz+1)*9 + (dy+1)*3 + (dx+1)
         unsigned dirs = 0;
         const bool zlo = tz == 0, zhi = tz == TZ - 1, ylo = ty == 0, yhi = ty == TY - 1;
@@ -245,10 +281,30 @@ __global__ __launch_bounds__(256) void k_flood_round(Tiles t, const unsigned lon
                     dirs |= vis ? (1u << ((dzz + 1) * 9 + (dyy + 1) * 3 + (dxx + 1))) : 0u;
                 }
         if (exhausted) dirs |= 1u << 13; // iteration cap hit before the local fix-point: revisit this tile
-        if (dirs) atomicOr(&s_dirs, dirs);
+        if (dirs) atomicOr(&L.dirs, dirs);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flood_round(Tiles t, const unsigned long long *__restrict__ cand,
+                                                     unsigned long long *reached, uint8_t *dirty_cur,
+                                                     uint8_t *dirty_next, unsigned int *counter_next) {
+    __shared__ TileLds L;
+    __shared__ int s_go;
+    const int64_t tile = blockIdx.x;
+    if (threadIdx.x == 0) { // one lane consumes the flag, so no wave can see it already cleared
+        s_go = dirty_cur[tile];
+        if (s_go) dirty_cur[tile] = 0;
+        L.dirs = 0;
     }
     __syncthreads();
-    if (threadIdx.x < 27 && (s_dirs >> threadIdx.x & 1u)) {
+    if (!s_go) return; // uniform per workgroup
+    // halo words may be rewritten concurrently by the neighbouring tile's workgroup; a stale read is still correct
+    // (the writer re-marks this tile for the next round), so plain loads/stores + the kernel boundary suffice
+    tile_update<false>(t, cand, reached, tile, L);
+    __syncthreads();
+    const int64_t txi = tile % t.wx, r1 = tile / t.wx;
+    const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+    if (threadIdx.x < 27 && (L.dirs >> threadIdx.x & 1u)) {
         const int d = threadIdx.x;
         const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
         if (nz >= 0 && nz < t.ntz && ny >= 0 && ny < t.nty && nx >= 0 && nx < t.wx) {
@@ -287,13 +343,8 @@ __global__ void k_flood_enqueue(Tiles t, uint8_t *dirty, Queue *q, unsigned int 
 __global__ __launch_bounds__(256) void k_flood_persistent(Tiles t, const unsigned long long *__restrict__ cand,
                                                           unsigned long long *reached, Queue *q, unsigned int *queued,
                                                           unsigned int *ring, unsigned int qmask, unsigned int max_spins) {
-    __shared__ unsigned long long sR[HZ * HY * 3];
-    __shared__ unsigned int s_dirs;
+    __shared__ TileLds L;
     __shared__ int s_tile;
-    const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> 4;
-    const int me = ((tz + 1) * HY + (ty + 1)) * 3 + 1;
-    const uint32_t st = t.strct;
-    const bool xrun = (st >> 12 & 1) && (st >> 14 & 1);
     unsigned int my_visits = 0;
     for (;;) {
         if (threadIdx.x == 0) {
@@ -318,78 +369,17 @@ __global__ __launch_bounds__(256) void k_flood_persistent(Tiles t, const unsigne
             if (tile >= 0 && ++my_visits > max_spins) { AT_STORE(&q->abort, 2u); tile = -1; }
             if (tile >= 0) atomicExch(&queued[tile], 0u); // cleared BEFORE staging: later changes re-queue the tile
             s_tile = tile;
-            s_dirs = 0;
+            L.dirs = 0;
         }
         __syncthreads();
         const int tile = s_tile;
         if (tile < 0) return;
-        const int64_t txi = tile % t.wx, r1 = tile / t.wx;
-        const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
-        const int64_t z0 = tzi * TZ, y0 = tyi * TY;
-        for (int idx = threadIdx.x; idx < HZ * HY * 3; idx += 256) {
-            const int xx = idx % 3, rr = idx / 3;
-            const int yy = rr % HY, zz = rr / HY;
-            const int64_t z = z0 + zz - 1, y = y0 + yy - 1, w = txi + xx - 1;
-            unsigned long long v = 0;
-            if (z >= 0 && z < t.dz && y >= 0 && y < t.dy && w >= 0 && w < t.wx)
-                v = AT_LOAD(&reached[(z * t.dy + y) * t.wx + w]);
-            sR[idx] = v;
-        }
-        const int64_t z = z0 + tz, y = y0 + ty;
-        const bool inside = z < t.dz && y < t.dy;
-        const unsigned long long c = inside ? cand[(z * t.dy + y) * t.wx + txi] : 0ull;
-        __syncthreads();
-        const unsigned long long r_in = sR[me];
-        unsigned long long r = r_in;
-        bool exhausted = true;
-        for (int it = 0; it < 1024; it++) {
-            unsigned long long nb = 0;
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++)
-#pragma unroll
-                for (int jj = 0; jj < 3; jj++) {
-                    const uint32_t m3 = (st >> (kk * 9 + jj * 3)) & 7u;
-                    if (!m3) continue;
-                    const int src = ((tz + 1 - (kk - 1)) * HY + (ty + 1 - (jj - 1))) * 3;
-                    const unsigned long long n = sR[src + 1];
-                    if (m3 & 2u) nb |= n;
-                    if (m3 & 4u) nb |= (n << 1) | (sR[src] >> 63);
-                    if (m3 & 1u) nb |= (n >> 1) | (sR[src + 2] << 63);
-                }
-            unsigned long long nr = r | (nb & c);
-            if (xrun) nr = fill_runs(nr, c);
-            const bool changed = nr != r;
-            r = nr;
-            if (!__syncthreads_or(changed)) {
-                exhausted = false;
-                break;
-            }
-            if (changed) sR[me] = r;
-            __syncthreads();
-        }
-        const unsigned long long chg = r ^ r_in;
-        if (chg) {
-            atomicOr(&reached[(z * t.dy + y) * t.wx + txi], r);
-            unsigned dirs = 0;
-            const bool zlo = tz == 0, zhi = tz == TZ - 1, ylo = ty == 0, yhi = ty == TY - 1;
-            const bool xlo = chg & 1ull, xhi = chg >> 63;
-#pragma unroll
-            for (int dzz = -1; dzz <= 1; dzz++)
-#pragma unroll
-                for (int dyy = -1; dyy <= 1; dyy++)
-#pragma unroll
-                    for (int dxx = -1; dxx <= 1; dxx++) {
-                        if (!dzz && !dyy && !dxx) continue;
-                        const bool vis = (dzz == 0 || (dzz < 0 ? zlo : zhi)) && (dyy == 0 || (dyy < 0 ? ylo : yhi)) &&
-                                         (dxx == 0 || (dxx < 0 ? xlo : xhi));
-                        dirs |= vis ? (1u << ((dzz + 1) * 9 + (dyy + 1) * 3 + (dxx + 1))) : 0u;
-                    }
-            if (exhausted) dirs |= 1u << 13;
-            if (dirs) atomicOr(&s_dirs, dirs);
-        }
+        tile_update<true>(t, cand, reached, tile, L);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every publishing wave drains before the pushes
         __syncthreads();
-        if (threadIdx.x < 27 && (s_dirs >> threadIdx.x & 1u)) {
+        const int64_t txi = tile % t.wx, r1 = tile / t.wx;
+        const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+        if (threadIdx.x < 27 && (L.dirs >> threadIdx.x & 1u)) {
             const int d = threadIdx.x;
             const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
             if (nz >= 0 && nz < t.ntz && ny >= 0 && ny < t.nty && nx >= 0 && nx < t.wx) {
@@ -537,6 +527,24 @@ extern "C" int ivx_dev_flood_seed(const ivx_flood_plan *p, int dtype, const void
     const FScratch s = make_fscratch(t);
     char *scr = (char *)scratch_;
     hipStream_t st = ivx::S(stream);
+    if (nseeds <= 16) { // the usual case (one click = one seed): seeds travel as kernel arguments, no staging, no sync
+        SeedPack sp;
+        sp.n = (int)nseeds;
+        for (int64_t n = 0; n < nseeds; n++)
+            for (int q = 0; q < 3; q++) sp.xyz[n][q] = seeds_xyz[3 * n + q];
+        unsigned long long *c = (unsigned long long *)cand, *r = (unsigned long long *)reached;
+        uint8_t *dirty = (uint8_t *)(scr + s.off_dirty0);
+        if (nseeds == 0) return IVX_OK;
+        switch (dtype) {
+        case IVX_I16: hipLaunchKernelGGL(k_flood_seed_args<int16_t>, dim3(1), dim3(64), 0, st, (const int16_t *)data, t, t0, t1, sp, c, r, dirty); break;
+        case IVX_U8: hipLaunchKernelGGL(k_flood_seed_args<uint8_t>, dim3(1), dim3(64), 0, st, (const uint8_t *)data, t, t0, t1, sp, c, r, dirty); break;
+        case IVX_U16: hipLaunchKernelGGL(k_flood_seed_args<uint16_t>, dim3(1), dim3(64), 0, st, (const uint16_t *)data, t, t0, t1, sp, c, r, dirty); break;
+        case IVX_F64: hipLaunchKernelGGL(k_flood_seed_args<double>, dim3(1), dim3(64), 0, st, (const double *)data, t, t0, t1, sp, c, r, dirty); break;
+        default: ivx::set_error("flood: unsupported dtype %d", dtype); return IVX_EINVAL;
+        }
+        IVX_LAUNCH_CHECK();
+        return IVX_OK;
+    }
     int64_t *d_seeds = (int64_t *)(scr + s.off_seeds);
     for (int64_t b = 0; b < nseeds; b += (int64_t)SEED_CHUNK) {
         const int64_t m = nseeds - b < (int64_t)SEED_CHUNK ? nseeds - b : (int64_t)SEED_CHUNK;
@@ -632,8 +640,9 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
             IVX_LAUNCH_CHECK();
         }
         unsigned int h[BATCH];
-        IVX_HIP(hipMemcpyAsync(h, cnt, BATCH * 4, hipMemcpyDeviceToHost, st));
-        IVX_HIP(hipStreamSynchronize(st));
+        uint32_t seq;
+        if ((rc = ivx::mailbox_publish(cnt, BATCH, st, &seq))) return rc;
+        if ((rc = ivx::mailbox_wait(seq, st, h, BATCH))) return rc;
         int used = BATCH;
         for (int b = 0; b < BATCH; b++)
             if (h[b] == 0) { used = b + 1; break; }

@@ -210,6 +210,9 @@ __global__ __launch_bounds__(256) void k_mc_count(const uint64_t *__restrict__ b
                                                   uint64_t pbits, uint16_t *__restrict__ counts,
                                                   uint32_t *__restrict__ bsum) {
     __shared__ uint32_t s_part[4];
+    __shared__ uint8_t s_ntri[256];
+    s_ntri[threadIdx.x] = MC_NTRI[threadIdx.x];
+    __syncthreads();
     const size_t wid = (size_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t n = 0;
     if (wid < nwords) {
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void k_mc_count(const uint64_t *__restrict__ b
         while (act) {
             const int b = __builtin_ctzll(act);
             act &= act - 1;
-            n += MC_NTRI[case_of(r.c, b)];
+            n += s_ntri[case_of(r.c, b)];
         }
         counts[wid] = (uint16_t)n;
     }
@@ -263,27 +266,49 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
 }
 
 // ---- 4. emit: one lane per TRIANGLE ---------------------------------------------------------------
+// edge e -> (axis, low corner, low-corner offset) without tables: edges 0-3 run along x with (dy,dz) = (e&1, e>>1&1),
+// 4-7 along y with (dx,dz), 8-11 along z with (dx,dy)  (tools/gen_mc_tables.py conventions).
+__device__ __forceinline__ void edge_decode(int e, int &ax, int &bx, int &by, int &bz) {
+    ax = e >> 2;
+    const int a = e & 1, b = (e >> 1) & 1;
+    bx = ax == 0 ? 0 : a;
+    by = ax == 0 ? a : (ax == 1 ? 0 : b);
+    bz = ax == 2 ? 0 : b;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const uint64_t *__restrict__ bits, Geom g,
                                                  size_t nwords, uint64_t pbits, double iso,
                                                  const uint16_t *__restrict__ counts,
                                                  const uint64_t *__restrict__ boff, float *__restrict__ tris,
                                                  uint64_t max_tris) {
-    __shared__ uint64_t s_c[8][256];   // corner words, SoA
+    __shared__ uint64_t s_lo[4][256];  // the four row words of each cell word (corner words 0,2,4,6), SoA
     __shared__ uint64_t s_act[256];
     __shared__ uint32_t s_base[257];   // exclusive prefix of the per-word triangle counts
     __shared__ int32_t s_k[256], s_j[256], s_w[256];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint8_t s_carry[256];   // bit q = bit 0 of the NEXT word of row q (corner words 1,3,5,7 = lo>>1 | carry<<63)
+    __shared__ uint8_t s_ntri[256];
+    __shared__ uint8_t s_tri[256 * 16];
     __shared__ float s_out[256 * 9];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // case tables -> LDS (dependent look-ups then cost an LDS access instead of a global one)
+    s_ntri[tid] = MC_NTRI[tid];
+#pragma unroll
+    for (int q = 0; q < 15; q++) s_tri[tid * 16 + q] = MC_TRI[tid][q];
     const size_t wid = (size_t)blockIdx.x * 256 + tid;
     const uint32_t n = wid < nwords ? (uint32_t)counts[wid] : 0u;
     if (n) {
         const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
         const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
         const Corner8 r = load_corners(bits, g, k, j, w, pbits);
+        unsigned carry = 0;
 #pragma unroll
-        for (int c = 0; c < 8; c++) s_c[c][tid] = r.c[c];
+        for (int q = 0; q < 4; q++) {
+            s_lo[q][tid] = r.c[2 * q];
+            carry |= (unsigned)(r.c[2 * q + 1] >> 63) << q;
+        }
+        s_carry[tid] = (uint8_t)carry;
         s_act[tid] = r.active;
         s_k[tid] = (int32_t)k; s_j[tid] = (int32_t)j; s_w[tid] = (int32_t)w;
     }
@@ -318,33 +343,41 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const 
             const int ww = lo;
             uint32_t rel = T_ - s_base[ww];
             uint64_t cw[8];
+            const unsigned carry = s_carry[ww];
 #pragma unroll
-            for (int c = 0; c < 8; c++) cw[c] = s_c[c][ww];
+            for (int q = 0; q < 4; q++) {
+                cw[2 * q] = s_lo[q][ww];
+                cw[2 * q + 1] = (cw[2 * q] >> 1) | ((uint64_t)((carry >> q) & 1u) << 63);
+            }
             uint64_t act = s_act[ww];
             int b = 0, idx = 0;
             for (;;) { // walk the word's active cells until the one holding triangle `rel`
                 b = __builtin_ctzll(act);
                 idx = case_of(cw, b);
-                const uint32_t nt = MC_NTRI[idx];
+                const uint32_t nt = s_ntri[idx];
                 if (rel < nt) break;
                 rel -= nt;
                 act &= act - 1;
             }
             const int64_t k = s_k[ww], j = s_j[ww], i = (int64_t)s_w[ww] * 64 + b;
             float *o = s_out + tid * 9;
+            double s0[3], s1[3];
+            int ax[3], bx[3], by[3], bz[3];
+#pragma unroll
+            for (int v = 0; v < 3; v++) { // issue the six gathers of the triangle back to back
+                const int e = s_tri[idx * 16 + 3 * rel + v];
+                edge_decode(e, ax[v], bx[v], by[v], bz[v]);
+                s0[v] = mc_at(a, g, k + bz[v], j + by[v], i + bx[v]);
+                s1[v] = mc_at(a, g, k + bz[v] + (ax[v] == 2), j + by[v] + (ax[v] == 1), i + bx[v] + (ax[v] == 0));
+            }
 #pragma unroll
             for (int v = 0; v < 3; v++) {
-                const int e = MC_TRI[idx][3 * rel + v];
-                const int c0_ = MC_EDGE_CORNERS[e][0], c1_ = MC_EDGE_CORNERS[e][1];
-                const double s0 = mc_at(a, g, k + ((c0_ >> 2) & 1), j + ((c0_ >> 1) & 1), i + (c0_ & 1));
-                const double s1 = mc_at(a, g, k + ((c1_ >> 2) & 1), j + ((c1_ >> 1) & 1), i + (c1_ & 1));
-                const double tt = (iso - s0) / (s1 - s0);
-                double p0 = (double)(i + MC_EDGE_BASE[e][0] - g.pxy);
-                double p1 = (double)(j + MC_EDGE_BASE[e][1] - g.yoff);
-                double p2 = (double)(k + MC_EDGE_BASE[e][2] + g.zoff);
-                const int ax = MC_EDGE_AXIS[e];
-                if (ax == 0) p0 += tt;
-                else if (ax == 1) p1 += tt;
+                const double tt = (iso - s0[v]) / (s1[v] - s0[v]);
+                double p0 = (double)(i + bx[v] - g.pxy);
+                double p1 = (double)(j + by[v] - g.yoff);
+                double p2 = (double)(k + bz[v] + g.zoff);
+                if (ax[v] == 0) p0 += tt;
+                else if (ax[v] == 1) p1 += tt;
                 else p2 += tt;
                 o[3 * v + 0] = (float)(g.sx * p0);
                 o[3 * v + 1] = (float)(g.sy * p1);
@@ -437,10 +470,10 @@ extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scr
     const size_t nb = s.nblocks * (size_t)p->niso;
     hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, st, bsum, nb, boff);
     IVX_LAUNCH_CHECK();
-    uint64_t total = 0;
-    IVX_HIP(hipMemcpyAsync(&total, boff + nb, 8, hipMemcpyDeviceToHost, st));
-    IVX_HIP(hipStreamSynchronize(st));
-    *ntris = (int64_t)total;
+    uint32_t seq, tw[2];
+    if ((rc = ivx::mailbox_publish(boff + nb, 2, st, &seq))) return rc;
+    if ((rc = ivx::mailbox_wait(seq, st, tw, 2))) return rc;
+    *ntris = (int64_t)(((uint64_t)tw[1] << 32) | tw[0]);
     return IVX_OK;
 }
 
