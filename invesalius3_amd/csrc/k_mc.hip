@@ -282,12 +282,13 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const 
                                                  const uint16_t *__restrict__ counts,
                                                  const uint64_t *__restrict__ boff, float *__restrict__ tris,
                                                  uint64_t max_tris) {
-    __shared__ uint64_t s_lo[4][256];  // the four row words of each cell word (corner words 0,2,4,6), SoA
-    __shared__ uint64_t s_act[256];
-    __shared__ uint32_t s_base[257];   // exclusive prefix of the per-word triangle counts
+    constexpr int WIN = 1024;            // triangle descriptors staged per window
+    __shared__ uint32_t s_desc[WIN];     // (word-in-block << 24) | (cell bit << 16) | (case << 8) | triangle-in-case
+    __shared__ uint32_t s_base[257];     // exclusive prefix of the per-word triangle counts
     __shared__ int32_t s_k[256], s_j[256], s_w[256];
+    __shared__ int64_t s_row[256];       // element offset of source row (k - pb, flipped j) -- valid when s_in != 0
+    __shared__ uint8_t s_in[256];        // rows (k,k+1) x (j,j+1) all inside the source piece
     __shared__ uint32_t s_wave[4];
-    __shared__ uint8_t s_carry[256];   // bit q = bit 0 of the NEXT word of row q (corner words 1,3,5,7 = lo>>1 | carry<<63)
     __shared__ uint8_t s_ntri[256];
     __shared__ uint8_t s_tri[256 * 16];
     __shared__ float s_out[256 * 9];
@@ -298,19 +299,16 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const 
     for (int q = 0; q < 15; q++) s_tri[tid * 16 + q] = MC_TRI[tid][q];
     const size_t wid = (size_t)blockIdx.x * 256 + tid;
     const uint32_t n = wid < nwords ? (uint32_t)counts[wid] : 0u;
+    Corner8 r;
+    r.active = 0;
     if (n) {
         const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
         const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
-        const Corner8 r = load_corners(bits, g, k, j, w, pbits);
-        unsigned carry = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            s_lo[q][tid] = r.c[2 * q];
-            carry |= (unsigned)(r.c[2 * q + 1] >> 63) << q;
-        }
-        s_carry[tid] = (uint8_t)carry;
-        s_act[tid] = r.active;
+        r = load_corners(bits, g, k, j, w, pbits);
         s_k[tid] = (int32_t)k; s_j[tid] = (int32_t)j; s_w[tid] = (int32_t)w;
+        const int64_t ka = k - g.pb, ja = (g.NY - 1 - j) - g.pxy; // source row of corner (dy=0, dz=0)
+        s_in[tid] = (ka >= 0 && ka + 1 < g.nz && ja - 1 >= 0 && ja < g.ny) ? 1 : 0;
+        s_row[tid] = (ka * g.ny + ja) * g.nx;
     }
     uint32_t inc = n;
 #pragma unroll
@@ -322,73 +320,79 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const 
     __syncthreads();
     uint32_t wbase = 0;
     for (int q = 0; q < wv; q++) wbase += s_wave[q];
-    s_base[tid] = wbase + inc - n;
+    const uint32_t mybase = wbase + inc - n;
+    s_base[tid] = mybase;
     if (tid == 255) s_base[256] = wbase + inc;
     __syncthreads();
     const uint32_t total = s_base[256];
     if (total == 0) return;
     const uint64_t gbase = boff[blockIdx.x];
     if (gbase + total > max_tris) return; // never write past the buffer the caller sized from the count
+    const int64_t plane = g.ny * g.nx;
 
-    for (uint32_t c0 = 0; c0 < total; c0 += 256) {
-        const uint32_t T_ = c0 + tid;
-        if (T_ < total) {
-            // owning word: largest ww with s_base[ww] <= T_  (words with zero triangles are skipped by <=)
-            int lo = 0, hi = 256;
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const int mid = (lo + hi) >> 1;
-                if (s_base[mid] <= T_) lo = mid; else hi = mid;
-            }
-            const int ww = lo;
-            uint32_t rel = T_ - s_base[ww];
-            uint64_t cw[8];
-            const unsigned carry = s_carry[ww];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                cw[2 * q] = s_lo[q][ww];
-                cw[2 * q + 1] = (cw[2 * q] >> 1) | ((uint64_t)((carry >> q) & 1u) << 63);
-            }
-            uint64_t act = s_act[ww];
-            int b = 0, idx = 0;
-            for (;;) { // walk the word's active cells until the one holding triangle `rel`
-                b = __builtin_ctzll(act);
-                idx = case_of(cw, b);
-                const uint32_t nt = s_ntri[idx];
-                if (rel < nt) break;
-                rel -= nt;
+    for (uint32_t win0 = 0; win0 < total; win0 += WIN) {
+        // the OWNER of each word lists its triangles (one case evaluation per active cell, not per triangle)
+        if (n && mybase < win0 + WIN && mybase + n > win0) {
+            uint64_t act = r.active;
+            uint32_t pos = mybase;
+            while (act) {
+                const int b = __builtin_ctzll(act);
                 act &= act - 1;
-            }
-            const int64_t k = s_k[ww], j = s_j[ww], i = (int64_t)s_w[ww] * 64 + b;
-            float *o = s_out + tid * 9;
-            double s0[3], s1[3];
-            int ax[3], bx[3], by[3], bz[3];
-#pragma unroll
-            for (int v = 0; v < 3; v++) { // issue the six gathers of the triangle back to back
-                const int e = s_tri[idx * 16 + 3 * rel + v];
-                edge_decode(e, ax[v], bx[v], by[v], bz[v]);
-                s0[v] = mc_at(a, g, k + bz[v], j + by[v], i + bx[v]);
-                s1[v] = mc_at(a, g, k + bz[v] + (ax[v] == 2), j + by[v] + (ax[v] == 1), i + bx[v] + (ax[v] == 0));
-            }
-#pragma unroll
-            for (int v = 0; v < 3; v++) {
-                const double tt = (iso - s0[v]) / (s1[v] - s0[v]);
-                double p0 = (double)(i + bx[v] - g.pxy);
-                double p1 = (double)(j + by[v] - g.yoff);
-                double p2 = (double)(k + bz[v] + g.zoff);
-                if (ax[v] == 0) p0 += tt;
-                else if (ax[v] == 1) p1 += tt;
-                else p2 += tt;
-                o[3 * v + 0] = (float)(g.sx * p0);
-                o[3 * v + 1] = (float)(g.sy * p1);
-                o[3 * v + 2] = (float)(g.sz * p2);
+                const int idx = case_of(r.c, b);
+                const uint32_t nt = s_ntri[idx];
+                for (uint32_t t = 0; t < nt; t++, pos++)
+                    if (pos >= win0 && pos < win0 + WIN)
+                        s_desc[pos - win0] = ((uint32_t)tid << 24) | ((uint32_t)b << 16) | ((uint32_t)idx << 8) | t;
             }
         }
         __syncthreads();
-        const uint32_t nt_chunk = total - c0 < 256 ? total - c0 : 256;
-        float *dst = tris + (gbase + c0) * 9;
-        for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
-        __syncthreads();
+        const uint32_t wtot = total - win0 < WIN ? total - win0 : WIN;
+        for (uint32_t c0 = 0; c0 < wtot; c0 += 256) {
+            const uint32_t T_ = c0 + tid;
+            if (T_ < wtot) {
+                const uint32_t d = s_desc[T_];
+                const int ww = d >> 24, b = (d >> 16) & 63, idx = (d >> 8) & 255, rel = d & 7;
+                const int32_t k = s_k[ww], j = s_j[ww], i = s_w[ww] * 64 + b;
+                const int32_t ia = i - g.pxy;
+                const bool fast = s_in[ww] && ia >= 0 && ia + 1 < g.nx;
+                const T *cell = a + (fast ? s_row[ww] + ia : 0); // corner (0,0,0); dy -> -nx (flipped), dz -> +plane
+                float *o = s_out + tid * 9;
+                double s0[3], s1[3];
+                int ax[3], bx[3], by[3], bz[3];
+#pragma unroll
+                for (int v = 0; v < 3; v++) { // issue the six gathers of the triangle back to back
+                    const int e = s_tri[idx * 16 + 3 * rel + v];
+                    edge_decode(e, ax[v], bx[v], by[v], bz[v]);
+                    if (fast) {
+                        const int64_t o0 = (int64_t)bz[v] * plane - (int64_t)by[v] * g.nx + bx[v];
+                        const int64_t o1 = o0 + (ax[v] == 2 ? plane : (ax[v] == 1 ? -g.nx : 1));
+                        s0[v] = (double)cell[o0];
+                        s1[v] = (double)cell[o1];
+                    } else {
+                        s0[v] = mc_at(a, g, k + bz[v], j + by[v], i + bx[v]);
+                        s1[v] = mc_at(a, g, k + bz[v] + (ax[v] == 2), j + by[v] + (ax[v] == 1), i + bx[v] + (ax[v] == 0));
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 3; v++) {
+                    const double tt = (iso - s0[v]) / (s1[v] - s0[v]);
+                    double p0 = (double)(i + bx[v] - g.pxy);
+                    double p1 = (double)(j + by[v] - (int32_t)g.yoff);
+                    double p2 = (double)(k + bz[v] + g.zoff);
+                    if (ax[v] == 0) p0 += tt;
+                    else if (ax[v] == 1) p1 += tt;
+                    else p2 += tt;
+                    o[3 * v + 0] = (float)(g.sx * p0);
+                    o[3 * v + 1] = (float)(g.sy * p1);
+                    o[3 * v + 2] = (float)(g.sz * p2);
+                }
+            }
+            __syncthreads();
+            const uint32_t nt_chunk = wtot - c0 < 256 ? wtot - c0 : 256;
+            float *dst = tris + (gbase + win0 + c0) * 9;
+            for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
+            __syncthreads();
+        }
     }
 }
 
