@@ -43,7 +43,7 @@ static inline size_t dtype_size(int dt) {
 }
 
 // Cached device workspaces for the host-level entry points (grow-only, freed by ivx_release_workspace).
-enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_COUNT };
+enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_CCL0, WS_CCL1, WS_COUNT };
 int ws_get(int slot, size_t nbytes, void **dptr);
 // pinned host staging (grow-only)
 int hs_get(int slot, size_t nbytes, void **hptr);
@@ -55,6 +55,11 @@ int download_strided(void *dst, const int64_t shape[3], const int64_t strides[3]
                      int hslot);
 int download_strided2(void *dst, const int64_t shape[2], const int64_t strides[2], const void *src_dev, size_t isz,
                       int hslot);
+
+// run-based union-find flood (k_ccl.hip)
+void ccl_invalidate(const void *scratch);
+bool ccl_supported(uint32_t strct_bits);
+int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, const void *scratch_key, hipStream_t st);
 
 // GPU -> host mailbox in pinned, host-coherent memory: a 1-thread kernel copies up to 32 dwords and then stores a
 // sequence number; the host spins on the sequence word instead of paying a stream synchronisation round trip

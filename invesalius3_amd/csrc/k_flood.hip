@@ -198,25 +198,36 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     const int64_t txi = tile % t.wx, r1 = tile / t.wx;
     const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
     const int64_t z0 = tzi * TZ, y0 = tyi * TY;
-    // stage: lane idx <-> halo row idx (324 rows, 2 passes); 3 words per row, loads issued back to back
-    for (int idx = threadIdx.x; idx < HZ * HY; idx += 256) {
-        const int yy = idx % HY, zz = idx / HY;
-        const int64_t z = z0 + zz - 1, y = y0 + yy - 1;
-        unsigned long long w3[3] = {0ull, 0ull, 0ull};
-        if (z >= 0 && z < t.dz && y >= 0 && y < t.dy) {
-            unsigned long long *row = reached + (z * t.dy + y) * t.wx;
+    // stage: lane idx <-> halo row idx (324 rows = 2 rows per lane for the first 68 lanes); 3 words per row; all six
+    // loads of a lane are issued before any of them is consumed
+    unsigned long long w3[2][3] = {{0ull, 0ull, 0ull}, {0ull, 0ull, 0ull}};
 #pragma unroll
-            for (int xx = 0; xx < 3; xx++) {
-                const int64_t w = txi + xx - 1;
-                if (w >= 0 && w < t.wx)
-                    w3[xx] = ATOMIC ? __hip_atomic_load(row + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : row[w];
+    for (int pass = 0; pass < 2; pass++) {
+        const int idx = threadIdx.x + pass * 256;
+        if (idx < HZ * HY) {
+            const int yy = idx % HY, zz = idx / HY;
+            const int64_t z = z0 + zz - 1, y = y0 + yy - 1;
+            if (z >= 0 && z < t.dz && y >= 0 && y < t.dy) {
+                unsigned long long *row = reached + (z * t.dy + y) * t.wx;
+#pragma unroll
+                for (int xx = 0; xx < 3; xx++) {
+                    const int64_t w = txi + xx - 1;
+                    if (w >= 0 && w < t.wx)
+                        w3[pass][xx] = ATOMIC ? __hip_atomic_load(row + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : row[w];
+                }
             }
         }
-        const unsigned long long cl = w3[0] >> 63, cr = w3[2] & 1ull;
-        L.sN[idx] = w3[1];
-        L.sD[idx] = w3[1] | (w3[1] << 1) | (w3[1] >> 1) | cl | (cr << 63);
-        L.sCL[idx] = (unsigned char)cl;
-        L.sCR[idx] = (unsigned char)cr;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int idx = threadIdx.x + pass * 256;
+        if (idx < HZ * HY) {
+            const unsigned long long cl = w3[pass][0] >> 63, cr = w3[pass][2] & 1ull, n = w3[pass][1];
+            L.sN[idx] = n;
+            L.sD[idx] = n | (n << 1) | (n >> 1) | cl | (cr << 63);
+            L.sCL[idx] = (unsigned char)cl;
+            L.sCR[idx] = (unsigned char)cr;
+        }
     }
     const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> 4;
     const int64_t z = z0 + tz, y = y0 + ty;
@@ -312,8 +323,8 @@ __global__ __launch_bounds__(256) void k_flood_round(Tiles t, const unsigned lon
             // byte flags: use a 32-bit atomic on the containing word
             unsigned int *wp = (unsigned int *)(dirty_next + (nt & ~(int64_t)3));
             const unsigned int bit = 1u << (8 * (nt & 3));
-            const unsigned int old = atomicOr(wp, bit);
-            if (!(old & (0xffu << (8 * (nt & 3))))) atomicAdd(counter_next, 1u);
+            atomicOr(wp, bit);            // no returned value: nothing waits for the round trip
+            atomicAdd(counter_next, 1u);  // counts marking events; only "zero or not" is ever tested
         }
     }
 }
@@ -527,6 +538,7 @@ extern "C" int ivx_dev_flood_seed(const ivx_flood_plan *p, int dtype, const void
     const FScratch s = make_fscratch(t);
     char *scr = (char *)scratch_;
     hipStream_t st = ivx::S(stream);
+    ivx::ccl_invalidate(scratch_); // a seed may add a bit to the candidate plane
     if (nseeds <= 16) { // the usual case (one click = one seed): seeds travel as kernel arguments, no staging, no sync
         SeedPack sp;
         sp.n = (int)nseeds;
@@ -573,6 +585,7 @@ extern "C" int ivx_dev_flood_clear(const ivx_flood_plan *p, uint64_t *reached, v
     IVX_HIP(hipMemsetAsync(reached, 0, (size_t)(t.dz * t.dy * t.wx) * 8, ivx::S(stream)));
     IVX_HIP(hipMemsetAsync(scratch, 0, s.off_seeds, ivx::S(stream)));
     IVX_HIP(hipMemsetAsync((char *)scratch + s.off_ring, 0xff, (size_t)s.qcap * 4, ivx::S(stream)));
+    ivx::ccl_invalidate(scratch);
     return IVX_OK;
 }
 
@@ -588,12 +601,24 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
     hipStream_t st = ivx::S(stream);
     uint8_t *dirty[2] = {(uint8_t *)(scr + s.off_dirty0), (uint8_t *)(scr + s.off_dirty1)};
     unsigned int *cnt = (unsigned int *)(scr + s.off_cnt);
-    static const bool use_rounds = [] {
-        // default: one launch per round (measured faster at 512^3: 1.00 ms vs 1.47 ms, the asynchronous frontier
-        // revisits tiles ~2.7x more often).  IVX_FLOOD_MODE=persistent selects the single-launch device-side queue.
+    // IVX_FLOOD_MODE: "rounds" (default) = tile frontier, one launch per round, with an escape to the union-find path
+    // when a flood needs more than CCL_ESCAPE_ROUNDS rounds (serpentine / maze-like regions); "ccl" = run-based
+    // union-find from the start (k_ccl.hip; no frontier, flat cost); "persistent" = tile frontier, single launch +
+    // device queue.  Measured at 512^3 on the bench blob (20 rounds): rounds 0.74 ms, ccl 0.86 ms, persistent 1.4 ms.
+    static const int mode = [] {
         const char *e = getenv("IVX_FLOOD_MODE");
-        return !(e && !strcmp(e, "persistent"));
+        if (e && !strcmp(e, "ccl")) return 0;
+        if (e && !strcmp(e, "persistent")) return 2;
+        return 1;
     }();
+    constexpr int CCL_ESCAPE_ROUNDS = 48;
+    if (mode == 0 && ivx::ccl_supported(p->strct_bits)) {
+        if (rounds) *rounds = 1;
+        // the dirty-tile list is not used by this path; keep it empty so a later frontier run starts clean
+        IVX_HIP(hipMemsetAsync(dirty[0], 0, (size_t)t.ntiles, st));
+        return ivx::ccl_run(p, cand, reached, scratch_, st);
+    }
+    const bool use_rounds = mode != 2;
     static const unsigned int max_spins = [] {
         const char *e = getenv("IVX_FLOOD_MAX_SPINS");
         return e ? (unsigned int)strtoul(e, nullptr, 10) : (1u << 20);
@@ -643,11 +668,26 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
         uint32_t seq;
         if ((rc = ivx::mailbox_publish(cnt, BATCH, st, &seq))) return rc;
         if ((rc = ivx::mailbox_wait(seq, st, h, BATCH))) return rc;
+        static const bool trace = getenv("IVX_FLOOD_TRACE") != nullptr;
+        if (trace) {
+            fprintf(stderr, "ivx flood: tile marks after rounds %d..%d:", total_rounds + 1, total_rounds + BATCH);
+            for (int b = 0; b < BATCH; b++) fprintf(stderr, " %u", h[b]);
+            fprintf(stderr, "  (of %lld tiles)\n", (long long)t.ntiles);
+        }
         int used = BATCH;
         for (int b = 0; b < BATCH; b++)
             if (h[b] == 0) { used = b + 1; break; }
         total_rounds += used;
         if (h[BATCH - 1] == 0) break;
+        if (total_rounds >= CCL_ESCAPE_ROUNDS && ivx::ccl_supported(p->strct_bits)) {
+            // long, thin region: stop paying one launch per tile hop -- every reached bit so far is correct, the
+            // union-find path completes the components they belong to in one flat pass
+            IVX_HIP(hipMemsetAsync(dirty[0], 0, (size_t)t.ntiles, st));
+            IVX_HIP(hipMemsetAsync(dirty[1], 0, (size_t)t.ntiles, st));
+            if ((rc = ivx::ccl_run(p, cand, reached, scratch_, st))) return rc;
+            total_rounds += 1;
+            break;
+        }
         IVX_REQUIRE(total_rounds < (1 << 24), IVX_EHIP, "flood: did not converge");
     }
     if (rounds) *rounds = total_rounds;

@@ -152,3 +152,54 @@ def test_full_size_512_properties(ivxlib):
     again = out.copy()
     floodfill.floodfill_threshold(img, [(int(x), int(y), int(z))], 200, 32767, 1, strct, again)
     assert np.array_equal(again, out)
+
+
+def test_long_serpentine_escapes_to_union_find(ivxlib, oracle):
+    """a corridor that needs hundreds of tile hops: the frontier hands over to the union-find path (k_ccl.hip)
+    after 48 rounds; the result must still be the oracle's"""
+    from invesalius3_amd import invesalius_rs as floodfill
+    dz, dy, dx = 4, 400, 200
+    img = np.zeros((dz, dy, dx), np.int16)
+    for y in range(0, dy, 2):
+        img[1, y, :] = 1
+        xs = dx - 1 if (y // 2) % 2 == 0 else 0
+        if y + 1 < dy:
+            img[1, y + 1, xs] = 1
+    img[3, ::7, ::5] = 1  # unrelated specks
+    for strct in (generate_binary_structure(3, 1), generate_binary_structure(3, 3)):
+        og = np.zeros(img.shape, np.uint8)
+        orf = og.copy()
+        floodfill.floodfill_threshold(img, [(0, 0, 1)], 1, 1, 9, strct, og)
+        oracle.floodfill_threshold(img, [(0, 0, 1)], 1, 1, 9, strct, orf)
+        assert np.array_equal(og, orf)
+        assert (og == 9).sum() >= dx * dy // 2
+
+
+@pytest.mark.parametrize("mode", ["ccl", "persistent", "rounds"])
+def test_all_flood_engines_agree(ivxlib, oracle, mode):
+    """the three engines (tile frontier per round, persistent frontier, union-find) in a fresh process each"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import synth_volume\n"
+        "from scipy.ndimage import generate_binary_structure\n"
+        "from invesalius3_amd import invesalius_rs as ff\n"
+        "from oracle import oracle as orc\n"
+        "img = synth_volume((40, 72, 136), seed=91)\n"
+        "rng = np.random.default_rng(3)\n"
+        "for conn in (1, 2, 3):\n"
+        "    s = generate_binary_structure(3, conn)\n"
+        "    z, y, x = np.unravel_index(np.argmax(img), img.shape)\n"
+        "    seeds = [(int(x), int(y), int(z)), (5, 5, 5)]\n"
+        "    og = (rng.random(img.shape) < 0.02).astype(np.uint8); orf = og.copy()\n"
+        "    ff.floodfill_threshold(img, seeds, -820, 3071, 1, s, og)\n"
+        "    orc.floodfill_threshold(img, seeds, -820, 3071, 1, s, orf)\n"
+        "    assert np.array_equal(og, orf), conn\n"
+        "print('engines-ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                   os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IVX_FLOOD_MODE=mode)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "engines-ok" in r.stdout, r.stdout + r.stderr
