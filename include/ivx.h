@@ -205,6 +205,10 @@ int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *cand, uint64
 /* out[v] = fill where reached (uint8 out), or data[v] = fill (in-place form, dtype of data) */
 int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reached, int dtype, void *target,
                         double fill, void *stream);
+/* both writes of a GUI region-grow in one pass: out[v] = fill and mask[v] = select where reached
+ * (floodfill_threshold's out + `mask[out_mask.astype(bool)] = 254`, styles.py:3200-3214) */
+int ivx_dev_flood_apply2(const ivx_flood_plan *p, const uint64_t *reached, uint8_t *out, int fill, uint8_t *mask,
+                         int select, void *stream);
 /* number of reached voxels */
 int ivx_dev_flood_count(const ivx_flood_plan *p, const uint64_t *reached, int64_t *count, void *stream);
 int ivx_floodfill_threshold(int dtype, const void *data, const int64_t shape[3], const int64_t strides[3],

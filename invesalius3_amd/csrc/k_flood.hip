@@ -22,6 +22,7 @@
 //                       (agent-scope atomics); the host loops rounds until no tile is dirty.  Global rounds are
 //                       bounded by the number of TILES on the longest path, not voxels.
 //   k_flood_apply       reached bits -> out[v] = fill (only words with reached bits touch memory).
+#include <math.h>
 #include <stdlib.h>
 
 #include "ivx_internal.h"
@@ -87,6 +88,34 @@ template <typename T> __device__ __forceinline__ double as_double(T v) { return 
 
 // ---- candidates: one lane per output byte (8 voxels) ------------------------------------------------
 // BAR: 0 none, 1 uint8 barrier array (out != fill), 2 in-place (data value != fill)
+// fast path: int16/uint16 data, dx % 16 == 0, 16-B aligned pointers: one lane = 16 voxels (2 x 16-B data loads,
+// one 16-B barrier load, one 2-B store), the same access shape as the threshold kernel
+template <typename T, int BAR>
+__global__ __launch_bounds__(256) void k_flood_candidates16(const short8_t *__restrict__ data,
+                                                            const uint4 *__restrict__ bar, int64_t nchunks, double t0,
+                                                            double t1, double fill, uint16_t *__restrict__ cand) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int lo = (int)ceil(t0 < -70000.0 ? -70000.0 : t0), hi = (int)floor(t1 > 70000.0 ? 70000.0 : t1); // integer data
+    const unsigned fb = (unsigned)(uint8_t)fill;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += stride) {
+        const short8_t a = __builtin_nontemporal_load(&data[2 * c]);
+        const short8_t b = __builtin_nontemporal_load(&data[2 * c + 1]);
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (BAR == 1) q = bar[c];
+        const unsigned bw[4] = {q.x, q.y, q.z, q.w};
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int v = (int)(T)(e < 8 ? a[e & 7] : b[e & 7]);
+            bool ok = v >= lo && v <= hi;
+            if (BAR == 1) ok = ok && ((bw[e >> 2] >> (8 * (e & 3))) & 0xffu) != fb;
+            if (BAR == 2) ok = ok && (double)v != fill;
+            m |= ok ? (1u << e) : 0u;
+        }
+        cand[c] = (uint16_t)m;
+    }
+}
+
 template <typename T, int BAR>
 __global__ __launch_bounds__(256) void k_flood_candidates(const T *__restrict__ data, const uint8_t *__restrict__ bar,
                                                           Tiles t, double t0, double t1, double fill,
@@ -436,6 +465,27 @@ __global__ __launch_bounds__(256) void k_flood_apply(Tiles t, const uint8_t *__r
     }
 }
 
+// out[v] = fill AND mask[v] = select where reached: floodfill_threshold's `out` plus the caller's
+// `mask[out_mask.astype(bool)] = 254` (styles.py:3214) in one pass over the reached bits
+__global__ __launch_bounds__(256) void k_flood_apply2(Tiles t, const uint8_t *__restrict__ reached, uint8_t *__restrict__ out,
+                                                      uint8_t fill, uint8_t *__restrict__ mask, uint8_t select) {
+    const int64_t bpr = t.wx * 8;
+    const int64_t total = t.dz * t.dy * bpr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const unsigned m = reached[i];
+        if (!m) continue;
+        const int64_t row = i / bpr, q = i - row * bpr;
+        const int64_t base = row * t.dx + q * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (m >> e & 1u) {
+                out[base + e] = fill;
+                mask[base + e] = select;
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_flood_count(const unsigned long long *__restrict__ bits, int64_t nwords,
                                                      unsigned long long *__restrict__ total) {
     unsigned long long s = 0;
@@ -456,6 +506,20 @@ static int run_candidates(const Tiles &t, const void *data, double t0, double t1
                           double fill, uint8_t *cand, hipStream_t st) {
     const int64_t total = t.dz * t.dy * t.wx * 8;
     if (!total) return IVX_OK;
+    if (sizeof(T) == 2 && t.dx % 64 == 0 && (((uintptr_t)data | (uintptr_t)bar | (uintptr_t)cand) & 15) == 0) {
+        // rows are whole words, so the bit volume is one flat array of 16-voxel chunks
+        const int64_t nchunks = t.dz * t.dy * t.dx / 16;
+        const int64_t blocks = ivx::cdiv(nchunks, 256);
+        const int gg = (int)(blocks < 16384 ? blocks : 16384);
+        const short8_t *d8 = (const short8_t *)data;
+        const uint4 *b4 = (const uint4 *)bar;
+        uint16_t *c16 = (uint16_t *)cand;
+        if (bar_mode == 0) hipLaunchKernelGGL((k_flood_candidates16<T, 0>), dim3(gg), dim3(256), 0, st, d8, b4, nchunks, t0, t1, fill, c16);
+        else if (bar_mode == 1) hipLaunchKernelGGL((k_flood_candidates16<T, 1>), dim3(gg), dim3(256), 0, st, d8, b4, nchunks, t0, t1, fill, c16);
+        else hipLaunchKernelGGL((k_flood_candidates16<T, 2>), dim3(gg), dim3(256), 0, st, d8, b4, nchunks, t0, t1, fill, c16);
+        IVX_LAUNCH_CHECK();
+        return IVX_OK;
+    }
     const int g = grid_for(total);
     if (bar_mode == 0)
         hipLaunchKernelGGL((k_flood_candidates<T, 0>), dim3(g), dim3(256), 0, st, (const T *)data, bar, t, t0, t1, fill, cand);
@@ -727,6 +791,19 @@ extern "C" int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reac
     case IVX_F64: hipLaunchKernelGGL(k_flood_apply<double>, dim3(g), dim3(256), 0, st, t, r, (double *)target, fill); break;
     default: ivx::set_error("flood: unsupported dtype %d", dtype); return IVX_EINVAL;
     }
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_apply2(const ivx_flood_plan *p, const uint64_t *reached, uint8_t *out, int fill,
+                                    uint8_t *mask, int select, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    const int64_t total = t.dz * t.dy * t.wx * 8;
+    if (!total) return IVX_OK;
+    hipLaunchKernelGGL(k_flood_apply2, dim3(grid_for(total)), dim3(256), 0, ivx::S(stream), t, (const uint8_t *)reached, out,
+                       (uint8_t)fill, mask, (uint8_t)select);
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }

@@ -181,9 +181,11 @@ class DeviceVolume:
         rounds = ctypes.c_int(0)
         L.check(lib.ivx_dev_flood_run(p, self.cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
                                       st), "region_grow")
-        L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
         if select_value is not None:
-            L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.mask.ptr, ctypes.c_double(select_value), st))
+            L.check(lib.ivx_dev_flood_apply2(p, self.reached.ptr, self.out_mask.ptr, int(fill), self.mask.ptr,
+                                             int(select_value), st))
+        else:
+            L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
         return rounds.value
 
     def region_grow_confidence(self, seed_xyz, strct, confid_mult=2.5, confid_iters=3, select_value=254):

@@ -193,9 +193,11 @@ def _make_slab_volume():
                                                self.flood_scratch.ptr, st), "region_grow")
             self._rounds = 0
             slab_region_grow(self, self.comm, self.lay)
-            L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
             if select_value is not None:
-                L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.mask.ptr, ctypes.c_double(select_value), st))
+                L.check(lib.ivx_dev_flood_apply2(p, self.reached.ptr, self.out_mask.ptr, int(fill), self.mask.ptr,
+                                                 int(select_value), st))
+            else:
+                L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
             return self._rounds
 
         def reached_count(self) -> int:
