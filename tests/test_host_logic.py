@@ -1,0 +1,64 @@
+"""CPU: host-side logic of the package that needs no device (argument checking, bounds, STL sink, layout helpers)."""
+import numpy as np
+import pytest
+
+
+def test_integer_threshold_bounds():
+    from invesalius3_amd.slice_ import _int_bounds
+    assert _int_bounds((226, 3071)) == (226, 3071)
+    assert _int_bounds((225.5, 3071.9)) == (226, 3071)  # v >= 225.5  <=>  v >= 226 for integer voxels
+    assert _int_bounds((-1e12, 1e12)) == (-(2 ** 31), 2 ** 31 - 1)
+
+
+def test_argument_errors_do_not_need_a_device():
+    from invesalius3_amd import invesalius_rs as rs, slice_, surface_process as sp
+    img = np.zeros((2, 3, 4), np.int16)
+    with pytest.raises(TypeError):
+        slice_.do_threshold_to_all_slices(np.zeros((3, 4, 5), np.int16), img, (0, 1))
+    with pytest.raises(ValueError):
+        slice_.do_threshold_to_all_slices(np.zeros((2, 3, 4), np.uint8), img, (0, 1))
+    with pytest.raises(TypeError):
+        rs.floodfill_threshold(img.astype(np.float32), [(0, 0, 0)], 0, 1, 1, np.ones((3, 3, 3)), np.zeros((2, 3, 4), np.uint8))
+    with pytest.raises(TypeError):
+        rs.floodfill_threshold(img, [(0, 0, 0)], 0, 1, 1, np.ones((3, 3, 3)), np.zeros((2, 3, 4), np.int16))
+    with pytest.raises(TypeError):
+        rs.mida(img, 0, 1, 1, np.zeros((3, 4), np.uint8))
+    with pytest.raises(OverflowError):
+        rs.mida(img, 0, 70000, 1, np.zeros((3, 4), np.int16))
+    with pytest.raises(ValueError):
+        sp.marching_cubes(np.zeros((2, 2, 2), np.uint8), (1, 1, 1), [1, 2, 3])
+    with pytest.raises(TypeError):
+        sp.marching_cubes(np.zeros((2, 2, 2), np.float32), (1, 1, 1), [1])
+
+
+def test_stl_sink_layout(tmp_path):
+    """vtkSTLWriter binary layout (surface.py:1827-1829): 80 B header, u32 count, 50 B per triangle"""
+    from invesalius3_amd import surface_process as sp
+    tris = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 1], [0, 1, 1], [1, 0, 1]]], np.float32)
+    p = tmp_path / "s.stl"
+    sp.write_stl_binary(str(p), tris)
+    raw = p.read_bytes()
+    assert len(raw) == 80 + 4 + 2 * 50
+    assert raw[:40] == b"Visualization Toolkit generated SLA File"
+    assert np.frombuffer(raw[80:84], "<u4")[0] == 2
+    rec = np.frombuffer(raw[84:], dtype=[("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+    assert np.array_equal(rec["v"], tris)
+    np.testing.assert_allclose(rec["n"], [[0, 0, 1], [0, 0, -1]])
+
+
+def test_structures_accepted_by_the_union_find_engine():
+    """host-side mirror of ccl_supported(): symmetric strct with both x neighbours in the centre row"""
+    from scipy.ndimage import generate_binary_structure
+
+    def bits(s):
+        s = np.asarray(s, np.uint8)
+        return sum(1 << k for k, v in enumerate(s.ravel()) if v)
+
+    def supported(b):
+        b |= 1 << 13
+        return all(((b >> k) & 1) == ((b >> (26 - k)) & 1) for k in range(27)) and (b >> 12) & 1 and (b >> 14) & 1
+    for conn in (1, 2, 3):
+        assert supported(bits(generate_binary_structure(3, conn)))
+    one_way = np.zeros((3, 3, 3), np.uint8)
+    one_way[1, 1, 2] = 1
+    assert not supported(bits(one_way))
