@@ -199,6 +199,14 @@ def main():
                       "marching_cubes": mc_ms}
         dom = max(stage_time, key=lambda k: stage_time[k])
         achieved = stage_bytes[dom] / (stage_time[dom] * 1e-3) / 1e9 if stage_time[dom] > 0 else 0.0
+        # HBM traffic of the dominant stage from the committed PMC passes (rocprofv3 cannot run inside the bench):
+        # profiles/pmc_traffic.json = 2 x FETCH_SIZE + WRITE_SIZE per step, produced by tools/summarize_pmc.py
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["traffic_bytes_per_step"].get(dom) if n == 512 and world == 1 else None
+        except (OSError, ValueError, KeyError):
+            traffic = None
         res = {
             "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
             "value": round(world * nvox / (dt / args.steps) / 1e6, 2),
@@ -214,7 +222,8 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_mvoxel_per_s": {k: round(nvox / (v * 1e-3) / 1e6, 1) for k, v in stage_time.items() if v > 0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes": stage_bytes[dom], "ms": round(stage_time[dom], 4),
                          "per_stage_frac": {k: round(stage_bytes[k] / (stage_time[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                             for k in stage_time if stage_time[k] > 0}},
             "device": L.device_name(),

@@ -48,6 +48,22 @@ def main():
     print(out)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out + "\n")
+    if len(sys.argv) > 4:  # <traffic.json> <steps of the kernel-trace run incl. warmup>
+        import json
+        nsteps = int(sys.argv[4])
+        stage_of = lambda k: ("threshold" if k.startswith("k_threshold") else "marching_cubes" if k.startswith("k_mc_")
+                              else "region_grow" if k.startswith(("k_flood_", "k_ccl_", "k_scan_")) and not k.startswith("k_flood_count")
+                              else None)
+        traffic = {}
+        for k, (calls, avg, pct) in stats.items():
+            st = stage_of(k)
+            if st is None or not fe.get(k) or not wr.get(k):
+                continue
+            per_launch = (2 * sum(fe[k]) / len(fe[k]) + sum(wr[k]) / len(wr[k])) * 1024
+            traffic[st] = traffic.get(st, 0.0) + per_launch * calls / nsteps
+        json.dump({"unit": "bytes per bench step (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B), kernels of the stage only",
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
+                   "traffic_bytes_per_step": {k: round(v) for k, v in traffic.items()}}, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":
