@@ -245,6 +245,10 @@ int ivx_fill_holes_automatically(uint8_t *mask, const int64_t shape[3], const in
  * ---------------------------------------------------------------------------------------------- */
 int ivx_dev_lut_u16(const int16_t *img, int64_t n, double window, double level, int top255, uint16_t *out,
                     void *stream);
+/* same LUT, int16 out: the image get_LUT_value_255 hands to floodfill_threshold in the "dynamic" / "confidence"
+ * region-growing modes with use_ww_wl (invesalius/data/styles.py:3166-3171, 3222-3225) */
+int ivx_dev_lut_i16(const int16_t *img, int64_t n, double window, double level, int top255, int16_t *out,
+                    void *stream);
 int ivx_dev_shift_min_u16(const int16_t *img, int64_t n, int imin, uint16_t *out, void *stream);
 int ivx_dev_morph_gradient_u16(const uint16_t *in, int64_t dz, int64_t dy, int64_t dx, const int size[3],
                                uint16_t *out, void *stream);

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void k_fill_small(uint8_t *__restrict__ mask, 
 
 // ---- window / level LUT -------------------------------------------------------------------------------------
 // np.piecewise on an int16 array: result dtype int16, the float64 expression is truncated toward zero.
+template <typename O>
 __global__ __launch_bounds__(256) void k_lut_u16(const int16_t *__restrict__ img, int64_t n, double window, double level,
-                                                 double top, uint16_t *__restrict__ out) {
+                                                 double top, O *__restrict__ out) {
     const double lo = level - 0.5 - (window - 1.0) / 2.0;
     const double hi = level - 0.5 + (window - 1.0) / 2.0;
     const int16_t topv = (int16_t)top;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_lut_u16(const int16_t *__restrict__ img
         if (d <= lo) r = 0;
         else if (d > hi) r = topv;
         else r = (int16_t)(((d - (level - 0.5)) / (window - 1.0) + 0.5) * top);
-        out[i] = (uint16_t)r; // .astype("uint16")
+        out[i] = (O)r; // int16 as np.piecewise leaves it, or .astype("uint16")
     }
 }
 __global__ __launch_bounds__(256) void k_shift_min_u16(const int16_t *__restrict__ img, int64_t n, int imin,
@@ -214,7 +215,15 @@ extern "C" int ivx_fill_holes_automatically(uint8_t *mask, const int64_t shape[3
 extern "C" int ivx_dev_lut_u16(const int16_t *img, int64_t n, double window, double level, int top255, uint16_t *out,
                                void *stream) {
     if (n == 0) return IVX_OK;
-    hipLaunchKernelGGL(k_lut_u16, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), img, n, window, level,
+    hipLaunchKernelGGL(k_lut_u16<uint16_t>, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), img, n, window, level,
+                       top255 ? 255.0 : window, out);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+extern "C" int ivx_dev_lut_i16(const int16_t *img, int64_t n, double window, double level, int top255, int16_t *out,
+                               void *stream) {
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_lut_u16<int16_t>, dim3(grid_for(n, 4)), dim3(256), 0, ivx::S(stream), img, n, window, level,
                        top255 ? 255.0 : window, out);
     IVX_LAUNCH_CHECK();
     return IVX_OK;

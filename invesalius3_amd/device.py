@@ -160,10 +160,21 @@ class DeviceVolume:
                                               int(bool(preserve)), None, self.mask.ptr, self.stream), "threshold")
 
     # -- region growing (floodfill.rs:96-166 on the image; styles.py:3151-3216) ----------------------------
-    def region_grow(self, seeds_xyz, t0, t1, strct, fill: int = 1, select_value: int | None = 254) -> int:
+    def lut_image_255(self, ww, wl) -> DeviceBuffer:
+        """get_LUT_value_255(image, ww, wl) (imagedata_utils.py:540-552) as a resident int16 volume: the image the
+        "dynamic" and "confidence" region-growing modes flood when use_ww_wl is set (styles.py:3166-3171, 3222-3225)."""
+        buf = DeviceBuffer(self.n * 2)
+        L.check(L.lib().ivx_dev_lut_i16(self.image.ptr, c64(self.n), ctypes.c_double(float(ww)), ctypes.c_double(float(wl)),
+                                        1, buf.ptr, self.stream), "lut_image_255")
+        return buf
+
+    def region_grow(self, seeds_xyz, t0, t1, strct, fill: int = 1, select_value: int | None = 254,
+                    image: DeviceBuffer | None = None) -> int:
         """floodfill_threshold(image, seeds, t0, t1, fill, strct, out_mask) followed (when select_value is not None)
-        by `mask[out_mask.astype(bool)] = select_value` (styles.py:3214).  Returns the number of global rounds."""
+        by `mask[out_mask.astype(bool)] = select_value` (styles.py:3214).  `image` = an alternative resident int16
+        volume (e.g. lut_image_255).  Returns the number of global rounds."""
         lib = L.lib()
+        img_ptr = (image or self.image).ptr
         s3 = np.ascontiguousarray(strct, dtype=np.uint8)
         bits = ctypes.c_uint32(0)
         L.check(lib.ivx_flood_strct_bits(L.ptr(s3), L.i64(s3.shape), ctypes.byref(bits)))
@@ -173,9 +184,9 @@ class DeviceVolume:
         st = self.stream
         t0, t1 = float(int(t0)), float(int(t1))  # wrapper int() truncation for integer images
         L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
-        L.check(lib.ivx_dev_flood_candidates(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1),
+        L.check(lib.ivx_dev_flood_candidates(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1),
                                              self.out_mask.ptr, 1, ctypes.c_double(fill), self.cand.ptr, st))
-        L.check(lib.ivx_dev_flood_seed(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
+        L.check(lib.ivx_dev_flood_seed(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
                                        c64(len(seeds)), self.cand.ptr, self.reached.ptr, self.flood_scratch.ptr, st),
                 "region_grow")
         rounds = ctypes.c_int(0)
@@ -188,7 +199,8 @@ class DeviceVolume:
             L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
         return rounds.value
 
-    def region_grow_confidence(self, seed_xyz, strct, confid_mult=2.5, confid_iters=3, select_value=254):
+    def region_grow_confidence(self, seed_xyz, strct, confid_mult=2.5, confid_iters=3, select_value=254,
+                               image: DeviceBuffer | None = None):
         """do_rg_confidence (invesalius/data/styles.py:3220-3251): `confid_iters` rounds of
         mean +- confid_mult * std over the grown region -> floodfill_threshold into the SAME out_mask (never cleared:
         SURVEY quirk Q4).  Statistics are exact integer sums on the GPU; mean/std are formed in float64 on the host
@@ -203,13 +215,13 @@ class DeviceVolume:
         rounds = 0
         for _ in range(int(confid_iters)):
             acc = (ctypes.c_int64 * 3)()
-            L.check(lib.ivx_dev_masked_stats_i16(self.image.ptr, d_sel.ptr, c64(self.n), acc, self.stream))
+            L.check(lib.ivx_dev_masked_stats_i16((image or self.image).ptr, d_sel.ptr, c64(self.n), acc, self.stream))
             cnt, s1, s2 = int(acc[0]), int(acc[1]), int(acc[2])
             mean = s1 / cnt
             var = max(s2 / cnt - mean * mean, 0.0)
             std = float(np.sqrt(var))
             t0, t1 = mean - std * confid_mult, mean + std * confid_mult
-            rounds += self.region_grow([(x, y, z)], t0, t1, strct, fill=1, select_value=None)
+            rounds += self.region_grow([(x, y, z)], t0, t1, strct, fill=1, select_value=None, image=image)
             L.check(lib.ivx_dev_or_equal_u8(d_sel.ptr, self.out_mask.ptr, c64(self.n), 1, self.stream))
         if select_value is not None:
             L.check(lib.ivx_dev_flood_apply_where(self.mask.ptr, self.out_mask.ptr, c64(self.n), 1, int(select_value),
