@@ -25,12 +25,20 @@ template <typename T, int OP> struct Red {
     }
 };
 
+template <int OP> struct Red32 {
+    __device__ static __forceinline__ int comb(int a, int b) {
+        return OP == IVX_MIP_MAX ? (a > b ? a : b) : OP == IVX_MIP_MIN ? (a < b ? a : b) : a + b;
+    }
+};
+
 // generic strided reduce: out pixel (r, c) = reduce_l vol[r*sr + c*sc + l*sl], c contiguous (sc == 1).
 // One lane handles VEC adjacent c; the l range is split across blockIdx.y.
+// partial results are int32: a segment is at most 32767 samples of a <= 16-bit type, so |sum| < 2^31
+typedef int part_t;
 template <typename T, int OP, int VEC>
 __global__ __launch_bounds__(256) void k_reduce_strided(const T *__restrict__ vol, int64_t nr, int64_t nc, int64_t len,
                                                         int64_t sr, int64_t sl, int64_t seg,
-                                                        long long *__restrict__ partial) {
+                                                        part_t *__restrict__ partial) {
     const int64_t ncg = (nc + VEC - 1) / VEC;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nr * ncg) return;
@@ -38,9 +46,9 @@ __global__ __launch_bounds__(256) void k_reduce_strided(const T *__restrict__ vo
     const int64_t c0 = cg * VEC;
     const int64_t l0 = (int64_t)blockIdx.y * seg;
     const int64_t l1 = l0 + seg < len ? l0 + seg : len;
-    long long acc[VEC];
+    int acc[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; v++) acc[v] = Red<T, OP>::init();
+    for (int v = 0; v < VEC; v++) acc[v] = OP == IVX_MIP_MAX ? INT32_MIN : OP == IVX_MIP_MIN ? INT32_MAX : 0;
     const T *p = vol + r * sr + c0;
     const bool full = (c0 + VEC <= nc) && ((((uintptr_t)(p + l0 * sl)) | ((uintptr_t)(sl * sizeof(T)))) % (VEC * sizeof(T)) == 0);
     if (full) {
@@ -49,15 +57,15 @@ __global__ __launch_bounds__(256) void k_reduce_strided(const T *__restrict__ vo
         for (int64_t l = l0; l < l1; l++) {
             const vec_t x = *reinterpret_cast<const vec_t *>(p + l * sl);
 #pragma unroll
-            for (int v = 0; v < VEC; v++) acc[v] = Red<T, OP>::comb(acc[v], (long long)x[v]);
+            for (int v = 0; v < VEC; v++) acc[v] = Red32<OP>::comb(acc[v], (int)x[v]);
         }
     } else {
         for (int64_t l = l0; l < l1; l++)
 #pragma unroll
             for (int v = 0; v < VEC; v++)
-                if (c0 + v < nc) acc[v] = Red<T, OP>::comb(acc[v], (long long)p[l * sl + v]);
+                if (c0 + v < nc) acc[v] = Red32<OP>::comb(acc[v], (int)p[l * sl + v]);
     }
-    long long *o = partial + ((int64_t)blockIdx.y * nr + r) * nc + c0;
+    part_t *o = partial + ((int64_t)blockIdx.y * nr + r) * nc + c0;
 #pragma unroll
     for (int v = 0; v < VEC; v++)
         if (c0 + v < nc) o[v] = acc[v];
@@ -92,13 +100,13 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const T *__restrict__ vol, 
     if (lane == 0) partial[ray] = acc;
 }
 
-template <typename T, int OP>
-__global__ __launch_bounds__(256) void k_combine(const long long *__restrict__ partial, int64_t npix, int split,
+template <typename T, int OP, typename P>
+__global__ __launch_bounds__(256) void k_combine(const P *__restrict__ partial, int64_t npix, int split,
                                                  int64_t len, void *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
-    long long acc = partial[i];
-    for (int s = 1; s < split; s++) acc = Red<T, OP>::comb(acc, partial[(int64_t)s * npix + i]);
+    long long acc = (long long)partial[i];
+    for (int s = 1; s < split; s++) acc = Red<T, OP>::comb(acc, (long long)partial[(int64_t)s * npix + i]);
     if (OP == IVX_MIP_MEAN) ((double *)out)[i] = (double)acc / (double)len;
     else ((T *)out)[i] = (T)acc;
 }
@@ -121,7 +129,7 @@ static int run_reduce(const void *vol_, int64_t dz, int64_t dy, int64_t dx, int 
         hipLaunchKernelGGL((k_reduce_rows<T, OP, VEC>), dim3((unsigned)ivx::cdiv(npix, 4)), dim3(256), 0, st, vol, npix,
                            len, (long long *)part);
         IVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_combine<T, OP>), dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_combine<T, OP, long long>), dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st,
                            (const long long *)part, npix, 1, len, out);
         IVX_LAUNCH_CHECK();
         return IVX_OK;
@@ -131,19 +139,19 @@ static int run_reduce(const void *vol_, int64_t dz, int64_t dy, int64_t dx, int 
     const int64_t ncg = ivx::cdiv(nc, VEC);
     const int64_t nthreads = nr * ncg;
     const int64_t nblk = ivx::cdiv(nthreads, 256);
-    // split the ray so that >= ~4096 workgroups exist, but keep segments >= 16 samples
-    int64_t split = ivx::cdiv(4096, nblk);
-    if (split > len / 16) split = len / 16;
+    // split the ray so that >= ~2048 workgroups exist (segments >= 32 samples, <= 32767 so int32 partial sums hold)
+    int64_t split = ivx::cdiv(2048, nblk);
+    if (split > len / 32) split = len / 32;
+    if (split < ivx::cdiv(len, 32767)) split = ivx::cdiv(len, 32767);
     if (split < 1) split = 1;
-    if (split > 64) split = 64;
     const int64_t seg = ivx::cdiv(len, split);
     split = ivx::cdiv(len, seg);
-    if ((rc = ivx::ws_get(ivx::WS_AUX3, (size_t)npix * 8 * split, &part))) return rc;
+    if ((rc = ivx::ws_get(ivx::WS_AUX3, (size_t)npix * sizeof(part_t) * split, &part))) return rc;
     hipLaunchKernelGGL((k_reduce_strided<T, OP, VEC>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, vol, nr,
-                       nc, len, sr, sl, seg, (long long *)part);
+                       nc, len, sr, sl, seg, (part_t *)part);
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_combine<T, OP>), dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st,
-                       (const long long *)part, npix, (int)split, len, out);
+    hipLaunchKernelGGL((k_combine<T, OP, part_t>), dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st,
+                       (const part_t *)part, npix, (int)split, len, out);
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }

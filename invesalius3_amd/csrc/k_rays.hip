@@ -211,6 +211,20 @@ __global__ __launch_bounds__(256) void k_minmax_part(const T *__restrict__ vol, 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     T mn = vol[0], mx = vol[0];
+    constexpr int V = 16 / sizeof(T);
+    if ((((uintptr_t)vol) & 15) == 0) { // 16-B loads over the aligned body, scalar tail below
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        const int64_t nv = n / V;
+        for (int64_t q = i; q < nv; q += stride) {
+            const vec_t x = reinterpret_cast<const vec_t *>(vol)[q];
+#pragma unroll
+            for (int e = 0; e < V; e++) {
+                mn = x[e] < mn ? x[e] : mn;
+                mx = x[e] > mx ? x[e] : mx;
+            }
+        }
+        i += nv * V;
+    }
     for (; i < n; i += stride) {
         const T v = vol[i];
         mn = v < mn ? v : mn;
@@ -234,15 +248,22 @@ __global__ __launch_bounds__(256) void k_minmax_part(const T *__restrict__ vol, 
     }
 }
 template <typename T>
-__global__ void k_minmax_final(const T *__restrict__ part, int nparts, float *__restrict__ out) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ __launch_bounds__(64) void k_minmax_final(const T *__restrict__ part, int nparts, float *__restrict__ out) {
     T mn = part[0], mx = part[1];
-    for (int i = 1; i < nparts; i++) {
+    for (int i = threadIdx.x; i < nparts; i += 64) {
         mn = part[2 * i] < mn ? part[2 * i] : mn;
         mx = part[2 * i + 1] > mx ? part[2 * i + 1] : mx;
     }
-    out[0] = (float)mn; // the conversion is monotone, so min/max commute with it
-    out[1] = (float)mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)mn; // the conversion is monotone, so min/max commute with it
+        out[1] = (float)mx;
+    }
 }
 
 // ---- contour volume (calc_fcm_intensity, mips.rs:171-213) -------------------------------------------------------
