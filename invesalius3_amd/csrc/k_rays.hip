@@ -39,20 +39,24 @@ template <> __device__ __forceinline__ bool numcast<double>(float v, double *dst
 }
 
 // ---- ray functors --------------------------------------------------------------------------------------
+// Both functors are written branch-free (selects on an `active` predicate): a ray that has terminated, or a sample past
+// the end of the ray, leaves the state untouched.  Per-sample branches cost more than the arithmetic they skip.
 template <typename T> struct LmipRay { // mips.rs:24-37
     T maxv, tmin, tmax;
     bool start, first;
     __device__ __forceinline__ void init(T lo, T hi) { tmin = lo; tmax = hi; first = true; start = false; maxv = (T)0; }
-    __device__ __forceinline__ bool step(T v) { // returns true when the ray is finished
-        if (first) {
-            maxv = v;
-            start = maxv >= tmin && maxv <= tmax;
-            first = false;
-        }
-        if (v > maxv) maxv = v;
-        else if (v < maxv && start) return true;
-        if (v >= tmin && v <= tmax) start = true;
-        return false;
+    __device__ __forceinline__ bool step(T v, bool active) { // returns true when the ray finishes on this sample
+        const bool inwin = v >= tmin && v <= tmax;
+        // first sample: max_val = image[0], start = in-window(max_val); then the loop body sees val == max_val
+        const T m0 = first ? v : maxv;
+        const bool s0 = first ? inwin : start;
+        const bool gt = v > m0, lt = v < m0;
+        const bool fin = active && lt && s0;               // `else if val < max_val && start { break }`
+        const bool upd = active && !fin;
+        maxv = upd ? (gt ? v : m0) : maxv;
+        start = upd ? (s0 || inwin) : start;
+        first = first && !active;
+        return fin;
     }
 };
 
@@ -66,26 +70,22 @@ struct MidaRay { // mips.rs:136-163
         wl = wl_;
         ww = ww_;
     }
-    __device__ __forceinline__ bool step(float vl) {
+    __device__ __forceinline__ bool step(float vl, bool active) {
         const float fpi = inv_range * (vl - img_min);
-        float dl;
-        if (fpi > fmax) {
-            dl = fpi - fmax;
-            fmax = fpi;
-        } else dl = 0.0f;
+        const bool rise = fpi > fmax;
+        const float dl = rise ? fpi - fmax : 0.0f;
         const float bt = 1.0f - dl;
         // get_opacity, mips.rs:88-100
         const float min_value = wl - (ww / 2.0f), max_value = wl + (ww / 2.0f);
-        float alpha;
-        if (vl < min_value) alpha = 0.0f;
-        else if (vl > max_value) alpha = 1.0f;
-        else alpha = (vl - min_value) / (max_value - min_value);
+        const float ramp = (vl - min_value) / (max_value - min_value);
+        const float alpha = vl < min_value ? 0.0f : (vl > max_value ? 1.0f : ramp);
         const float colour = (bt * colour_p) + (1.0f - bt * alpha_p) * fpi * alpha;
         const float current_alpha = (bt * alpha_p) + (1.0f - bt * alpha_p) * alpha;
-        colour_p = colour;
-        alpha_p = current_alpha;
-        final_colour = colour;
-        return current_alpha >= 1.0f;
+        fmax = (active && rise) ? fpi : fmax;
+        colour_p = active ? colour : colour_p;
+        alpha_p = active ? current_alpha : alpha_p;
+        final_colour = active ? colour : final_colour;
+        return active && current_alpha >= 1.0f;
     }
 };
 
@@ -132,14 +132,24 @@ __global__ __launch_bounds__(256) void k_rays_strided(const T *__restrict__ vol,
         mr.init(minmax[0], range, (float)p0, (float)p1);
     }
     bool done = false;
-    for (int64_t l0 = 0; l0 < g.len; l0 += 8) { // 8 independent loads in flight per lane, one wave vote per block
-        T v[8];
+    // software pipeline: the 8 loads of the NEXT block are in flight while the current block's 8 samples are
+    // composited (the walk is a serial dependence chain, the loads are not); one wave vote per block for early exit
+    constexpr int B = 16; // samples per block: up to 2 x 16 loads in flight per lane
+    T cur[B], nxt[B];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (l0 + k < g.len) ? p[(l0 + k) * g.sl] : (T)0;
+    for (int k = 0; k < B; k++) cur[k] = (k < g.len) ? p[k * g.sl] : (T)0;
+    for (int64_t l0 = 0; l0 < g.len; l0 += B) {
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (!done && l0 + k < g.len) done = MODE == 0 ? lr.step(v[k]) : mr.step((float)v[k]);
+        for (int k = 0; k < B; k++) nxt[k] = (l0 + B + k < g.len) ? p[(l0 + B + k) * g.sl] : (T)0;
+#pragma unroll
+        for (int k = 0; k < B; k++)
+        {
+            const bool active = !done && l0 + k < g.len;
+            done |= MODE == 0 ? lr.step(cur[k], active) : mr.step((float)cur[k], active);
+        }
         if (__all(done)) break; // the whole wave's rays have terminated
+#pragma unroll
+        for (int k = 0; k < B; k++) cur[k] = nxt[k];
     }
     finish<T, U, MODE>(lr, mr, range, out + pix, status);
 }
@@ -195,9 +205,8 @@ __global__ __launch_bounds__(256) void k_rays_rows(const T *__restrict__ vol, in
         __builtin_amdgcn_wave_barrier();
         const T *mine = reinterpret_cast<const T *>(tile + lane * PITCH);
         const int n = (int)((len - c0) < CH ? (len - c0) : CH);
-        for (int e = 0; e < n; e++) {
-            if (!done) done = MODE == 0 ? lr.step(mine[e]) : mr.step((float)mine[e]);
-        }
+#pragma unroll 8
+        for (int e = 0; e < n; e++) done |= MODE == 0 ? lr.step(mine[e], !done) : mr.step((float)mine[e], !done);
         __builtin_amdgcn_wave_barrier();
         if (__all(done)) break;
     }
