@@ -31,7 +31,8 @@ typedef short short8_t __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int TY = 16, TZ = 16;       // tile rows / slices (tile is one 64-voxel word wide)
+constexpr int TY_LOG = 4, TY = 1 << TY_LOG, TZ = 16; // tile rows / slices (tile is one 64-voxel word wide)
+constexpr int NT = TY * TZ;           // lanes per tile workgroup (one per word)
 constexpr int HY = TY + 2, HZ = TZ + 2;
 constexpr int BATCH = 8;              // rounds launched between host checks
 
@@ -232,7 +233,7 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     unsigned long long w3[2][3] = {{0ull, 0ull, 0ull}, {0ull, 0ull, 0ull}};
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const int idx = threadIdx.x + pass * 256;
+        const int idx = threadIdx.x + pass * NT;
         if (idx < HZ * HY) {
             const int yy = idx % HY, zz = idx / HY;
             const int64_t z = z0 + zz - 1, y = y0 + yy - 1;
@@ -249,7 +250,7 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     }
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const int idx = threadIdx.x + pass * 256;
+        const int idx = threadIdx.x + pass * NT;
         if (idx < HZ * HY) {
             const unsigned long long cl = w3[pass][0] >> 63, cr = w3[pass][2] & 1ull, n = w3[pass][1];
             L.sN[idx] = n;
@@ -258,7 +259,7 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
             L.sCR[idx] = (unsigned char)cr;
         }
     }
-    const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> 4;
+    const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> TY_LOG;
     const int64_t z = z0 + tz, y = y0 + ty;
     const bool inside = z < t.dz && y < t.dy;
     const unsigned long long c = inside ? cand[(z * t.dy + y) * t.wx + txi] : 0ull;
@@ -325,7 +326,7 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     }
 }
 
-__global__ __launch_bounds__(256) void k_flood_round(Tiles t, const unsigned long long *__restrict__ cand,
+__global__ __launch_bounds__(NT) void k_flood_round(Tiles t, const unsigned long long *__restrict__ cand,
                                                      unsigned long long *reached, uint8_t *dirty_cur,
                                                      uint8_t *dirty_next, unsigned int *counter_next) {
     __shared__ TileLds L;
@@ -380,7 +381,7 @@ __global__ void k_flood_enqueue(Tiles t, uint8_t *dirty, Queue *q, unsigned int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_flood_persistent(Tiles t, const unsigned long long *__restrict__ cand,
+__global__ __launch_bounds__(NT) void k_flood_persistent(Tiles t, const unsigned long long *__restrict__ cand,
                                                           unsigned long long *reached, Queue *q, unsigned int *queued,
                                                           unsigned int *ring, unsigned int qmask, unsigned int max_spins) {
     __shared__ TileLds L;
@@ -698,7 +699,7 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
                            queued, ring, s.qcap - 1);
         IVX_LAUNCH_CHECK();
         const int64_t grid = t.ntiles < 1024 ? t.ntiles : 1024; // <= 4 workgroups per CU; no residency requirement
-        hipLaunchKernelGGL(k_flood_persistent, dim3((unsigned)grid), dim3(256), 0, st, t,
+        hipLaunchKernelGGL(k_flood_persistent, dim3((unsigned)grid), dim3(NT), 0, st, t,
                            (const unsigned long long *)cand, (unsigned long long *)reached, q, queued, ring,
                            s.qcap - 1, max_spins);
         IVX_LAUNCH_CHECK();
@@ -723,7 +724,7 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
         IVX_HIP(hipMemsetAsync(cnt, 0, BATCH * 4, st));
         for (int b = 0; b < BATCH; b++) {
             // BATCH is even, so every batch starts with dirty[0] as the current list
-            hipLaunchKernelGGL(k_flood_round, dim3((unsigned)t.ntiles), dim3(256), 0, st, t,
+            hipLaunchKernelGGL(k_flood_round, dim3((unsigned)t.ntiles), dim3(NT), 0, st, t,
                                (const unsigned long long *)cand, (unsigned long long *)reached, dirty[b & 1],
                                dirty[(b + 1) & 1], cnt + b);
             IVX_LAUNCH_CHECK();
