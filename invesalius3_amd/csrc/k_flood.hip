@@ -40,6 +40,7 @@ struct Tiles {
     int64_t dz, dy, dx, wx;
     int64_t nty, ntz, ntiles;
     uint32_t strct;
+    int conn; // 6 / 18 / 26 when strct is exactly scipy's generate_binary_structure(3, 1|2|3), else 0 (generic path)
 };
 
 static int make_tiles(const ivx_flood_plan *p, Tiles *t) {
@@ -49,6 +50,18 @@ static int make_tiles(const ivx_flood_plan *p, Tiles *t) {
     t->nty = ivx::cdiv(p->dy, TY); t->ntz = ivx::cdiv(p->dz, TZ);
     t->ntiles = t->wx * t->nty * t->ntz;
     t->strct = p->strct_bits & ~(1u << 13); // the centre never matters
+    {
+        uint32_t m6 = 0, m18 = 0, m26 = 0;
+        for (int k = 0; k < 27; k++) {
+            const int nzc = (k / 9 != 1) + ((k / 3) % 3 != 1) + (k % 3 != 1);
+            if (nzc <= 1) m6 |= 1u << k;
+            if (nzc <= 2) m18 |= 1u << k;
+            m26 |= 1u << k;
+        }
+        const uint32_t sb = p->strct_bits | (1u << 13);
+        t->conn = sb == m26 ? 26 : sb == m18 ? 18 : sb == m6 ? 6 : 0;
+    }
+    if (getenv("IVX_FLOOD_DBG")) t->strct |= 1u << 30;
     IVX_REQUIRE(t->ntiles < 0x7fffffffll, IVX_EINVAL, "flood: too many tiles");
     return IVX_OK;
 }
@@ -215,14 +228,23 @@ __device__ __forceinline__ unsigned long long fill_runs(unsigned long long seed,
 // and new bits is a valid intermediate state -- and ONE barrier per iteration (the termination vote) is enough.
 // ATOMIC: stage / publish with agent-scope atomics (needed when other workgroups update neighbours concurrently
 // AND no kernel boundary follows, i.e. in the persistent frontier).
+__device__ unsigned long long g_dbg[16];
+#define DBG_T(i) if (DBG && threadIdx.x == 0) g_dbg[i] = __builtin_readcyclecounter();
+// workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), NOT for its global stores/atomics in flight:
+// __syncthreads() also drains vmcnt, which would park the whole tile behind the publish stores (~2.5 us).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0), vmcnt/expcnt untouched
+    __builtin_amdgcn_s_barrier();
+}
 struct TileLds {
     unsigned long long sN[HZ * HY];
     unsigned long long sD[HZ * HY];
     unsigned char sCL[HZ * HY], sCR[HZ * HY];
     unsigned int dirs;
+    unsigned int vote[2]; // workgroup "anything changed" vote, double-buffered: ONE s_barrier per iteration
 };
 
-template <bool ATOMIC>
+template <bool ATOMIC, int CONN, bool DBG = false>
 __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long long *__restrict__ cand,
                                             unsigned long long *reached, int64_t tile, TileLds &L) {
     const int64_t txi = tile % t.wx, r1 = tile / t.wx;
@@ -263,7 +285,9 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     const int64_t z = z0 + tz, y = y0 + ty;
     const bool inside = z < t.dz && y < t.dy;
     const unsigned long long c = inside ? cand[(z * t.dy + y) * t.wx + txi] : 0ull;
+    if (threadIdx.x == 0) L.vote[0] = 0u;
     __syncthreads();
+    DBG_T(1)
     const int me = (tz + 1) * HY + (ty + 1);
     const unsigned long long r_in = L.sN[me];
     const unsigned long long mycl = L.sCL[me], mycr = L.sCR[me];
@@ -273,6 +297,23 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     bool exhausted = true;
     for (int it = 0; it < 2048; it++) {
         unsigned long long nb = 0;
+        if (CONN != 0) {
+            // standard 6 / 18 / 26 structures: the row pattern is known at compile time, so the nine LDS reads are
+            // issued back to back (no scalar branches between them) and OR'ed once they land
+            unsigned long long v[9];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) {
+                    const int nz = (kk != 1) + (jj != 1); // non-zero offsets among (dz, dy)
+                    const int src = (tz + 1 - (kk - 1)) * HY + (ty + 1 - (jj - 1));
+                    const bool full = CONN == 26 || (CONN == 18 && nz <= 1) || (CONN == 6 && nz == 0); // x pattern 111
+                    const bool mid = (CONN == 18 && nz == 2) || (CONN == 6 && nz == 1);                // x pattern 010
+                    v[kk * 3 + jj] = full ? L.sD[src] : (mid ? L.sN[src] : 0ull);
+                }
+#pragma unroll
+            for (int q = 0; q < 9; q++) nb |= v[q];
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 3; kk++)
 #pragma unroll
@@ -289,6 +330,7 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
                     if (m3 & 1u) nb |= (n >> 1) | ((unsigned long long)L.sCR[src] << 63); // ii = 0: source bit x+1
                 }
             }
+        }
         unsigned long long nr = r | (nb & c);
         if (xrun) nr = fill_runs(nr, c);
         const bool changed = nr != r;
@@ -297,17 +339,25 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
             L.sN[me] = r;
             L.sD[me] = r | (r << 1) | (r >> 1) | mycl | (mycr << 63);
         }
-        if (!__syncthreads_or(changed)) {
+        // vote: __syncthreads_or() costs ~1500 cycles on gfx950 (library workgroup reduction); a wave ballot + one
+        // LDS flag + one barrier does the same in ~200.  Flag it&1 is read now, flag (it+1)&1 is cleared for the next
+        // iteration (nobody touches it between this barrier and the next one's writers).
+        if (__any(changed) && (threadIdx.x & 63) == 0) L.vote[it & 1] = 1u;
+        if (threadIdx.x == 0) L.vote[(it + 1) & 1] = 0u;
+        __syncthreads();
+        if (!L.vote[it & 1]) {
             exhausted = false;
             break;
         }
     }
+    DBG_T(2)
+    if (DBG && threadIdx.x == 0) g_dbg[8] = 0;
     const unsigned long long chg = r ^ r_in;
+    unsigned dirs = 0;
     if (chg) {
         if (ATOMIC) atomicOr(&reached[(z * t.dy + y) * t.wx + txi], r); // monotone publish: bits are never lost
         else reached[(z * t.dy + y) * t.wx + txi] = r;
         // which neighbour tiles can see this change?  direction d = (dz+1)*9 + (dy+1)*3 + (dx+1)
-        unsigned dirs = 0;
         const bool zlo = tz == 0, zhi = tz == TZ - 1, ylo = ty == 0, yhi = ty == TY - 1;
         const bool xlo = chg & 1ull, xhi = chg >> 63;
 #pragma unroll
@@ -322,8 +372,11 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
                     dirs |= vis ? (1u << ((dzz + 1) * 9 + (dyy + 1) * 3 + (dxx + 1))) : 0u;
                 }
         if (exhausted) dirs |= 1u << 13; // iteration cap hit before the local fix-point: revisit this tile
-        if (dirs) atomicOr(&L.dirs, dirs);
     }
+    // OR across the wave in registers, then ONE LDS atomic per wave (256 same-address LDS atomics serialise)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dirs |= __shfl_xor(dirs, o, 64);
+    if ((threadIdx.x & 63) == 0 && dirs) atomicOr(&L.dirs, dirs);
 }
 
 __global__ __launch_bounds__(NT) void k_flood_round(Tiles t, const unsigned long long *__restrict__ cand,
@@ -339,10 +392,17 @@ __global__ __launch_bounds__(NT) void k_flood_round(Tiles t, const unsigned long
     }
     __syncthreads();
     if (!s_go) return; // uniform per workgroup
+    const bool dbg = t.strct >> 30 & 1u;
+    if (dbg && threadIdx.x == 0) g_dbg[0] = __builtin_readcyclecounter();
     // halo words may be rewritten concurrently by the neighbouring tile's workgroup; a stale read is still correct
     // (the writer re-marks this tile for the next round), so plain loads/stores + the kernel boundary suffice
-    tile_update<false>(t, cand, reached, tile, L);
-    __syncthreads();
+    if (dbg) tile_update<false, 26, true>(t, cand, reached, tile, L);
+    else if (t.conn == 26) tile_update<false, 26>(t, cand, reached, tile, L);
+    else if (t.conn == 18) tile_update<false, 18>(t, cand, reached, tile, L);
+    else if (t.conn == 6) tile_update<false, 6>(t, cand, reached, tile, L);
+    else tile_update<false, 0>(t, cand, reached, tile, L);
+    lds_barrier(); // L.dirs complete; the publish stores keep flying (the kernel boundary orders them for the next round)
+    if (dbg && threadIdx.x == 0) g_dbg[3] = __builtin_readcyclecounter();
     const int64_t txi = tile % t.wx, r1 = tile / t.wx;
     const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
     if (threadIdx.x < 27 && (L.dirs >> threadIdx.x & 1u)) {
@@ -357,6 +417,12 @@ __global__ __launch_bounds__(NT) void k_flood_round(Tiles t, const unsigned long
             atomicAdd(counter_next, 1u);  // counts marking events; only "zero or not" is ever tested
         }
     }
+    if (dbg && threadIdx.x == 0) g_dbg[4] = __builtin_readcyclecounter();
+}
+extern "C" int ivx_debug_read(unsigned long long *out16) {
+    IVX_HIP(hipDeviceSynchronize());
+    IVX_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dbg), 16 * 8));
+    return IVX_OK;
 }
 
 // ---- persistent tile frontier: ONE launch, device-side work queue ---------------------------------------
@@ -415,7 +481,10 @@ __global__ __launch_bounds__(NT) void k_flood_persistent(Tiles t, const unsigned
         __syncthreads();
         const int tile = s_tile;
         if (tile < 0) return;
-        tile_update<true>(t, cand, reached, tile, L);
+        if (t.conn == 26) tile_update<true, 26>(t, cand, reached, tile, L);
+        else if (t.conn == 18) tile_update<true, 18>(t, cand, reached, tile, L);
+        else if (t.conn == 6) tile_update<true, 6>(t, cand, reached, tile, L);
+        else tile_update<true, 0>(t, cand, reached, tile, L);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every publishing wave drains before the pushes
         __syncthreads();
         const int64_t txi = tile % t.wx, r1 = tile / t.wx;
