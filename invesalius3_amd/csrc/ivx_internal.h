@@ -43,7 +43,7 @@ static inline size_t dtype_size(int dt) {
 }
 
 // Cached device workspaces for the host-level entry points (grow-only, freed by ivx_release_workspace).
-enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_CCL0, WS_CCL1, WS_COUNT };
+enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_CCL0, WS_CCL1, WS_MCLIST, WS_COUNT };
 int ws_get(int slot, size_t nbytes, void **dptr);
 // pinned host staging (grow-only)
 int hs_get(int slot, size_t nbytes, void **hptr);

@@ -22,6 +22,9 @@
 //                    output line once.
 // Output order == the oracle's (iso-major, then k, j, i raster order of cells), so parity is an array compare.
 // Vertex arithmetic is done in double and rounded once to float32, exactly like the oracle.
+#include <map>
+#include <mutex>
+
 #include "ivx_internal.h"
 
 #define MC_TABLE_QUAL __device__ const
@@ -276,40 +279,18 @@ __device__ __forceinline__ void edge_decode(int e, int &ax, int &bx, int &by, in
     bz = ax == 2 ? 0 : b;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const uint64_t *__restrict__ bits, Geom g,
-                                                 size_t nwords, uint64_t pbits, double iso,
-                                                 const uint16_t *__restrict__ counts,
-                                                 const uint64_t *__restrict__ boff, float *__restrict__ tris,
-                                                 uint64_t max_tris) {
-    constexpr int WIN = 1024;            // triangle descriptors staged per window
-    __shared__ uint32_t s_desc[WIN];     // (word-in-block << 24) | (cell bit << 16) | (case << 8) | triangle-in-case
-    __shared__ uint32_t s_base[257];     // exclusive prefix of the per-word triangle counts
-    __shared__ int32_t s_k[256], s_j[256], s_w[256];
-    __shared__ int64_t s_row[256];       // element offset of source row (k - pb, flipped j) -- valid when s_in != 0
-    __shared__ uint8_t s_in[256];        // rows (k,k+1) x (j,j+1) all inside the source piece
+// 4a. list: the OWNER of each cell word writes one 64-bit descriptor per triangle into a flat global list, in output
+//     order: (cell word id << 17) | (cell bit << 11) | (case << 3) | triangle-in-case.  One case evaluation per
+//     active cell; only workgroups that own triangles do anything beyond a 256-entry scan.
+__global__ __launch_bounds__(256) void k_mc_list(const uint64_t *__restrict__ bits, Geom g, size_t nwords, uint64_t pbits,
+                                                 const uint16_t *__restrict__ counts, const uint64_t *__restrict__ boff,
+                                                 uint64_t *__restrict__ list, uint64_t max_tris) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint8_t s_ntri[256];
-    __shared__ uint8_t s_tri[256 * 16];
-    __shared__ float s_out[256 * 9];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // case tables -> LDS (dependent look-ups then cost an LDS access instead of a global one)
     s_ntri[tid] = MC_NTRI[tid];
-#pragma unroll
-    for (int q = 0; q < 15; q++) s_tri[tid * 16 + q] = MC_TRI[tid][q];
     const size_t wid = (size_t)blockIdx.x * 256 + tid;
     const uint32_t n = wid < nwords ? (uint32_t)counts[wid] : 0u;
-    Corner8 r;
-    r.active = 0;
-    if (n) {
-        const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
-        const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
-        r = load_corners(bits, g, k, j, w, pbits);
-        s_k[tid] = (int32_t)k; s_j[tid] = (int32_t)j; s_w[tid] = (int32_t)w;
-        const int64_t ka = k - g.pb, ja = (g.NY - 1 - j) - g.pxy; // source row of corner (dy=0, dz=0)
-        s_in[tid] = (ka >= 0 && ka + 1 < g.nz && ja - 1 >= 0 && ja < g.ny) ? 1 : 0;
-        s_row[tid] = (ka * g.ny + ja) * g.nx;
-    }
     uint32_t inc = n;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -318,83 +299,95 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, const 
     }
     if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
+    if (!n) return;
     uint32_t wbase = 0;
     for (int q = 0; q < wv; q++) wbase += s_wave[q];
-    const uint32_t mybase = wbase + inc - n;
-    s_base[tid] = mybase;
-    if (tid == 255) s_base[256] = wbase + inc;
-    __syncthreads();
-    const uint32_t total = s_base[256];
-    if (total == 0) return;
-    const uint64_t gbase = boff[blockIdx.x];
-    if (gbase + total > max_tris) return; // never write past the buffer the caller sized from the count
-    const int64_t plane = g.ny * g.nx;
-
-    for (uint32_t win0 = 0; win0 < total; win0 += WIN) {
-        // the OWNER of each word lists its triangles (one case evaluation per active cell, not per triangle)
-        if (n && mybase < win0 + WIN && mybase + n > win0) {
-            uint64_t act = r.active;
-            uint32_t pos = mybase;
-            while (act) {
-                const int b = __builtin_ctzll(act);
-                act &= act - 1;
-                const int idx = case_of(r.c, b);
-                const uint32_t nt = s_ntri[idx];
-                for (uint32_t t = 0; t < nt; t++, pos++)
-                    if (pos >= win0 && pos < win0 + WIN)
-                        s_desc[pos - win0] = ((uint32_t)tid << 24) | ((uint32_t)b << 16) | ((uint32_t)idx << 8) | t;
-            }
-        }
-        __syncthreads();
-        const uint32_t wtot = total - win0 < WIN ? total - win0 : WIN;
-        for (uint32_t c0 = 0; c0 < wtot; c0 += 256) {
-            const uint32_t T_ = c0 + tid;
-            if (T_ < wtot) {
-                const uint32_t d = s_desc[T_];
-                const int ww = d >> 24, b = (d >> 16) & 63, idx = (d >> 8) & 255, rel = d & 7;
-                const int32_t k = s_k[ww], j = s_j[ww], i = s_w[ww] * 64 + b;
-                const int32_t ia = i - g.pxy;
-                const bool fast = s_in[ww] && ia >= 0 && ia + 1 < g.nx;
-                const T *cell = a + (fast ? s_row[ww] + ia : 0); // corner (0,0,0); dy -> -nx (flipped), dz -> +plane
-                float *o = s_out + tid * 9;
-                double s0[3], s1[3];
-                int ax[3], bx[3], by[3], bz[3];
+    uint64_t pos = boff[blockIdx.x] + wbase + inc - n;
+    if (pos + n > max_tris) return; // never write past the list the caller sized from the count
+    const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
+    const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
+    const Corner8 r = load_corners(bits, g, k, j, w, pbits);
+    uint64_t act = r.active;
+    while (act) {
+        const int b = __builtin_ctzll(act);
+        act &= act - 1;
+        const int idx = case_of(r.c, b);
+        const uint32_t nt = s_ntri[idx];
+        const uint64_t d0 = ((uint64_t)wid << 17) | ((uint64_t)b << 11) | ((uint64_t)idx << 3);
 #pragma unroll
-                for (int v = 0; v < 3; v++) { // issue the six gathers of the triangle back to back
-                    const int e = s_tri[idx * 16 + 3 * rel + v];
-                    edge_decode(e, ax[v], bx[v], by[v], bz[v]);
-                    if (fast) {
-                        const int64_t o0 = (int64_t)bz[v] * plane - (int64_t)by[v] * g.nx + bx[v];
-                        const int64_t o1 = o0 + (ax[v] == 2 ? plane : (ax[v] == 1 ? -g.nx : 1));
-                        s0[v] = (double)cell[o0];
-                        s1[v] = (double)cell[o1];
-                    } else {
-                        s0[v] = mc_at(a, g, k + bz[v], j + by[v], i + bx[v]);
-                        s1[v] = mc_at(a, g, k + bz[v] + (ax[v] == 2), j + by[v] + (ax[v] == 1), i + bx[v] + (ax[v] == 0));
-                    }
-                }
-#pragma unroll
-                for (int v = 0; v < 3; v++) {
-                    const double tt = (iso - s0[v]) / (s1[v] - s0[v]);
-                    double p0 = (double)(i + bx[v] - g.pxy);
-                    double p1 = (double)(j + by[v] - (int32_t)g.yoff);
-                    double p2 = (double)(k + bz[v] + g.zoff);
-                    if (ax[v] == 0) p0 += tt;
-                    else if (ax[v] == 1) p1 += tt;
-                    else p2 += tt;
-                    o[3 * v + 0] = (float)(g.sx * p0);
-                    o[3 * v + 1] = (float)(g.sy * p1);
-                    o[3 * v + 2] = (float)(g.sz * p2);
-                }
-            }
-            __syncthreads();
-            const uint32_t nt_chunk = wtot - c0 < 256 ? wtot - c0 : 256;
-            float *dst = tris + (gbase + win0 + c0) * 9;
-            for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
-            __syncthreads();
-        }
+        for (uint32_t t = 0; t < MC_MAX_TRI; t++)
+            if (t < nt) list[pos + t] = d0 | t;
+        pos += nt;
     }
 }
+
+// 4b. emit: a flat, regular kernel -- one lane per triangle of the list, 256 consecutive triangles per workgroup.
+//     Nothing but the 9-KB staging buffer in LDS, so eight workgroups share a CU and hide each other's gather latency.
+template <typename T>
+__global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g, double iso,
+                                                 const uint64_t *__restrict__ list, uint64_t ntris,
+                                                 float *__restrict__ tris) {
+    __shared__ uint8_t s_tri[256 * 16];
+    __shared__ float s_out[256 * 9];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 15; q++) s_tri[tid * 16 + q] = MC_TRI[tid][q];
+    const uint64_t T0 = (uint64_t)blockIdx.x * 256;
+    const uint64_t T_ = T0 + tid;
+    const bool live = T_ < ntris;
+    const uint64_t d = live ? list[T_] : 0ull;
+    __syncthreads();
+    if (live) {
+        const uint64_t wid = d >> 17;
+        const int b = (int)(d >> 11) & 63, idx = (int)(d >> 3) & 255, rel = (int)d & 7;
+        // nwords < 2^32 is checked on the host: 32-bit divisions
+        const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
+        const int32_t k = (int32_t)(row / (uint32_t)(g.NY - 1)), j = (int32_t)(row - (uint32_t)k * (uint32_t)(g.NY - 1));
+        const int32_t i = (int32_t)w * 64 + b;
+        const int64_t ka = k - g.pb, ja = (g.NY - 1 - j) - g.pxy; // source row of corner (dy=0, dz=0)
+        const int32_t ia = i - g.pxy;
+        const bool fast = ka >= 0 && ka + 1 < g.nz && ja - 1 >= 0 && ja < g.ny && ia >= 0 && ia + 1 < g.nx;
+        const int64_t plane = g.ny * g.nx;
+        const T *cell = a + (fast ? (ka * g.ny + ja) * g.nx + ia : 0); // corner (0,0,0); dy -> -nx (flipped), dz -> +plane
+        float *o = s_out + tid * 9;
+        double s0[3], s1[3];
+        int ax[3], bx[3], by[3], bz[3];
+#pragma unroll
+        for (int v = 0; v < 3; v++) { // issue the six gathers of the triangle back to back
+            const int e = s_tri[idx * 16 + 3 * rel + v];
+            edge_decode(e, ax[v], bx[v], by[v], bz[v]);
+            if (fast) {
+                const int64_t o0 = (int64_t)bz[v] * plane - (int64_t)by[v] * g.nx + bx[v];
+                const int64_t o1 = o0 + (ax[v] == 2 ? plane : (ax[v] == 1 ? -g.nx : 1));
+                s0[v] = (double)cell[o0];
+                s1[v] = (double)cell[o1];
+            } else {
+                s0[v] = mc_at(a, g, k + bz[v], j + by[v], i + bx[v]);
+                s1[v] = mc_at(a, g, k + bz[v] + (ax[v] == 2), j + by[v] + (ax[v] == 1), i + bx[v] + (ax[v] == 0));
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            const double tt = (iso - s0[v]) / (s1[v] - s0[v]);
+            double p0 = (double)(i + bx[v] - g.pxy);
+            double p1 = (double)(j + by[v] - (int32_t)g.yoff);
+            double p2 = (double)(k + bz[v] + g.zoff);
+            if (ax[v] == 0) p0 += tt;
+            else if (ax[v] == 1) p1 += tt;
+            else p2 += tt;
+            o[3 * v + 0] = (float)(g.sx * p0);
+            o[3 * v + 1] = (float)(g.sy * p1);
+            o[3 * v + 2] = (float)(g.sz * p2);
+        }
+    }
+    __syncthreads();
+    const uint32_t nt_chunk = ntris - T0 < 256 ? (uint32_t)(ntris - T0) : 256u;
+    float *dst = tris + T0 * 9;
+    for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
+}
+
+static std::map<const void *, uint64_t> g_split; // scratch -> number of iso-0 triangles (two-iso pieces)
+static std::mutex g_split_mu;
 
 static inline uint64_t pad_bits(const ivx_mc_params *p, int q) { return p->pad_value >= p->iso[q] ? ~0ull : 0ull; }
 
@@ -423,14 +416,34 @@ template <typename T>
 static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, const char *scratch,
                     float *tris, int64_t max_tris, hipStream_t st) {
     if (s.nblocks == 0) return IVX_OK;
+    IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
     const uint64_t *boff = (const uint64_t *)(scratch + s.off_boff);
-    // iso 1's output starts where iso 0's ends: boff is one scan over [iso0 blocks | iso1 blocks]
+    void *d_list;
+    int rc = ivx::ws_get(ivx::WS_MCLIST, (size_t)max_tris * 8 + 64, &d_list);
+    if (rc) return rc;
+    // iso 1's triangles follow iso 0's: boff is one scan over [iso0 blocks | iso1 blocks], so both list passes write
+    // disjoint ranges of ONE list and a single flat emit per iso covers [first, last) of that iso
+    // triangle ranges per iso: [0, split) and [split, total); `split` was read by ivx_dev_mc_count through the mailbox
+    uint64_t hb[3] = {0, (uint64_t)max_tris, (uint64_t)max_tris};
+    if (p->niso == 2) {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        auto it = g_split.find(scratch);
+        IVX_REQUIRE(it != g_split.end(), IVX_EINVAL, "mc: ivx_dev_mc_emit must follow ivx_dev_mc_count on the same scratch");
+        hb[1] = it->second;
+    }
     for (int q = 0; q < p->niso; q++) {
         const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
         const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
-        hipLaunchKernelGGL((k_mc_emit<T>), dim3((unsigned)s.nblocks), dim3(256), 0, st, (const T *)a, bits, g,
-                           s.nwords, pad_bits(p, q), p->iso[q], counts, boff + (size_t)q * s.nblocks, tris,
-                           (uint64_t)max_tris);
+        hipLaunchKernelGGL(k_mc_list, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q), counts,
+                           boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
+        IVX_LAUNCH_CHECK();
+    }
+    for (int q = 0; q < p->niso; q++) {
+        const uint64_t first = hb[q], last = hb[q + 1] < (uint64_t)max_tris ? hb[q + 1] : (uint64_t)max_tris;
+        if (last <= first) continue;
+        const uint64_t n = last - first;
+        hipLaunchKernelGGL((k_mc_emit<T>), dim3((unsigned)ivx::cdiv((int64_t)n, 256)), dim3(256), 0, st, (const T *)a, g,
+                           p->iso[q], (const uint64_t *)d_list + first, n, tris + first * 9);
         IVX_LAUNCH_CHECK();
     }
     return IVX_OK;
@@ -475,6 +488,13 @@ extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scr
     hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, st, bsum, nb, boff);
     IVX_LAUNCH_CHECK();
     uint32_t seq, tw[2];
+    if (p->niso == 2) { // also fetch where iso 0's triangles end (= boff[nblocks])
+        uint32_t seq0, t0[2];
+        if ((rc = ivx::mailbox_publish(boff + s.nblocks, 2, st, &seq0))) return rc;
+        if ((rc = ivx::mailbox_wait(seq0, st, t0, 2))) return rc;
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        g_split[scratch_] = ((uint64_t)t0[1] << 32) | t0[0];
+    }
     if ((rc = ivx::mailbox_publish(boff + nb, 2, st, &seq))) return rc;
     if ((rc = ivx::mailbox_wait(seq, st, tw, 2))) return rc;
     *ntris = (int64_t)(((uint64_t)tw[1] << 32) | tw[0]);
