@@ -542,11 +542,17 @@ __global__ __launch_bounds__(256) void k_flood_apply2(Tiles t, const uint8_t *__
     const int64_t bpr = t.wx * 8;
     const int64_t total = t.dz * t.dy * bpr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool aligned8 = (((uintptr_t)out | (uintptr_t)mask) & 7) == 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const unsigned m = reached[i];
         if (!m) continue;
         const int64_t row = i / bpr, q = i - row * bpr;
         const int64_t base = row * t.dx + q * 8;
+        if (m == 0xffu && ((t.dx & 7) == 0) && aligned8) { // inside a filled region: two 8-byte stores
+            *reinterpret_cast<unsigned long long *>(out + base) = 0x0101010101010101ull * fill;
+            *reinterpret_cast<unsigned long long *>(mask + base) = 0x0101010101010101ull * select;
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 8; e++)
             if (m >> e & 1u) {

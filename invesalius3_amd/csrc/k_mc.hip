@@ -107,6 +107,40 @@ __global__ __launch_bounds__(256) void k_mc_bits(const T *__restrict__ a, int64_
     const int64_t total = nrows_src * cpr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool vec = (nx % V == 0) && (((uintptr_t)a & 15) == 0);
+    if (vec && ws * 64 == nx) {
+        // rows are whole words: the volume is one flat array of chunks; 4 independent 16-B loads per lane in flight
+        const int64_t nchunk = nrows_src * (nx / V);
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        const vec_t *src = reinterpret_cast<const vec_t *>(a);
+        for (int64_t t0 = ((int64_t)blockIdx.x * blockDim.x) * 4 + threadIdx.x; t0 < nchunk; t0 += stride * 4) {
+            vec_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t t = t0 + (int64_t)u * blockDim.x;
+                if (t < nchunk) x[u] = __builtin_nontemporal_load(&src[t]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t t = t0 + (int64_t)u * blockDim.x;
+                if (t >= nchunk) continue;
+                unsigned m0 = 0, m1 = 0;
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    const double d = (double)(T)x[u][e];
+                    m0 |= d >= iso0 ? (1u << e) : 0u;
+                    if (NISO == 2) m1 |= d >= iso1 ? (1u << e) : 0u;
+                }
+                if (OB == 1) {
+                    bits0[t] = (uint8_t)m0;
+                    if (NISO == 2) bits1[t] = (uint8_t)m1;
+                } else {
+                    reinterpret_cast<uint16_t *>(bits0)[t] = (uint16_t)m0;
+                    if (NISO == 2) reinterpret_cast<uint16_t *>(bits1)[t] = (uint16_t)m1;
+                }
+            }
+        }
+        return;
+    }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int64_t row = t / cpr, q = t - row * cpr;
         const int64_t x0 = q * V;
@@ -148,30 +182,41 @@ __global__ __launch_bounds__(256) void k_mc_bits(const T *__restrict__ a, int64_
 }
 
 // ---- padded + flipped view of the source bit planes -----------------------------------------------------
-// word w of padded point row (k, jf): padded x = 64w .. 64w+63.  Pad rows / pad columns carry pbits.
-__device__ __forceinline__ uint64_t padded_word(const uint64_t *__restrict__ S, const Geom &g, int64_t k, int64_t jf,
-                                                int64_t w, uint64_t pbits) {
-    if (w >= g.WX) return 0ull;
+// Words w and w+1 of padded point row (k, jf): padded x = 64w .. 64w+127.  Pad rows / pad columns carry pbits.
+// Written without branches around the loads: the three source words are always fetched (clamped, always-valid
+// addresses) and masked afterwards, so the 12 loads of a cell word are all in flight together.
+__device__ __forceinline__ void padded_pair(const uint64_t *__restrict__ S, const Geom &g, int64_t k, int64_t jf,
+                                            int64_t w, uint64_t pbits, uint64_t &lo, uint64_t &hi) {
     const int64_t ja = (g.NY - 1 - jf) - g.pxy, ka = k - g.pb;
-    const int64_t rem = g.NX - w * 64; // padded points in this word
-    const uint64_t exist = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-    if (ja < 0 || ja >= g.ny || ka < 0 || ka >= g.nz) return pbits & exist;
-    const uint64_t *row = S + (ka * g.ny + ja) * g.ws;
-    uint64_t v;
-    // bits of source x in [64w - pxy, 64w + 64 - pxy)
-    const uint64_t cur = w < g.ws ? row[w] : 0ull;
-    if (g.pxy) {
-        const uint64_t prev = (w > 0 && w - 1 < g.ws) ? row[w - 1] : 0ull;
-        v = (cur << 1) | (prev >> 63);
-    } else {
-        v = cur;
+    const bool row_in = ja >= 0 && ja < g.ny && ka >= 0 && ka < g.nz;
+    const int64_t rj = ja < 0 ? 0 : (ja >= g.ny ? g.ny - 1 : ja), rk = ka < 0 ? 0 : (ka >= g.nz ? g.nz - 1 : ka);
+    const uint64_t *row = S + (rk * g.ny + rj) * g.ws;
+    // source words w-1, w, w+1 (clamped index, masked when outside [0, ws) or when the row is padding)
+    const int64_t wm = w - 1 < 0 ? 0 : (w - 1 >= g.ws ? g.ws - 1 : w - 1);
+    const int64_t wc = w >= g.ws ? g.ws - 1 : w;
+    const int64_t wp = w + 1 >= g.ws ? g.ws - 1 : w + 1;
+    uint64_t sm = row[wm], sc = row[wc], sp = row[wp];
+    sm = (row_in && w - 1 >= 0 && w - 1 < g.ws) ? sm : 0ull;
+    sc = (row_in && w < g.ws) ? sc : 0ull;
+    sp = (row_in && w + 1 < g.ws) ? sp : 0ull;
+    // bits of source x in [64w - pxy, 64w + 64 - pxy) and the following 64
+    uint64_t v0 = g.pxy ? ((sc << 1) | (sm >> 63)) : sc;
+    uint64_t v1 = g.pxy ? ((sp << 1) | (sc >> 63)) : sp;
+    // positions of each word that exist in the padded row, and those backed by source voxels
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int64_t ww = w + q;
+        const int64_t rem = g.NX - ww * 64; // padded points in this word
+        const uint64_t exist = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+        uint64_t src = row_in ? exist : 0ull;
+        if (g.pxy && ww == 0) src &= ~1ull;
+        const int64_t top = g.pxy + g.nx - ww * 64; // first padded-x (relative) beyond the source
+        src &= top >= 64 ? ~0ull : (top <= 0 ? 0ull : ((1ull << top) - 1ull));
+        uint64_t &v = q == 0 ? v0 : v1;
+        v = (v & src) | (pbits & exist & ~src);
     }
-    // positions that are padding inside an existing row: padded x < pxy or padded x >= pxy + nx
-    uint64_t src = exist;
-    if (g.pxy && w == 0) src &= ~1ull;
-    const int64_t hi = g.pxy + g.nx - w * 64; // first padded-x (relative) beyond the source
-    if (hi < 64) src &= hi <= 0 ? 0ull : ((1ull << hi) - 1ull);
-    return (v & src) | (pbits & exist & ~src);
+    lo = v0;
+    hi = v1;
 }
 
 struct Corner8 {
@@ -185,8 +230,8 @@ __device__ __forceinline__ Corner8 load_corners(const uint64_t *__restrict__ bit
     for (int dz = 0; dz < 2; dz++)
 #pragma unroll
         for (int dy = 0; dy < 2; dy++) {
-            const uint64_t lo = padded_word(bits, g, k + dz, j + dy, w, pbits);
-            const uint64_t nx = padded_word(bits, g, k + dz, j + dy, w + 1, pbits);
+            uint64_t lo, nx;
+            padded_pair(bits, g, k + dz, j + dy, w, pbits, lo, nx);
             r.c[4 * dz + 2 * dy] = lo;
             r.c[4 * dz + 2 * dy + 1] = (lo >> 1) | (nx << 63);
         }
@@ -243,13 +288,20 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
                                                   uint64_t *__restrict__ boff) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
+    constexpr int PER = 8; // consecutive elements per lane: 8192 per pass
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + threadIdx.x;
-        const uint64_t v = i < n ? (uint64_t)bsum[i] : 0ull;
-        uint64_t inc = v;
+    for (size_t base = 0; base < n; base += 1024 * PER) {
+        const size_t i0 = base + (size_t)threadIdx.x * PER;
+        uint32_t v[PER];
+        uint64_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            v[q] = i0 + q < n ? bsum[i0 + q] : 0u;
+            sum += v[q];
+        }
+        uint64_t inc = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint64_t t = __shfl_up(inc, o, 64);
@@ -257,12 +309,15 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
         }
         if (lane == 63) s_wave[wv] = inc;
         __syncthreads();
-        uint64_t wbase = 0;
-        for (int q = 0; q < wv; q++) wbase += s_wave[q];
-        const uint64_t carry = s_carry;
-        if (i < n) boff[i] = carry + wbase + inc - v;
+        uint64_t off = s_carry + inc - sum;
+        for (int q = 0; q < wv; q++) off += s_wave[q];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            if (i0 + q < n) boff[i0 + q] = off;
+            off += v[q];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wbase + inc;
+        if (threadIdx.x == 1023) s_carry = off;
         __syncthreads();
     }
     if (threadIdx.x == 0) boff[n] = s_carry;
@@ -398,8 +453,8 @@ static int run_bits(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     const int64_t nrows_src = g.nz * g.ny;
     const int64_t total = nrows_src * (g.ws * 64 / V);
     if (total == 0) return IVX_OK;
-    const int64_t blocks = ivx::cdiv(total, 256);
-    const int grid = (int)(blocks < 32768 ? blocks : 32768);
+    const int64_t blocks = ivx::cdiv(total, 256 * 4);
+    const int grid = (int)(blocks < 1 ? 1 : (blocks < 16384 ? blocks : 16384));
     uint8_t *b0 = (uint8_t *)(scratch + s.off_bits);
     uint8_t *b1 = b0 + s.bits_words * 8;
     if (p->niso == 2)
