@@ -56,6 +56,27 @@ def set_mask_threshold(mask_matrix, image_matrix, threshold_range):
     _threshold(mask_matrix, image_matrix, threshold_range, False, False)
 
 
+def do_threshold_to_a_slice(slice_matrix: np.ndarray, mask: np.ndarray, threshold) -> np.ndarray:
+    """Slice.do_threshold_to_a_slice (invesalius/data/slice_.py:1722-1737): returns a NEW uint8 array with
+    255*in_range and the existing 1/2/253/254 of `mask` preserved.  2-D (or any-D) int16 slice, same-shape uint8 mask."""
+    if slice_matrix.dtype != np.int16 or mask.dtype != np.uint8 or slice_matrix.shape != mask.shape:
+        raise TypeError("slice must be int16 and mask a uint8 array of the same shape")
+    out = np.array(mask, dtype=np.uint8, copy=True)
+    img3 = slice_matrix.reshape((1, -1, slice_matrix.shape[-1])) if slice_matrix.ndim != 3 else slice_matrix
+    m3 = out.reshape(img3.shape)
+    # full-matrix layout expected by the C entry point: one flag row / column in front of every axis
+    big = np.zeros(tuple(s + 1 for s in img3.shape), np.uint8)
+    big[1:, 1:, 1:] = m3
+    _threshold(big, np.ascontiguousarray(img3), threshold, True, False)
+    return big[1:, 1:, 1:].reshape(slice_matrix.shape).copy()
+
+
+def set_mask_threshold_slice(slice_: np.ndarray, threshold_range) -> np.ndarray:
+    """Per-slice preview branch of Slice.SetMaskThreshold (slice_.py:1253-1256):
+    ``(255 * ((slice_ >= thresh_min) & (slice_ <= thresh_max))).astype("uint8")``."""
+    return do_threshold_to_a_slice(slice_, np.zeros(slice_.shape, np.uint8), threshold_range)
+
+
 def project(slab: np.ndarray, axis: int, projection: int) -> np.ndarray:
     """MaxIP / MinIP / MeanIP of a slab: ``np.array(tmp_array).max|min|mean(axis)``
     (invesalius/data/slice_.py:885-889, 969-973, 1056-1060)."""

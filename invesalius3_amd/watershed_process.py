@@ -51,10 +51,17 @@ def merge(mask: np.ndarray, tmp_mask: np.ndarray, overwrite: bool):
                                         int(bool(overwrite))), "watershed merge")
 
 
-def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_ww_wl, wl, ww, q=None):
+def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_ww_wl, wl, ww, q=None, flood=None):
     """Same signature and side effects as watershed_process.do_watershed (:19-60): writes the uint8 label volume to
-    the memmap `tfile` and signals ``q.put(1)``.  Cost image on the GPU; flood = the reference's own third-party
-    call (see module docstring)."""
+    the memmap `tfile` and signals ``q.put(1)``.  The cost image is made on the GPU.
+
+    The marker flood is NOT implemented in libivx (module docstring): by default this raises NotImplementedError --
+    there is no silent CPU path in this package.  Pass ``flood="third-party-cpu"`` to run, explicitly, the same
+    scipy / scikit-image call the reference makes on the GPU-made cost image."""
+    if flood != "third-party-cpu":
+        raise NotImplementedError(
+            "the watershed marker flood has no HIP implementation yet (bit-exact parallel tie-breaking is an open "
+            "problem, DESIGN.md section 6); pass flood='third-party-cpu' to use the reference's own scipy/skimage call")
     from scipy import ndimage
 
     mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")

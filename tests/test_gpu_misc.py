@@ -97,7 +97,10 @@ def test_do_watershed_ift_pipeline_matches_reference_calls(ivxlib, tmp_path):
     np.memmap(tfile, shape=image.shape, dtype="uint8", mode="w+").flush()
     q = queue.Queue()
     bstruct = generate_binary_structure(3, 1)
-    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), False, 0, 0, q)
+    with pytest.raises(NotImplementedError):  # no silent CPU path: the flood must be requested explicitly
+        wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), False, 0, 0, q)
+    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), False, 0, 0, q,
+                    flood="third-party-cpu")
     assert q.get() == 1
     got = np.array(np.memmap(tfile, shape=image.shape, dtype="uint8", mode="r"))
     exp = ndimage.watershed_ift((image - image.min()).astype("uint16"), markers.astype("int8"), bstruct)

@@ -89,3 +89,21 @@ def test_full_size_property_512(ivxlib):
     mask[1:, 0, 0] = 0
     slice_.do_threshold_to_all_slices(mask, img, BONE)
     assert np.array_equal(mask[1:, 1:, 1:], before[1:, 1:, 1:])
+
+
+def test_per_slice_entry_points_reference_fixtures(ivxlib, oracle):
+    """tests/test_bone_thresholding.py:51-118 through the GPU: SetMaskThreshold preview and do_threshold_to_a_slice"""
+    from invesalius3_amd import slice_
+    rng = np.random.default_rng(1)
+    sl = rng.integers(0, BONE[0] - 1, (10, 10), dtype=np.int16)
+    sl[5:8, 5:8] = (BONE[0] + BONE[1]) // 2
+    sl[0, :4] = [226, 3071, 225, 3072]
+    m = np.zeros((10, 10), np.uint8)
+    m[0:2, 0:2] = 1
+    m[2:4, 2:4] = 2
+    m[4:6, 4:6] = 253
+    m[6:8, 6:8] = 254
+    assert np.array_equal(slice_.do_threshold_to_a_slice(sl, m, BONE), oracle.do_threshold_to_a_slice(sl, m, BONE))
+    assert np.array_equal(slice_.set_mask_threshold_slice(sl, BONE), oracle.set_mask_threshold_slice(sl, BONE))
+    big = synth_volume((1, 37, 53), seed=5)[0]
+    assert np.array_equal(slice_.set_mask_threshold_slice(big, (-300, 900)), oracle.set_mask_threshold_slice(big, (-300, 900)))
