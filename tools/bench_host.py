@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rates of the HOST-level entry points (numpy in, numpy out, strided (d+1,h+1,w+1) mask): what a
+drop-in caller that does not keep the volume resident pays.  512^3, wall-clock around the Python call."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
+from scipy.ndimage import generate_binary_structure  # noqa: E402
+
+from bench import BONE, synth_v512  # noqa: E402
+from invesalius3_amd import invesalius_rs as rs, slice_, surface_process as sp  # noqa: E402
+
+
+def timeit(fn, reps=3):
+    fn()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        t.append(time.perf_counter() - t0)
+    return min(t)
+
+
+def main():
+    n = 512
+    img = synth_v512((n, n, n))
+    nvox = img.size
+    mask = np.zeros((n + 1,) * 3, np.uint8)
+    res = {}
+
+    def thr():
+        mask[1:, 0, 0] = 0
+        slice_.do_threshold_to_all_slices(mask, img, BONE)
+    res["do_threshold_to_all_slices (strided mask, preserve rule)"] = timeit(thr)
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    out = np.zeros(img.shape, np.uint8)
+    s26 = generate_binary_structure(3, 3)
+
+    def grow():
+        out[:] = 0
+        rs.floodfill_threshold(img, [(int(x), int(y), int(z))], BONE[0], BONE[1], 1, s26, out)
+    res["floodfill_threshold (26-conn, dense out)"] = timeit(grow)
+    view = mask[1:, 1:, 1:]
+
+    def grow_view():
+        rs.floodfill_threshold_inplace(view, [(int(x), int(y), int(z))], 253, 255, 254, s26)
+        view[view == 254] = 255
+    res["floodfill_threshold_inplace (mask view [1:,1:,1:])"] = timeit(grow_view, reps=2)
+    tri = [None]
+
+    def mc():
+        tri[0] = sp.create_surface_piece(None, mask, slice(0, n), (1.0, 1.0, 1.0), 0, 0, True)
+    res["create_surface_piece (whole volume, from_binary)"] = timeit(mc)
+    o2 = np.zeros((n, n), np.int16)
+    res["mida axis 0"] = timeit(lambda: rs.mida(img, 0, 300, 600, o2))
+    res["project MaxIP axis 0"] = timeit(lambda: slice_.project(img, 0, slice_.PROJECTION_MaxIP))
+    print(json.dumps({"size": "512^3", "triangles": int(len(tri[0])),
+                      "results": {k: {"s": round(v, 4), "Mvoxel/s": round(nvox / v / 1e6, 1)} for k, v in res.items()}}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
