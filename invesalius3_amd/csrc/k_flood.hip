@@ -9,19 +9,24 @@
 // so a parallel fix-point gives the same bytes.
 //
 // MI355X design (memory-bound, no MFMA):
-//   k_flood_candidates  ONE streaming pass over data (+ barrier): 2 B + 1 B read per voxel, 1 bit written.
-//                       C is 1 bit/voxel (64 voxels of an x-row per uint64): 16 MiB at 512^3, i.e. it lives in
-//                       L2 / Infinity Cache for the whole flood.
-//   k_flood_round       one workgroup per DIRTY tile of 64(x) x 16(y) x 16(z) voxels = 256 words, one lane per
-//                       word.  The reached-bits of the tile plus a one-row/one-word halo are staged in LDS
-//                       (18x18x3 words, 7.6 KiB) and iterated to the tile-local fix-point:
-//                         - 26/18/6-neighbour gather = OR of <= 9 LDS rows with +-1 bit shifts,
+//   k_flood_candidates16  ONE streaming pass over data (+ barrier): 2 B + 1 B read per voxel, 1 bit written (lane = 16
+//                       voxels).  C is 1 bit/voxel (64 voxels of an x-row per uint64): 16 MiB at 512^3, i.e. it lives
+//                       in L2 / Infinity Cache for the whole flood.
+//   k_flood_round_list  one workgroup per DIRTY tile of 64(x) x 16(y) x 16(z) voxels = 256 words, one lane per word,
+//                       tiles taken from a compact per-round list.  The reached bits of the tile plus a one-row halo
+//                       are staged in LDS together with their x-dilated twins (tile_update) and iterated to the
+//                       tile-local fix-point:
+//                         - 26/18/6-neighbour gather = OR of <= 9 LDS words, a compile-time pattern for the three
+//                           standard structures so the reads issue back to back,
 //                         - propagation ALONG x inside a word is closed in O(1) with the carry trick
-//                           ((C + R) ^ C) & C  (and its bit-reversed twin), i.e. a 64-voxel run fills in one step.
-//                       A tile whose boundary changed marks exactly the neighbour tiles that can see the change
-//                       (agent-scope atomics); the host loops rounds until no tile is dirty.  Global rounds are
-//                       bounded by the number of TILES on the longest path, not voxels.
-//   k_flood_apply       reached bits -> out[v] = fill (only words with reached bits touch memory).
+//                           ((C + R) ^ C) & C  (and its bit-reversed twin), i.e. a 64-voxel run fills in one step,
+//                         - one s_barrier per iteration (wave ballot + LDS flag vote).
+//                       A tile whose boundary changed enlists exactly the neighbour tiles that can see the change
+//                       (byte flags de-duplicate); the host launches rounds in batches of 8 and reads the per-round
+//                       list lengths through a pinned mailbox.  Global rounds are bounded by the number of TILES on
+//                       the longest path, not voxels; past 48 rounds the union-find engine (k_ccl.hip) takes over.
+//   k_flood_persistent  the same tile update in ONE launch with a device-side ticket queue (opt-in, measured slower).
+//   k_flood_apply(2)    reached bits -> out[v] = fill (only words with reached bits touch memory).
 #include <math.h>
 #include <stdlib.h>
 
@@ -70,7 +75,7 @@ static int make_tiles(const ivx_flood_plan *p, Tiles *t) {
 constexpr size_t SEED_CHUNK = 4096;
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FScratch {
-    size_t off_dirty0, off_dirty1, off_cnt, off_queue, off_queued, off_seeds, off_status, off_ring, total;
+    size_t off_dirty0, off_dirty1, off_cnt, off_queue, off_queued, off_seeds, off_status, off_ring, off_list0, off_list1, total;
     uint32_t qcap;
 };
 // persistent-frontier queue header (device)
@@ -94,7 +99,9 @@ static FScratch make_fscratch(const Tiles &t) {
     uint32_t q = 64;
     while ((int64_t)q < 2 * t.ntiles + 2048) q <<= 1; // <= ntiles queued + <= 1024 waiting tickets, 2x slack
     s.qcap = q;
-    s.total = al256(s.off_ring + (size_t)q * 4);
+    s.off_list0 = al256(s.off_ring + (size_t)q * 4);
+    s.off_list1 = al256(s.off_list0 + (size_t)t.ntiles * 4);
+    s.total = al256(s.off_list1 + (size_t)t.ntiles * 4);
     return s;
 }
 
@@ -379,54 +386,66 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     if ((threadIdx.x & 63) == 0 && dirs) atomicOr(&L.dirs, dirs);
 }
 
-__global__ __launch_bounds__(NT) void k_flood_round(Tiles t, const unsigned long long *__restrict__ cand,
-                                                     unsigned long long *reached, uint8_t *dirty_cur,
-                                                     uint8_t *dirty_next, unsigned int *counter_next) {
-    __shared__ TileLds L;
-    __shared__ int s_go;
-    const int64_t tile = blockIdx.x;
-    if (threadIdx.x == 0) { // one lane consumes the flag, so no wave can see it already cleared
-        s_go = dirty_cur[tile];
-        if (s_go) dirty_cur[tile] = 0;
-        L.dirs = 0;
-    }
-    __syncthreads();
-    if (!s_go) return; // uniform per workgroup
-    const bool dbg = t.strct >> 30 & 1u;
-    if (dbg && threadIdx.x == 0) g_dbg[0] = __builtin_readcyclecounter();
-    // halo words may be rewritten concurrently by the neighbouring tile's workgroup; a stale read is still correct
-    // (the writer re-marks this tile for the next round), so plain loads/stores + the kernel boundary suffice
-    if (dbg) tile_update<false, 26, true>(t, cand, reached, tile, L);
-    else if (t.conn == 26) tile_update<false, 26>(t, cand, reached, tile, L);
-    else if (t.conn == 18) tile_update<false, 18>(t, cand, reached, tile, L);
-    else if (t.conn == 6) tile_update<false, 6>(t, cand, reached, tile, L);
-    else tile_update<false, 0>(t, cand, reached, tile, L);
-    lds_barrier(); // L.dirs complete; the publish stores keep flying (the kernel boundary orders them for the next round)
-    if (dbg && threadIdx.x == 0) g_dbg[3] = __builtin_readcyclecounter();
-    const int64_t txi = tile % t.wx, r1 = tile / t.wx;
-    const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
-    if (threadIdx.x < 27 && (L.dirs >> threadIdx.x & 1u)) {
-        const int d = threadIdx.x;
-        const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
-        if (nz >= 0 && nz < t.ntz && ny >= 0 && ny < t.nty && nx >= 0 && nx < t.wx) {
-            const int64_t nt = (nz * t.nty + ny) * t.wx + nx;
-            // byte flags: use a 32-bit atomic on the containing word
-            unsigned int *wp = (unsigned int *)(dirty_next + (nt & ~(int64_t)3));
-            const unsigned int bit = 1u << (8 * (nt & 3));
-            atomicOr(wp, bit);            // no returned value: nothing waits for the round trip
-            atomicAdd(counter_next, 1u);  // counts marking events; only "zero or not" is ever tested
-        }
-    }
-    if (dbg && threadIdx.x == 0) g_dbg[4] = __builtin_readcyclecounter();
-}
+// diagnostic only (not part of include/ivx.h): cycle stamps written under IVX_FLOOD_DBG=1, see tools/dbg_tile.py
 extern "C" int ivx_debug_read(unsigned long long *out16) {
     IVX_HIP(hipDeviceSynchronize());
     IVX_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dbg), 16 * 8));
     return IVX_OK;
 }
 
+// ---- list-driven round: only as many workgroups as there are dirty tiles do any work ------------------------------------
+// The dirty set of a round is a compact list (plus the byte flags, which de-duplicate marks).  A workgroup takes list
+// entries blockIdx.x, blockIdx.x + gridDim.x, ...; an idle round costs one small launch instead of ntiles empty workgroups,
+// and the dirty tiles of a busy round start at once instead of waiting for the dispatcher to walk past the clean ones.
+__global__ void k_flood_build_list(Tiles t, const uint8_t *__restrict__ dirty, unsigned int *__restrict__ list,
+                                   unsigned int *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < t.ntiles && dirty[i]) list[atomicAdd(count, 1u)] = (unsigned int)i;
+}
+
+__global__ __launch_bounds__(NT) void k_flood_round_list(Tiles t, const unsigned long long *__restrict__ cand,
+                                                          unsigned long long *reached, const unsigned int *__restrict__ list_cur,
+                                                          const unsigned int *__restrict__ n_cur, uint8_t *dirty_cur,
+                                                          uint8_t *dirty_next, unsigned int *list_next,
+                                                          unsigned int *n_next) {
+    __shared__ TileLds L;
+    const unsigned int n = *n_cur;
+    for (unsigned int li = blockIdx.x; li < n; li += gridDim.x) {
+        const int64_t tile = list_cur[li];
+        if (threadIdx.x == 0) {
+            dirty_cur[tile] = 0;
+            L.dirs = 0;
+        }
+        __syncthreads();
+        const bool dbg = (t.strct >> 30 & 1u) && li == 0; // IVX_FLOOD_DBG: cycle stamps of the first tile (tools/dbg_tile.py)
+        if (dbg && threadIdx.x == 0) g_dbg[0] = __builtin_readcyclecounter();
+        if (dbg) tile_update<false, 26, true>(t, cand, reached, tile, L);
+        else if (t.conn == 26) tile_update<false, 26>(t, cand, reached, tile, L);
+        else if (t.conn == 18) tile_update<false, 18>(t, cand, reached, tile, L);
+        else if (t.conn == 6) tile_update<false, 6>(t, cand, reached, tile, L);
+        else tile_update<false, 0>(t, cand, reached, tile, L);
+        lds_barrier(); // L.dirs complete; the publish stores keep flying (the kernel boundary orders them for the next round)
+        if (dbg && threadIdx.x == 0) g_dbg[3] = __builtin_readcyclecounter();
+        const int64_t txi = tile % t.wx, r1 = tile / t.wx;
+        const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+        if (threadIdx.x < 27 && (L.dirs >> threadIdx.x & 1u)) {
+            const int d = threadIdx.x;
+            const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
+            if (nz >= 0 && nz < t.ntz && ny >= 0 && ny < t.nty && nx >= 0 && nx < t.wx) {
+                const int64_t nt = (nz * t.nty + ny) * t.wx + nx;
+                unsigned int *wp = (unsigned int *)(dirty_next + (nt & ~(int64_t)3));
+                const unsigned int sh = 8 * (unsigned int)(nt & 3);
+                const unsigned int old = atomicOr(wp, 1u << sh);
+                if (!((old >> sh) & 0xffu)) list_next[atomicAdd(n_next, 1u)] = (unsigned int)nt; // first mark: enlist
+            }
+        }
+        if (dbg && threadIdx.x == 0) g_dbg[4] = __builtin_readcyclecounter();
+        __syncthreads(); // L is reused by the next list entry of this workgroup
+    }
+}
+
 // ---- persistent tile frontier: ONE launch, device-side work queue ---------------------------------------
-// Same tile update as k_flood_round, but workgroups pull dirty tiles from a ring buffer and push the neighbour
+// Same tile update as k_flood_round_list, but workgroups pull dirty tiles from a ring buffer and push the neighbour
 // tiles whose halo they changed, until nothing is queued or in flight (`pending` == 0).  Cross-workgroup traffic
 // (reached words, queue words, flags) uses 4/8-byte agent-scope atomics on both sides (the placement-independent
 // form of the CDNA4 guide, G16): words are published with atomicOr (monotone, so two workgroups that happen to
@@ -795,22 +814,34 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
         IVX_HIP(hipMemsetAsync(dirty[1], 0, (size_t)t.ntiles, st));
     }
     int total_rounds = 0;
-    for (;;) {
-        IVX_HIP(hipMemsetAsync(cnt, 0, BATCH * 4, st));
+    unsigned int *list[2] = {(unsigned int *)(scr + s.off_list0), (unsigned int *)(scr + s.off_list1)};
+    // counters live in a ring of 2*BATCH dwords: round r reads cnt[r % 2B] (entries of its list) and appends to
+    // cnt[(r+1) % 2B]; the entries a batch will write are zeroed just before the batch
+    IVX_HIP(hipMemsetAsync(cnt, 0, 2 * BATCH * 4, st));
+    hipLaunchKernelGGL(k_flood_build_list, dim3((unsigned)ivx::cdiv(t.ntiles, 256)), dim3(256), 0, st, t, dirty[0], list[0], cnt);
+    IVX_LAUNCH_CHECK();
+    const unsigned grid = (unsigned)(t.ntiles < 1024 ? t.ntiles : 1024);
+    for (int batch = 0;; batch++) {
+        const int base = (batch & 1) * BATCH;
+        if (batch > 0) { // zero cnt[base+1 .. base+BATCH] (mod 2B); cnt[base] holds the live count of the next list
+            IVX_HIP(hipMemsetAsync(cnt + base + 1, 0, (BATCH - 1) * 4, st));
+            IVX_HIP(hipMemsetAsync(cnt + (base + BATCH) % (2 * BATCH), 0, 4, st));
+        }
         for (int b = 0; b < BATCH; b++) {
-            // BATCH is even, so every batch starts with dirty[0] as the current list
-            hipLaunchKernelGGL(k_flood_round, dim3((unsigned)t.ntiles), dim3(NT), 0, st, t,
-                               (const unsigned long long *)cand, (unsigned long long *)reached, dirty[b & 1],
-                               dirty[(b + 1) & 1], cnt + b);
+            // BATCH is even, so every batch starts with list[0] / dirty[0] as the current set
+            hipLaunchKernelGGL(k_flood_round_list, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+                               (unsigned long long *)reached, list[b & 1], cnt + base + b, dirty[b & 1], dirty[(b + 1) & 1],
+                               list[(b + 1) & 1], cnt + (base + b + 1) % (2 * BATCH));
             IVX_LAUNCH_CHECK();
         }
-        unsigned int h[BATCH];
+        unsigned int h2[2 * BATCH], h[BATCH];
         uint32_t seq;
-        if ((rc = ivx::mailbox_publish(cnt, BATCH, st, &seq))) return rc;
-        if ((rc = ivx::mailbox_wait(seq, st, h, BATCH))) return rc;
+        if ((rc = ivx::mailbox_publish(cnt, 2 * BATCH, st, &seq))) return rc;
+        if ((rc = ivx::mailbox_wait(seq, st, h2, 2 * BATCH))) return rc;
+        for (int b = 0; b < BATCH; b++) h[b] = h2[(base + b + 1) % (2 * BATCH)]; // tiles enlisted BY round b
         static const bool trace = getenv("IVX_FLOOD_TRACE") != nullptr;
         if (trace) {
-            fprintf(stderr, "ivx flood: tile marks after rounds %d..%d:", total_rounds + 1, total_rounds + BATCH);
+            fprintf(stderr, "ivx flood: tiles enlisted by rounds %d..%d:", total_rounds + 1, total_rounds + BATCH);
             for (int b = 0; b < BATCH; b++) fprintf(stderr, " %u", h[b]);
             fprintf(stderr, "  (of %lld tiles)\n", (long long)t.ntiles);
         }
