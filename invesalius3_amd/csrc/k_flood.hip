@@ -40,6 +40,7 @@ constexpr int TY_LOG = 4, TY = 1 << TY_LOG, TZ = 16; // tile rows / slices (tile
 constexpr int NT = TY * TZ;           // lanes per tile workgroup (one per word)
 constexpr int HY = TY + 2, HZ = TZ + 2;
 constexpr int BATCH = 8;              // rounds launched between host checks
+constexpr int SUB = 1;                // gather/update steps per termination vote (measured: 4 doubles the tile time)
 
 struct Tiles {
     int64_t dz, dy, dx, wx;
@@ -303,6 +304,12 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     const bool xrun = (st >> 12 & 1) && (st >> 14 & 1); // both x neighbours of the centre row present
     bool exhausted = true;
     for (int it = 0; it < 2048; it++) {
+      bool changed = false;
+      // SUB gather/update steps per vote: LDS is coherent inside the workgroup and bits are only OR'ed in, so steps need
+      // no barrier between them -- a wave always sees its own rows' previous step (program order), other waves' rows
+      // whenever they land.  Only the termination vote needs the barrier.
+#pragma unroll
+      for (int sub = 0; sub < SUB; sub++) {
         unsigned long long nb = 0;
         if (CONN != 0) {
             // standard 6 / 18 / 26 structures: the row pattern is known at compile time, so the nine LDS reads are
@@ -340,12 +347,14 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
         }
         unsigned long long nr = r | (nb & c);
         if (xrun) nr = fill_runs(nr, c);
-        const bool changed = nr != r;
-        if (changed) {
+        const bool ch = nr != r;
+        if (ch) {
             r = nr;
             L.sN[me] = r;
             L.sD[me] = r | (r << 1) | (r >> 1) | mycl | (mycr << 63);
         }
+        changed |= ch;
+      }
         // vote: __syncthreads_or() costs ~1500 cycles on gfx950 (library workgroup reduction); a wave ballot + one
         // LDS flag + one barrier does the same in ~200.  Flag it&1 is read now, flag (it+1)&1 is cleared for the next
         // iteration (nobody touches it between this barrier and the next one's writers).
