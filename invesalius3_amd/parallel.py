@@ -130,11 +130,13 @@ def _make_slab_volume():
         """This rank's Z-slab (+ halo slices) resident in HBM.  Same call surface as DeviceVolume; region growing and
         marching cubes are the sharded versions."""
 
-        def __init__(self, image_slab: np.ndarray, rank: int, world: int, dist, spacing=(1.0, 1.0, 1.0)):
+        def __init__(self, image_slab: np.ndarray, rank: int, world: int, dist=None, spacing=(1.0, 1.0, 1.0), comm=None):
             import torch
 
             self.lay = slab_layout(rank, world, image_slab.shape[0])
-            self.comm = TorchComm(dist, rank, world, device="cuda")
+            # `comm` may be injected (tests/test_gpu_slab.py drives several ranks on ONE GPU through an in-process
+            # loop-back that has the same exchange / allreduce_sum interface as TorchComm)
+            self.comm = comm if comm is not None else TorchComm(dist, rank, world, device="cuda")
             self._torch = torch
             # one-time halo exchange of the IMAGE (static input): my first slice goes down, my last slice goes up
             down = torch.from_numpy(np.ascontiguousarray(image_slab[0])).cuda()
