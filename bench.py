@@ -138,7 +138,7 @@ def main():
     if dist is not None:
         from invesalius3_amd.parallel import SlabVolume
 
-        vol = SlabVolume(img, rank, world, dist)
+        vol = SlabVolume(img, rank, world, dist, device=local_rank)
     else:
         vol = DeviceVolume(img)
     nvox = img.size

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <map>
 #include <mutex>
 
 #include "ivx_internal.h"
@@ -41,6 +42,29 @@ int ws_get(int slot, size_t nbytes, void **dptr) {
     *dptr = s.p;
     return IVX_OK;
 }
+
+static std::map<std::pair<int, hipStream_t>, Slot> g_ws_stream;
+
+int ws_get_s(int slot, hipStream_t stream, size_t nbytes, void **dptr) {
+    if (stream == nullptr) return ws_get(slot, nbytes, dptr);
+    std::lock_guard<std::mutex> lk(g_mu);
+    Slot &s = g_ws_stream[std::make_pair(slot, stream)];
+    if (nbytes == 0) nbytes = 16;
+    if (s.n < nbytes) {
+        if (s.p) IVX_HIP(hipFree(s.p)); // synchronises the device: nothing can still be using the old block
+        s.p = nullptr;
+        s.n = 0;
+        size_t want = nbytes + (nbytes >> 3) + 4096;
+        IVX_HIP(hipMalloc(&s.p, want));
+        s.n = want;
+    }
+    *dptr = s.p;
+    return IVX_OK;
+}
+
+static std::recursive_mutex g_host_mu;
+HostCallGuard::HostCallGuard() { g_host_mu.lock(); }
+HostCallGuard::~HostCallGuard() { g_host_mu.unlock(); }
 
 int hs_get(int slot, size_t nbytes, void **hptr) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -273,6 +297,9 @@ int ivx_release_workspace(void) {
         if (g_hs[i].p) (void)hipHostFree(g_hs[i].p);
         g_hs[i] = Slot();
     }
+    for (auto &kv : g_ws_stream)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    g_ws_stream.clear();
     return IVX_OK;
 }
 

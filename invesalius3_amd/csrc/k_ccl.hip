@@ -393,7 +393,7 @@ struct CclState {
     uint32_t nruns = 0;
 };
 static std::map<const void *, CclState> g_state;
-static const void *g_tab_owner = nullptr; // the tables live in shared library workspaces: valid for ONE scratch at a time
+static std::map<hipStream_t, const void *> g_tab_owner; // the tables live in per-stream workspaces: ONE scratch per stream at a time
 static std::mutex g_state_mu;
 
 static inline int grid_for(int64_t n) {
@@ -429,13 +429,13 @@ int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, co
     {
         std::lock_guard<std::mutex> lk(g_state_mu);
         state = g_state[scratch_key];
-        if (g_tab_owner != scratch_key) state = CclState(); // another flood rebuilt the shared tables meanwhile
-        g_tab_owner = scratch_key;
+        if (g_tab_owner[st] != scratch_key) state = CclState(); // another flood on this stream rebuilt the tables meanwhile
+        g_tab_owner[st] = scratch_key;
     }
     const int64_t nsb = cdiv(g.nwords, 256 * SCAN_ITEMS);
     void *d_wbase, *d_tab;
     int rc;
-    if ((rc = ws_get(WS_CCL0, (size_t)g.nwords * 4 + (size_t)nsb * 4 + 64, &d_wbase))) return rc;
+    if ((rc = ws_get_s(WS_CCL0, st, (size_t)g.nwords * 4 + (size_t)nsb * 4 + 64, &d_wbase))) return rc;
     uint32_t *wbase = (uint32_t *)d_wbase;
     uint32_t *bsum = wbase + g.nwords;
     uint32_t *d_total = bsum + nsb;
@@ -461,7 +461,7 @@ int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, co
         g_state[scratch_key] = state;
         return IVX_OK;
     }
-    if ((rc = ws_get(WS_CCL1, (size_t)state.nruns * 5 + 64, &d_tab))) return rc;
+    if ((rc = ws_get_s(WS_CCL1, st, (size_t)state.nruns * 5 + 64, &d_tab))) return rc;
     uint32_t *parent = (uint32_t *)d_tab;
     uint8_t *flag = (uint8_t *)(parent + state.nruns);
     if (!state.built) {

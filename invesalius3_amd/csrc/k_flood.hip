@@ -932,7 +932,7 @@ extern "C" int ivx_dev_flood_count(const ivx_flood_plan *p, const uint64_t *reac
     const int64_t nw = t.dz * t.dy * t.wx;
     if (!nw) return IVX_OK;
     void *d_tot;
-    if ((rc = ivx::ws_get(ivx::WS_SMALL, 64, &d_tot))) return rc;
+    if ((rc = ivx::ws_get_s(ivx::WS_SMALL, ivx::S(stream), 64, &d_tot))) return rc;
     hipStream_t st = ivx::S(stream);
     IVX_HIP(hipMemsetAsync(d_tot, 0, 8, st));
     hipLaunchKernelGGL(k_flood_count, dim3(grid_for(nw)), dim3(256), 0, st, (const unsigned long long *)reached, nw,
@@ -1039,6 +1039,7 @@ extern "C" int ivx_floodfill_threshold(int dtype, const void *data, const int64_
                                        const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1, int fill,
                                        const uint8_t *strct, const int64_t sshape[3], uint8_t *out,
                                        const int64_t out_strides[3]) {
+    ivx::HostCallGuard host_guard__;
     return flood_host(dtype, (void *)data, shape, strides, seeds_xyz, nseeds, t0, t1, (double)(uint8_t)fill, strct,
                       sshape, out, out_strides, 0);
 }
@@ -1046,5 +1047,6 @@ extern "C" int ivx_floodfill_threshold(int dtype, const void *data, const int64_
 extern "C" int ivx_floodfill_threshold_inplace(int dtype, void *data, const int64_t shape[3], const int64_t strides[3],
                                                const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1,
                                                double fill, const uint8_t *strct, const int64_t sshape[3]) {
+    ivx::HostCallGuard host_guard__;
     return flood_host(dtype, data, shape, strides, seeds_xyz, nseeds, t0, t1, fill, strct, sshape, nullptr, strides, 1);
 }

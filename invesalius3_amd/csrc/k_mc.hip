@@ -474,7 +474,7 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
     const uint64_t *boff = (const uint64_t *)(scratch + s.off_boff);
     void *d_list;
-    int rc = ivx::ws_get(ivx::WS_MCLIST, (size_t)max_tris * 8 + 64, &d_list);
+    int rc = ivx::ws_get_s(ivx::WS_MCLIST, st, (size_t)max_tris * 8 + 64, &d_list);
     if (rc) return rc;
     // iso 1's triangles follow iso 0's: boff is one scan over [iso0 blocks | iso1 blocks], so both list passes write
     // disjoint ranges of ONE list and a single flat emit per iso covers [first, last) of that iso
@@ -573,6 +573,7 @@ extern "C" int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void
 
 extern "C" int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *tris,
                                   int64_t max_tris, int64_t *ntris) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     Geom g;
     int rc = make_geom(p, &g);

@@ -125,7 +125,7 @@ static int run_reduce(const void *vol_, int64_t dz, int64_t dy, int64_t dx, int 
     void *part;
     int rc;
     if (axis == 2) {
-        if ((rc = ivx::ws_get(ivx::WS_AUX3, (size_t)npix * 8, &part))) return rc;
+        if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * 8, &part))) return rc;
         hipLaunchKernelGGL((k_reduce_rows<T, OP, VEC>), dim3((unsigned)ivx::cdiv(npix, 4)), dim3(256), 0, st, vol, npix,
                            len, (long long *)part);
         IVX_LAUNCH_CHECK();
@@ -146,7 +146,7 @@ static int run_reduce(const void *vol_, int64_t dz, int64_t dy, int64_t dx, int 
     if (split < 1) split = 1;
     const int64_t seg = ivx::cdiv(len, split);
     split = ivx::cdiv(len, seg);
-    if ((rc = ivx::ws_get(ivx::WS_AUX3, (size_t)npix * sizeof(part_t) * split, &part))) return rc;
+    if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * sizeof(part_t) * split, &part))) return rc;
     hipLaunchKernelGGL((k_reduce_strided<T, OP, VEC>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, vol, nr,
                        nc, len, sr, sl, seg, (part_t *)part);
     IVX_LAUNCH_CHECK();
@@ -186,6 +186,7 @@ extern "C" int ivx_dev_mip_reduce(int dtype, const void *vol, int64_t dz, int64_
 
 extern "C" int ivx_mip_reduce(int dtype, const void *vol, const int64_t shape[3], const int64_t strides[3], int axis,
                               int op, void *out, const int64_t out_strides[2]) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     IVX_REQUIRE(axis >= 0 && axis <= 2, IVX_EINVAL, "mip: axis %d", axis);
     const size_t isz = dtype_size(dtype);

@@ -190,6 +190,7 @@ extern "C" int ivx_dev_fill_holes(uint8_t *mask, const uint32_t *labels, int64_t
 extern "C" int ivx_fill_holes_automatically(uint8_t *mask, const int64_t shape[3], const int64_t mst[3],
                                             const uint32_t *labels, const int64_t lst[3], uint32_t nlabels,
                                             uint32_t max_size, int *modified) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     const size_t n = (size_t)shape[0] * shape[1] * shape[2];
     *modified = 0;
@@ -253,7 +254,7 @@ extern "C" int ivx_dev_watershed_merge(uint8_t *mask, const uint8_t *tmp, int64_
 }
 extern "C" int ivx_dev_masked_stats_i16(const int16_t *img, const uint8_t *sel, int64_t n, int64_t out3[3], void *stream) {
     void *d_acc;
-    int rc = ivx::ws_get(ivx::WS_SMALL, 256, &d_acc);
+    int rc = ivx::ws_get_s(ivx::WS_SMALL, ivx::S(stream), 256, &d_acc);
     if (rc) return rc;
     hipStream_t st = ivx::S(stream);
     unsigned long long *acc = (unsigned long long *)((char *)d_acc + 128);
@@ -284,6 +285,7 @@ extern "C" int ivx_dev_flood_apply_where(uint8_t *dst, const uint8_t *src, int64
 extern "C" int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int use_ww_wl,
                                      double window, double level, const int gradient_size[3] /* NULL = none */,
                                      uint16_t *out) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     const int64_t n = shape[0] * shape[1] * shape[2];
     if (n == 0) return IVX_OK;
@@ -319,6 +321,7 @@ extern "C" int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3],
 
 extern "C" int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mst[3], const uint8_t *tmp,
                                    const int64_t tst[3], int overwrite) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     const int64_t n = shape[0] * shape[1] * shape[2];
     if (n == 0) return IVX_OK;

@@ -379,7 +379,7 @@ static int launch_rays(const void *vol, int64_t dz, int64_t dy, int64_t dx, int 
 template <typename T> static int run_minmax(const void *vol, int64_t n, float *out, hipStream_t st) {
     void *part;
     const int nb = (int)(ivx::cdiv(n, 256) < 2048 ? ivx::cdiv(n, 256) : 2048);
-    int rc = ivx::ws_get(ivx::WS_AUX3, (size_t)nb * 2 * sizeof(T) + 64, &part);
+    int rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)nb * 2 * sizeof(T) + 64, &part);
     if (rc) return rc;
     hipLaunchKernelGGL(k_minmax_part<T>, dim3(nb), dim3(256), 0, st, (const T *)vol, n, (T *)part);
     IVX_LAUNCH_CHECK();
@@ -489,6 +489,7 @@ static int host_status(const HostRay &h) {
 
 extern "C" int ivx_mida(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
                         double wl, double ww, int out_dtype, void *out, const int64_t out_strides[2]) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     IVX_REQUIRE((dtype == IVX_I16 && out_dtype == IVX_I16) || (dtype == IVX_U8 && out_dtype == IVX_U8) ||
                     (dtype == IVX_F64 && out_dtype == IVX_U8),
@@ -510,6 +511,7 @@ extern "C" int ivx_mida(int dtype, const void *img, const int64_t shape[3], cons
 
 extern "C" int ivx_lmip(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
                         double tmin, double tmax, void *out, const int64_t out_strides[2]) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     if (axis < 0 || axis > 2) return IVX_OK;
     if (shape[0] * shape[1] * shape[2] == 0) return IVX_OK;
@@ -524,6 +526,7 @@ extern "C" int ivx_lmip(int dtype, const void *img, const int64_t shape[3], cons
 extern "C" int ivx_fast_countour_mip(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3],
                                      float n, int axis, double wl, double ww, int tmip, void *out,
                                      const int64_t out_strides[2]) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     const int64_t nvox = shape[0] * shape[1] * shape[2];
     HostRay h;

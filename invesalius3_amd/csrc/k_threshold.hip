@@ -103,6 +103,7 @@ extern "C" int ivx_dev_threshold_i16(const int16_t *img, int64_t dz, int64_t dy,
 extern "C" int ivx_threshold_all_slices(const int16_t *img, const int64_t shape[3], const int64_t ist[3], int lo,
                                         int hi, int preserve, int honour_flags, uint8_t *mask,
                                         const int64_t mst[3]) {
+    ivx::HostCallGuard host_guard__;
     using namespace ivx;
     const int64_t dz = shape[0], dy = shape[1], dx = shape[2];
     IVX_REQUIRE(dz >= 0 && dy >= 0 && dx >= 0, IVX_EINVAL, "threshold: negative shape");

@@ -68,6 +68,16 @@ def local_seeds(lay: SlabLayout, seeds_xyz_global):
     return out
 
 
+class DevPlane:
+    """A block of device memory handed to / received from a communicator (anything with data_ptr() and nbytes)."""
+
+    def __init__(self, ptr: int, nbytes: int, keep=None):
+        self.ptr, self.nbytes, self._keep = int(ptr), int(nbytes), keep
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+
 class TorchComm:
     """Neighbour exchange + scalar all-reduce over torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
 
@@ -76,9 +86,29 @@ class TorchComm:
 
         self.dist, self.rank, self.world, self.device, self.torch = dist, rank, world, device, torch
 
+    def _as_tensor(self, x):
+        """DevPlane (raw HBM owned by libivx) -> a CUDA uint8 tensor RCCL can send; tensors pass through."""
+        if x is None or not isinstance(x, DevPlane):
+            return x
+        from . import _lib as L
+
+        t = self.torch.empty(x.nbytes, dtype=self.torch.uint8, device="cuda")
+        L.check(L.lib().ivx_memcpy_d2d(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(x.ptr), ctypes.c_size_t(x.nbytes), None))
+        L.synchronize()
+        return t
+
+    def exchange_host(self, to_down: np.ndarray, to_up: np.ndarray):
+        """numpy planes (the one-time halo of the static input image)."""
+        torch = self.torch
+        mk = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)) if self.device != "cpu" else \
+            (lambda a: torch.from_numpy(np.ascontiguousarray(a)))
+        fd, fu = self.exchange(mk(to_down), mk(to_up))
+        return (None if fd is None else fd.cpu().numpy()), (None if fu is None else fu.cpu().numpy())
+
     def exchange(self, to_down, to_up):
         """Send `to_down` to rank-1 and `to_up` to rank+1; returns (from_down, from_up) (None at the ends)."""
         torch, dist = self.torch, self.dist
+        to_down, to_up = self._as_tensor(to_down), self._as_tensor(to_up)
         ops, from_down, from_up = [], None, None
         if self.rank > 0:
             from_down = torch.empty_like(to_down)
@@ -124,34 +154,30 @@ def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
 # ---------------------------------------------------------------------------------------------------------------
 def _make_slab_volume():
     from . import _lib as L
-    from .device import DeviceVolume, c64
+    from .device import DeviceBuffer, DeviceVolume, c64
 
     class SlabVolume(DeviceVolume):
         """This rank's Z-slab (+ halo slices) resident in HBM.  Same call surface as DeviceVolume; region growing and
         marching cubes are the sharded versions."""
 
-        def __init__(self, image_slab: np.ndarray, rank: int, world: int, dist=None, spacing=(1.0, 1.0, 1.0), comm=None):
-            import torch
-
+        def __init__(self, image_slab: np.ndarray, rank: int, world: int, dist=None, spacing=(1.0, 1.0, 1.0), comm=None,
+                     device=None):
             self.lay = slab_layout(rank, world, image_slab.shape[0])
             # `comm` may be injected (tests/test_gpu_slab.py drives several ranks on ONE GPU through an in-process
             # loop-back that has the same exchange / allreduce_sum interface as TorchComm)
             self.comm = comm if comm is not None else TorchComm(dist, rank, world, device="cuda")
-            self._torch = torch
             # one-time halo exchange of the IMAGE (static input): my first slice goes down, my last slice goes up
-            down = torch.from_numpy(np.ascontiguousarray(image_slab[0])).cuda()
-            up = torch.from_numpy(np.ascontiguousarray(image_slab[-1])).cuda()
-            from_down, from_up = self.comm.exchange(down, up)
+            from_down, from_up = self.comm.exchange_host(image_slab[0], image_slab[-1])
             parts = []
             if self.lay.hb:
-                parts.append(from_down.cpu().numpy()[None])
+                parts.append(np.asarray(from_down).reshape(image_slab.shape[1:])[None])
             parts.append(image_slab)
             if self.lay.ht:
-                parts.append(from_up.cpu().numpy()[None])
+                parts.append(np.asarray(from_up).reshape(image_slab.shape[1:])[None])
             local = np.concatenate(parts) if len(parts) > 1 else image_slab
-            super().__init__(np.ascontiguousarray(local), spacing=spacing, device=torch.cuda.current_device())
+            super().__init__(np.ascontiguousarray(local), spacing=spacing, device=device)
             self.plane_words = self.dy * self.plan.wx
-            self._send = [torch.empty(self.plane_words, dtype=torch.int64, device="cuda") for _ in range(2)]
+            self._send = [DeviceBuffer(self.plane_words * 8) for _ in range(2)]
 
         # -- backend protocol of slab_region_grow ---------------------------------------------------------------
         def flood_run(self):
@@ -161,11 +187,11 @@ def _make_slab_volume():
             self._rounds += r.value
 
         def export_plane(self, z: int):
-            t = self._send[0 if z == self.lay.first_interior else 1]
-            L.check(L.lib().ivx_memcpy_d2d(ctypes.c_void_p(t.data_ptr()), self.reached.at(z * self.plane_words * 8),
+            b = self._send[0 if z == self.lay.first_interior else 1]
+            L.check(L.lib().ivx_memcpy_d2d(b.ptr, self.reached.at(z * self.plane_words * 8),
                                            ctypes.c_size_t(self.plane_words * 8), self.stream))
-            self.sync()  # the plane must be complete before RCCL (torch's stream) reads it
-            return t
+            self.sync()  # the plane must be complete before the communicator (RCCL runs on torch's stream) reads it
+            return DevPlane(b.ptr.value, self.plane_words * 8, keep=b)
 
         def or_plane(self, z: int, tensor) -> int:
             chg = ctypes.c_int(0)

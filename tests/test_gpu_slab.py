@@ -1,7 +1,8 @@
 """GPU: the multi-GPU slab backend (invesalius3_amd.parallel.SlabVolume) with 2 and 3 ranks driven on ONE device through
 an in-process loop-back communicator (same interface as TorchComm; RCCL itself needs >= 2 GPUs).  Exercises the real HIP
 path of every sharded step -- image halo, reached-plane export / OR, convergence loop, per-rank marching-cubes piece --
-against the single-volume oracle."""
+against the single-volume oracle.  No torch here: planes are raw device buffers (DevPlane); TorchComm wraps them in
+CUDA tensors only when real RCCL traffic is needed."""
 import threading
 
 import numpy as np
@@ -28,12 +29,17 @@ class LoopbackComm:
     def __init__(self, w, rank):
         self.w, self.rank, self.world = w, rank, w.world
 
+    def exchange_host(self, to_down, to_up):
+        return self.exchange(np.array(to_down), np.array(to_up))
+
     def exchange(self, to_down, to_up):
+        # same process, same device: the peer reads the sender's plane in place (the sender does not touch it again
+        # before the second barrier)
         w = self.w
         if self.rank > 0:
-            w.box[(self.rank, "down")] = to_down.clone()
+            w.box[(self.rank, "down")] = to_down
         if self.rank < self.world - 1:
-            w.box[(self.rank, "up")] = to_up.clone()
+            w.box[(self.rank, "up")] = to_up
         w.barrier.wait()
         from_down = w.box[(self.rank - 1, "up")] if self.rank > 0 else None
         from_up = w.box[(self.rank + 1, "down")] if self.rank < self.world - 1 else None
@@ -51,8 +57,6 @@ class LoopbackComm:
 
 @pytest.mark.parametrize("world,conn", [(2, 3), (3, 1)])
 def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
-    import torch  # SlabVolume stages its planes in torch CUDA tensors (RCCL buffers)
-
     from invesalius3_amd.parallel import SlabVolume
 
     nz = 24
@@ -96,4 +100,3 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
     cat = np.concatenate([res[r]["tris"] for r in range(world)])
     key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
     assert len(cat) == len(whole) and np.array_equal(key(cat), key(whole))
-    del torch
