@@ -20,7 +20,18 @@ void set_error(const char *fmt, ...);
         }                                                                                  \
     } while (0)
 
-#define IVX_LAUNCH_CHECK() IVX_HIP(hipGetLastError())
+// IVX_TRACE=1: synchronise after every kernel launch and log its source line (localises asynchronous GPU faults)
+bool trace_enabled();
+#define IVX_LAUNCH_CHECK()                                                                 \
+    do {                                                                                   \
+        IVX_HIP(hipGetLastError());                                                        \
+        if (ivx::trace_enabled()) {                                                        \
+            fprintf(stderr, "ivx trace: launched %s:%d ...", __FILE__, __LINE__);          \
+            fflush(stderr);                                                                \
+            IVX_HIP(hipDeviceSynchronize());                                               \
+            fprintf(stderr, " ok\n");                                                      \
+        }                                                                                  \
+    } while (0)
 
 #define IVX_REQUIRE(cond, code, ...)                                                       \
     do {                                                                                   \

@@ -1,7 +1,10 @@
 // ivx_runtime.hip -- runtime plumbing of libivx.so: errors, device memory, streams, events,
 // cached workspaces and the strided host<->dense device staging used by the host-level entry points.
+#include <execinfo.h>
+#include <signal.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #include <map>
 #include <mutex>
@@ -17,6 +20,11 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+bool trace_enabled() {
+    static const bool on = getenv("IVX_TRACE") != nullptr;
+    return on;
 }
 
 struct Slot {
@@ -63,7 +71,15 @@ int ws_get_s(int slot, hipStream_t stream, size_t nbytes, void **dptr) {
 }
 
 static std::recursive_mutex g_host_mu;
-HostCallGuard::HostCallGuard() { g_host_mu.lock(); }
+static void ivx_bt_handler(int sig);
+HostCallGuard::HostCallGuard() {
+    g_host_mu.lock();
+    static const bool bt = getenv("IVX_BACKTRACE") != nullptr;
+    if (bt) { // re-arm on every host call: test runners install their own handlers after the library is loaded
+        signal(SIGABRT, ivx_bt_handler);
+        signal(SIGSEGV, ivx_bt_handler);
+    }
+}
 HostCallGuard::~HostCallGuard() { g_host_mu.unlock(); }
 
 int hs_get(int slot, size_t nbytes, void **hptr) {
@@ -200,6 +216,23 @@ int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords) {
 } // namespace ivx
 
 using namespace ivx;
+
+// IVX_BACKTRACE=1: print a native backtrace on SIGABRT / SIGSEGV (diagnostic aid; off by default)
+static void ivx::ivx_bt_handler(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "ivx: fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+__attribute__((constructor)) static void ivx_install_bt() {
+    if (getenv("IVX_BACKTRACE")) {
+        signal(SIGABRT, ivx_bt_handler);
+        signal(SIGSEGV, ivx_bt_handler);
+    }
+}
 
 extern "C" {
 

@@ -189,12 +189,13 @@ __device__ __forceinline__ void padded_pair(const uint64_t *__restrict__ S, cons
                                             int64_t w, uint64_t pbits, uint64_t &lo, uint64_t &hi) {
     const int64_t ja = (g.NY - 1 - jf) - g.pxy, ka = k - g.pb;
     const bool row_in = ja >= 0 && ja < g.ny && ka >= 0 && ka < g.nz;
-    const int64_t rj = ja < 0 ? 0 : (ja >= g.ny ? g.ny - 1 : ja), rk = ka < 0 ? 0 : (ka >= g.nz ? g.nz - 1 : ka);
+    // clamp into [0, n-1], and to 0 when the piece is EMPTY along that axis (n == 0: every row is padding, the loads
+    // then hit word 0 of the scratch block, which always exists, and are masked away)
+    const auto clampi = [](int64_t v, int64_t n) { return v >= n ? (n > 0 ? n - 1 : 0) : (v < 0 ? 0 : v); };
+    const int64_t rj = clampi(ja, g.ny), rk = clampi(ka, g.nz);
     const uint64_t *row = S + (rk * g.ny + rj) * g.ws;
     // source words w-1, w, w+1 (clamped index, masked when outside [0, ws) or when the row is padding)
-    const int64_t wm = w - 1 < 0 ? 0 : (w - 1 >= g.ws ? g.ws - 1 : w - 1);
-    const int64_t wc = w >= g.ws ? g.ws - 1 : w;
-    const int64_t wp = w + 1 >= g.ws ? g.ws - 1 : w + 1;
+    const int64_t wm = clampi(w - 1, g.ws), wc = clampi(w, g.ws), wp = clampi(w + 1, g.ws);
     uint64_t sm = row[wm], sc = row[wc], sp = row[wp];
     sm = (row_in && w - 1 >= 0 && w - 1 < g.ws) ? sm : 0ull;
     sc = (row_in && w < g.ws) ? sc : 0ull;

@@ -86,3 +86,18 @@ def test_full_size_properties_512(ivxlib):
     assert len(pieces) == len(whole)
     key = lambda a: np.sort(a.reshape(len(a), -1).view([("", np.float32)] * 9), axis=0)
     assert np.array_equal(key(pieces), key(whole))
+
+
+def test_empty_pieces_after_large_allocations(ivxlib, oracle):
+    """regression: a piece that is empty along an axis is ALL padding; the branch-free corner loads must not touch
+    memory outside the scratch block (this faulted the GPU when earlier calls had left larger workspaces behind)"""
+    from invesalius3_amd import surface_process as sp
+    big = np.zeros((40, 64, 64), np.int16)
+    big[10:30, 10:50, 10:50] = 1000
+    assert len(sp.marching_cubes(big, (1, 1, 1), [500.0, 900.0], pad_value=-32768.0)) > 0
+    for shape in ((0, 6, 7), (5, 0, 7), (5, 6, 0), (0, 0, 0), (1, 1, 1)):
+        for pads in ((True, True, True), (False, False, False), (True, False, True)):
+            a = np.zeros(shape, np.uint8)
+            g = sp.marching_cubes(a, (1, 1, 1), [127.0], 0, *pads, 255.0 if shape == (1, 1, 1) else 0.0)
+            r = oracle.marching_cubes(a, (1, 1, 1), [127.0], 0, *pads, 255.0 if shape == (1, 1, 1) else 0.0)
+            assert g.shape == r.shape and np.array_equal(g, r)
