@@ -267,6 +267,23 @@ int ivx_dev_or_equal_u8(uint8_t *dst, const uint8_t *src, int64_t n, int value, 
 /* dst[v] = fill where src[v] == value  (mask[out_mask.astype(bool)] = 254, styles.py:3214,3249) */
 int ivx_dev_flood_apply_where(uint8_t *dst, const uint8_t *src, int64_t n, int value, int fill, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * resample a slab through the 4x4 view matrix (re-oriented volumes, the step in front of the projections)
+ *   replaces apply_view_matrix_transform  invesalius_rs/src/transforms_py.rs:12-49,95-147
+ *            coord_transform               invesalius_rs/src/transforms.rs:9-55
+ *            nearest / trilinear / tricubic / Lanczos-4 with single wrap-around  invesalius_rs/src/interpolation.rs
+ * m is row-major; orientation 0/1/2 = AXIAL/CORONAL/SAGITAL adds n to z/y/x of the output index; minterpol
+ * 0 nearest, 1 trilinear, 2 tricubic, else Lanczos; out has the volume's dtype.  A NumCast failure -> IVX_EDOM.
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_apply_view_matrix_transform(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx,
+                                        const double spacing[3], const double m[16], int64_t n, int orientation,
+                                        int minterpol, double cval, void *out, int64_t oz, int64_t oy, int64_t ox,
+                                        int *status, void *stream);
+int ivx_apply_view_matrix_transform(int dtype, const void *vol, const int64_t shape[3], const int64_t strides[3],
+                                    const double spacing[3], const double m[16], int64_t n, int orientation,
+                                    int minterpol, double cval, void *out, const int64_t oshape[3],
+                                    const int64_t ostrides[3]);
+
 #ifdef __cplusplus
 }
 #endif

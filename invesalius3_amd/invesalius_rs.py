@@ -139,3 +139,26 @@ def fill_holes_automatically(mask: np.ndarray, labels: np.ndarray, nlabels: int,
         ctypes.c_uint32(int(nlabels)), ctypes.c_uint32(int(max_size)), ctypes.byref(modified)),
         "fill_holes_automatically")
     return bool(modified.value)
+
+
+_ORIENTATION = {"AXIAL": 0, "CORONAL": 1, "SAGITAL": 2}
+
+
+def apply_view_matrix_transform(volume, spacing, m, n, orientation, minterpol, cval, out):
+    """apply_view_matrix_transform (invesalius_rs/src/transforms_py.rs:95-147 -> transforms.rs:9-55): resample `volume`
+    through the 4x4 matrix `m` into `out` (same dtype: int16 / uint8 / float64).  `m` must be a C-contiguous float64
+    4x4 (the reference calls ``m.as_slice().unwrap()``); `cval` must fit the dtype (``cval.extract::<T>()``)."""
+    if volume.ndim != 3 or out.ndim != 3 or volume.dtype != out.dtype:
+        raise TypeError("Invalid volume or output type")
+    code = L.dtype_code(volume, (L.U8, L.I16, L.F64))
+    mm = np.asarray(m)
+    if mm.dtype != np.float64 or mm.shape != (4, 4) or not mm.flags["C_CONTIGUOUS"]:
+        raise TypeError("m must be a C-contiguous float64 4x4 matrix")
+    sp = np.ascontiguousarray(spacing, dtype=np.float64)
+    if sp.shape != (3,):
+        raise TypeError("spacing must have 3 entries")
+    cval = _fits(cval, volume.dtype, "cval")
+    L.check(L.lib().ivx_apply_view_matrix_transform(
+        code, L.ptr(volume), L.i64(volume.shape), L.i64(volume.strides), L.ptr(sp), L.ptr(mm), ctypes.c_int64(int(n)),
+        _ORIENTATION.get(orientation, -1), int(minterpol), ctypes.c_double(cval), L.ptr(out), L.i64(out.shape),
+        L.i64(out.strides)), "apply_view_matrix_transform")

@@ -488,3 +488,110 @@ int64_t orc_marching_cubes(int dt, const void *a, const int64_t shape[3], const 
     }
     return nt;
 }
+
+/* ------------------------------------------------------------------------
+ * apply_view_matrix_transform           invesalius_rs/src/transforms_py.rs:12-49
+ *   coord_transform                      invesalius_rs/src/transforms.rs:9-55
+ *   get_value / trilinear / tricubic / lanczos   invesalius_rs/src/interpolation.rs:6-188
+ * All arithmetic in double, in the reference's evaluation order (build with
+ * -ffp-contract=off).  The 4x4 matrix is row-major; nalgebra's gemv accumulates
+ * column by column, i.e. ((m0*c0 + m1*c1) + m2*c2) + m3*c3 per component.
+ * orientation: 0 AXIAL (z = n + cz), 1 CORONAL (y = n + cy), 2 SAGITAL (x = n + cx),
+ * anything else: no offset.  A NumCast failure (tricubic / Lanczos overshoot
+ * outside T) returns ORC_EDOM (the reference panics).
+ * ---------------------------------------------------------------------- */
+typedef struct { int dt; const char *v; int64_t dz, dy, dx; const int64_t *s; } tvol_t;
+static inline double tv_get(const tvol_t *t, int64_t x, int64_t y, int64_t z) { /* interpolation.rs:6-35 */
+    if (x < 0) x += t->dx; else if (x >= t->dx) x -= t->dx;
+    if (y < 0) y += t->dy; else if (y >= t->dy) y -= t->dy;
+    if (z < 0) z += t->dz; else if (z >= t->dz) z -= t->dz;
+    return ld(t->dt, AT(t->v, t->s, z, y, x));
+}
+static int numcast_f64(int dt, double v, double *out) { /* NumCast::from(f64) -> T, then back to double */
+    if (dt == DT_F64) { *out = v; return 0; }
+    if (v != v) return -1;
+    if (dt == DT_I16) { if (!(v > -32769.0 && v < 32768.0)) return -1; *out = (double)(int16_t)v; return 0; }
+    if (dt == DT_U8) { if (!(v > -1.0 && v < 256.0)) return -1; *out = (double)(uint8_t)v; return 0; }
+    return -1;
+}
+static double cubic1(const double p[4], double x) { /* interpolation.rs:37-43 */
+    return p[1] + 0.5 * x * (p[2] - p[0] + x * (2.0 * p[0] - 5.0 * p[1] + 4.0 * p[2] - p[3] + x * (3.0 * (p[1] - p[2]) + p[3] - p[0])));
+}
+static double bicubic(double p[4][4], double x, double y) {
+    double a[4];
+    for (int i = 0; i < 4; i++) a[i] = cubic1(p[i], y);
+    return cubic1(a, x);
+}
+static double lanczos_k(double x, int a) { /* interpolation.rs:55-64 */
+    const double PI = 3.14159265358979323846264338327950288;
+    if (x == 0.0) return 1.0;
+    if (-(double)a <= x && x < (double)a) {
+        const double af = (double)a;
+        return (af * sin(PI * x) * sin(PI * (x / af))) / (PI * PI * x * x);
+    }
+    return 0.0;
+}
+static double tv_trilinear(const tvol_t *t, double x, double y, double z) {
+    const int64_t x0 = (int64_t)floor(x), x1 = x0 + 1, y0 = (int64_t)floor(y), y1 = y0 + 1, z0 = (int64_t)floor(z), z1 = z0 + 1;
+    const double xd = x - (double)x0, yd = y - (double)y0, zd = z - (double)z0;
+    const double v000 = tv_get(t, x0, y0, z0), v100 = tv_get(t, x1, y0, z0), v010 = tv_get(t, x0, y1, z0), v001 = tv_get(t, x0, y0, z1);
+    const double v110 = tv_get(t, x1, y1, z0), v101 = tv_get(t, x1, y0, z1), v011 = tv_get(t, x0, y1, z1), v111 = tv_get(t, x1, y1, z1);
+    const double c00 = v000 * (1.0 - xd) + v100 * xd, c10 = v010 * (1.0 - xd) + v110 * xd;
+    const double c01 = v001 * (1.0 - xd) + v101 * xd, c11 = v011 * (1.0 - xd) + v111 * xd;
+    const double c0 = c00 * (1.0 - yd) + c10 * yd, c1 = c01 * (1.0 - yd) + c11 * yd;
+    return c0 * (1.0 - zd) + c1 * zd;
+}
+static double tv_tricubic(const tvol_t *t, double x, double y, double z) {
+    const int64_t xi = (int64_t)floor(x), yi = (int64_t)floor(y), zi = (int64_t)floor(z);
+    double p[4][4][4], r[4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++)
+        p[i][j][k] = tv_get(t, xi + i - 1, yi + j - 1, zi + k - 1);
+    for (int i = 0; i < 4; i++) r[i] = bicubic(p[i], y - (double)yi, z - (double)zi);
+    return cubic1(r, x - (double)xi);
+}
+static double tv_lanczos(const tvol_t *t, double x, double y, double z) {
+    const int a = 4;
+    const int64_t xd = (int64_t)floor(x), yd = (int64_t)floor(y), zd = (int64_t)floor(z);
+    const int64_t xi = xd - a + 1, xf = xd + a, yi = yd - a + 1, yf = yd + a, zi = zd - a + 1, zf = zd + a;
+    double tx[7][7], ty[7], lz = 0.0;
+    for (int64_t kk = zi; kk < zf; kk++) for (int64_t jj = yi; jj < yf; jj++) {
+        double lx = 0.0;
+        for (int64_t ii = xi; ii < xf; ii++) lx += tv_get(t, ii, jj, kk) * lanczos_k(x - (double)ii, a);
+        tx[kk - zi][jj - yi] = lx;
+    }
+    for (int m = 0; m < 7; m++) {
+        double ly = 0.0;
+        for (int64_t jj = yi; jj < yf; jj++) ly += tx[m][jj - yi] * lanczos_k(y - (double)jj, a);
+        ty[m] = ly;
+    }
+    for (int64_t kk = zi; kk < zf; kk++) lz += ty[kk - zi] * lanczos_k(z - (double)kk, a);
+    return lz;
+}
+int orc_apply_view_matrix_transform(int dt, const void *vol, const int64_t shape[3], const int64_t s[3], const double spacing[3],
+                                    const double m[16], int64_t n, int orientation, int minterpol, double cval, void *out_,
+                                    const int64_t oshape[3], const int64_t os[3]) {
+    tvol_t t = {dt, (const char *)vol, shape[0], shape[1], shape[2], s};
+    const double sx = spacing[0], sy = spacing[1], sz = spacing[2];
+    const double dz = (double)shape[0], dy = (double)shape[1], dx = (double)shape[2];
+    char *out = (char *)out_;
+    int rc = ORC_OK;
+    for (int64_t cz = 0; cz < oshape[0]; cz++) for (int64_t cy = 0; cy < oshape[1]; cy++) for (int64_t cx = 0; cx < oshape[2]; cx++) {
+        int64_t z = cz, y = cy, x = cx;
+        if (orientation == 0) z = n + cz; else if (orientation == 1) y = n + cy; else if (orientation == 2) x = n + cx;
+        const double c0 = (double)z * sz, c1 = (double)y * sy, c2 = (double)x * sx, c3 = 1.0;
+        double nc[4];
+        for (int r = 0; r < 4; r++) nc[r] = ((m[4 * r] * c0 + m[4 * r + 1] * c1) + m[4 * r + 2] * c2) + m[4 * r + 3] * c3;
+        const double nz = (nc[0] / nc[3]) / sz, ny = (nc[1] / nc[3]) / sy, nx = (nc[2] / nc[3]) / sx;
+        double v = cval;
+        if (nz >= 0.0 && nz < dz - 1.0 && ny >= 0.0 && ny < dy - 1.0 && nx >= 0.0 && nx < dx - 1.0) {
+            if (minterpol == 0) v = ld(dt, AT(t.v, s, (int64_t)nz, (int64_t)ny, (int64_t)nx));
+            else {
+                const double f = minterpol == 1 ? tv_trilinear(&t, nx, ny, nz) : minterpol == 2 ? tv_tricubic(&t, nx, ny, nz) : tv_lanczos(&t, nx, ny, nz);
+                if (numcast_f64(dt, f, &v)) { rc = ORC_EDOM; v = cval; }
+                else if (minterpol != 1 && v < cval) v = cval;
+            }
+        }
+        st(dt, out + cz * os[0] + cy * os[1] + cx * os[2], v);
+    }
+    return rc;
+}

@@ -336,3 +336,21 @@ def watershed_merge(mask, tmp_mask, overwrite):
         sel = (mask == 0) | (mask == 2) | (mask == 253)
         mask[(tmp_mask == 2) & sel] = 2
         mask[(tmp_mask == 1) & sel] = 253
+
+
+# ----------------------------------------------------------------------------------------------
+# apply_view_matrix_transform               invesalius_rs/src/transforms_py.rs:12-147
+# ----------------------------------------------------------------------------------------------
+ORIENTATION = {"AXIAL": 0, "CORONAL": 1, "SAGITAL": 2}
+
+
+def apply_view_matrix_transform(volume, spacing, m, n, orientation, minterpol, cval, out):
+    """coord_transform over `out` (transforms.rs:9-55): nearest / trilinear / tricubic / Lanczos-4 resampling of
+    `volume` through the 4x4 matrix `m` (row-major, C-contiguous float64)."""
+    assert volume.dtype == out.dtype and volume.ndim == 3 and out.ndim == 3
+    mm = np.ascontiguousarray(m, dtype=np.float64).reshape(16)
+    sp = np.ascontiguousarray(spacing, dtype=np.float64)
+    _check(lib().orc_apply_view_matrix_transform(
+        DT[volume.dtype], _p(volume), _i64(volume.shape), _i64(volume.strides), _p(sp), _p(mm), ctypes.c_int64(int(n)),
+        ORIENTATION.get(orientation, -1), int(minterpol), ctypes.c_double(float(cval)), _p(out), _i64(out.shape),
+        _i64(out.strides)))

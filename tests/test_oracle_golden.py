@@ -171,3 +171,32 @@ def test_marching_cubes_pieces_concatenate(oracle):
     key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
     assert len(cat) == len(whole)
     assert np.array_equal(key(cat), key(whole))
+
+
+# ---- apply_view_matrix_transform: no reference test exists; cross-check the restatement against scipy ---------------
+def test_view_transform_trilinear_matches_scipy_map_coordinates(oracle):
+    """independent check of the oracle (transforms.rs / interpolation.rs restatement): for sample points strictly inside
+    the volume, trilinear resampling == scipy.ndimage.map_coordinates(order=1) up to float rounding"""
+    rng = np.random.default_rng(21)
+    vol = rng.normal(0, 100, (14, 16, 18))
+    th = 0.4
+    R = np.eye(4)
+    R[1:3, 1:3] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    c = np.array([7.0, 8.0, 9.0])
+    T0, T1 = np.eye(4), np.eye(4)
+    T0[:3, 3], T1[:3, 3] = -c, c
+    M = np.ascontiguousarray(T1 @ R @ T0)
+    out = np.zeros((4, 16, 18))
+    oracle.apply_view_matrix_transform(vol, (1.0, 1.0, 1.0), M, 5, "AXIAL", 1, -1e9, out)
+    zz, yy, xx = np.meshgrid(np.arange(5, 9), np.arange(16), np.arange(18), indexing="ij")
+    pts = np.stack([zz, yy, xx, np.ones_like(zz)]).reshape(4, -1).astype(float)
+    q = M @ pts
+    ref = ndimage.map_coordinates(vol, q[:3], order=1, mode="nearest").reshape(out.shape)
+    inside = (out != -1e9)
+    assert inside.mean() > 0.5
+    np.testing.assert_allclose(out[inside], ref[inside], rtol=0, atol=1e-9)
+    # nearest = truncation of the transformed coordinate
+    outn = np.zeros((4, 16, 18))
+    oracle.apply_view_matrix_transform(vol, (1.0, 1.0, 1.0), M, 5, "AXIAL", 0, -1e9, outn)
+    qi = q[:3].astype(int).reshape(3, *out.shape)
+    assert np.array_equal(outn[inside], vol[qi[0][inside], qi[1][inside], qi[2][inside]])
