@@ -164,6 +164,22 @@ int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t stri
                        int64_t max_tris, int64_t *ntris);
 
 /* ------------------------------------------------------------------------------------------------
+ * indexed surface ("point merge"): unique vertices + int32 faces instead of a soup
+ *   replaces vtkAppendPolyData + vtkCleanPolyData of join_process_surface
+ *            invesalius/data/surface_process.py:229-268
+ * A vertex is a grid edge that crosses the iso-surface, so ids come from popcount scans of the crossing bit planes
+ * (no hashing, no sorting); verts[faces] is bit-identical to the soup of ivx_dev_mc_emit, in the same triangle
+ * order.  Edges that cross exactly AT a grid point (the sample equals the iso-value) share that point's one vertex,
+ * so coincident positions are merged exactly as an exact-arithmetic point merge would; faces that thereby collapse
+ * (two equal ids) are kept, so the triangle count and order stay those of the soup.  Protocol: ivx_dev_mc_count -> ivx_dev_mc_indexed_count -> ivx_dev_mc_indexed_emit (same params/scratch).
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, const void *scratch, int64_t *nverts, void *stream);
+int ivx_dev_mc_indexed_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *verts, int64_t max_verts,
+                            int32_t *faces, int64_t max_tris, void *stream);
+int ivx_marching_cubes_indexed(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *verts,
+                               int64_t max_verts, int32_t *faces, int64_t max_tris, int64_t *nverts, int64_t *ntris);
+
+/* ------------------------------------------------------------------------------------------------
  * seeded region growing
  *   replaces generic_floodfill_threshold          invesalius_rs/src/floodfill.rs:96-166
  *            generic_floodfill_threshold_inplace  invesalius_rs/src/floodfill.rs:168-237

@@ -22,6 +22,7 @@
 //                    output line once.
 // Output order == the oracle's (iso-major, then k, j, i raster order of cells), so parity is an array compare.
 // Vertex arithmetic is done in double and rounded once to float32, exactly like the oracle.
+#include <cmath>
 #include <map>
 #include <mutex>
 
@@ -443,27 +444,27 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
 }
 
 static std::map<const void *, uint64_t> g_split; // scratch -> number of iso-0 triangles (two-iso pieces)
+static std::map<const void *, uint32_t> g_vsplit; // scratch -> number of iso-0 vertices (indexed mesh)
 static std::mutex g_split_mu;
 
 static inline uint64_t pad_bits(const ivx_mc_params *p, int q) { return p->pad_value >= p->iso[q] ? ~0ull : 0ull; }
 
 template <typename T>
-static int run_bits(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, char *scratch,
-                    hipStream_t st) {
+static int run_bits(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, uint8_t *b0, double iso0,
+                    double iso1, hipStream_t st) {
     constexpr int V = 16 / sizeof(T);
     const int64_t nrows_src = g.nz * g.ny;
     const int64_t total = nrows_src * (g.ws * 64 / V);
     if (total == 0) return IVX_OK;
     const int64_t blocks = ivx::cdiv(total, 256 * 4);
     const int grid = (int)(blocks < 1 ? 1 : (blocks < 16384 ? blocks : 16384));
-    uint8_t *b0 = (uint8_t *)(scratch + s.off_bits);
     uint8_t *b1 = b0 + s.bits_words * 8;
     if (p->niso == 2)
         hipLaunchKernelGGL((k_mc_bits<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)a, nrows_src, g.nx, g.ws,
-                           p->iso[0], p->iso[1], b0, b1);
+                           iso0, iso1, b0, b1);
     else
         hipLaunchKernelGGL((k_mc_bits<T, 1>), dim3(grid), dim3(256), 0, st, (const T *)a, nrows_src, g.nx, g.ws,
-                           p->iso[0], 0.0, b0, b0);
+                           iso0, 0.0, b0, b0);
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
@@ -505,6 +506,258 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     return IVX_OK;
 }
 
+// =====================================================================================================================
+// Indexed mesh ("point merge" of join_process_surface, invesalius/data/surface_process.py:229-268: the reference appends
+// the pieces and runs vtkCleanPolyData to merge coincident points).  Here the merge needs no hashing or sorting: a
+// vertex IS a grid edge whose end points differ in the inside-bit plane, so
+//   crossing planes   cx = P ^ (P >> 1 | carry), cy = P(j) ^ P(j+1), cz = P(k) ^ P(k+1)   (P = padded point words)
+//   vertex id         = (scan of popcounts over point words in raster order) + rank of the edge inside its word
+//                       (x edges first, then y, then z)
+//   k_mci_vertices    one interpolation per UNIQUE vertex (3.2 M instead of 19 M for the bench surface)
+//   k_mci_faces       one lane per triangle of the flat list: three edge -> id look-ups (bit planes + popcounts)
+// verts[faces] reproduces the soup of ivx_dev_mc_emit bit for bit.
+// =====================================================================================================================
+struct Cross {
+    uint64_t cx, cy, cz; // regular crossings: bit b = the edge leaving point (64w+b, jf, k) in +x / +y / +z
+    uint64_t cp;         // point vertices (only with POINTS): the point's value IS the iso-value and a neighbour is outside
+    uint64_t e0, ex, ey, ez; // "value == iso" at the point itself and at its +x / +y / +z neighbour
+};
+// S = inside plane (value >= iso), Q = strictly-inside plane (value > iso); E = S & ~Q marks points sitting exactly
+// on the iso-value.  A crossing edge with such an end point puts its vertex ON that grid point (t is exactly 0 or 1),
+// and every such edge around the point yields the same position: those become ONE "point vertex", owned by the point.
+template <bool POINTS>
+__device__ __forceinline__ Cross crossings(const uint64_t *__restrict__ S, const uint64_t *__restrict__ Q, const Geom &g,
+                                           int64_t k, int64_t jf, int64_t w, uint64_t pbits, uint64_t qbits) {
+    uint64_t p0, p0n, py, pyn, pz, pzn, q0, q0n, qy, qyn, qz, qzn;
+    padded_pair(S, g, k, jf, w, pbits, p0, p0n);
+    padded_pair(S, g, k, jf + 1, w, pbits, py, pyn);
+    padded_pair(S, g, k + 1, jf, w, pbits, pz, pzn);
+    padded_pair(Q, g, k, jf, w, qbits, q0, q0n);
+    padded_pair(Q, g, k, jf + 1, w, qbits, qy, qyn);
+    padded_pair(Q, g, k + 1, jf, w, qbits, qz, qzn);
+    const int64_t rem = g.NX - w * 64;                 // points of this word
+    const uint64_t pts = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    const int64_t remx = g.NX - 1 - w * 64;            // x edges of this word (last point has none)
+    const uint64_t xed = remx >= 64 ? ~0ull : (remx <= 0 ? 0ull : ((1ull << remx) - 1ull));
+    const bool hasy = jf + 1 < g.NY, hasz = k + 1 < g.NZ;
+    Cross c;
+    c.e0 = p0 & ~q0 & pts;
+    c.ex = (((p0 & ~q0) >> 1) | ((p0n & ~q0n) << 63)) & xed;
+    c.ey = hasy ? (py & ~qy & pts) : 0ull;
+    c.ez = hasz ? (pz & ~qz & pts) : 0ull;
+    const uint64_t rx = (p0 ^ ((p0 >> 1) | (p0n << 63))) & xed;
+    const uint64_t ry = hasy ? ((p0 ^ py) & pts) : 0ull;
+    const uint64_t rz = hasz ? ((p0 ^ pz) & pts) : 0ull;
+    c.cx = rx & ~(c.e0 | c.ex);
+    c.cy = ry & ~(c.e0 | c.ey);
+    c.cz = rz & ~(c.e0 | c.ez);
+    c.cp = 0ull;
+    if (POINTS && c.e0) {
+        uint64_t prev = 0ull, t0, t1, rxm, rym = 0ull, rzm = 0ull;
+        if (w > 0) {
+            padded_pair(S, g, k, jf, w - 1, pbits, t0, t1);
+            prev = t0 >> 63;
+        }
+        rxm = (p0 ^ ((p0 << 1) | prev)) & (w > 0 ? ~0ull : ~1ull);
+        if (jf > 0) {
+            padded_pair(S, g, k, jf - 1, w, pbits, t0, t1);
+            rym = p0 ^ t0;
+        }
+        if (k > 0) {
+            padded_pair(S, g, k - 1, jf, w, pbits, t0, t1);
+            rzm = p0 ^ t0;
+        }
+        c.cp = c.e0 & (rx | ry | rz | rxm | rym | rzm);
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_mci_count(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb,
+                                                   Geom g, int64_t npw, uint64_t pbits, uint64_t qbits,
+                                                   uint32_t *__restrict__ vcnt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npw; i += stride) {
+        const int64_t w = i % g.WX, r = i / g.WX, jf = r % g.NY, k = r / g.NY;
+        const Cross c = crossings<true>(bits, qb, g, k, jf, w, pbits, qbits);
+        vcnt[i] = (uint32_t)(__popcll(c.cx) + __popcll(c.cy) + __popcll(c.cz) + __popcll(c.cp));
+    }
+}
+
+// exclusive scan of u32 in place (three passes, 4096 elements per workgroup) -- same scheme as k_ccl.hip
+constexpr int MSCAN = 16;
+__global__ __launch_bounds__(256) void k_mscan_block(uint32_t *__restrict__ data, int64_t n, uint32_t *__restrict__ bsum) {
+    __shared__ uint32_t s_wave[4];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * MSCAN;
+    uint32_t v[MSCAN], sum = 0;
+#pragma unroll
+    for (int q = 0; q < MSCAN; q++) {
+        v[q] = base + q < n ? data[base + q] : 0u;
+        sum += v[q];
+    }
+    uint32_t inc = sum;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t off = inc - sum;
+    for (int q = 0; q < wv; q++) off += s_wave[q];
+#pragma unroll
+    for (int q = 0; q < MSCAN; q++) {
+        if (base + q < n) data[base + q] = off;
+        off += v[q];
+    }
+    if (threadIdx.x == 255) bsum[blockIdx.x] = off;
+}
+__global__ __launch_bounds__(1024) void k_mscan_sums(uint32_t *__restrict__ bsum, int64_t nb, uint32_t *__restrict__ total) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+        const int64_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? bsum[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        uint32_t wb = 0;
+        for (int q = 0; q < wv; q++) wb += s_wave[q];
+        const uint32_t carry = s_carry;
+        if (i < nb) bsum[i] = carry + wb + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wb + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(256) void k_mscan_add(uint32_t *__restrict__ data, int64_t n, const uint32_t *__restrict__ bsum) {
+    const uint32_t add = bsum[blockIdx.x];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * MSCAN;
+#pragma unroll
+    for (int q = 0; q < MSCAN; q++)
+        if (base + q < n) data[base + q] += add;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mci_vertices(const T *__restrict__ a, const uint64_t *__restrict__ bits,
+                                                      const uint64_t *__restrict__ qb, Geom g, int64_t npw, uint64_t pbits,
+                                                      uint64_t qbits, double iso, const uint32_t *__restrict__ vbase,
+                                                      uint32_t id0, float *__restrict__ verts, uint64_t max_verts) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t pw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pw < npw; pw += stride) {
+        const int64_t w = pw % g.WX, r = pw / g.WX, jf = r % g.NY, k = r / g.NY;
+        const Cross c = crossings<true>(bits, qb, g, k, jf, w, pbits, qbits);
+        if (!(c.cx | c.cy | c.cz | c.cp)) continue;
+        uint64_t id = (uint64_t)id0 + vbase[pw];
+#pragma unroll
+        for (int ax = 0; ax < 4; ax++) {
+            uint64_t m = ax == 0 ? c.cx : (ax == 1 ? c.cy : (ax == 2 ? c.cz : c.cp));
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int64_t i = w * 64 + b;
+                double p0 = (double)(i - g.pxy), p1 = (double)(jf - g.yoff), p2 = (double)(k + g.zoff);
+                if (ax < 3) {
+                    const double s0 = mc_at(a, g, k, jf, i);
+                    const double s1 = mc_at(a, g, k + (ax == 2), jf + (ax == 1), i + (ax == 0));
+                    const double tt = (iso - s0) / (s1 - s0);
+                    if (ax == 0) p0 += tt;
+                    else if (ax == 1) p1 += tt;
+                    else p2 += tt;
+                }
+                if (id < max_verts) {
+                    float *o = verts + id * 3;
+                    o[0] = (float)(g.sx * p0);
+                    o[1] = (float)(g.sy * p1);
+                    o[2] = (float)(g.sz * p2);
+                }
+                id++;
+            }
+        }
+    }
+}
+
+// id of the vertex on the edge leaving point (i, jf, k) along axis ax
+__device__ __forceinline__ uint32_t vertex_id(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb,
+                                              const Geom &g, uint64_t pbits, uint64_t qbits,
+                                              const uint32_t *__restrict__ vbase, int64_t k, int64_t jf, int64_t i, int ax) {
+    int64_t w = i >> 6;
+    int b = (int)(i & 63);
+    const Cross c = crossings<false>(bits, qb, g, k, jf, w, pbits, qbits);
+    const bool elo = (c.e0 >> b) & 1ull;
+    const bool ehi = ((ax == 0 ? c.ex : (ax == 1 ? c.ey : c.ez)) >> b) & 1ull;
+    if (!(elo | ehi)) {
+        const uint64_t below = (1ull << b) - 1ull;
+        uint32_t rank;
+        if (ax == 0) rank = (uint32_t)__popcll(c.cx & below);
+        else if (ax == 1) rank = (uint32_t)(__popcll(c.cx) + __popcll(c.cy & below));
+        else rank = (uint32_t)(__popcll(c.cx) + __popcll(c.cy) + __popcll(c.cz & below));
+        return vbase[(k * g.NY + jf) * g.WX + w] + rank;
+    }
+    // the vertex sits on a grid point: it is that point's vertex
+    if (!elo) {
+        if (ax == 0) i++;
+        else if (ax == 1) jf++;
+        else k++;
+        w = i >> 6;
+        b = (int)(i & 63);
+    }
+    const Cross t = crossings<true>(bits, qb, g, k, jf, w, pbits, qbits);
+    const uint32_t rank = (uint32_t)(__popcll(t.cx) + __popcll(t.cy) + __popcll(t.cz) + __popcll(t.cp & ((1ull << b) - 1ull)));
+    return vbase[(k * g.NY + jf) * g.WX + w] + rank;
+}
+
+__global__ __launch_bounds__(256) void k_mci_faces(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb,
+                                                   Geom g, uint64_t pbits, uint64_t qbits,
+                                                   const uint32_t *__restrict__ vbase, uint32_t id0,
+                                                   const uint64_t *__restrict__ list, uint64_t ntris,
+                                                   int32_t *__restrict__ faces) {
+    __shared__ uint8_t s_tri[256 * 16];
+#pragma unroll
+    for (int q = 0; q < 15; q++) s_tri[threadIdx.x * 16 + q] = MC_TRI[threadIdx.x][q];
+    __syncthreads();
+    const uint64_t T_ = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (T_ >= ntris) return;
+    const uint64_t d = list[T_];
+    const uint64_t wid = d >> 17;
+    const int b = (int)(d >> 11) & 63, idx = (int)(d >> 3) & 255, rel = (int)d & 7;
+    const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
+    const int64_t k = row / (uint32_t)(g.NY - 1), j = row - (uint32_t)k * (uint32_t)(g.NY - 1);
+    const int64_t i = (int64_t)w * 64 + b;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        const int e = s_tri[idx * 16 + 3 * rel + v];
+        int ax, bx, by, bz;
+        edge_decode(e, ax, bx, by, bz);
+        faces[T_ * 3 + v] = (int32_t)(id0 + vertex_id(bits, qb, g, pbits, qbits, vbase, k + bz, j + by, i + bx, ax));
+    }
+}
+
+// per-stream workspace WS_MCV: strict[niso][bits_words] u64 | per iso: vbase[npw] u32, bsum[nsb], total[16]
+struct MciLayout {
+    int64_t npw, nsb;
+    size_t off_v, per_iso, total;
+};
+static MciLayout mci_layout(const Geom &g, const Scratch &s, int niso) {
+    MciLayout m;
+    m.npw = g.NZ * g.NY * g.WX;
+    m.nsb = ivx::cdiv(m.npw, 256 * 16);
+    m.off_v = al256((size_t)niso * s.bits_words * 8 + 16);
+    m.per_iso = al256(((size_t)m.npw + (size_t)m.nsb + 16) * 4);
+    m.total = m.off_v + (size_t)niso * m.per_iso;
+    return m;
+}
+static inline uint64_t pad_qbits(const ivx_mc_params *p, int q) { return p->pad_value > p->iso[q] ? ~0ull : 0ull; }
+
 } // namespace
 
 extern "C" int ivx_dev_mc_scratch_bytes(const ivx_mc_params *p, size_t *nbytes) {
@@ -526,9 +779,9 @@ extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scr
     if (s.nwords == 0) return IVX_OK;
     IVX_REQUIRE(s.nblocks * (size_t)p->niso < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
     switch (p->dtype) {
-    case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, scratch, st); break;
-    case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, scratch, st); break;
-    default: rc = run_bits<uint16_t>(p, g, s, a, scratch, st); break;
+    case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+    case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+    default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
     }
     if (rc) return rc;
     uint32_t *bsum = (uint32_t *)(scratch + s.off_bsum);
@@ -598,5 +851,153 @@ extern "C" int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const i
     if ((rc = ws_get(WS_OUT, (size_t)cnt * 36, &d_tris))) return rc;
     if ((rc = ivx_dev_mc_emit(p, d_a, d_scr, (float *)d_tris, cnt, nullptr))) return rc;
     IVX_HIP(hipMemcpy(tris, d_tris, (size_t)cnt * 36, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+
+// ---- indexed mesh API: must follow ivx_dev_mc_count on the same params / scratch / stream --------------------------
+extern "C" int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, const void *scratch_, int64_t *nverts,
+                                        void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    const Scratch s = make_scratch(g, p->niso);
+    *nverts = 0;
+    if (s.nwords == 0) return IVX_OK;
+    hipStream_t st = ivx::S(stream);
+    const MciLayout m = mci_layout(g, s, p->niso);
+    void *d_v;
+    if ((rc = ivx::ws_get_s(ivx::WS_MCV, st, m.total, &d_v))) return rc;
+    // strictly-inside planes: value > iso  <=>  value >= nextafter(iso, +inf)
+    const double n0 = std::nextafter(p->iso[0], HUGE_VAL), n1 = std::nextafter(p->iso[1], HUGE_VAL);
+    switch (p->dtype) {
+    case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
+    case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
+    default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
+    }
+    if (rc) return rc;
+    uint32_t tot[2] = {0, 0};
+    for (int q = 0; q < p->niso; q++) {
+        uint32_t *vbase = (uint32_t *)((char *)d_v + m.off_v + (size_t)q * m.per_iso);
+        uint32_t *bsum = vbase + m.npw, *d_total = bsum + m.nsb;
+        const uint64_t *bits = (const uint64_t *)((const char *)scratch_ + s.off_bits) + (size_t)q * s.bits_words;
+        const uint64_t *qb = (const uint64_t *)d_v + (size_t)q * s.bits_words;
+        const int64_t blocks = ivx::cdiv(m.npw, 256);
+        hipLaunchKernelGGL(k_mci_count, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, bits, qb, g,
+                           m.npw, pad_bits(p, q), pad_qbits(p, q), vbase);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_mscan_block, dim3((unsigned)m.nsb), dim3(256), 0, st, vbase, m.npw, bsum);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_mscan_sums, dim3(1), dim3(1024), 0, st, bsum, m.nsb, d_total);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_mscan_add, dim3((unsigned)m.nsb), dim3(256), 0, st, vbase, m.npw, bsum);
+        IVX_LAUNCH_CHECK();
+        uint32_t seq;
+        if ((rc = ivx::mailbox_publish(d_total, 1, st, &seq))) return rc;
+        if ((rc = ivx::mailbox_wait(seq, st, &tot[q], 1))) return rc;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        g_vsplit[scratch_] = tot[0];
+    }
+    *nverts = (int64_t)tot[0] + (int64_t)tot[1];
+    return IVX_OK;
+}
+
+template <typename T>
+static int run_indexed(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, const char *scratch,
+                       float *verts, int64_t max_verts, int32_t *faces, int64_t max_tris, hipStream_t st) {
+    IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
+    const MciLayout m = mci_layout(g, s, p->niso);
+    void *d_v, *d_list;
+    int rc;
+    if ((rc = ivx::ws_get_s(ivx::WS_MCV, st, m.total, &d_v))) return rc;
+    if ((rc = ivx::ws_get_s(ivx::WS_MCLIST, st, (size_t)max_tris * 8 + 64, &d_list))) return rc;
+    const uint64_t *boff = (const uint64_t *)(scratch + s.off_boff);
+    uint64_t tb[3] = {0, (uint64_t)max_tris, (uint64_t)max_tris};
+    uint32_t vsplit = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        auto iv = g_vsplit.find(scratch);
+        IVX_REQUIRE(iv != g_vsplit.end(), IVX_EINVAL, "mc: ivx_dev_mc_indexed_emit must follow ivx_dev_mc_indexed_count");
+        vsplit = iv->second;
+        if (p->niso == 2) {
+            auto it = g_split.find(scratch);
+            IVX_REQUIRE(it != g_split.end(), IVX_EINVAL, "mc: ivx_dev_mc_indexed_emit must follow ivx_dev_mc_count");
+            tb[1] = it->second;
+        }
+    }
+    for (int q = 0; q < p->niso; q++) {
+        const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
+        const uint64_t *qb = (const uint64_t *)d_v + (size_t)q * s.bits_words;
+        const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
+        const uint32_t *vbase = (const uint32_t *)((const char *)d_v + m.off_v + (size_t)q * m.per_iso);
+        const uint32_t id0 = q == 0 ? 0u : vsplit;
+        hipLaunchKernelGGL(k_mc_list, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q), counts,
+                           boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
+        IVX_LAUNCH_CHECK();
+        const int64_t blocks = ivx::cdiv(m.npw, 256);
+        hipLaunchKernelGGL((k_mci_vertices<T>), dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st,
+                           (const T *)a, bits, qb, g, m.npw, pad_bits(p, q), pad_qbits(p, q), p->iso[q], vbase, id0, verts,
+                           (uint64_t)max_verts);
+        IVX_LAUNCH_CHECK();
+        const uint64_t first = tb[q], last = tb[q + 1] < (uint64_t)max_tris ? tb[q + 1] : (uint64_t)max_tris;
+        if (last > first) {
+            hipLaunchKernelGGL(k_mci_faces, dim3((unsigned)ivx::cdiv((int64_t)(last - first), 256)), dim3(256), 0, st, bits, qb,
+                               g, pad_bits(p, q), pad_qbits(p, q), vbase, id0, (const uint64_t *)d_list + first, last - first,
+                               faces + first * 3);
+            IVX_LAUNCH_CHECK();
+        }
+    }
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_mc_indexed_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *verts,
+                                       int64_t max_verts, int32_t *faces, int64_t max_tris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    const Scratch s = make_scratch(g, p->niso);
+    if (s.nwords == 0 || max_tris <= 0) return IVX_OK;
+    IVX_REQUIRE(max_verts < 0x7fffffffll, IVX_EINVAL, "mc: more than 2^31 vertices do not fit int32 face indices");
+    hipStream_t st = ivx::S(stream);
+    switch (p->dtype) {
+    case IVX_U8: return run_indexed<uint8_t>(p, g, s, a, (const char *)scratch, verts, max_verts, faces, max_tris, st);
+    case IVX_I16: return run_indexed<int16_t>(p, g, s, a, (const char *)scratch, verts, max_verts, faces, max_tris, st);
+    default: return run_indexed<uint16_t>(p, g, s, a, (const char *)scratch, verts, max_verts, faces, max_tris, st);
+    }
+}
+
+// Host form: strided piece in, indexed mesh out.  verts == NULL -> counts only (*nverts, *ntris).
+extern "C" int ivx_marching_cubes_indexed(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *verts,
+                                          int64_t max_verts, int32_t *faces, int64_t max_tris, int64_t *nverts,
+                                          int64_t *ntris) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    const size_t isz = dtype_size(p->dtype);
+    const int64_t shape[3] = {p->nz, p->ny, p->nx};
+    const size_t n = (size_t)p->nz * p->ny * p->nx;
+    void *d_a, *d_scr;
+    size_t sb;
+    if ((rc = ivx_dev_mc_scratch_bytes(p, &sb))) return rc;
+    if ((rc = ws_get(WS_IN, n * isz, &d_a))) return rc;
+    if ((rc = ws_get(WS_AUX0, sb, &d_scr))) return rc;
+    if ((rc = upload_strided(d_a, a, shape, strides, isz, WS_IN))) return rc;
+    int64_t nt = 0, nv = 0;
+    if ((rc = ivx_dev_mc_count(p, d_a, d_scr, &nt, nullptr))) return rc;
+    if ((rc = ivx_dev_mc_indexed_count(p, d_a, d_scr, &nv, nullptr))) return rc;
+    *ntris = nt;
+    *nverts = nv;
+    if (!verts || !faces || nt == 0) return IVX_OK;
+    IVX_REQUIRE(max_tris >= nt && max_verts >= nv, IVX_ERANGE, "mc: output buffers too small (%lld verts, %lld triangles needed)",
+                (long long)nv, (long long)nt);
+    void *d_verts, *d_faces;
+    if ((rc = ws_get(WS_OUT, (size_t)nv * 12 + 64, &d_verts))) return rc;
+    if ((rc = ws_get(WS_AUX1, (size_t)nt * 12 + 64, &d_faces))) return rc;
+    if ((rc = ivx_dev_mc_indexed_emit(p, d_a, d_scr, (float *)d_verts, nv, (int32_t *)d_faces, nt, nullptr))) return rc;
+    IVX_HIP(hipMemcpy(verts, d_verts, (size_t)nv * 12, hipMemcpyDeviceToHost));
+    IVX_HIP(hipMemcpy(faces, d_faces, (size_t)nt * 12, hipMemcpyDeviceToHost));
     return IVX_OK;
 }

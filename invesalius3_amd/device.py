@@ -131,6 +131,8 @@ class DeviceVolume:
         self.flood_scratch = DeviceBuffer(ns.value)
         self._mc_scratch = None
         self._tris = None
+        self._verts = None
+        self._faces = None
         self.sync()
 
     # -- plumbing -------------------------------------------------------------------------------------
@@ -139,7 +141,7 @@ class DeviceVolume:
 
     def close(self):
         for b in (self.image, self.mask, self.out_mask, self.cand, self.reached, self.flood_scratch, self._mc_scratch,
-                  self._tris):
+                  self._tris, self._verts, self._faces):
             if b is not None:
                 b.close()
         if self.stream is not None:
@@ -286,6 +288,40 @@ class DeviceVolume:
             self.sync()
             return self._tris.download((nt, 3, 3), np.float32)
         return nt
+
+    def marching_cubes_indexed(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False,
+                               params: L.McParams | None = None, z0: int = 0):
+        """Same surface with coincident points merged (ivx.h "indexed surface").  Returns (n_verts, n_tris), or the
+        (V,3) float32 / (T,3) int32 arrays when download=True; the device buffers stay in self._verts / self._faces."""
+        lib = L.lib()
+        p = params if params is not None else self._mc_params(from_binary, min_value, max_value, fill_border_holes)
+        nb = ctypes.c_size_t(0)
+        L.check(lib.ivx_dev_mc_scratch_bytes(ctypes.byref(p), ctypes.byref(nb)))
+        if self._mc_scratch is None or self._mc_scratch.nbytes < nb.value:
+            if self._mc_scratch is not None:
+                self._mc_scratch.close()
+            self._mc_scratch = DeviceBuffer(nb.value)
+        isz = 1 if p.dtype == L.U8 else 2
+        src = (self.mask if p.dtype == L.U8 else self.image).at(z0 * self.dy * self.dx * isz)
+        nt, nv = ctypes.c_int64(0), ctypes.c_int64(0)
+        with self.timer.span("mc_count"):
+            L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nt), self.stream), "mc_count")
+        with self.timer.span("mci_count"):
+            L.check(lib.ivx_dev_mc_indexed_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nv), self.stream),
+                    "mc_indexed_count")
+        for name, need in (("_verts", nv.value * 12), ("_faces", nt.value * 12)):
+            buf = getattr(self, name)
+            if buf is None or buf.nbytes < need:
+                if buf is not None:
+                    buf.close()
+                setattr(self, name, DeviceBuffer(int(need * 1.25) + 4096))
+        with self.timer.span("mci_emit"):
+            L.check(lib.ivx_dev_mc_indexed_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._verts.ptr, c64(nv.value),
+                                                self._faces.ptr, c64(nt.value), self.stream), "mc_indexed_emit")
+        if download:
+            self.sync()
+            return self._verts.download((nv.value, 3), np.float32), self._faces.download((nt.value, 3), np.int32)
+        return nv.value, nt.value
 
     # -- projections ---------------------------------------------------------------------------------
     def project(self, axis: int, op: int, out: DeviceBuffer):

@@ -47,6 +47,54 @@ def marching_cubes(a, spacing, iso_values, roi_start=0, pad_xy=True, pad_bottom=
     return tris
 
 
+def _mc_params(a, spacing, iso_values, roi_start, pad_xy, pad_bottom, pad_top, pad_value, vtk_pz):
+    code = L.dtype_code(a, (L.U8, L.I16, L.U16))
+    iso = [float(v) for v in iso_values]
+    if not 1 <= len(iso) <= 2:
+        raise ValueError("one or two iso-values")
+    if vtk_pz is None:
+        vtk_pz = 1 if (pad_xy and pad_bottom) else 0
+    p = L.McParams()
+    p.dtype, p.pad_xy, p.pad_bottom, p.pad_top = code, int(bool(pad_xy)), int(bool(pad_bottom)), int(bool(pad_top))
+    p.vtk_pz, p.niso = int(vtk_pz), len(iso)
+    p.nz, p.ny, p.nx = a.shape
+    p.roi_start = int(roi_start)
+    p.pad_value = float(pad_value)
+    p.spacing[:] = [float(s) for s in spacing]
+    p.iso[:] = iso + [0.0] * (2 - len(iso))
+    return p
+
+
+def marching_cubes_indexed(a, spacing, iso_values, roi_start=0, pad_xy=True, pad_bottom=True, pad_top=True, pad_value=0.0,
+                           vtk_pz=None):
+    """The same surface as `marching_cubes`, with coincident points merged: returns ``(verts (V,3) float32,
+    faces (T,3) int32)`` such that ``verts[faces]`` is the soup, triangle for triangle.  This is what
+    join_process_surface gets out of vtkAppendPolyData + vtkCleanPolyData (surface_process.py:229-268)."""
+    if a.ndim != 3:
+        raise TypeError("piece must be 3-D")
+    p = _mc_params(a, spacing, iso_values, roi_start, pad_xy, pad_bottom, pad_top, pad_value, vtk_pz)
+    nv, nt = ctypes.c_int64(0), ctypes.c_int64(0)
+    lib = L.lib()
+    L.check(lib.ivx_marching_cubes_indexed(ctypes.byref(p), L.ptr(a), L.i64(a.strides), None, ctypes.c_int64(0), None,
+                                           ctypes.c_int64(0), ctypes.byref(nv), ctypes.byref(nt)), "marching_cubes_indexed")
+    verts = np.empty((nv.value, 3), np.float32)
+    faces = np.empty((nt.value, 3), np.int32)
+    if nt.value:
+        L.check(lib.ivx_marching_cubes_indexed(ctypes.byref(p), L.ptr(a), L.i64(a.strides), L.ptr(verts),
+                                               ctypes.c_int64(nv.value), L.ptr(faces), ctypes.c_int64(nt.value),
+                                               ctypes.byref(nv), ctypes.byref(nt)), "marching_cubes_indexed")
+    return verts, faces
+
+
+def mass_properties(tris):
+    """Enclosed volume and surface area of a closed triangle soup (what vtkMassProperties reports in
+    join_process_surface, surface_process.py:430-447), accumulated in float64."""
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 3, 3).astype(np.float64)
+    vol = np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() / 6.0
+    area = np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum() / 2.0
+    return float(abs(vol)), float(area)
+
+
 def create_surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
                          fill_border_holes=True) -> np.ndarray:
     """One piece of surface_process.py:71-201 (arguments reduced to the ones that reach the geometry).

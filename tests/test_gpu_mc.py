@@ -101,3 +101,53 @@ def test_empty_pieces_after_large_allocations(ivxlib, oracle):
             g = sp.marching_cubes(a, (1, 1, 1), [127.0], 0, *pads, 255.0 if shape == (1, 1, 1) else 0.0)
             r = oracle.marching_cubes(a, (1, 1, 1), [127.0], 0, *pads, 255.0 if shape == (1, 1, 1) else 0.0)
             assert g.shape == r.shape and np.array_equal(g, r)
+
+
+@pytest.mark.parametrize("case", ["random_i16", "mask_u8", "two_iso", "no_pad", "on_grid", "on_grid_pad"])
+def test_indexed_mesh_is_the_merged_soup(ivxlib, oracle, case):
+    """point merge (vtkCleanPolyData's job in join_process_surface): verts[faces] == the soup, bit for bit and in
+    order; vertices are unique; their number equals the number of distinct soup vertices"""
+    from invesalius3_amd import surface_process as sp
+    rng = np.random.default_rng(17)
+    if case == "random_i16":
+        a = rng.integers(-1000, 1000, (9, 12, 70)).astype(np.int16)
+        args = ((0.5, 0.75, 2.0), [0.5], 3, True, True, True, float(np.iinfo(np.int16).min), 1)
+    elif case == "mask_u8":
+        img = synth_volume((30, 40, 72), seed=81)
+        a = np.where(img > -800, 255, 0).astype(np.uint8)
+        a[rng.random(a.shape) < 0.01] = 254
+        args = ((1.0, 1.0, 1.0), [127.0], 0, True, True, True, 0.0, 1)
+    elif case == "two_iso":
+        a = synth_volume((21, 40, 48), seed=82)
+        args = ((0.4785156, 0.4785156, 2.0), [226.0, 3071.0], 20, True, False, True, float(np.iinfo(np.int16).min), 0)
+    elif case == "on_grid":
+        # many samples equal the iso-value: crossings land exactly on grid points and must share one vertex
+        a = rng.integers(0, 5, (8, 9, 131)).astype(np.int16)
+        args = ((1.0, 0.5, 0.25), [2.0, 3.0], 5, True, True, True, -5.0, 1)
+    elif case == "on_grid_pad":
+        # ... and so does the padding value
+        a = rng.integers(0, 4, (5, 6, 64)).astype(np.uint8)
+        args = ((1.0, 1.0, 1.0), [2.0], 0, True, True, True, 2.0, 1)
+    else:
+        a = rng.integers(0, 255, (6, 7, 130)).astype(np.uint8)
+        args = ((1.0, 2.0, 3.0), [100.0], 0, False, False, False, 0.0, 0)
+    verts, faces = sp.marching_cubes_indexed(a, *args)
+    soup = oracle.marching_cubes(a, *args)
+    assert faces.shape == (len(soup), 3) and faces.dtype == np.int32
+    assert np.array_equal(verts[faces], soup)
+    ni = len(args[1])
+    if ni == 1:
+        uniq = np.unique(soup.reshape(-1, 3), axis=0)
+        assert len(verts) == len(uniq) == len(np.unique(verts, axis=0))
+    else:
+        # the two iso-surfaces are merged separately (their vertices never coincide geometrically unless a sample
+        # sits between equal iso-values); check uniqueness inside each index range
+        s0 = oracle.marching_cubes(a, args[0], args[1][:1], *args[2:])
+        n0 = len(np.unique(s0.reshape(-1, 3), axis=0))
+        s1 = oracle.marching_cubes(a, args[0], args[1][1:], *args[2:])
+        n1 = len(np.unique(s1.reshape(-1, 3), axis=0))
+        assert len(verts) == n0 + n1
+        assert len(np.unique(verts[:n0], axis=0)) == n0 and len(np.unique(verts[n0:], axis=0)) == n1
+    assert faces.min() == 0 and faces.max() == len(verts) - 1
+    vol, area = sp.mass_properties(verts[faces])
+    assert area > 0
