@@ -180,6 +180,25 @@ int ivx_marching_cubes_indexed(const ivx_mc_params *p, const void *a, const int6
                                int64_t max_verts, int32_t *faces, int64_t max_tris, int64_t *nverts, int64_t *ntris);
 
 /* ------------------------------------------------------------------------------------------------
+ * surface post-processing on the indexed mesh (join_process_surface, invesalius/data/surface_process.py)
+ *   ivx_*_mesh_keep_largest     replaces vtkPolyDataConnectivityFilter + SetExtractionModeToLargestRegion
+ *                               surface_process.py:376-391.  Regions = triangles connected through shared vertex
+ *                               ids; the region with the most triangles is kept (the one whose first triangle comes
+ *                               first wins a tie); kept triangles stay in order, vertices are compacted in order.
+ *   ivx_*_mesh_mass_properties  replaces vtkMassProperties (GetVolume / GetSurfaceArea) surface_process.py:452-458.
+ *                               out8 = {volume, area, vol_x, vol_y, vol_z, kx, ky, kz}; faces == NULL -> `verts` is a
+ *                               soup (3 vertices per triangle).
+ * Device forms take device pointers; sizes come back on the host.  out_verts/out_faces == NULL -> sizes only.
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_mesh_keep_largest(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, float *out_verts,
+                              int64_t max_verts, int32_t *out_faces, int64_t max_tris, int64_t *out_nverts,
+                              int64_t *out_ntris, int64_t *nregions, void *stream);
+int ivx_dev_mesh_mass_properties(const float *verts, const int32_t *faces, int64_t ntris, double *out8, void *stream);
+int ivx_mesh_keep_largest(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, float *out_verts,
+                          int32_t *out_faces, int64_t *out_nverts, int64_t *out_ntris, int64_t *nregions);
+int ivx_mesh_mass_properties(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, double *out8);
+
+/* ------------------------------------------------------------------------------------------------
  * seeded region growing
  *   replaces generic_floodfill_threshold          invesalius_rs/src/floodfill.rs:96-166
  *            generic_floodfill_threshold_inplace  invesalius_rs/src/floodfill.rs:168-237

@@ -27,6 +27,7 @@
 #include <mutex>
 
 #include "ivx_internal.h"
+#include "scan_u32.h"
 
 #define MC_TABLE_QUAL __device__ const
 #include "../../include/ivx_mc_tables.h"
@@ -583,70 +584,6 @@ __global__ __launch_bounds__(256) void k_mci_count(const uint64_t *__restrict__ 
     }
 }
 
-// exclusive scan of u32 in place (three passes, 4096 elements per workgroup) -- same scheme as k_ccl.hip
-constexpr int MSCAN = 16;
-__global__ __launch_bounds__(256) void k_mscan_block(uint32_t *__restrict__ data, int64_t n, uint32_t *__restrict__ bsum) {
-    __shared__ uint32_t s_wave[4];
-    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * MSCAN;
-    uint32_t v[MSCAN], sum = 0;
-#pragma unroll
-    for (int q = 0; q < MSCAN; q++) {
-        v[q] = base + q < n ? data[base + q] : 0u;
-        sum += v[q];
-    }
-    uint32_t inc = sum;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) s_wave[wv] = inc;
-    __syncthreads();
-    uint32_t off = inc - sum;
-    for (int q = 0; q < wv; q++) off += s_wave[q];
-#pragma unroll
-    for (int q = 0; q < MSCAN; q++) {
-        if (base + q < n) data[base + q] = off;
-        off += v[q];
-    }
-    if (threadIdx.x == 255) bsum[blockIdx.x] = off;
-}
-__global__ __launch_bounds__(1024) void k_mscan_sums(uint32_t *__restrict__ bsum, int64_t nb, uint32_t *__restrict__ total) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
-        const int64_t i = b0 + threadIdx.x;
-        const uint32_t v = i < nb ? bsum[i] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) s_wave[wv] = inc;
-        __syncthreads();
-        uint32_t wb = 0;
-        for (int q = 0; q < wv; q++) wb += s_wave[q];
-        const uint32_t carry = s_carry;
-        if (i < nb) bsum[i] = carry + wb + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wb + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = s_carry;
-}
-__global__ __launch_bounds__(256) void k_mscan_add(uint32_t *__restrict__ data, int64_t n, const uint32_t *__restrict__ bsum) {
-    const uint32_t add = bsum[blockIdx.x];
-    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * MSCAN;
-#pragma unroll
-    for (int q = 0; q < MSCAN; q++)
-        if (base + q < n) data[base + q] += add;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_mci_vertices(const T *__restrict__ a, const uint64_t *__restrict__ bits,
                                                       const uint64_t *__restrict__ qb, Geom g, int64_t npw, uint64_t pbits,
@@ -885,12 +822,7 @@ extern "C" int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, c
         hipLaunchKernelGGL(k_mci_count, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, bits, qb, g,
                            m.npw, pad_bits(p, q), pad_qbits(p, q), vbase);
         IVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_mscan_block, dim3((unsigned)m.nsb), dim3(256), 0, st, vbase, m.npw, bsum);
-        IVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_mscan_sums, dim3(1), dim3(1024), 0, st, bsum, m.nsb, d_total);
-        IVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_mscan_add, dim3((unsigned)m.nsb), dim3(256), 0, st, vbase, m.npw, bsum);
-        IVX_LAUNCH_CHECK();
+        if ((rc = scan_u32_exclusive(vbase, m.npw, bsum, d_total, st))) return rc;
         uint32_t seq;
         if ((rc = ivx::mailbox_publish(d_total, 1, st, &seq))) return rc;
         if ((rc = ivx::mailbox_wait(seq, st, &tot[q], 1))) return rc;

@@ -86,13 +86,41 @@ def marching_cubes_indexed(a, spacing, iso_values, roi_start=0, pad_xy=True, pad
     return verts, faces
 
 
-def mass_properties(tris):
-    """Enclosed volume and surface area of a closed triangle soup (what vtkMassProperties reports in
-    join_process_surface, surface_process.py:430-447), accumulated in float64."""
-    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 3, 3).astype(np.float64)
-    vol = np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() / 6.0
-    area = np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum() / 2.0
-    return float(abs(vol)), float(area)
+def mass_properties(verts, faces=None):
+    """``(volume, area)`` of a triangle mesh, the two numbers join_process_surface reports through
+    vtkMassProperties (surface_process.py:452-458).  ``faces=None`` takes ``verts`` as a (T,3,3) soup."""
+    return mass_properties_full(verts, faces)[:2]
+
+
+def mass_properties_full(verts, faces=None):
+    """(volume, area, vol_x, vol_y, vol_z, kx, ky, kz): the weighted discrete-divergence terms behind the volume."""
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(8, np.float64)
+    if faces is None:
+        if len(v) % 3:
+            raise ValueError("a soup has 3 vertices per triangle")
+        f, nt = None, len(v) // 3
+    else:
+        f = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+        nt = len(f)
+    L.check(L.lib().ivx_mesh_mass_properties(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f) if f is not None else None,
+                                             ctypes.c_int64(nt), L.ptr(out)), "mesh_mass_properties")
+    return tuple(float(x) for x in out)
+
+
+def keep_largest(verts, faces):
+    """Largest connected region of an indexed mesh (vtkPolyDataConnectivityFilter, LargestRegion;
+    surface_process.py:376-391): most triangles, earliest first triangle on a tie.  Returns
+    ``(verts', faces', n_regions)`` with the kept triangles in their original order and the vertices compacted."""
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    f = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+    ov = np.empty_like(v)
+    of = np.empty_like(f)
+    nv, nt, nr = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(L.lib().ivx_mesh_keep_largest(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), L.ptr(ov),
+                                          L.ptr(of), ctypes.byref(nv), ctypes.byref(nt), ctypes.byref(nr)),
+            "mesh_keep_largest")
+    return ov[: nv.value].copy(), of[: nt.value].copy(), nr.value
 
 
 def create_surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
@@ -130,6 +158,30 @@ def create_surface(image, mask_matrix, spacing, min_value, max_value, from_binar
         parts.append(create_surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
                                           fill_border_holes))
     return np.concatenate(parts) if parts else np.empty((0, 3, 3), np.float32)
+
+
+def join_process_surface(image, mask_matrix, spacing, min_value, max_value, from_binary, fill_border_holes=True,
+                         keep_largest_region=False):
+    """The geometry of join_process_surface (surface_process.py:204-472) for the stages built here: the pieces'
+    surfaces appended and point-merged (== one indexed marching-cubes pass over the whole volume: pieces share
+    exactly one slice, so their cells partition the volume's), optionally the largest region only, then area and
+    volume.  Returns ``(verts, faces, {"volume": v, "area": a})``.  Smoothing, decimation, hole filling and normals
+    (VTK filters in the reference) are not part of this path."""
+    dz = image.shape[0] if image is not None else mask_matrix.shape[0] - 1
+    if from_binary:
+        a = mask_matrix[1: dz + 1, 1:, 1:]
+        padv, isos = 0.0, [127.0]
+    else:
+        a = image
+        padv, isos = float(np.iinfo(image.dtype).min), [float(min_value), float(max_value)]
+    if fill_border_holes:
+        verts, faces = marching_cubes_indexed(a, spacing, isos, 0, True, True, True, padv, 1)
+    else:
+        verts, faces = marching_cubes_indexed(a, spacing, isos, 0, False, False, False, padv, 0)
+    if keep_largest_region and len(faces):
+        verts, faces, _ = keep_largest(verts, faces)
+    volume, area = mass_properties(verts, faces)
+    return verts, faces, {"volume": volume, "area": area}
 
 
 def write_stl_binary(path, tris):

@@ -13,6 +13,8 @@ import ctypes
 import os
 import subprocess
 
+import math
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -354,3 +356,80 @@ def apply_view_matrix_transform(volume, spacing, m, n, orientation, minterpol, c
         DT[volume.dtype], _p(volume), _i64(volume.shape), _i64(volume.strides), _p(sp), _p(mm), ctypes.c_int64(int(n)),
         ORIENTATION.get(orientation, -1), int(minterpol), ctypes.c_double(float(cval)), _p(out), _i64(out.shape),
         _i64(out.strides)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Surface post-processing (join_process_surface, invesalius/data/surface_process.py:376-391, 452-458).
+# PARITY UNPINNED: the reference delegates both steps to VTK 9.3 (vtkPolyDataConnectivityFilter, vtkMassProperties),
+# which is third party and not installed here.  What follows restates their published algorithms; the tests anchor
+# them on size-independent properties instead (analytic volume/area of closed shapes, divergence theorem,
+# scipy.sparse.csgraph components).
+# ---------------------------------------------------------------------------------------------------------------------
+def mesh_keep_largest(verts, faces):
+    """Largest region by triangle count, first region (smallest first-triangle id) on a tie; triangles keep their
+    order, vertices are compacted in order.  Returns (verts, faces, n_regions)."""
+    v = np.asarray(verts, np.float32).reshape(-1, 3)
+    f = np.asarray(faces, np.int64).reshape(-1, 3)
+    if len(f) == 0:
+        return v[:0].copy(), f[:0].astype(np.int32), 0
+    parent = np.arange(len(v))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for a, b, c in f:
+        for q in (b, c):
+            ra, rq = find(a), find(q)
+            if ra != rq:
+                parent[max(ra, rq)] = min(ra, rq)
+    lab = np.array([find(a) for a in f[:, 0]])
+    best, best_n = None, 0
+    seen = {}
+    for t, r in enumerate(lab):  # regions in order of their first triangle
+        seen.setdefault(r, t)
+    for r, _t in sorted(seen.items(), key=lambda kv: kv[1]):
+        n = int((lab == r).sum())
+        if n > best_n:
+            best, best_n = r, n
+    keep = lab == best
+    kf = f[keep]
+    used = np.zeros(len(v), bool)
+    used[kf.ravel()] = True
+    remap = np.cumsum(used) - 1
+    return v[used].copy(), remap[kf].astype(np.int32), len(seen)
+
+
+def mesh_mass_properties(verts, faces=None):
+    """vtkMassProperties' algorithm (Alyassin et al. 1994) in float64, sequential sums:
+    returns (volume, area, vol_x, vol_y, vol_z, kx, ky, kz)."""
+    v = np.asarray(verts, np.float32).reshape(-1, 3).astype(np.float64)
+    t = v.reshape(-1, 3, 3) if faces is None else v[np.asarray(faces, np.int64).reshape(-1, 3)]
+    n = len(t)
+    if n == 0:
+        return (0.0,) * 8
+    e0, e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0], t[:, 2] - t[:, 1]
+    u = np.stack([e0[:, 1] * e1[:, 2] - e0[:, 2] * e1[:, 1], e0[:, 2] * e1[:, 0] - e0[:, 0] * e1[:, 2],
+                  e0[:, 0] * e1[:, 1] - e0[:, 1] * e1[:, 0]], axis=1)
+    ln = np.sqrt((u * u).sum(1))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        u = np.where(ln[:, None] != 0.0, u / ln[:, None], 0.0)
+    a0, a1, a2 = np.abs(u).T
+    munc = [int(((a0 > a1) & (a0 > a2)).sum()), int(((a1 > a0) & (a1 > a2)).sum()), int(((a2 > a0) & (a2 > a1)).sum())]
+    wxyz = int(((a0 == a1) & (a0 == a2)).sum())
+    wxy = int(((a0 == a1) & (a0 > a2)).sum())
+    wxz = int(((a0 == a2) & (a0 > a1)).sum())
+    wyz = int(((a1 == a2) & (a0 < a2)).sum())
+    a = np.sqrt((e1 * e1).sum(1))
+    b = np.sqrt((e0 * e0).sum(1))
+    c = np.sqrt((e2 * e2).sum(1))
+    s = 0.5 * (a + b + c)
+    area = np.sqrt(np.abs(s * (s - a) * (s - b) * (s - c)))
+    avg = (t[:, 0] + t[:, 1] + t[:, 2]) / 3.0
+    vol = [math.fsum(area * u[:, q] * avg[:, q]) for q in range(3)]
+    kx = (munc[0] + wxyz / 3.0 + (wxy + wxz) / 2.0) / n
+    ky = (munc[1] + wxyz / 3.0 + (wxy + wyz) / 2.0) / n
+    kz = (munc[2] + wxyz / 3.0 + (wxz + wyz) / 2.0) / n
+    return (abs(kx * vol[0] + ky * vol[1] + kz * vol[2]), math.fsum(area), vol[0], vol[1], vol[2], kx, ky, kz)

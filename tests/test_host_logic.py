@@ -62,3 +62,24 @@ def test_structures_accepted_by_the_union_find_engine():
     one_way = np.zeros((3, 3, 3), np.uint8)
     one_way[1, 1, 2] = 1
     assert not supported(bits(one_way))
+
+
+def test_mesh_oracle_anchors(oracle):
+    """the mesh oracle (parity unpinned vs VTK) against analytic shapes and scipy's connected components"""
+    # unit cube, outward triangles
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
+    f = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7],
+                  [2, 7, 6], [3, 0, 4], [3, 4, 7]], np.int32)
+    m = oracle.mesh_mass_properties(v * np.float32(2.0), f)
+    assert m[0] == pytest.approx(8.0, rel=1e-12) and m[1] == pytest.approx(24.0, rel=1e-12)
+    assert m[5] + m[6] + m[7] == pytest.approx(1.0)
+    # two cubes + a lone triangle: the first cube wins the tie, vertices are compacted
+    v2 = np.concatenate([v, v + np.float32(5.0), np.zeros((3, 3), np.float32)])
+    f2 = np.concatenate([f + 8, f, [[16, 17, 18]]]).astype(np.int32)
+    kv, kf, nreg = oracle.mesh_keep_largest(v2, f2)
+    assert nreg == 3 and np.array_equal(kf, f) and np.array_equal(kv, v + np.float32(5.0))
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    e = np.concatenate([f2[:, [0, 1]], f2[:, [0, 2]]])
+    g = coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(len(v2), len(v2)))
+    assert connected_components(g, directed=False)[0] == 3
