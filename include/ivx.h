@@ -44,6 +44,7 @@ extern "C" {
 #define IVX_I16 1
 #define IVX_F64 2
 #define IVX_U16 3
+#define IVX_F32 4
 
 /* projection ops for ivx_*mip_reduce (numpy .max/.min/.mean, invesalius/data/slice_.py:885-889) */
 #define IVX_MIP_MAX 0
@@ -197,6 +198,35 @@ int ivx_dev_mesh_mass_properties(const float *verts, const int32_t *faces, int64
 int ivx_mesh_keep_largest(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, float *out_verts,
                           int32_t *out_faces, int64_t *out_nverts, int64_t *out_ntris, int64_t *nregions);
 int ivx_mesh_mass_properties(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, double *out8);
+
+/* ------------------------------------------------------------------------------------------------
+ * context-aware smoothing of the indexed surface
+ *   replaces context_aware_smoothing           invesalius_rs/src/mesh_py.rs:7-330 -> mesh.rs:27-86
+ *            (python: invesalius_rs.Mesh.ca_smoothing / ca_smoothing, invesalius_rs/__init__.py:220-275;
+ *             caller: join_process_surface, invesalius/data/surface_process.py:313-317)
+ * verts: (nverts,3) IVX_F32 or IVX_F64, smoothed IN PLACE; faces: (ntris,3) int32 (the reference's (M,4) rows minus
+ * their leading count column, which must be 3); normals: (ntris,3) float64 cell normals; t / tmax / bmin / n_iters as in
+ * the reference ("angle", "max distance", "min weight", "steps").  Optional outputs (NULL to skip): the staircase
+ * flags (nverts bytes) and the per-vertex weights (nverts doubles).  Results are bit-identical to a statement-by-
+ * statement restatement of mesh.rs (oracle/ivx_oracle_mesh.c), its quirks included.
+ *   ivx_*_mesh_propagate_weights  propagate_weights (mesh.rs:204-288) alone, from explicit seed flags
+ *   ivx_*_mesh_face_normals       unit cell normals of the triangles (what vtkPolyDataNormals hands the reference)
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_context_aware_smoothing(void *verts, int vdtype, int64_t nverts, const int32_t *faces, int64_t ntris,
+                                    const double *normals, double t, double tmax, double bmin, int n_iters,
+                                    uint8_t *staircase_out, double *weights_out, void *stream);
+int ivx_dev_mesh_propagate_weights(const void *verts, int vdtype, int64_t nverts, const int32_t *faces, int64_t ntris,
+                                   const uint8_t *seed_flags, double tmax, double bmin, double *weights, void *stream);
+int ivx_dev_mesh_face_normals(const void *verts, int vdtype, const int32_t *faces, int64_t ntris, double *normals,
+                              void *stream);
+/* host forms; normals == NULL -> computed from the geometry */
+int ivx_context_aware_smoothing(void *verts, int vdtype, int64_t nverts, const int32_t *faces, int64_t ntris,
+                                const double *normals, double t, double tmax, double bmin, int n_iters,
+                                uint8_t *staircase_out, double *weights_out);
+int ivx_mesh_propagate_weights(const void *verts, int vdtype, int64_t nverts, const int32_t *faces, int64_t ntris,
+                               const uint8_t *seed_flags, double tmax, double bmin, double *weights);
+int ivx_mesh_face_normals(const void *verts, int vdtype, int64_t nverts, const int32_t *faces, int64_t ntris,
+                          double *normals);
 
 /* ------------------------------------------------------------------------------------------------
  * seeded region growing

@@ -162,3 +162,110 @@ def apply_view_matrix_transform(volume, spacing, m, n, orientation, minterpol, c
         code, L.ptr(volume), L.i64(volume.shape), L.i64(volume.strides), L.ptr(sp), L.ptr(mm), ctypes.c_int64(int(n)),
         _ORIENTATION.get(orientation, -1), int(minterpol), ctypes.c_double(cval), L.ptr(out), L.i64(out.shape),
         L.i64(out.strides)), "apply_view_matrix_transform")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# context-aware smoothing: invesalius_rs/__init__.py:114-275 (Mesh, ca_smoothing) over mesh_py.rs context_aware_smoothing
+# ---------------------------------------------------------------------------------------------------------------------
+_FACE_DTYPES = (np.int64, np.int32, np.uint64, np.uint32)
+
+
+def context_aware_smoothing(vertices, faces, normals, t, tmax, bmin, n_iters):
+    """mesh_py.rs:7-330.  ``vertices`` (N,3) float32/float64 is smoothed IN PLACE; ``faces`` is the vtkCellArray
+    layout the reference passes, (M,4) rows ``[3, v0, v1, v2]`` of int64/int32/uint64/uint32; ``normals`` (M,3)
+    float32/float64 cell normals.  Any other dtype is the TypeError PyO3 raises for an unmatched enum."""
+    if not isinstance(vertices, np.ndarray) or vertices.dtype not in (np.float32, np.float64):
+        raise TypeError("vertices must be a float32 or float64 ndarray")
+    if not isinstance(faces, np.ndarray) or faces.dtype not in _FACE_DTYPES:
+        raise TypeError("faces must be an int64, int32, uint64 or uint32 ndarray")
+    if not isinstance(normals, np.ndarray) or normals.dtype not in (np.float32, np.float64):
+        raise TypeError("normals must be a float32 or float64 ndarray")
+    if vertices.ndim != 2 or vertices.shape[1] != 3 or faces.ndim != 2 or faces.shape[1] != 4:
+        raise TypeError("vertices must be (N,3) and faces (M,4)")
+    if normals.shape != (faces.shape[0], 3):
+        raise TypeError("normals must be (M,3)")
+    if not vertices.flags.c_contiguous or not vertices.flags.writeable:
+        raise TypeError("vertices must be a writable C-contiguous array")  # PyReadwriteArray's requirement
+    if int(n_iters) < 0:
+        raise OverflowError("n_iters must fit a u32")
+    if len(faces) and not np.all(faces[:, 0] == 3):
+        raise ValueError("faces rows must start with the vertex count 3 (triangles)")
+    f3 = np.ascontiguousarray(faces[:, 1:], dtype=np.int64)
+    if len(f3) and (f3.min() < 0 or f3.max() >= len(vertices)):
+        raise IndexError("face index out of bounds")  # the reference panics on the out-of-bounds row access
+    f3 = f3.astype(np.int32)
+    nrm = np.ascontiguousarray(normals, dtype=np.float64)
+    L.check(L.lib().ivx_context_aware_smoothing(L.ptr(vertices), L.dtype_code(vertices, (L.F32, L.F64)),
+                                                ctypes.c_int64(len(vertices)), L.ptr(f3), ctypes.c_int64(len(f3)),
+                                                L.ptr(nrm), ctypes.c_double(t), ctypes.c_double(tmax),
+                                                ctypes.c_double(bmin), ctypes.c_int(int(n_iters)), None, None),
+            "context_aware_smoothing")
+
+
+class Mesh:
+    """invesalius_rs.Mesh (invesalius_rs/__init__.py:114-249) without the vtkPolyData constructor (no VTK on this
+    path): built from arrays, or copied from another Mesh."""
+
+    def __init__(self, pd=None, other=None, vertices=None, faces=None, normals=None):
+        if pd is not None:
+            raise TypeError("vtkPolyData input is outside this path; pass vertices, faces and normals")
+        if other is not None:
+            if not isinstance(other, Mesh):
+                raise TypeError("other must be a Mesh instance")
+            self._vertices = np.ascontiguousarray(other.vertices.copy())
+            self._faces = np.ascontiguousarray(other.faces.copy())
+            self._normals = np.ascontiguousarray(other.normals.copy())
+        elif vertices is not None and faces is not None and normals is not None:
+            self._vertices = np.ascontiguousarray(vertices)
+            self._faces = np.ascontiguousarray(faces)
+            self._normals = np.ascontiguousarray(normals)
+        else:
+            raise ValueError("Must provide either pd, other, or (vertices, faces, normals)")
+
+    @classmethod
+    def from_indexed(cls, verts, faces3):
+        """(V,3) vertices + (T,3) faces of `surface_process.marching_cubes_indexed` -> Mesh with unit cell normals."""
+        v = np.ascontiguousarray(verts)
+        f3 = np.ascontiguousarray(faces3, dtype=np.int32)
+        nrm = np.zeros((len(f3), 3), np.float64)
+        if len(f3):
+            L.check(L.lib().ivx_mesh_face_normals(L.ptr(v), L.dtype_code(v, (L.F32, L.F64)), ctypes.c_int64(len(v)),
+                                                  L.ptr(f3), ctypes.c_int64(len(f3)), L.ptr(nrm)), "mesh_face_normals")
+        f4 = np.empty((len(f3), 4), np.int64)
+        f4[:, 0] = 3
+        f4[:, 1:] = f3
+        return cls(vertices=v, faces=f4, normals=nrm)
+
+    @property
+    def vertices(self):
+        return self._vertices
+
+    @property
+    def faces(self):
+        return self._faces
+
+    @property
+    def normals(self):
+        return self._normals
+
+    def ca_smoothing(self, T, tmax, bmin, n_iters):
+        context_aware_smoothing(self._vertices, self._faces, self._normals, T, tmax, bmin, n_iters)
+
+
+def ca_smoothing(mesh, T, tmax, bmin, n_iters):
+    """invesalius_rs/__init__.py:251-275: smooths ``mesh`` in place."""
+    mesh.ca_smoothing(T, tmax, bmin, n_iters)
+
+
+def propagate_weights(vertices, faces3, seed_flags, tmax, bmin):
+    """mesh.rs:204-288 on its own: weights from explicit seed flags (synchronous schedule, see k_smooth.hip)."""
+    v = np.ascontiguousarray(vertices)
+    f3 = np.ascontiguousarray(faces3, dtype=np.int32)
+    s = np.ascontiguousarray(seed_flags, dtype=np.uint8)
+    if s.shape != (len(v),):
+        raise ValueError("one seed flag per vertex")
+    w = np.zeros(len(v), np.float64)
+    L.check(L.lib().ivx_mesh_propagate_weights(L.ptr(v), L.dtype_code(v, (L.F32, L.F64)), ctypes.c_int64(len(v)), L.ptr(f3),
+                                               ctypes.c_int64(len(f3)), L.ptr(s), ctypes.c_double(tmax),
+                                               ctypes.c_double(bmin), L.ptr(w)), "mesh_propagate_weights")
+    return w

@@ -433,3 +433,70 @@ def mesh_mass_properties(verts, faces=None):
     ky = (munc[1] + wxyz / 3.0 + (wxy + wyz) / 2.0) / n
     kz = (munc[2] + wxyz / 3.0 + (wxz + wyz) / 2.0) / n
     return (abs(kx * vol[0] + ky * vol[1] + kz * vol[2]), math.fsum(area), vol[0], vol[1], vol[2], kx, ky, kz)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Context-aware smoothing: C restatement of invesalius_rs/src/mesh.rs (oracle/ivx_oracle_mesh.c)
+# ---------------------------------------------------------------------------------------------------------------------
+def context_aware_smoothing(vertices, faces4, normals, t, tmax, bmin, n_iters, details=False):
+    """Smooths ``vertices`` (float32/float64, C-contiguous) IN PLACE like the reference; faces4 = (M,4) [3,v0,v1,v2].
+    details=True also returns (staircase flags, weights)."""
+    lib_ = lib()
+    assert vertices.dtype in (np.float32, np.float64) and vertices.flags.c_contiguous
+    f4 = np.ascontiguousarray(faces4, dtype=np.int64)
+    nrm = np.ascontiguousarray(normals, dtype=np.float64)
+    nv = len(vertices)
+    flags = np.zeros(nv, np.uint8)
+    w = np.zeros(nv, np.float64)
+    lib_.orc_context_aware_smoothing.restype = ctypes.c_int
+    rc = lib_.orc_context_aware_smoothing(ctypes.c_void_p(vertices.ctypes.data), ctypes.c_int(vertices.dtype == np.float64),
+                                         ctypes.c_int64(nv), ctypes.c_void_p(f4.ctypes.data), ctypes.c_int64(len(f4)),
+                                         ctypes.c_void_p(nrm.ctypes.data), ctypes.c_double(t), ctypes.c_double(tmax),
+                                         ctypes.c_double(bmin), ctypes.c_int(n_iters), ctypes.c_void_p(flags.ctypes.data),
+                                         ctypes.c_void_p(w.ctypes.data))
+    if rc:
+        raise RuntimeError("orc_context_aware_smoothing -> %d" % rc)
+    return (flags, w) if details else None
+
+
+def mesh_vertex_connectivity(faces3, nv):
+    """build_vertex_connectivity (mesh.rs:102-121): CSR (off, idx) of unique neighbours in order of first appearance."""
+    lib_ = lib()
+    f3 = np.asarray(faces3, np.int64).reshape(-1, 3)
+    f4 = np.empty((len(f3), 4), np.int64)
+    f4[:, 0] = 3
+    f4[:, 1:] = f3
+    off = np.zeros(nv + 1, np.int64)
+    lib_.orc_mesh_vertex_connectivity(ctypes.c_void_p(f4.ctypes.data), ctypes.c_int64(len(f4)), ctypes.c_int64(nv),
+                                     ctypes.c_void_p(off.ctypes.data), None)
+    idx = np.zeros(max(int(off[-1]), 1), np.int64)
+    lib_.orc_mesh_vertex_connectivity(ctypes.c_void_p(f4.ctypes.data), ctypes.c_int64(len(f4)), ctypes.c_int64(nv),
+                                     ctypes.c_void_p(off.ctypes.data), ctypes.c_void_p(idx.ctypes.data))
+    return off, idx[: int(off[-1])]
+
+
+def mesh_propagate_weights(vertices, faces3, seed_flags, tmax, bmin):
+    lib_ = lib()
+    v = np.ascontiguousarray(vertices)
+    off, idx = mesh_vertex_connectivity(faces3, len(v))
+    idx = np.ascontiguousarray(idx if len(idx) else np.zeros(1, np.int64))
+    s = np.ascontiguousarray(seed_flags, dtype=np.uint8)
+    w = np.zeros(len(v), np.float64)
+    rc = lib_.orc_mesh_propagate_weights(ctypes.c_void_p(v.ctypes.data), ctypes.c_int(v.dtype == np.float64),
+                                        ctypes.c_int64(len(v)), ctypes.c_void_p(off.ctypes.data),
+                                        ctypes.c_void_p(idx.ctypes.data), ctypes.c_void_p(s.ctypes.data),
+                                        ctypes.c_double(tmax), ctypes.c_double(bmin), ctypes.c_void_p(w.ctypes.data))
+    if rc:
+        raise RuntimeError("orc_mesh_propagate_weights -> %d" % rc)
+    return w
+
+
+def mesh_face_normals(vertices, faces3):
+    v = np.asarray(vertices).astype(np.float64)
+    f = np.asarray(faces3, np.int64).reshape(-1, 3)
+    a, b = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
+    n = np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2],
+                  a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], axis=1)
+    ln = np.sqrt(n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1] + n[:, 2] * n[:, 2])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(ln[:, None] != 0.0, n / ln[:, None], n)

@@ -1,0 +1,118 @@
+"""Context-aware smoothing (invesalius_rs.Mesh / ca_smoothing; mesh.rs:27-395): HIP path vs the C restatement,
+bit for bit, through the reference's python surface."""
+import numpy as np
+import pytest
+
+from conftest import synth_volume
+
+pytestmark = pytest.mark.gpu
+
+OPTS = (0.7, 3.0, 0.5, 10)  # task_navigator.py:827 defaults: angle, max distance, min weight, steps
+
+
+def _mc_mesh(seed=5, shape=(28, 36, 70), iso=250.0):
+    from invesalius3_amd import surface_process as sp
+    img = synth_volume(shape, seed=seed)
+    return sp.marching_cubes_indexed(img, (0.4785156, 0.4785156, 1.25), [iso], 0, True, True, True,
+                                     float(np.iinfo(np.int16).min), 1)
+
+
+@pytest.mark.parametrize("vdtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fdtype", [np.int64, np.uint32])
+def test_ca_smoothing_matches_oracle(ivxlib, oracle, vdtype, fdtype):
+    from invesalius3_amd import invesalius_rs as rs
+    verts, faces = _mc_mesh()
+    mesh = rs.Mesh.from_indexed(verts.astype(vdtype), faces)
+    assert np.array_equal(mesh.normals, oracle.mesh_face_normals(mesh.vertices, faces))
+    mesh = rs.Mesh(vertices=mesh.vertices, faces=mesh.faces.astype(fdtype), normals=mesh.normals.astype(np.float32))
+    want = mesh.vertices.copy()
+    oracle.context_aware_smoothing(want, mesh.faces, mesh.normals, *OPTS)
+    before = mesh.vertices.copy()
+    rs.ca_smoothing(mesh, *OPTS)
+    assert mesh.vertices.dtype == vdtype
+    assert np.array_equal(mesh.vertices, want)
+    assert not np.array_equal(mesh.vertices, before)
+    # copy constructor + method form
+    m2 = rs.Mesh(other=rs.Mesh(vertices=before, faces=mesh.faces, normals=mesh.normals))
+    m2.ca_smoothing(*OPTS)
+    assert np.array_equal(m2.vertices, want)
+
+
+def test_staircase_flags_weights_and_quirks(ivxlib, oracle):
+    import ctypes
+    from invesalius3_amd import _lib as L
+    verts, faces = _mc_mesh(seed=6, shape=(12, 16, 66))
+    # add isolated vertices (never in a face) and a degenerate triangle
+    verts = np.concatenate([verts, np.float32([[1e3, 0, 0], [0, 1e3, 0]])])
+    faces = np.concatenate([faces, np.int32([[0, 0, 1]])])
+    nrm = oracle.mesh_face_normals(verts, faces)
+    f4 = np.concatenate([np.full((len(faces), 1), 3), faces], axis=1).astype(np.int64)
+    want = verts.copy()
+    flags0, w0 = oracle.context_aware_smoothing(want, f4, nrm, *OPTS, details=True)
+    got = verts.copy()
+    flags = np.zeros(len(verts), np.uint8)
+    w = np.zeros(len(verts), np.float64)
+    L.check(L.lib().ivx_context_aware_smoothing(L.ptr(got), L.F32, ctypes.c_int64(len(got)), L.ptr(faces),
+                                                ctypes.c_int64(len(faces)), L.ptr(nrm), ctypes.c_double(OPTS[0]),
+                                                ctypes.c_double(OPTS[1]), ctypes.c_double(OPTS[2]), ctypes.c_int(OPTS[3]),
+                                                L.ptr(flags), L.ptr(w)))
+    assert np.array_equal(flags, flags0) and np.array_equal(w, w0) and np.array_equal(got, want)
+    assert flags[:-2].all() and not flags[-2:].any() and np.array_equal(got[-2:], verts[-2:])
+    # normals == NULL: computed on the device, same result
+    got2 = verts.copy()
+    L.check(L.lib().ivx_context_aware_smoothing(L.ptr(got2), L.F32, ctypes.c_int64(len(got2)), L.ptr(faces),
+                                                ctypes.c_int64(len(faces)), None, ctypes.c_double(OPTS[0]),
+                                                ctypes.c_double(OPTS[1]), ctypes.c_double(OPTS[2]), ctypes.c_int(OPTS[3]),
+                                                None, None))
+    assert np.array_equal(got2, want)
+
+
+def test_vertex_3_gets_every_face(ivxlib, oracle):
+    """Q-M1 on the device: vertex id 3 is a seed although no triangle touches it"""
+    from invesalius3_amd import invesalius_rs as rs
+    v = np.zeros((6, 3), np.float32)
+    v[:, 0] = np.arange(6)
+    v[:, 1] = [0, 1, 0, 7, 1, 0]
+    f4 = np.array([[3, 0, 1, 2], [3, 2, 4, 5]], np.int32)
+    nrm = np.array([[0, 0, 1.0], [0, 0, 1.0]])
+    want = v.copy()
+    flags0, w0 = oracle.context_aware_smoothing(want, f4, nrm, 0.7, 3.0, 0.5, 3, details=True)
+    assert flags0[3] == 1
+    rs.context_aware_smoothing(v, f4, nrm, 0.7, 3.0, 0.5, 3)
+    assert np.array_equal(v, want)
+
+
+def test_propagate_weights_partial_seeds_matches_oracle(ivxlib, oracle):
+    from invesalius3_amd import invesalius_rs as rs
+    verts, faces = _mc_mesh(seed=8, shape=(20, 24, 66))
+    rng = np.random.default_rng(1)
+    for frac, tmax in ((0.002, 3.0), (0.05, 1.0), (0.0, 2.0)):
+        seeds = (rng.random(len(verts)) < frac).astype(np.uint8)
+        w = rs.propagate_weights(verts, faces, seeds, tmax, 0.5)
+        w0 = oracle.mesh_propagate_weights(verts, faces, seeds, tmax, 0.5)
+        assert np.array_equal(w, w0)
+        if frac:
+            assert (w[seeds == 1] == 1.0).all() and 0.5 <= w.min() and (w > 0.5).sum() > seeds.sum()
+        else:
+            assert (w == 0.5).all()
+
+
+def test_argument_errors(ivxlib):
+    from invesalius3_amd import invesalius_rs as rs
+    v = np.zeros((4, 3), np.float32)
+    f4 = np.array([[3, 0, 1, 2]], np.int64)
+    n = np.zeros((1, 3), np.float64)
+    with pytest.raises(TypeError):
+        rs.context_aware_smoothing(v.astype(np.float16), f4, n, 0.7, 3.0, 0.5, 1)
+    with pytest.raises(TypeError):
+        rs.context_aware_smoothing(v, f4.astype(np.int16), n, 0.7, 3.0, 0.5, 1)
+    with pytest.raises(TypeError):
+        rs.context_aware_smoothing(v, f4[:, 1:], n, 0.7, 3.0, 0.5, 1)
+    with pytest.raises(IndexError):
+        rs.context_aware_smoothing(v, np.array([[3, 0, 1, 9]], np.int64), n, 0.7, 3.0, 0.5, 1)
+    with pytest.raises(OverflowError):
+        rs.context_aware_smoothing(v, f4, n, 0.7, 3.0, 0.5, -1)
+    # empty mesh: nothing to do
+    rs.context_aware_smoothing(np.zeros((0, 3), np.float32), np.zeros((0, 4), np.int64), np.zeros((0, 3)), 0.7, 3.0, 0.5, 2)
+    with pytest.raises(ValueError):
+        rs.Mesh()
