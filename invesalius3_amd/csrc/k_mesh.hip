@@ -152,7 +152,19 @@ __global__ __launch_bounds__(256) void k_mesh_best(const uint32_t *__restrict__ 
         key = k > key ? k : key;
         regions += __shfl_xor(regions, o, 64);
     }
+    // one atomic pair per WORKGROUP (the grid is capped at 1024 of them): ~50 k same-address atomics took 1 ms
+    __shared__ unsigned long long s_key[4];
+    __shared__ uint32_t s_reg[4];
     if ((threadIdx.x & 63) == 0) {
+        s_key[threadIdx.x >> 6] = key;
+        s_reg[threadIdx.x >> 6] = regions;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; q++) {
+            key = s_key[q] > key ? s_key[q] : key;
+            regions += s_reg[q];
+        }
         if (key) atomicMax(best, key);
         if (regions) atomicAdd(nreg, regions);
     }
@@ -359,7 +371,7 @@ extern "C" int ivx_dev_mesh_keep_largest(const float *verts, int64_t nverts, con
     hipLaunchKernelGGL(k_mesh_tricount, dim3((unsigned)ivx::cdiv(ntris, 256 * TPL)), dim3(256), 0, st, faces, ntris, root, cnt,
                        mintri);
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mesh_best, dim3(gv), dim3(256), 0, st, cnt, mintri, nverts, best, nreg);
+    hipLaunchKernelGGL(k_mesh_best, dim3(std::min(gv, 1024u)), dim3(256), 0, st, cnt, mintri, nverts, best, nreg);
     IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_mesh_mark, dim3(gt), dim3(256), 0, st, faces, ntris, root, mintri, best, keep, usedv);
     IVX_LAUNCH_CHECK();

@@ -34,19 +34,23 @@ __global__ __launch_bounds__(256) void k_sm_zero(uint32_t *__restrict__ a, int64
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = 0u;
 }
-__global__ __launch_bounds__(256) void k_sm_count(const int32_t *__restrict__ faces, int64_t nt, uint32_t *__restrict__ cnt) {
+// the counting pass keeps what atomicAdd returns (the entry's slot inside its vertex' list): the fill is then a plain scatter
+__global__ __launch_bounds__(256) void k_sm_count(const int32_t *__restrict__ faces, int64_t nt, uint32_t *__restrict__ cnt,
+                                                  uint32_t *__restrict__ slot) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * nt) atomicAdd(&cnt[(uint32_t)faces[i]], 1u);
+    if (i < 3 * nt) slot[i] = atomicAdd(&cnt[(uint32_t)faces[i]], 1u);
 }
 __global__ __launch_bounds__(256) void k_sm_fill(const int32_t *__restrict__ faces, int64_t nt, const uint32_t *__restrict__ foff,
-                                                 uint32_t *__restrict__ cursor, uint32_t *__restrict__ inc) {
+                                                 const uint32_t *__restrict__ slot, uint32_t *__restrict__ inc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * nt) return;
-    const uint32_t v = (uint32_t)faces[i];
-    inc[foff[v] + atomicAdd(&cursor[v], 1u)] = (uint32_t)(i / 3);
+    inc[foff[(uint32_t)faces[i]] + slot[i]] = (uint32_t)(i / 3);
 }
 
-// one lane per vertex: sort its incident faces, then list unique neighbours in the reference's order
+// one lane per vertex: sort its incident faces, then list unique neighbours in the reference's order.
+// Lists of up to RL entries (practically all of a marching-cubes surface: valence ~6) live in registers -- every loop
+// below is fully unrolled with constant indices -- longer ones spill over to their global slots.
+constexpr int RL = 12;
 __global__ __launch_bounds__(256) void k_sm_adjacency(const int32_t *__restrict__ faces, int64_t nv,
                                                       const uint32_t *__restrict__ foff, uint32_t *__restrict__ inc,
                                                       uint32_t *__restrict__ adjpad, uint32_t *__restrict__ deg) {
@@ -56,31 +60,71 @@ __global__ __launch_bounds__(256) void k_sm_adjacency(const int32_t *__restrict_
         deg[v] = 0u;
         return;
     }
-    const uint32_t b = foff[v], e = foff[v + 1];
-    for (uint32_t i = b + 1; i < e; i++) { // insertion sort: lists are ~6 long
-        const uint32_t x = inc[i];
-        uint32_t j = i;
-        while (j > b && inc[j - 1] > x) {
-            inc[j] = inc[j - 1];
-            j--;
-        }
-        inc[j] = x;
-    }
+    const uint32_t b = foff[v], e = foff[v + 1], len = e - b;
     uint32_t *out = adjpad + 2 * (int64_t)b;
-    uint32_t n = 0, last = 0xffffffffu;
-    for (uint32_t i = b; i < e; i++) {
-        const uint32_t f = inc[i];
-        if (f == last) continue; // a face listed twice (degenerate triangle) was already walked
-        last = f;
+    uint32_t n = 0;
+    uint32_t nb[RL];
+    auto add_face = [&](uint32_t f) {
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             const uint32_t vj = (uint32_t)faces[3 * (int64_t)f + q];
             if (vj == (uint32_t)v) continue;
             bool found = false;
-            for (uint32_t k = 0; k < n; k++) found |= out[k] == vj;
-            if (!found) out[n++] = vj;
+#pragma unroll
+            for (int k = 0; k < RL; k++) found |= (uint32_t)k < n && nb[k] == vj;
+            for (uint32_t k = RL; k < n; k++) found |= out[k] == vj;
+            if (found) continue;
+#pragma unroll
+            for (int k = 0; k < RL; k++)
+                if ((uint32_t)k == n) nb[k] = vj;
+            if (n >= (uint32_t)RL) out[n] = vj;
+            n++;
+        }
+    };
+    if (len <= (uint32_t)RL) {
+        uint32_t fl[RL];
+#pragma unroll
+        for (int k = 0; k < RL; k++) fl[k] = (uint32_t)k < len ? inc[b + k] : 0xffffffffu;
+        // odd-even transposition sort: RL passes of constant-index compare-exchanges (padding sorts to the end)
+#pragma unroll
+        for (int pass = 0; pass < RL; pass++) {
+#pragma unroll
+            for (int k = pass & 1; k + 1 < RL; k += 2) {
+                const uint32_t lo = fl[k] < fl[k + 1] ? fl[k] : fl[k + 1];
+                const uint32_t hi = fl[k] < fl[k + 1] ? fl[k + 1] : fl[k];
+                fl[k] = lo;
+                fl[k + 1] = hi;
+            }
+        }
+        uint32_t last = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < RL; k++) {
+            if ((uint32_t)k < len) {
+                inc[b + k] = fl[k]; // the staircase pass reads the sorted list
+                if (fl[k] != last) add_face(fl[k]); // a face listed twice (degenerate triangle) is walked once
+                last = fl[k];
+            }
+        }
+    } else {
+        for (uint32_t i = b + 1; i < e; i++) { // insertion sort in place
+            const uint32_t x = inc[i];
+            uint32_t j = i;
+            while (j > b && inc[j - 1] > x) {
+                inc[j] = inc[j - 1];
+                j--;
+            }
+            inc[j] = x;
+        }
+        uint32_t last = 0xffffffffu;
+        for (uint32_t i = b; i < e; i++) {
+            const uint32_t f = inc[i];
+            if (f != last) add_face(f);
+            last = f;
         }
     }
+#pragma unroll
+    for (int k = 0; k < RL; k++)
+        if ((uint32_t)k < n) out[k] = nb[k];
     deg[v] = n;
 }
 __global__ __launch_bounds__(256) void k_sm_compact_adj(int64_t nv, const uint32_t *__restrict__ foff,
@@ -320,15 +364,14 @@ static int build_topology(const int32_t *faces, int64_t nv, int64_t nt, const Sm
     int rc;
     hipLaunchKernelGGL(k_sm_zero, dim3(std::min(grid_for(nv + 2), 16384u)), dim3(256), 0, st, b.foff, nv + 2);
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sm_zero, dim3(std::min(grid_for(nv + 2), 16384u)), dim3(256), 0, st, b.cursor, nv + 2);
-    IVX_LAUNCH_CHECK();
+    uint32_t *slot = b.adj; // free until k_sm_compact_adj writes the adjacency
     if (nt) {
-        hipLaunchKernelGGL(k_sm_count, dim3(grid_for(3 * nt)), dim3(256), 0, st, faces, nt, b.foff);
+        hipLaunchKernelGGL(k_sm_count, dim3(grid_for(3 * nt)), dim3(256), 0, st, faces, nt, b.foff, slot);
         IVX_LAUNCH_CHECK();
     }
     if ((rc = scan_u32_exclusive(b.foff, nv + 1, b.bsum, b.misc + 8, st))) return rc;
     if (nt) {
-        hipLaunchKernelGGL(k_sm_fill, dim3(grid_for(3 * nt)), dim3(256), 0, st, faces, nt, b.foff, b.cursor, b.inc);
+        hipLaunchKernelGGL(k_sm_fill, dim3(grid_for(3 * nt)), dim3(256), 0, st, faces, nt, b.foff, slot, b.inc);
         IVX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_sm_adjacency, dim3(grid_for(nv + 1)), dim3(256), 0, st, faces, nv, b.foff, b.inc, b.adjpad, b.aoff);

@@ -116,3 +116,19 @@ def test_argument_errors(ivxlib):
     rs.context_aware_smoothing(np.zeros((0, 3), np.float32), np.zeros((0, 4), np.int64), np.zeros((0, 3)), 0.7, 3.0, 0.5, 2)
     with pytest.raises(ValueError):
         rs.Mesh()
+
+
+def test_high_valence_fan_spills_out_of_registers(ivxlib, oracle):
+    """a 40-triangle fan: the hub's incident-face and neighbour lists are longer than the in-register fast path"""
+    from invesalius3_amd import invesalius_rs as rs
+    k = 40
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    v = np.concatenate([[[0, 0, 0.3]], np.stack([np.cos(ang), np.sin(ang), 0 * ang], 1)]).astype(np.float32)
+    rng = np.random.default_rng(2)
+    order = rng.permutation(k)  # faces in scrambled order: the hub's neighbours appear in that order
+    f3 = np.array([[0, 1 + i, 1 + (i + 1) % k] for i in order], np.int32)
+    mesh = rs.Mesh.from_indexed(v, f3)
+    want = mesh.vertices.copy()
+    oracle.context_aware_smoothing(want, mesh.faces, mesh.normals, *OPTS)
+    rs.ca_smoothing(mesh, *OPTS)
+    assert np.array_equal(mesh.vertices, want)

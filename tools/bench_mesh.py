@@ -1,4 +1,7 @@
-"""Times the indexed-mesh path (point merge) next to the soup on the bench volume.  python tools/bench_mesh.py [n]"""
+"""Times the surface stages after marching cubes on the bench volume: indexed mesh (point merge), keep-largest,
+mass properties, context-aware smoothing -- device-resident, events on the volume's stream -- and the CPU oracle's
+smoothing on the same mesh for scale.  python tools/bench_mesh.py [n] [--cpu]"""
+import ctypes
 import json
 import sys
 import time
@@ -7,29 +10,82 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from bench import synth_v512  # noqa: E402
-from invesalius3_amd.device import DeviceVolume  # noqa: E402
+from invesalius3_amd import _lib as L  # noqa: E402
+from invesalius3_amd.device import DeviceBuffer, DeviceVolume  # noqa: E402
+
+
+def timed(vol, fn, reps=5):
+    fn()
+    vol.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    vol.sync()
+    return (time.perf_counter() - t0) * 1e3 / reps, r
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
+    cpu = "--cpu" in sys.argv
     img = synth_v512((n, n, n))
     vol = DeviceVolume(img, spacing=(0.5, 0.5, 0.5))
     vol.threshold(226, 3071)
-    out = {}
-    for name, fn in (("soup", vol.marching_cubes), ("indexed", vol.marching_cubes_indexed)):
-        fn()
+    lib = L.lib()
+    out = {"n": n}
+    out["soup_ms"], nt = timed(vol, vol.marching_cubes)
+    out["indexed_ms"], (nv, nt) = timed(vol, vol.marching_cubes_indexed)
+    out["verts"], out["tris"] = nv, nt
+    c64 = ctypes.c_int64
+    ov, of, mass = DeviceBuffer(nv * 12 + 16), DeviceBuffer(nt * 12 + 16), DeviceBuffer(64)
+    nrm = DeviceBuffer(nt * 24 + 16)
+    n1, n2, nr = c64(0), c64(0), c64(0)
+
+    def keep():
+        L.check(lib.ivx_dev_mesh_keep_largest(vol._verts.ptr, c64(nv), vol._faces.ptr, c64(nt), ov.ptr, c64(nv), of.ptr, c64(nt),
+                                              ctypes.byref(n1), ctypes.byref(n2), ctypes.byref(nr), vol.stream))
+        return n1.value, n2.value, nr.value
+
+    out["keep_largest_ms"], out["largest"] = timed(vol, keep)
+
+    def massp():
+        L.check(lib.ivx_dev_mesh_mass_properties(vol._verts.ptr, vol._faces.ptr, c64(nt), mass.ptr, vol.stream))
+
+    out["mass_ms"], _ = timed(vol, massp)
+    vol.sync()
+    out["volume_area"] = [float(x) for x in mass.download((8,), np.float64)[:2]]
+
+    def normals():
+        L.check(lib.ivx_dev_mesh_face_normals(vol._verts.ptr, L.F32, vol._faces.ptr, c64(nt), nrm.ptr, vol.stream))
+
+    out["normals_ms"], _ = timed(vol, normals)
+    verts0 = vol._verts.download((nv, 3), np.float32)
+    faces0 = vol._faces.download((nt, 3), np.int32)
+    work = DeviceBuffer(nv * 12 + 16)
+
+    def smooth(iters):
+        def run():
+            L.check(lib.ivx_memcpy_d2d(work.ptr, vol._verts.ptr, ctypes.c_size_t(nv * 12), vol.stream))
+            L.check(lib.ivx_dev_context_aware_smoothing(work.ptr, L.F32, c64(nv), vol._faces.ptr, c64(nt), nrm.ptr,
+                                                        ctypes.c_double(0.7), ctypes.c_double(3.0), ctypes.c_double(0.5),
+                                                        ctypes.c_int(iters), None, None, vol.stream))
+        return run
+
+    t0, _ = timed(vol, smooth(0), 3)
+    t10, _ = timed(vol, smooth(10), 3)
+    out["smooth_setup_ms"] = t0  # copy + topology + seeds + weights
+    out["smooth_10_steps_ms"] = t10 - t0
+    out["smooth_halfstep_us"] = (t10 - t0) / 20 * 1e3
+    if cpu:
+        from oracle import oracle
+        nrm_h = nrm.download((nt, 3), np.float64)
+        f4 = np.concatenate([np.full((nt, 1), 3), faces0], axis=1).astype(np.int64)
+        want = verts0.copy()
+        t = time.perf_counter()
+        oracle.context_aware_smoothing(want, f4, nrm_h, 0.7, 3.0, 0.5, 10)
+        out["cpu_oracle_smooth_s"] = time.perf_counter() - t
+        smooth(10)()
         vol.sync()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            r = fn()
-        vol.sync()
-        out[name] = {"ms": (time.perf_counter() - t0) * 100.0, "result": r}
-    nv, nt = out["indexed"]["result"]
-    out["bytes_soup"] = nt * 36
-    out["bytes_indexed"] = nv * 12 + nt * 12
-    verts, faces = vol.marching_cubes_indexed(download=True)
-    soup = vol.marching_cubes(download=True)
-    out["verts_faces_equal_soup"] = bool(np.array_equal(verts[faces], soup))
+        out["smooth_equals_oracle"] = bool(np.array_equal(work.download((nv, 3), np.float32), want))
     print(json.dumps(out))
 
 
