@@ -45,6 +45,8 @@ extern "C" {
 #define IVX_F64 2
 #define IVX_U16 3
 #define IVX_F32 4
+#define IVX_I32 5
+#define IVX_I64 6
 
 /* projection ops for ivx_*mip_reduce (numpy .max/.min/.mean, invesalius/data/slice_.py:885-889) */
 #define IVX_MIP_MAX 0
@@ -227,6 +229,41 @@ int ivx_mesh_propagate_weights(const void *verts, int vdtype, int64_t nverts, co
                                const uint8_t *seed_flags, double tmax, double bmin, double *weights);
 int ivx_mesh_face_normals(const void *verts, int vdtype, int64_t nverts, const int32_t *faces, int64_t ntris,
                           double *normals);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3-D mask editing (callers: invesalius/data/mask3d_editor_state.py:176,221,259)
+ *   ivx_*_mask_cut       replaces mask_cut        invesalius_rs/src/mask_cut_py.rs:9-69 -> mask_cut.rs:7-61
+ *                        out (dz,dy,dx) uint8 edited in place; mask2d (mh,mw) bytes (numpy bool); m, mv 4x4 row-major
+ *                        float64 (world->screen, world->camera); edit_mode 0 = include, 1 = exclude
+ *   ivx_*_brush_mask     replaces brush_mask_rs   invesalius_rs/src/brush_mask_py.rs:8-28 -> brush_mask.rs:5-71
+ *                        orig may be NULL (edit_mode 0 then paints 255)
+ *   ivx_*_polygon2mask   replaces polygon2mask_rs invesalius_rs/src/polygon_mask_py.rs:7-27 -> polygon_mask.rs:4-79
+ *                        out (w,h) bytes; points (npts,2) float64
+ *   ivx_*_count_regions  replaces count_regions   invesalius_rs/src/count_regions_py.rs:9-26 -> count_regions.rs:5-18
+ *                        labels IVX_I16 / IVX_I32 / IVX_I64; IVX_ERANGE where the reference panics (label outside
+ *                        [0, number_regions])
+ * Host forms take numpy-style byte strides.
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_mask_cut(uint8_t *out, int64_t dz, int64_t dy, int64_t dx, double sx, double sy, double sz, double max_depth,
+                     const uint8_t *mask2d, int64_t mh, int64_t mw, const double *m, const double *mv, int edit_mode,
+                     void *stream);
+int ivx_dev_brush_mask(uint8_t *out, const uint8_t *orig, int64_t dz, int64_t dy, int64_t dx, const double spacing[3],
+                       const double center[3], double radius, int edit_mode, void *stream);
+/* points_dev: device copy read by the kernel; points_host: the same points on the host (bounding box) */
+int ivx_dev_polygon2mask(int64_t w, int64_t h, const double *points_dev, const double *points_host, int64_t npts,
+                         uint8_t *out, void *stream);
+/* counts: device scratch of number_regions + 1 words; status: device int, non-zero after the call = label out of range */
+int ivx_dev_count_regions(int ldtype, const void *labels, int64_t n, int64_t number_regions, uint32_t *counts,
+                          uint32_t *out, int *status, void *stream);
+int ivx_mask_cut(uint8_t *out, const int64_t shape[3], const int64_t out_strides[3], double sx, double sy, double sz,
+                 double max_depth, const uint8_t *mask2d, int64_t mh, int64_t mw, const int64_t mask_strides[2],
+                 const double *m, const double *mv, int edit_mode);
+int ivx_brush_mask(uint8_t *out, const int64_t shape[3], const int64_t out_strides[3], const uint8_t *orig,
+                   const int64_t orig_strides[3], const double spacing[3], const double center[3], double radius,
+                   int edit_mode);
+int ivx_polygon2mask(int64_t w, int64_t h, const double *points, int64_t npts, uint8_t *out);
+int ivx_count_regions(int ldtype, const void *labels, const int64_t shape[3], const int64_t label_strides[3],
+                      int64_t number_regions, uint32_t *out);
 
 /* ------------------------------------------------------------------------------------------------
  * seeded region growing

@@ -269,3 +269,84 @@ def propagate_weights(vertices, faces3, seed_flags, tmax, bmin):
                                                ctypes.c_int64(len(f3)), L.ptr(s), ctypes.c_double(tmax),
                                                ctypes.c_double(bmin), L.ptr(w)), "mesh_propagate_weights")
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3-D mask editing: mask_cut / brush_mask_rs / polygon2mask_rs (invesalius_rs/__init__.py:86-88) and count_regions
+# (invesalius_rs/__init__.py:108-111)
+# ---------------------------------------------------------------------------------------------------------------------
+def _mat4(a, name):
+    a = np.asarray(a)
+    if a.dtype != np.float64 or a.ndim != 2:
+        raise TypeError("%s must be a 2-D float64 array" % name)
+    if a.shape != (4, 4):
+        raise ValueError("%s must be 4x4" % name)  # Matrix4::from_row_slice panics on any other length
+    return np.ascontiguousarray(a)
+
+
+def mask_cut(image, sx, sy, sz, max_depth, mask, m, mv, out, edit_mode):
+    """mask_cut_py.rs:9-69.  ``image`` is only type-checked (the reference never reads it); ``out`` uint8 (d,h,w) is
+    edited in place; ``mask`` is the 2-D bool polygon filter, ``m`` / ``mv`` the world->screen and world->camera
+    matrices."""
+    if not isinstance(image, np.ndarray) or image.ndim != 3 or image.dtype not in (np.int16, np.uint8, np.float64):
+        raise TypeError("Invalid image or mask type")
+    if not isinstance(out, np.ndarray) or out.ndim != 3 or out.dtype != np.uint8:
+        raise TypeError("Invalid image or mask type")
+    if not isinstance(mask, np.ndarray) or mask.dtype != np.bool_ or mask.ndim != 2:
+        raise TypeError("mask must be a 2-D bool array")
+    if not out.flags.writeable:
+        raise TypeError("out must be writable")
+    m, mv = _mat4(m, "m"), _mat4(mv, "mv")
+    mk = mask.view(np.uint8)
+    L.check(L.lib().ivx_mask_cut(L.ptr(out), L.i64(out.shape), L.i64(out.strides), ctypes.c_double(sx), ctypes.c_double(sy),
+                                 ctypes.c_double(sz), ctypes.c_double(max_depth), L.ptr(mk), ctypes.c_int64(mk.shape[0]),
+                                 ctypes.c_int64(mk.shape[1]), L.i64(mk.strides), L.ptr(m), L.ptr(mv),
+                                 ctypes.c_int(int(edit_mode))), "mask_cut")
+
+
+def brush_mask_rs(out, orig, spacing, center, radius, edit_mode):
+    """brush_mask_py.rs:8-28: spherical brush on a uint8 mask, in place.  edit_mode 1 erases, 0 reveals ``orig``
+    (or paints 255 when ``orig`` is None)."""
+    if not isinstance(out, np.ndarray) or out.ndim != 3 or out.dtype != np.uint8:
+        raise TypeError("Invalid mask type for brush mask")
+    if orig is not None and (not isinstance(orig, np.ndarray) or orig.ndim != 3 or orig.dtype != np.uint8):
+        raise TypeError("orig must be a 3-D uint8 array or None")
+    if orig is not None and orig.shape != out.shape:
+        raise IndexError("orig and out differ in shape")  # orig_array[[z, y, x]] would panic
+    if not out.flags.writeable:
+        raise TypeError("out must be writable")
+    sp = (ctypes.c_double * 3)(*[float(v) for v in spacing])
+    ce = (ctypes.c_double * 3)(*[float(v) for v in center])
+    L.check(L.lib().ivx_brush_mask(L.ptr(out), L.i64(out.shape), L.i64(out.strides), L.ptr(orig) if orig is not None else None,
+                                   L.i64(orig.strides) if orig is not None else None, sp, ce, ctypes.c_double(radius),
+                                   ctypes.c_int(int(edit_mode))), "brush_mask")
+
+
+def polygon2mask_rs(shape, polygon):
+    """polygon_mask_py.rs:7-27: ``shape`` = (w, h); ``polygon`` (N,2) float64 points; returns a (w,h) bool array."""
+    w, h = (int(v) for v in shape)
+    if w < 0 or h < 0:
+        raise OverflowError("shape must be non-negative")
+    if not isinstance(polygon, np.ndarray) or polygon.dtype != np.float64 or polygon.ndim != 2:
+        raise TypeError("polygon must be a 2-D float64 array")
+    if polygon.shape[0] and polygon.shape[1] < 2:
+        raise IndexError("polygon rows need two coordinates")
+    pts = np.ascontiguousarray(polygon[:, :2])
+    out = np.zeros((w, h), np.uint8)
+    L.check(L.lib().ivx_polygon2mask(ctypes.c_int64(w), ctypes.c_int64(h), L.ptr(pts), ctypes.c_int64(len(pts)), L.ptr(out)),
+            "polygon2mask")
+    return out.view(np.bool_)
+
+
+def count_regions(image, number_regions):
+    """invesalius_rs/__init__.py:108-111: uint32 array holding, for every voxel, the number of voxels that carry its
+    label.  Labels are int16 / int32 / int64 in [0, number_regions]; anything else is where the reference panics."""
+    if not isinstance(image, np.ndarray) or image.ndim != 3 or image.dtype not in (np.int16, np.int32, np.int64):
+        raise TypeError("labels must be a 3-D int16, int32 or int64 array")
+    if int(number_regions) < 0:
+        raise OverflowError("number_regions must be non-negative")
+    out = np.zeros(image.shape, np.uint32)
+    L.check(L.lib().ivx_count_regions(L.dtype_code(image, (L.I16, L.I32, L.I64)), L.ptr(image), L.i64(image.shape),
+                                      L.i64(image.strides), ctypes.c_int64(int(number_regions)), L.ptr(out)),
+            "count_regions")  # IVX_ERANGE -> IndexError
+    return out

@@ -500,3 +500,45 @@ def mesh_face_normals(vertices, faces3):
     ln = np.sqrt(n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1] + n[:, 2] * n[:, 2])
     with np.errstate(invalid="ignore", divide="ignore"):
         return np.where(ln[:, None] != 0.0, n / ln[:, None], n)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3-D mask editing kernels (oracle/ivx_oracle_edit.c)
+# ---------------------------------------------------------------------------------------------------------------------
+def mask_cut(out, sx, sy, sz, max_depth, mask, m, mv, edit_mode):
+    """in place on a C-contiguous uint8 (d,h,w) array"""
+    assert out.dtype == np.uint8 and out.flags.c_contiguous
+    mk = np.ascontiguousarray(mask).view(np.uint8)
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    mv = np.ascontiguousarray(mv, dtype=np.float64)
+    lib().orc_mask_cut(ctypes.c_double(sx), ctypes.c_double(sy), ctypes.c_double(sz), ctypes.c_double(max_depth),
+                       ctypes.c_void_p(mk.ctypes.data), ctypes.c_int64(mk.shape[0]), ctypes.c_int64(mk.shape[1]),
+                       ctypes.c_void_p(m.ctypes.data), ctypes.c_void_p(mv.ctypes.data), ctypes.c_void_p(out.ctypes.data),
+                       _i64(out.shape), ctypes.c_int(edit_mode))
+
+
+def brush_mask(out, orig, spacing, center, radius, edit_mode):
+    assert out.dtype == np.uint8 and out.flags.c_contiguous
+    o = np.ascontiguousarray(orig) if orig is not None else None
+    lib().orc_brush_mask(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(o.ctypes.data) if o is not None else None,
+                         _i64(out.shape), (ctypes.c_double * 3)(*spacing), (ctypes.c_double * 3)(*center),
+                         ctypes.c_double(radius), ctypes.c_int(edit_mode))
+
+
+def polygon2mask(shape, polygon):
+    w, h = shape
+    pts = np.ascontiguousarray(polygon, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros((w, h), np.uint8)
+    lib().orc_polygon2mask(ctypes.c_int64(w), ctypes.c_int64(h), ctypes.c_void_p(pts.ctypes.data), ctypes.c_int64(len(pts)),
+                           ctypes.c_void_p(out.ctypes.data))
+    return out.view(np.bool_)
+
+
+def count_regions(image, number_regions):
+    lab = np.ascontiguousarray(image, dtype=np.int64)
+    out = np.zeros(lab.shape, np.uint32)
+    rc = lib().orc_count_regions(ctypes.c_void_p(lab.ctypes.data), ctypes.c_int64(lab.size), ctypes.c_int64(number_regions),
+                                 ctypes.c_void_p(out.ctypes.data))
+    if rc == -1:
+        raise IndexError("label out of range")
+    return out

@@ -1,0 +1,124 @@
+"""3-D mask editing kernels (mask_cut, brush_mask_rs, polygon2mask_rs, count_regions of invesalius_rs) -- HIP path vs
+the C restatements, bit for bit, through the reference's python call surface."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _camera(shape, spacing):
+    """a perspective world->screen matrix and a world->camera matrix looking at the volume centre"""
+    d, h, w = shape
+    c = np.array([w * spacing[0], h * spacing[1], d * spacing[2]]) / 2.0
+    eye = c + np.array([0.3 * w * spacing[0], -0.2 * h * spacing[1], 2.2 * d * spacing[2]])
+    f = c - eye
+    f /= np.linalg.norm(f)
+    s = np.cross(f, [0.0, 1.0, 0.0])
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    view = np.eye(4)
+    view[0, :3], view[1, :3], view[2, :3] = s, u, -f
+    view[:3, 3] = -view[:3, :3] @ eye
+    near, far, t = 1.0, 1e4, 0.6
+    proj = np.array([[1 / t, 0, 0, 0], [0, 1 / t, 0, 0], [0, 0, -(far + near) / (far - near), -2 * far * near / (far - near)],
+                     [0, 0, -1, 0]])
+    return np.ascontiguousarray(proj @ view), np.ascontiguousarray(view)
+
+
+@pytest.mark.parametrize("edit_mode", [0, 1])
+@pytest.mark.parametrize("shape", [(40, 48, 64), (7, 9, 13)])
+def test_mask_cut_matches_oracle(ivxlib, oracle, edit_mode, shape):
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(11)
+    sp = (0.5, 0.5, 1.25)
+    out = rng.choice(np.array([0, 1, 127, 128, 254, 255], np.uint8), size=shape, p=[0.5, 0.05, 0.05, 0.05, 0.05, 0.3])
+    m, mv = _camera(shape, sp)
+    poly = rs.polygon2mask_rs((60, 80), np.array([[10.0, 12.0], [50.0, 20.0], [44.0, 70.0], [15.0, 55.0]]))
+    filt = np.ascontiguousarray(poly.T)  # (h, w) as the caller hands it over
+    depth = float(np.linalg.norm(mv[:3, 3])) * 1.02
+    want = out.copy()
+    oracle.mask_cut(want, *sp, depth, filt, m, mv, edit_mode)
+    image = np.zeros(shape, np.int16)
+    got = out.copy()
+    rs.mask_cut(image, *sp, depth, filt, m, mv, got, edit_mode)
+    assert np.array_equal(got, want)
+    assert 0 < (got != out).sum() < out.size
+    # strided target: the interior view of a (d+1,h+1,w+1) mask matrix, as mask3d_editor_state uses it
+    big = np.zeros(tuple(s + 1 for s in shape), np.uint8)
+    big[1:, 1:, 1:] = out
+    rs.mask_cut(image, *sp, depth, filt, m, mv, big[1:, 1:, 1:], edit_mode)
+    assert np.array_equal(big[1:, 1:, 1:], want) and not big[0].any() and not big[:, 0].any() and not big[:, :, 0].any()
+
+
+def test_mask_cut_type_errors(ivxlib):
+    from invesalius3_amd import invesalius_rs as rs
+    out = np.zeros((2, 2, 2), np.uint8)
+    img = np.zeros((2, 2, 2), np.int16)
+    e = np.eye(4)
+    with pytest.raises(TypeError):
+        rs.mask_cut(img.astype(np.float32), 1, 1, 1, 1, np.zeros((2, 2), bool), e, e, out, 0)
+    with pytest.raises(TypeError):
+        rs.mask_cut(img, 1, 1, 1, 1, np.zeros((2, 2), bool), e, e, out.astype(np.int16), 0)
+    with pytest.raises(TypeError):
+        rs.mask_cut(img, 1, 1, 1, 1, np.zeros((2, 2), np.uint8), e, e, out, 0)
+    with pytest.raises(TypeError):
+        rs.mask_cut(img, 1, 1, 1, 1, np.zeros((2, 2), bool), e.astype(np.float32), e, out, 0)
+
+
+@pytest.mark.parametrize("edit_mode", [0, 1, 5])
+@pytest.mark.parametrize("with_orig", [True, False])
+def test_brush_mask_matches_oracle(ivxlib, oracle, edit_mode, with_orig):
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(5)
+    shape = (30, 33, 41)
+    base = rng.choice(np.array([0, 1, 200, 255], np.uint8), size=shape)
+    orig = rng.choice(np.array([0, 3, 254], np.uint8), size=shape) if with_orig else None
+    for centre, radius in (((10.2, 8.1, 20.5), 4.7), ((0.3, 16.0, 58.0), 6.0), ((-40.0, 5.0, 5.0), 3.0), ((9.0, 9.0, 9.0), 0.0)):
+        want = base.copy()
+        oracle.brush_mask(want, orig, (0.5, 0.5, 2.0), centre, radius, edit_mode)
+        got = base.copy()
+        rs.brush_mask_rs(got, orig, (0.5, 0.5, 2.0), centre, radius, edit_mode)
+        assert np.array_equal(got, want)
+    with pytest.raises(TypeError):
+        rs.brush_mask_rs(base.astype(np.int16), None, (1, 1, 1), (0, 0, 0), 1.0, 1)
+
+
+def test_polygon2mask_matches_oracle(ivxlib, oracle):
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(9)
+    for shape, n in (((64, 48), 3), ((200, 150), 17), ((31, 77), 40), ((5, 5), 0), ((0, 9), 4)):
+        pts = rng.uniform(-10, max(shape) + 10, (n, 2))
+        got = rs.polygon2mask_rs(shape, pts)
+        want = oracle.polygon2mask(shape, pts)
+        assert got.dtype == np.bool_ and got.shape == tuple(shape)
+        assert np.array_equal(got, want)
+    # integer-valued vertices sit exactly on pixel centres: the strict/non-strict comparisons must agree too
+    pts = np.array([[4.0, 4.0], [20.0, 4.0], [20.0, 16.0], [12.0, 10.0], [4.0, 16.0]])
+    assert np.array_equal(rs.polygon2mask_rs((24, 20), pts), oracle.polygon2mask((24, 20), pts))
+    with pytest.raises(TypeError):
+        rs.polygon2mask_rs((4, 4), pts.astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32, np.int64])
+def test_count_regions_matches_oracle(ivxlib, oracle, dtype):
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(3)
+    lab = np.zeros((24, 40, 64), dtype)
+    lab[rng.random(lab.shape) < 0.2] = 1
+    lab[5:9, 5:20, 3:60] = 7
+    lab[rng.random(lab.shape) < 0.01] = rng.integers(2, 300)
+    nreg = int(lab.max())
+    got = rs.count_regions(lab, nreg)
+    assert got.dtype == np.uint32 and np.array_equal(got, oracle.count_regions(lab, nreg))
+    assert np.array_equal(got, np.bincount(lab.ravel().astype(np.int64), minlength=nreg + 1)[lab])
+    # a non-contiguous view
+    view = lab[::2, 1:, ::3]
+    assert np.array_equal(rs.count_regions(view, nreg), oracle.count_regions(view, nreg))
+    with pytest.raises(IndexError):
+        rs.count_regions(lab, nreg - 1)
+    neg = lab.copy()
+    neg[0, 0, 0] = -1
+    with pytest.raises(IndexError):
+        rs.count_regions(neg, nreg)
+    with pytest.raises(TypeError):
+        rs.count_regions(lab.astype(np.uint8), nreg)
