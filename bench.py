@@ -145,7 +145,7 @@ def main():
 
     def step():
         with vol.timer.span("zero_out_mask"):
-            vol.out_mask.zero(vol.stream)
+            vol.zero_out_mask()
         with vol.timer.span("threshold"):
             vol.threshold(BONE[0], BONE[1], preserve=False)
         with vol.timer.span("region_grow"):

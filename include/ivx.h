@@ -90,6 +90,11 @@ int ivx_release_workspace(void);
  * ---------------------------------------------------------------------------------------------- */
 int ivx_dev_threshold_i16(const int16_t *img, int64_t dz, int64_t dy, int64_t dx, int lo, int hi,
                           int preserve, const uint8_t *skip_flags, uint8_t *mask, void *stream);
+/* threshold (no preserve rule, no skip flags) that also emits the mask's inside-bit plane (mask >= 127), in the
+ * layout of the region-growing / marching-cubes planes (64 x-voxels per uint64).  Needs dx % 64 == 0 and 16-byte
+ * aligned buffers (IVX_EINVAL otherwise: use ivx_dev_threshold_i16).  bits: dz*dy*(dx/64) words. */
+int ivx_dev_threshold_i16_bits(const int16_t *img, int64_t dz, int64_t dy, int64_t dx, int lo, int hi, uint8_t *mask,
+                               uint64_t *bits, void *stream);
 /* Host form.  `mask` points at the FULL (dz+1,dy+1,dx+1) matrix of invesalius/data/mask.py:422-431
  * (flag cells in the index-0 planes); strides in bytes.  With honour_flags the per-slice flag
  * mask[n,0,0] is tested and then set to 1 (slice_.py:1761-1767); without it every slice is
@@ -159,6 +164,9 @@ typedef struct ivx_mc_params {
 int ivx_dev_mc_scratch_bytes(const ivx_mc_params *p, size_t *nbytes);
 /* classify + per-row-group triangle counts + scan; *ntris (host) receives the total */
 int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch, int64_t *ntris, void *stream);
+/* same, from an inside plane (value >= iso[0]) the caller already holds; niso must be 1 */
+int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch, int64_t *ntris,
+                          void *stream);
 /* emit; must follow ivx_dev_mc_count with the same params/scratch */
 int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *tris, int64_t max_tris,
                     void *stream);
@@ -302,6 +310,8 @@ int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *r
 int ivx_dev_flood_mark_slab(const ivx_flood_plan *p, void *scratch, int64_t z0, int64_t z1, void *stream);
 /* multi-GPU slab halo: reached[z] |= plane & cand[z] (plane = the Z-neighbour's boundary plane, dy*wx words);
  * *changed (host) = number of words that gained bits; the tiles touching z are re-marked dirty */
+/* whole-plane dst |= src (op 0) / dst &= ~src (op 1) */
+int ivx_dev_bits_combine(uint64_t *dst, const uint64_t *src, int64_t nwords, int op, void *stream);
 int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z,
                            const uint64_t *plane, void *scratch, int *changed, void *stream);
 /* out[v] = fill where reached (uint8 out), or data[v] = fill (in-place form, dtype of data) */

@@ -959,6 +959,23 @@ __global__ __launch_bounds__(256) void k_flood_or_plane(unsigned long long *__re
     }
 }
 
+__global__ __launch_bounds__(256) void k_bits_combine(unsigned long long *__restrict__ dst,
+                                                      const unsigned long long *__restrict__ src, int64_t n, int op) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = op == 0 ? (dst[i] | src[i]) : (dst[i] & ~src[i]);
+}
+// whole-plane dst |= src (op 0) or dst &= ~src (op 1): keeps a derived inside plane in step with `mask[reached] = v`
+extern "C" int ivx_dev_bits_combine(uint64_t *dst, const uint64_t *src, int64_t nwords, int op, void *stream) {
+    IVX_REQUIRE(nwords >= 0 && (op == 0 || op == 1), IVX_EINVAL, "bits_combine: bad arguments");
+    if (nwords == 0) return IVX_OK;
+    const int64_t blocks = ivx::cdiv(nwords, 256);
+    hipLaunchKernelGGL(k_bits_combine, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, ivx::S(stream),
+                       (unsigned long long *)dst, (const unsigned long long *)src, nwords, op);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
 extern "C" int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z,
                                       const uint64_t *plane, void *scratch_, int *changed, void *stream) {
     Tiles t;

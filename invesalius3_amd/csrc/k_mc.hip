@@ -705,22 +705,11 @@ extern "C" int ivx_dev_mc_scratch_bytes(const ivx_mc_params *p, size_t *nbytes) 
     return IVX_OK;
 }
 
-extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch_, int64_t *ntris, void *stream) {
-    Geom g;
-    int rc = make_geom(p, &g);
-    if (rc) return rc;
-    const Scratch s = make_scratch(g, p->niso);
+// classify + count + scan over the inside planes already sitting in scratch
+static int mc_count_planes(const ivx_mc_params *p, const Geom &g, const Scratch &s, void *scratch_, int64_t *ntris,
+                           hipStream_t st) {
     char *scratch = (char *)scratch_;
-    hipStream_t st = ivx::S(stream);
-    *ntris = 0;
-    if (s.nwords == 0) return IVX_OK;
-    IVX_REQUIRE(s.nblocks * (size_t)p->niso < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
-    switch (p->dtype) {
-    case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
-    case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
-    default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
-    }
-    if (rc) return rc;
+    int rc;
     uint32_t *bsum = (uint32_t *)(scratch + s.off_bsum);
     uint64_t *boff = (uint64_t *)(scratch + s.off_boff);
     for (int q = 0; q < p->niso; q++) {
@@ -745,6 +734,44 @@ extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scr
     if ((rc = ivx::mailbox_wait(seq, st, tw, 2))) return rc;
     *ntris = (int64_t)(((uint64_t)tw[1] << 32) | tw[0]);
     return IVX_OK;
+}
+
+extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch_, int64_t *ntris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    const Scratch s = make_scratch(g, p->niso);
+    char *scratch = (char *)scratch_;
+    hipStream_t st = ivx::S(stream);
+    *ntris = 0;
+    if (s.nwords == 0) return IVX_OK;
+    IVX_REQUIRE(s.nblocks * (size_t)p->niso < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
+    switch (p->dtype) {
+    case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+    case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+    default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+    }
+    if (rc) return rc;
+    return mc_count_planes(p, g, s, scratch_, ntris, st);
+}
+
+// Same, with the inside plane (value >= iso[0], source coordinates, the layout of the region-growing planes) handed in
+// instead of being derived from the voxels: a resident pipeline that already holds it (ivx_dev_threshold_i16_bits)
+// skips the pass over the volume.  One iso-value only.
+extern "C" int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch_, int64_t *ntris,
+                                     void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    IVX_REQUIRE(p->niso == 1, IVX_EINVAL, "mc_count_bits: one iso-value only");
+    const Scratch s = make_scratch(g, p->niso);
+    hipStream_t st = ivx::S(stream);
+    *ntris = 0;
+    if (s.nwords == 0) return IVX_OK;
+    IVX_REQUIRE(s.nblocks < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
+    if (s.bits_words)
+        IVX_HIP(hipMemcpyAsync((char *)scratch_ + s.off_bits, inside_bits, s.bits_words * 8, hipMemcpyDeviceToDevice, st));
+    return mc_count_planes(p, g, s, scratch_, ntris, st);
 }
 
 extern "C" int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *tris,

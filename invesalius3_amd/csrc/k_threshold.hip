@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void k_threshold16(const short8_t *__restrict_
     }
 }
 
+// threshold + the mask's inside-bit plane (mask >= 127 <=> in range) in one pass: 2 B read, 1 + 1/8 B written per voxel.
+// The plane has the layout the region-growing and marching-cubes kernels share (64 x-voxels per uint64, rows whole
+// words: requires dx % 64 == 0), so a resident pipeline gets the flood's candidate plane and the surface's inside
+// plane as by-products of the pass that reads the image anyway.
+__global__ __launch_bounds__(256) void k_threshold16_bits(const short8_t *__restrict__ img, uchar16_t *__restrict__ mask,
+                                                          uint16_t *__restrict__ bits, int64_t nchunks, int lo, int hi) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += stride) {
+        const short8_t a = __builtin_nontemporal_load(&img[2 * c]);
+        const short8_t b = __builtin_nontemporal_load(&img[2 * c + 1]);
+        uchar16_t r;
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool in0 = (int)a[i] >= lo && (int)a[i] <= hi, in1 = (int)b[i] >= lo && (int)b[i] <= hi;
+            r[i] = in0 ? 255 : 0;
+            r[8 + i] = in1 ? 255 : 0;
+            m |= (in0 ? 1u : 0u) << i;
+            m |= (in1 ? 1u : 0u) << (8 + i);
+        }
+        mask[c] = r;
+        bits[c] = (uint16_t)m;
+    }
+}
+
 // scalar path: tails, unaligned pointers, slices whose size is not a multiple of 16
 template <bool PRESERVE>
 __global__ __launch_bounds__(256) void k_threshold1(const int16_t *__restrict__ img, uint8_t *__restrict__ mask,
@@ -96,6 +121,21 @@ extern "C" int ivx_dev_threshold_i16(const int16_t *img, int64_t dz, int64_t dy,
                                hi, skip_flags, slice);
         IVX_LAUNCH_CHECK();
     }
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_threshold_i16_bits(const int16_t *img, int64_t dz, int64_t dy, int64_t dx, int lo, int hi,
+                                          uint8_t *mask, uint64_t *bits, void *stream) {
+    IVX_REQUIRE(dz >= 0 && dy >= 0 && dx >= 0, IVX_EINVAL, "threshold: negative shape");
+    IVX_REQUIRE(dx % 64 == 0 && (((uintptr_t)img | (uintptr_t)mask | (uintptr_t)bits) & 15) == 0, IVX_EINVAL,
+                "threshold_bits: needs dx %% 64 == 0 and 16-byte aligned buffers (use ivx_dev_threshold_i16)");
+    const int64_t n = dz * dy * dx;
+    if (n == 0) return IVX_OK;
+    const int64_t nchunks = n / 16;
+    const int64_t blocks = ivx::cdiv(nchunks, 256);
+    hipLaunchKernelGGL(k_threshold16_bits, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, ivx::S(stream),
+                       (const short8_t *)img, (uchar16_t *)mask, (uint16_t *)bits, nchunks, lo, hi);
+    IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
 

@@ -8,6 +8,7 @@ HIP stream owned by the object, and `Timer` records HIP events on that same stre
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -50,6 +51,40 @@ class DeviceBuffer:
             self.close()
         except Exception:
             pass
+
+
+class TrackedBuffer(DeviceBuffer):
+    """A DeviceBuffer that reports every access from outside its owner (`ptr`, and through it upload / zero / at):
+    the owner then stops trusting what it derived from the contents (DeviceVolume's inside-bit plane of the mask,
+    the "out_mask is all zero" note).  The owner's own kernels use `raw`."""
+
+    def __init__(self, nbytes: int, on_touch):
+        self._on_touch = None
+        super().__init__(nbytes)
+        self._on_touch = on_touch
+
+    @property
+    def ptr(self):
+        if self._on_touch is not None:
+            self._on_touch()
+        return self._p
+
+    @ptr.setter
+    def ptr(self, v):
+        self._p = v
+
+    @property
+    def raw(self):
+        return self._p
+
+    def download(self, shape, dtype) -> np.ndarray:  # reading changes nothing
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        L.check(L.lib().ivx_memcpy_d2h(L.ptr(out), self._p, ctypes.c_size_t(out.nbytes)))
+        return out
+
+    def raw_at(self, offset_bytes: int) -> ctypes.c_void_p:
+        return ctypes.c_void_p(self._p.value + int(offset_bytes))
 
 
 class Timer:
@@ -114,13 +149,19 @@ class DeviceVolume:
         L.check(L.lib().ivx_stream_create(ctypes.byref(s)))
         self.stream = s
         self.timer = Timer(self.stream)
-        self.image = DeviceBuffer(self.n * 2)
-        self.mask = DeviceBuffer(self.n)       # dense interior of mask.matrix[1:,1:,1:]
-        self.out_mask = DeviceBuffer(self.n)   # region-growing `out` (styles.py:3190)
+        # Derived state the pipeline keeps about its buffers (see `threshold`): any access to these three buffers from
+        # outside this class's own kernels (their .ptr / upload / zero) drops the corresponding note.
+        self._mbits_valid = False   # self._mbits == (mask >= 127), the inside plane marching cubes needs at iso 127
+        self._mbits_range = None    # (lo, hi) while additionally _mbits == (lo <= image <= hi)
+        self._out_zero = False      # out_mask is all zero
+        self._fuse = os.environ.get("IVX_NO_FUSE", "") == ""
+        self.image = TrackedBuffer(self.n * 2, self._image_touched)
+        self.mask = TrackedBuffer(self.n, self._mask_touched)       # dense interior of mask.matrix[1:,1:,1:]
+        self.out_mask = TrackedBuffer(self.n, self._out_touched)    # region-growing `out` (styles.py:3190)
         if image is not None:
             self.image.upload(image)
         self.mask.zero(self.stream)
-        self.out_mask.zero(self.stream)
+        self.zero_out_mask()
         # region growing bit planes + tile work-list
         self.plan = L.FloodPlan(self.dz, self.dy, self.dx, (self.dx + 63) // 64, 0)
         nb, ns = ctypes.c_size_t(0), ctypes.c_size_t(0)
@@ -128,6 +169,8 @@ class DeviceVolume:
         L.check(L.lib().ivx_flood_scratch_bytes(ctypes.byref(self.plan), ctypes.byref(ns)))
         self.cand = DeviceBuffer(nb.value)
         self.reached = DeviceBuffer(nb.value)
+        self._mbits = DeviceBuffer(nb.value)
+        self._plane_words = nb.value // 8
         self.flood_scratch = DeviceBuffer(ns.value)
         self._mc_scratch = None
         self._tris = None
@@ -136,12 +179,27 @@ class DeviceVolume:
         self.sync()
 
     # -- plumbing -------------------------------------------------------------------------------------
+    def _image_touched(self):
+        self._mbits_range = None
+
+    def _mask_touched(self):
+        self._mbits_valid = False
+        self._mbits_range = None
+
+    def _out_touched(self):
+        self._out_zero = False
+
+    def zero_out_mask(self):
+        """out_mask = zeros (the np.zeros of styles.py:3190), remembered so that region growing can skip reading it"""
+        L.check(L.lib().ivx_memset(self.out_mask.raw, 0, ctypes.c_size_t(self.n), self.stream))
+        self._out_zero = True
+
     def sync(self):
         L.check(L.lib().ivx_stream_synchronize(self.stream))
 
     def close(self):
-        for b in (self.image, self.mask, self.out_mask, self.cand, self.reached, self.flood_scratch, self._mc_scratch,
-                  self._tris, self._verts, self._faces):
+        for b in (self.image, self.mask, self.out_mask, self.cand, self.reached, self._mbits, self.flood_scratch,
+                  self._mc_scratch, self._tris, self._verts, self._faces):
             if b is not None:
                 b.close()
         if self.stream is not None:
@@ -158,15 +216,26 @@ class DeviceVolume:
 
     # -- threshold (slice_.py:1240-1247 / 1722-1769) -------------------------------------------------------
     def threshold(self, lo: int, hi: int, preserve: bool = False):
-        L.check(L.lib().ivx_dev_threshold_i16(self.image.ptr, c64(self.dz), c64(self.dy), c64(self.dx), int(lo), int(hi),
-                                              int(bool(preserve)), None, self.mask.ptr, self.stream), "threshold")
+        """mask = 255 where lo <= image <= hi else 0 (with the preserve rule of do_threshold_to_a_slice when asked).
+        When the rows are whole 64-voxel words the same pass also writes the mask's inside-bit plane (1/8 B/voxel
+        more): it IS the candidate plane of a region growing with the same thresholds into a zero out_mask, and the
+        inside plane of marching cubes at iso 127 -- both then skip their own pass over the volume."""
+        lib = L.lib()
+        if self._fuse and not preserve and self.dx % 64 == 0:
+            L.check(lib.ivx_dev_threshold_i16_bits(self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(lo), int(hi),
+                                                   self.mask.raw, self._mbits.ptr, self.stream), "threshold")
+            self._mbits_valid, self._mbits_range = True, (int(lo), int(hi))
+            return
+        L.check(lib.ivx_dev_threshold_i16(self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(lo), int(hi),
+                                          int(bool(preserve)), None, self.mask.raw, self.stream), "threshold")
+        self._mask_touched()
 
     # -- region growing (floodfill.rs:96-166 on the image; styles.py:3151-3216) ----------------------------
     def lut_image_255(self, ww, wl) -> DeviceBuffer:
         """get_LUT_value_255(image, ww, wl) (imagedata_utils.py:540-552) as a resident int16 volume: the image the
         "dynamic" and "confidence" region-growing modes flood when use_ww_wl is set (styles.py:3166-3171, 3222-3225)."""
         buf = DeviceBuffer(self.n * 2)
-        L.check(L.lib().ivx_dev_lut_i16(self.image.ptr, c64(self.n), ctypes.c_double(float(ww)), ctypes.c_double(float(wl)),
+        L.check(L.lib().ivx_dev_lut_i16(self.image.raw, c64(self.n), ctypes.c_double(float(ww)), ctypes.c_double(float(wl)),
                                         1, buf.ptr, self.stream), "lut_image_255")
         return buf
 
@@ -176,7 +245,7 @@ class DeviceVolume:
         by `mask[out_mask.astype(bool)] = select_value` (styles.py:3214).  `image` = an alternative resident int16
         volume (e.g. lut_image_255).  Returns the number of global rounds."""
         lib = L.lib()
-        img_ptr = (image or self.image).ptr
+        img_ptr = image.ptr if image is not None else self.image.raw
         s3 = np.ascontiguousarray(strct, dtype=np.uint8)
         bits = ctypes.c_uint32(0)
         L.check(lib.ivx_flood_strct_bits(L.ptr(s3), L.i64(s3.shape), ctypes.byref(bits)))
@@ -186,19 +255,31 @@ class DeviceVolume:
         st = self.stream
         t0, t1 = float(int(t0)), float(int(t1))  # wrapper int() truncation for integer images
         L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
-        L.check(lib.ivx_dev_flood_candidates(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1),
-                                             self.out_mask.ptr, 1, ctypes.c_double(fill), self.cand.ptr, st))
+        # candidates = in range AND out_mask != fill.  With out_mask known to be zero (fill != 0) and the mask's plane
+        # known to be "image in [t0, t1]", the plane the threshold pass left behind is exactly that: no pass needed.
+        shared = (image is None and self._mbits_valid and self._out_zero and int(fill) != 0
+                  and self._mbits_range == (int(t0), int(t1)))
+        cand = self._mbits if shared else self.cand
+        if not shared:
+            L.check(lib.ivx_dev_flood_candidates(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1),
+                                                 self.out_mask.raw, 1, ctypes.c_double(fill), cand.ptr, st))
         L.check(lib.ivx_dev_flood_seed(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
-                                       c64(len(seeds)), self.cand.ptr, self.reached.ptr, self.flood_scratch.ptr, st),
-                "region_grow")
+                                       c64(len(seeds)), cand.ptr, self.reached.ptr, self.flood_scratch.ptr, st),
+                "region_grow")  # an in-range seed is already a candidate here: the kernel's OR is a no-op on a shared plane
         rounds = ctypes.c_int(0)
-        L.check(lib.ivx_dev_flood_run(p, self.cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
+        L.check(lib.ivx_dev_flood_run(p, cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
                                       st), "region_grow")
+        self._out_zero = False
         if select_value is not None:
-            L.check(lib.ivx_dev_flood_apply2(p, self.reached.ptr, self.out_mask.ptr, int(fill), self.mask.ptr,
+            L.check(lib.ivx_dev_flood_apply2(p, self.reached.ptr, self.out_mask.raw, int(fill), self.mask.raw,
                                              int(select_value), st))
+            if self._mbits_valid and not (shared and int(select_value) >= 127):
+                # mask[reached] = select_value: keep the inside plane in step (reached is a subset of a shared plane)
+                L.check(lib.ivx_dev_bits_combine(self._mbits.ptr, self.reached.ptr, c64(self._plane_words),
+                                                 0 if int(select_value) >= 127 else 1, st))
+                self._mbits_range = None
         else:
-            L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
+            L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.raw, ctypes.c_double(fill), st))
         return rounds.value
 
     def region_grow_confidence(self, seed_xyz, strct, confid_mult=2.5, confid_iters=3, select_value=254,
@@ -217,17 +298,18 @@ class DeviceVolume:
         rounds = 0
         for _ in range(int(confid_iters)):
             acc = (ctypes.c_int64 * 3)()
-            L.check(lib.ivx_dev_masked_stats_i16((image or self.image).ptr, d_sel.ptr, c64(self.n), acc, self.stream))
+            L.check(lib.ivx_dev_masked_stats_i16(image.ptr if image is not None else self.image.raw, d_sel.ptr, c64(self.n),
+                                                 acc, self.stream))
             cnt, s1, s2 = int(acc[0]), int(acc[1]), int(acc[2])
             mean = s1 / cnt
             var = max(s2 / cnt - mean * mean, 0.0)
             std = float(np.sqrt(var))
             t0, t1 = mean - std * confid_mult, mean + std * confid_mult
             rounds += self.region_grow([(x, y, z)], t0, t1, strct, fill=1, select_value=None, image=image)
-            L.check(lib.ivx_dev_or_equal_u8(d_sel.ptr, self.out_mask.ptr, c64(self.n), 1, self.stream))
+            L.check(lib.ivx_dev_or_equal_u8(d_sel.ptr, self.out_mask.raw, c64(self.n), 1, self.stream))
         if select_value is not None:
-            L.check(lib.ivx_dev_flood_apply_where(self.mask.ptr, self.out_mask.ptr, c64(self.n), 1, int(select_value),
-                                                  self.stream))
+            L.check(lib.ivx_dev_flood_apply_where(self.mask.ptr, self.out_mask.raw, c64(self.n), 1, int(select_value),
+                                                  self.stream))  # mask.ptr: drops the inside-plane note
         self.sync()
         d_sel.close()
         return rounds
@@ -272,10 +354,19 @@ class DeviceVolume:
                 self._mc_scratch.close()
             self._mc_scratch = DeviceBuffer(nb.value)
         isz = 1 if p.dtype == L.U8 else 2
-        src = (self.mask if p.dtype == L.U8 else self.image).at(z0 * self.dy * self.dx * isz)
+        src = (self.mask if p.dtype == L.U8 else self.image).raw_at(z0 * self.dy * self.dx * isz)
+        # the mask's inside plane at iso 127, if the pipeline still holds it: skip the pass over the voxels
+        plane = None
+        if (p.dtype == L.U8 and p.niso == 1 and p.iso[0] == 127.0 and self._mbits_valid and p.ny == self.dy
+                and p.nx == self.dx):
+            plane = self._mbits.at(z0 * self.dy * ((self.dx + 63) // 64) * 8)
         n = ctypes.c_int64(0)
         with self.timer.span("mc_count"):
-            L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_count")
+            if plane is not None:
+                L.check(lib.ivx_dev_mc_count_bits(ctypes.byref(p), plane, self._mc_scratch.ptr, ctypes.byref(n), self.stream),
+                        "mc_count")
+            else:
+                L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_count")
         nt = n.value
         if self._tris is None or self._tris.nbytes < nt * 36:
             if self._tris is not None:
@@ -302,10 +393,19 @@ class DeviceVolume:
                 self._mc_scratch.close()
             self._mc_scratch = DeviceBuffer(nb.value)
         isz = 1 if p.dtype == L.U8 else 2
-        src = (self.mask if p.dtype == L.U8 else self.image).at(z0 * self.dy * self.dx * isz)
+        src = (self.mask if p.dtype == L.U8 else self.image).raw_at(z0 * self.dy * self.dx * isz)
+        # the mask's inside plane at iso 127, if the pipeline still holds it: skip the pass over the voxels
+        plane = None
+        if (p.dtype == L.U8 and p.niso == 1 and p.iso[0] == 127.0 and self._mbits_valid and p.ny == self.dy
+                and p.nx == self.dx):
+            plane = self._mbits.at(z0 * self.dy * ((self.dx + 63) // 64) * 8)
         nt, nv = ctypes.c_int64(0), ctypes.c_int64(0)
         with self.timer.span("mc_count"):
-            L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nt), self.stream), "mc_count")
+            if plane is not None:
+                L.check(lib.ivx_dev_mc_count_bits(ctypes.byref(p), plane, self._mc_scratch.ptr, ctypes.byref(nt), self.stream),
+                        "mc_count")
+            else:
+                L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nt), self.stream), "mc_count")
         with self.timer.span("mci_count"):
             L.check(lib.ivx_dev_mc_indexed_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nv), self.stream),
                     "mc_indexed_count")
@@ -325,7 +425,7 @@ class DeviceVolume:
 
     # -- projections ---------------------------------------------------------------------------------
     def project(self, axis: int, op: int, out: DeviceBuffer):
-        L.check(L.lib().ivx_dev_mip_reduce(L.I16, self.image.ptr, c64(self.dz), c64(self.dy), c64(self.dx), int(axis),
+        L.check(L.lib().ivx_dev_mip_reduce(L.I16, self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(axis),
                                            int(op), out.ptr, self.stream), "project")
 
 

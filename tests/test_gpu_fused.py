@@ -1,0 +1,118 @@
+"""The resident pipeline's derived bit plane (DeviceVolume.threshold also emits the mask's inside plane, which then
+serves as the region-growing candidate plane and as marching cubes' inside plane): every shortcut must give exactly
+what the unfused kernels give, and every outside write to the buffers must drop the shortcut."""
+import numpy as np
+import pytest
+from scipy.ndimage import generate_binary_structure
+
+from conftest import synth_volume
+
+pytestmark = pytest.mark.gpu
+S26 = generate_binary_structure(3, 3).astype(np.uint8)
+
+
+def _oracle_step(oracle, img, lo, hi, seed, glo, ghi, select):
+    mask = np.where((img >= lo) & (img <= hi), 255, 0).astype(np.uint8)
+    out = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold(img, [seed], glo, ghi, 1, S26, out)
+    if select is not None:
+        mask[out.astype(bool)] = select
+    return mask, out
+
+
+def _soup(oracle, mask, spacing):
+    return oracle.marching_cubes(mask, spacing, [127.0], 0, True, True, True, 0.0, 1)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_bench_shaped_step_matches_oracle(ivxlib, oracle, monkeypatch, fuse):
+    from invesalius3_amd.device import DeviceVolume
+    if not fuse:
+        monkeypatch.setenv("IVX_NO_FUSE", "1")
+    img = synth_volume((24, 40, 128), seed=41)
+    lo, hi = 150, 3071
+    z, y, x = (int(v[0]) for v in np.nonzero((img >= lo) & (img <= hi)))
+    vol = DeviceVolume(img, spacing=(0.5, 0.5, 1.0))
+    for _ in range(2):  # the second pass starts from the first one's state
+        vol.zero_out_mask()
+        vol.threshold(lo, hi)
+        assert vol._mbits_valid == fuse
+        vol.region_grow([(x, y, z)], lo, hi, S26, fill=1, select_value=254)
+        soup = vol.marching_cubes(download=True)
+    mask0, out0 = _oracle_step(oracle, img, lo, hi, (x, y, z), lo, hi, 254)
+    assert np.array_equal(vol.download_mask(), mask0) and np.array_equal(vol.download_out_mask(), out0)
+    assert (mask0 == 254).any()
+    assert np.array_equal(soup, _soup(oracle, mask0, (0.5, 0.5, 1.0)))
+    vol.close()
+
+
+def test_other_thresholds_and_low_select_value(ivxlib, oracle):
+    """growing with different thresholds takes the generic candidates pass; select_value < 127 carves the inside plane"""
+    from invesalius3_amd.device import DeviceVolume
+    img = synth_volume((20, 32, 64), seed=42)
+    lo, hi, glo, ghi = 100, 3071, 300, 3071
+    z, y, x = (int(v[0]) for v in np.nonzero((img >= glo) & (img <= ghi)))
+    vol = DeviceVolume(img)
+    vol.threshold(lo, hi)
+    vol.region_grow([(x, y, z)], glo, ghi, S26, fill=1, select_value=1)
+    assert vol._mbits_valid and vol._mbits_range is None
+    mask0, out0 = _oracle_step(oracle, img, lo, hi, (x, y, z), glo, ghi, 1)
+    assert np.array_equal(vol.download_mask(), mask0) and np.array_equal(vol.download_out_mask(), out0)
+    assert np.array_equal(vol.marching_cubes(download=True), _soup(oracle, mask0, (1.0, 1.0, 1.0)))
+    # and back above 127 with yet another range, growing over a region wider than the mask
+    vol.zero_out_mask()
+    vol.region_grow([(x, y, z)], 50, 3071, S26, fill=1, select_value=200)
+    out1 = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold(img, [(x, y, z)], 50, 3071, 1, S26, out1)
+    mask0[out1.astype(bool)] = 200
+    assert np.array_equal(vol.download_mask(), mask0)
+    assert np.array_equal(vol.marching_cubes(download=True), _soup(oracle, mask0, (1.0, 1.0, 1.0)))
+    vol.close()
+
+
+def test_outside_writes_drop_the_shortcuts(ivxlib, oracle):
+    from invesalius3_amd.device import DeviceVolume
+    rng = np.random.default_rng(7)
+    img = synth_volume((16, 24, 64), seed=43)
+    lo, hi = 120, 3071
+    vol = DeviceVolume(img)
+    vol.threshold(lo, hi)
+    assert vol._mbits_valid
+    # 1. somebody uploads another mask: marching cubes must see it
+    custom = np.where(rng.random(img.shape) < 0.3, 255, 0).astype(np.uint8)
+    vol.mask.upload(custom)
+    assert not vol._mbits_valid
+    assert np.array_equal(vol.marching_cubes(download=True), _soup(oracle, custom, (1.0, 1.0, 1.0)))
+    # 2. out_mask is not zero (second flood into the same out_mask): the barrier must be honoured
+    vol.threshold(lo, hi)
+    cand = (img >= lo) & (img <= hi)
+    zs, ys, xs = np.nonzero(cand)
+    s1 = (int(xs[0]), int(ys[0]), int(zs[0]))
+    vol.zero_out_mask()
+    vol.region_grow([s1], lo, hi, S26, fill=1, select_value=None)
+    assert not vol._out_zero
+    s2 = (int(xs[-1]), int(ys[-1]), int(zs[-1]))
+    vol.region_grow([s2], lo, hi, S26, fill=1, select_value=None)
+    out0 = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold(img, [s1], lo, hi, 1, S26, out0)
+    oracle.floodfill_threshold(img, [s2], lo, hi, 1, S26, out0)
+    assert np.array_equal(vol.download_out_mask(), out0)
+    # 3. a new image under the same mask: the plane is still the mask's, but no longer "image in range"
+    vol.threshold(lo, hi)
+    vol.image.upload((img // 2).astype(np.int16))
+    assert vol._mbits_valid and vol._mbits_range is None
+    vol.zero_out_mask()
+    vol.region_grow([s1], lo, hi, S26, fill=1, select_value=None)
+    out1 = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold((img // 2).astype(np.int16), [s1], lo, hi, 1, S26, out1)
+    assert np.array_equal(vol.download_out_mask(), out1)
+    # 4. rows that are not whole words: no fused kernel, same results
+    img2 = synth_volume((10, 12, 50), seed=44)
+    v2 = DeviceVolume(img2)
+    v2.threshold(lo, hi)
+    assert not v2._mbits_valid
+    m2 = np.where((img2 >= lo) & (img2 <= hi), 255, 0).astype(np.uint8)
+    assert np.array_equal(v2.download_mask(), m2)
+    assert np.array_equal(v2.marching_cubes(download=True), _soup(oracle, m2, (1.0, 1.0, 1.0)))
+    v2.close()
+    vol.close()
