@@ -173,6 +173,23 @@ def main():
     dt = time.perf_counter() - t0
     spans = vol.timer.collect()
     reached = vol.reached_count()
+    # achievable streaming bandwidth on this box, measured the same way (HIP events, same stream): device-to-device
+    # copy of the int16 volume, read + written bytes over the time of the copy
+    copy_gbs = None
+    if rank == 0:
+        import ctypes
+
+        from invesalius3_amd.device import DeviceBuffer
+        tmp = DeviceBuffer(nvox * 2)
+        for _ in range(2):
+            L.check(L.lib().ivx_memcpy_d2d(tmp.ptr, vol.image.raw, ctypes.c_size_t(nvox * 2), vol.stream))
+        for _ in range(5):
+            with vol.timer.span("copy"):
+                L.check(L.lib().ivx_memcpy_d2d(tmp.ptr, vol.image.raw, ctypes.c_size_t(nvox * 2), vol.stream))
+        vol.sync()
+        copy_ms = float(np.median(vol.timer.collect()["copy"]))
+        copy_gbs = 4.0 * nvox / (copy_ms * 1e-3) / 1e9
+        tmp.close()
 
     if dist is not None:
         import torch
@@ -223,6 +240,8 @@ def main():
             "stage_mvoxel_per_s": {k: round(nvox / (v * 1e-3) / 1e6, 1) for k, v in stage_time.items() if v > 0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                         "frac_of_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "algorithmic_bytes": stage_bytes[dom], "ms": round(stage_time[dom], 4),
                          "per_stage_frac": {k: round(stage_bytes[k] / (stage_time[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                             for k in stage_time if stage_time[k] > 0}},

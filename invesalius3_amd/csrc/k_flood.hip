@@ -416,9 +416,10 @@ __global__ __launch_bounds__(NT) void k_flood_round_list(Tiles t, const unsigned
                                                           unsigned long long *reached, const unsigned int *__restrict__ list_cur,
                                                           const unsigned int *__restrict__ n_cur, uint8_t *dirty_cur,
                                                           uint8_t *dirty_next, unsigned int *list_next,
-                                                          unsigned int *n_next) {
+                                                          unsigned int *n_next, unsigned int *n_clear) {
     __shared__ TileLds L;
     const unsigned int n = *n_cur;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_clear = 0u; // the counter the round AFTER the next one appends to
     for (unsigned int li = blockIdx.x; li < n; li += gridDim.x) {
         const int64_t tile = list_cur[li];
         if (threadIdx.x == 0) {
@@ -824,41 +825,51 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
     }
     int total_rounds = 0;
     unsigned int *list[2] = {(unsigned int *)(scr + s.off_list0), (unsigned int *)(scr + s.off_list1)};
-    // counters live in a ring of 2*BATCH dwords: round r reads cnt[r % 2B] (entries of its list) and appends to
-    // cnt[(r+1) % 2B]; the entries a batch will write are zeroed just before the batch
-    IVX_HIP(hipMemsetAsync(cnt, 0, 2 * BATCH * 4, st));
+    // Counters live in a ring of RING dwords indexed by the round number: round r reads cnt[r % RING] (entries of its
+    // list), appends to cnt[(r+1) % RING] and clears cnt[(r+2) % RING] for the round after -- no host-side resets, so
+    // batches can be queued back to back.  The host stays ONE batch ahead of what it has seen: it queues batch k+1
+    // before it waits for batch k's counters (a kernel snapshot of the ring into the pinned mailbox), because the wait
+    // + re-launch round trip cost 35-45 us of idle GPU per batch; a batch that turns out to be unnecessary is a handful
+    // of empty launches that later work simply queues behind.
+    constexpr int RING = 2 * BATCH;
+    static const int batch_rounds = [] {
+        const char *e = getenv("IVX_FLOOD_BATCH");
+        const int v = e ? atoi(e) : 4;
+        return v < 2 ? 2 : (v > BATCH ? BATCH : v & ~1); // even, so every batch starts on list[0] / dirty[0]
+    }();
+    IVX_HIP(hipMemsetAsync(cnt, 0, RING * 4, st));
     hipLaunchKernelGGL(k_flood_build_list, dim3((unsigned)ivx::cdiv(t.ntiles, 256)), dim3(256), 0, st, t, dirty[0], list[0], cnt);
     IVX_LAUNCH_CHECK();
     const unsigned grid = (unsigned)(t.ntiles < 1024 ? t.ntiles : 1024);
-    for (int batch = 0;; batch++) {
-        const int base = (batch & 1) * BATCH;
-        if (batch > 0) { // zero cnt[base+1 .. base+BATCH] (mod 2B); cnt[base] holds the live count of the next list
-            IVX_HIP(hipMemsetAsync(cnt + base + 1, 0, (BATCH - 1) * 4, st));
-            IVX_HIP(hipMemsetAsync(cnt + (base + BATCH) % (2 * BATCH), 0, 4, st));
-        }
-        for (int b = 0; b < BATCH; b++) {
-            // BATCH is even, so every batch starts with list[0] / dirty[0] as the current set
+    int64_t next_round = 0; // absolute number of the next round to queue
+    auto queue_batch = [&](uint32_t *seq) -> int {
+        for (int b = 0; b < batch_rounds; b++, next_round++) {
+            const int r = (int)(next_round % RING), cur = (int)(next_round & 1);
             hipLaunchKernelGGL(k_flood_round_list, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
-                               (unsigned long long *)reached, list[b & 1], cnt + base + b, dirty[b & 1], dirty[(b + 1) & 1],
-                               list[(b + 1) & 1], cnt + (base + b + 1) % (2 * BATCH));
+                               (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
+                               cnt + (r + 1) % RING, cnt + (r + 2) % RING);
             IVX_LAUNCH_CHECK();
         }
-        unsigned int h2[2 * BATCH], h[BATCH];
-        uint32_t seq;
-        if ((rc = ivx::mailbox_publish(cnt, 2 * BATCH, st, &seq))) return rc;
-        if ((rc = ivx::mailbox_wait(seq, st, h2, 2 * BATCH))) return rc;
-        for (int b = 0; b < BATCH; b++) h[b] = h2[(base + b + 1) % (2 * BATCH)]; // tiles enlisted BY round b
+        return ivx::mailbox_publish(cnt, RING, st, seq);
+    };
+    uint32_t seq_cur = 0, seq_next = 0;
+    if ((rc = queue_batch(&seq_cur))) return rc;
+    for (int64_t first = 0;; first += batch_rounds) { // `first` = first round of the batch being waited for
+        if ((rc = queue_batch(&seq_next))) return rc; // stay one batch ahead
+        unsigned int h2[RING], h[BATCH];
+        if ((rc = ivx::mailbox_wait(seq_cur, st, h2, RING))) return rc;
+        for (int b = 0; b < batch_rounds; b++) h[b] = h2[(first + b + 1) % RING]; // tiles enlisted BY round first+b
         static const bool trace = getenv("IVX_FLOOD_TRACE") != nullptr;
         if (trace) {
-            fprintf(stderr, "ivx flood: tiles enlisted by rounds %d..%d:", total_rounds + 1, total_rounds + BATCH);
-            for (int b = 0; b < BATCH; b++) fprintf(stderr, " %u", h[b]);
+            fprintf(stderr, "ivx flood: tiles enlisted by rounds %d..%d:", total_rounds + 1, total_rounds + batch_rounds);
+            for (int b = 0; b < batch_rounds; b++) fprintf(stderr, " %u", h[b]);
             fprintf(stderr, "  (of %lld tiles)\n", (long long)t.ntiles);
         }
-        int used = BATCH;
-        for (int b = 0; b < BATCH; b++)
+        int used = batch_rounds;
+        for (int b = 0; b < batch_rounds; b++)
             if (h[b] == 0) { used = b + 1; break; }
         total_rounds += used;
-        if (h[BATCH - 1] == 0) break;
+        if (h[batch_rounds - 1] == 0) break; // converged; the batch queued ahead finds empty lists
         if (total_rounds >= CCL_ESCAPE_ROUNDS && ivx::ccl_supported(p->strct_bits)) {
             // long, thin region: stop paying one launch per tile hop -- every reached bit so far is correct, the
             // union-find path completes the components they belong to in one flat pass
@@ -869,6 +880,7 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
             break;
         }
         IVX_REQUIRE(total_rounds < (1 << 24), IVX_EHIP, "flood: did not converge");
+        seq_cur = seq_next;
     }
     if (rounds) *rounds = total_rounds;
     return IVX_OK;
