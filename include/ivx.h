@@ -52,6 +52,7 @@ extern "C" {
 #define IVX_MIP_MAX 0
 #define IVX_MIP_MIN 1
 #define IVX_MIP_MEAN 2
+#define IVX_MIP_SUM 3 /* exact int64 sums: what a Z-sharded MeanIP all-reduces before dividing */
 
 /* ------------------------------------------------------------------------------------------------
  * runtime

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_combine(const P *__restrict__ partial, 
     long long acc = (long long)partial[i];
     for (int s = 1; s < split; s++) acc = Red<T, OP>::comb(acc, (long long)partial[(int64_t)s * npix + i]);
     if (OP == IVX_MIP_MEAN) ((double *)out)[i] = (double)acc / (double)len;
+    else if (OP == IVX_MIP_SUM) ((long long *)out)[i] = acc;
     else ((T *)out)[i] = (T)acc;
 }
 
@@ -163,6 +164,7 @@ static int run_reduce_op(const void *vol, int64_t dz, int64_t dy, int64_t dx, in
     case IVX_MIP_MAX: return run_reduce<T, IVX_MIP_MAX>(vol, dz, dy, dx, axis, out, st);
     case IVX_MIP_MIN: return run_reduce<T, IVX_MIP_MIN>(vol, dz, dy, dx, axis, out, st);
     case IVX_MIP_MEAN: return run_reduce<T, IVX_MIP_MEAN>(vol, dz, dy, dx, axis, out, st);
+    case IVX_MIP_SUM: return run_reduce<T, IVX_MIP_SUM>(vol, dz, dy, dx, axis, out, st);
     }
     ivx::set_error("mip: unknown op %d", op);
     return IVX_EINVAL;
@@ -196,7 +198,7 @@ extern "C" int ivx_mip_reduce(int dtype, const void *vol, const int64_t shape[3]
     if (axis == 0) { osh[0] = shape[1]; osh[1] = shape[2]; }
     else if (axis == 1) { osh[0] = shape[0]; osh[1] = shape[2]; }
     else { osh[0] = shape[0]; osh[1] = shape[1]; }
-    const size_t osz = op == IVX_MIP_MEAN ? 8 : isz;
+    const size_t osz = (op == IVX_MIP_MEAN || op == IVX_MIP_SUM) ? 8 : isz;
     void *d_in, *d_out;
     int rc;
     if ((rc = ws_get(WS_IN, n * isz, &d_in))) return rc;

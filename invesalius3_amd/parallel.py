@@ -128,6 +128,32 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
+    def allreduce_array(self, a: np.ndarray, op: str) -> np.ndarray:
+        """Element-wise max / min / sum of one small host array per rank (a projection image)."""
+        a = np.ascontiguousarray(a)
+        wide = a.astype(np.int32) if a.dtype in (np.int16, np.uint16, np.uint8) else a  # neither gloo nor RCCL reduce 16-bit ints
+        t = self.torch.from_numpy(wide)
+        if self.device != "cpu":
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN,
+                                    "sum": self.dist.ReduceOp.SUM}[op])
+        return t.cpu().numpy().astype(a.dtype)
+
+    def allgather_rows(self, a: np.ndarray, rows_per_rank) -> np.ndarray:
+        """Concatenate every rank's rows (axis 0) in rank order; ranks may own different numbers of rows."""
+        torch = self.torch
+        a = np.ascontiguousarray(a)
+        most = max(rows_per_rank)
+        pad = np.zeros((most,) + a.shape[1:], a.dtype)
+        pad[: a.shape[0]] = a
+        t = torch.from_numpy(pad.view(np.uint8).reshape(-1))  # bytes: every backend moves uint8
+        if self.device != "cpu":
+            t = t.to(self.device)
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return np.concatenate([p.cpu().numpy().view(a.dtype).reshape(pad.shape)[:n] for p, n in zip(parts, rows_per_rank)],
+                              axis=0)
+
 
 def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
     """Iterate local fix-point + halo exchange to the global fix-point.  `backend` provides
@@ -147,6 +173,21 @@ def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
         rounds += 1
         if comm.allreduce_sum(changed) == 0:
             return rounds
+
+
+def slab_project_combine(partial: np.ndarray, comm: TorchComm, axis: int, op: str, rows_per_rank, global_dz: int,
+                         gather: bool = True) -> np.ndarray:
+    """MaxIP / MinIP / MeanIP of a Z-sharded volume (`slice_.py:885-889,969-973,1056-1060`).
+    `partial` is this rank's reduction over its OWN slices (halo slices excluded):
+      axis 0 (rays along Z, every rank holds a piece of every ray): op "max" / "min" -> the image dtype, all-reduced
+             with max / min; op "mean" -> exact int64 sums, all-reduced with sum, then divided by the global depth in
+             float64 (sums of < 2^53 are exact, so this is numpy's mean to the last bit);
+      axis 1 / 2 (rays inside a slice): the rank's rows are final; gather=True concatenates all ranks' rows."""
+    if axis == 0:
+        if op == "mean":
+            return comm.allreduce_array(partial.astype(np.int64), "sum").astype(np.float64) / float(global_dz)
+        return comm.allreduce_array(partial, op)
+    return comm.allgather_rows(partial, rows_per_rank) if gather else partial
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -235,6 +276,26 @@ def _make_slab_volume():
             L.check(L.lib().ivx_dev_flood_count(ctypes.byref(sub), self.reached.at(self.lay.hb * self.plane_words * 8),
                                                 ctypes.byref(n), self.stream))
             return n.value
+
+        def project_global(self, axis: int, op: str, gather: bool = True) -> np.ndarray:
+            """MaxIP ("max") / MinIP ("min") / MeanIP ("mean") of the WHOLE volume along `axis`, from every rank's
+            resident slab: local reduce over the interior slices on the GPU, then slab_project_combine."""
+            lay = self.lay
+            nint = lay.last_interior - lay.first_interior + 1
+            code = {"max": L.MIP_MAX, "min": L.MIP_MIN, "mean": L.MIP_SUM if axis == 0 else L.MIP_MEAN}[op]
+            oshape = (self.dy, self.dx) if axis == 0 else ((nint, self.dx) if axis == 1 else (nint, self.dy))
+            odt = np.int64 if code == L.MIP_SUM else (np.float64 if code == L.MIP_MEAN else np.int16)
+            out = DeviceBuffer(int(np.prod(oshape)) * np.dtype(odt).itemsize + 16)
+            src = self.image.raw_at(lay.first_interior * self.dy * self.dx * 2)
+            L.check(L.lib().ivx_dev_mip_reduce(L.I16, src, c64(nint), c64(self.dy), c64(self.dx), int(axis), int(code), out.ptr,
+                                               self.stream), "project")
+            self.sync()
+            partial = out.download(oshape, odt)
+            out.close()
+            if lay.world == 1:
+                return partial.astype(np.float64) / float(nint) if code == L.MIP_SUM else partial
+            rows = [lay.nz] * lay.world
+            return slab_project_combine(partial, self.comm, axis, op, rows, lay.nz * lay.world, gather)
 
         def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
             a = slab_mc_args(self.lay, fill_border_holes)

@@ -71,6 +71,16 @@ def main():
                               int(a["pad_bottom"]))
     np.save(os.path.join(outdir, "tris_%d.npy" % rank), tris)
     np.save(os.path.join(outdir, "rounds_%d.npy" % rank), np.array([rounds]))
+    # projections: local reduce over the rank's own slices (numpy stands in for the HIP kernel) + the real combine
+    own = local[lay.first_interior: lay.last_interior + 1]
+    for ax in (0, 1, 2):
+        for op in ("max", "min", "mean"):
+            if op == "mean":
+                partial = own.sum(axis=ax, dtype=np.int64) if ax == 0 else own.mean(axis=ax)
+            else:
+                partial = getattr(own, op)(axis=ax)
+            img = par.slab_project_combine(partial, comm, ax, op, [nz] * world, nz * world)
+            np.save(os.path.join(outdir, "proj_%d_%d_%s.npy" % (rank, ax, op)), img)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -54,6 +54,23 @@ class LoopbackComm:
         w.barrier.wait()
         return total
 
+    def allreduce_array(self, a, op):
+        w = self.w
+        w.box[(self.rank, "arr")] = np.array(a)
+        w.barrier.wait()
+        parts = [w.box[(r, "arr")] for r in range(self.world)]
+        out = {"max": np.maximum.reduce, "min": np.minimum.reduce, "sum": np.add.reduce}[op](parts)
+        w.barrier.wait()
+        return out
+
+    def allgather_rows(self, a, rows_per_rank):
+        w = self.w
+        w.box[(self.rank, "rows")] = np.array(a)
+        w.barrier.wait()
+        out = np.concatenate([w.box[(r, "rows")] for r in range(self.world)], axis=0)
+        w.barrier.wait()
+        return out
+
 
 @pytest.mark.parametrize("world,conn", [(2, 3), (3, 1)])
 def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
@@ -75,7 +92,8 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
             vol.region_grow(seeds, t0, t1, strct, fill=1, select_value=254)
             tris = vol.marching_cubes(from_binary=True, download=True)
             lay = vol.lay
-            res[rank] = dict(out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
+            proj = {(ax, op): vol.project_global(ax, op) for ax in (0, 1, 2) for op in ("max", "min", "mean")}
+            res[rank] = dict(proj=proj, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
                              mask=vol.download_mask()[lay.first_interior:lay.last_interior + 1], tris=tris,
                              count=vol.reached_count())
             vol.close()
@@ -100,3 +118,8 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
     cat = np.concatenate([res[r]["tris"] for r in range(world)])
     key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
     assert len(cat) == len(whole) and np.array_equal(key(cat), key(whole))
+    # projections of the whole volume, identical on every rank and equal to numpy on the unsharded array
+    for r in range(world):
+        for (ax, op), img in res[r]["proj"].items():
+            want = getattr(full, op)(axis=ax)
+            assert img.dtype == want.dtype and np.array_equal(img, want), (r, ax, op)

@@ -58,6 +58,13 @@ def test_slab_region_grow_and_mc_match_single_volume(tmp_path, oracle, world, co
     cat = np.concatenate([np.load(tmp_path / ("tris_%d.npy" % r)) for r in range(world)])
     key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
     assert len(cat) == len(whole) and np.array_equal(key(cat), key(whole))
+    # sharded MaxIP / MinIP / MeanIP: every rank ends with numpy's result on the whole volume
+    for r in range(world):
+        for ax in (0, 1, 2):
+            for op in ("max", "min", "mean"):
+                img = np.load(tmp_path / ("proj_%d_%d_%s.npy" % (r, ax, op)))
+                want = getattr(full, op)(axis=ax)
+                assert img.dtype == want.dtype and np.array_equal(img, want), (r, ax, op)
 
 
 def test_layout_helpers():
