@@ -255,20 +255,33 @@ class DeviceVolume:
         st = self.stream
         t0, t1 = float(int(t0)), float(int(t1))  # wrapper int() truncation for integer images
         L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
-        # candidates = in range AND out_mask != fill.  With out_mask known to be zero (fill != 0) and the mask's plane
-        # known to be "image in [t0, t1]", the plane the threshold pass left behind is exactly that: no pass needed.
-        shared = (image is None and self._mbits_valid and self._out_zero and int(fill) != 0
-                  and self._mbits_range == (int(t0), int(t1)))
-        cand = self._mbits if shared else self.cand
-        if not shared:
-            L.check(lib.ivx_dev_flood_candidates(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1),
-                                                 self.out_mask.raw, 1, ctypes.c_double(fill), cand.ptr, st))
+        cand, shared = self._candidate_plane(image, t0, t1, fill)
         L.check(lib.ivx_dev_flood_seed(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
                                        c64(len(seeds)), cand.ptr, self.reached.ptr, self.flood_scratch.ptr, st),
                 "region_grow")  # an in-range seed is already a candidate here: the kernel's OR is a no-op on a shared plane
         rounds = ctypes.c_int(0)
         L.check(lib.ivx_dev_flood_run(p, cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
                                       st), "region_grow")
+        self._apply_reached(fill, select_value, shared)
+        return rounds.value
+
+    def _candidate_plane(self, image, t0, t1, fill):
+        """The flood's candidate plane: in range AND out_mask != fill.  With out_mask known to be zero (fill != 0) and
+        the mask's plane known to be "image in [t0, t1]", the plane the threshold pass left behind is exactly that and
+        no pass over the volume is needed.  Returns (buffer, shared?)."""
+        shared = (image is None and self._mbits_valid and self._out_zero and int(fill) != 0
+                  and self._mbits_range == (int(t0), int(t1)))
+        if shared:
+            return self._mbits, True
+        img_ptr = image.ptr if image is not None else self.image.raw
+        L.check(L.lib().ivx_dev_flood_candidates(ctypes.byref(self.plan), L.I16, img_ptr, ctypes.c_double(t0),
+                                                 ctypes.c_double(t1), self.out_mask.raw, 1, ctypes.c_double(fill),
+                                                 self.cand.ptr, self.stream))
+        return self.cand, False
+
+    def _apply_reached(self, fill, select_value, shared):
+        """out_mask[reached] = fill and, when asked, mask[reached] = select_value; keeps the notes in step."""
+        lib, p, st = L.lib(), ctypes.byref(self.plan), self.stream
         self._out_zero = False
         if select_value is not None:
             L.check(lib.ivx_dev_flood_apply2(p, self.reached.ptr, self.out_mask.raw, int(fill), self.mask.raw,
@@ -280,7 +293,6 @@ class DeviceVolume:
                 self._mbits_range = None
         else:
             L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.raw, ctypes.c_double(fill), st))
-        return rounds.value
 
     def region_grow_confidence(self, seed_xyz, strct, confid_mult=2.5, confid_iters=3, select_value=254,
                                image: DeviceBuffer | None = None):

@@ -47,7 +47,7 @@ def run(args) -> dict:
         if args.seed:
             seeds = [tuple(args.seed[i:i + 3]) for i in range(0, len(args.seed), 3)]
             strct = np.ones((3, 3, 3), np.uint8) if args.connectivity == 26 else _strct(args.connectivity)
-            vol.out_mask.zero(vol.stream)
+            vol.zero_out_mask()
             with vol.timer.span("region_grow"):
                 rounds = vol.region_grow(seeds, lo, hi, strct, fill=1, select_value=None)
             vol.mask.zero(vol.stream)  # keep only the grown region

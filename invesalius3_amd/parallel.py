@@ -219,11 +219,12 @@ def _make_slab_volume():
             super().__init__(np.ascontiguousarray(local), spacing=spacing, device=device)
             self.plane_words = self.dy * self.plan.wx
             self._send = [DeviceBuffer(self.plane_words * 8) for _ in range(2)]
+            self._cand = self.cand
 
         # -- backend protocol of slab_region_grow ---------------------------------------------------------------
         def flood_run(self):
             r = ctypes.c_int(0)
-            L.check(L.lib().ivx_dev_flood_run(ctypes.byref(self.plan), self.cand.ptr, self.reached.ptr,
+            L.check(L.lib().ivx_dev_flood_run(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr,
                                               self.flood_scratch.ptr, ctypes.byref(r), self.stream), "flood_run")
             self._rounds += r.value
 
@@ -236,7 +237,7 @@ def _make_slab_volume():
 
         def or_plane(self, z: int, tensor) -> int:
             chg = ctypes.c_int(0)
-            L.check(L.lib().ivx_dev_flood_or_plane(ctypes.byref(self.plan), self.cand.ptr, self.reached.ptr, c64(z),
+            L.check(L.lib().ivx_dev_flood_or_plane(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr, c64(z),
                                                    ctypes.c_void_p(tensor.data_ptr()), self.flood_scratch.ptr,
                                                    ctypes.byref(chg), self.stream), "flood_or_plane")
             return chg.value
@@ -252,21 +253,18 @@ def _make_slab_volume():
             p, st = ctypes.byref(self.plan), self.stream
             t0, t1 = float(int(t0)), float(int(t1))
             L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
-            L.check(lib.ivx_dev_flood_candidates(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1),
-                                                 self.out_mask.ptr, 1, ctypes.c_double(fill), self.cand.ptr, st))
+            # same shortcut as the single-GPU pipeline: the plane the threshold pass left behind, when it provably IS
+            # the candidate plane of this slab (halo slices included: they were thresholded with the slab)
+            self._cand, shared = self._candidate_plane(None, t0, t1, fill)
             loc = local_seeds(self.lay, seeds_xyz_global)
             if loc:
                 seeds = np.ascontiguousarray(np.array(loc, dtype=np.int64).reshape(-1, 3))
-                L.check(lib.ivx_dev_flood_seed(p, L.I16, self.image.ptr, ctypes.c_double(t0), ctypes.c_double(t1),
-                                               L.ptr(seeds), c64(len(seeds)), self.cand.ptr, self.reached.ptr,
+                L.check(lib.ivx_dev_flood_seed(p, L.I16, self.image.raw, ctypes.c_double(t0), ctypes.c_double(t1),
+                                               L.ptr(seeds), c64(len(seeds)), self._cand.ptr, self.reached.ptr,
                                                self.flood_scratch.ptr, st), "region_grow")
             self._rounds = 0
             slab_region_grow(self, self.comm, self.lay)
-            if select_value is not None:
-                L.check(lib.ivx_dev_flood_apply2(p, self.reached.ptr, self.out_mask.ptr, int(fill), self.mask.ptr,
-                                                 int(select_value), st))
-            else:
-                L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.ptr, ctypes.c_double(fill), st))
+            self._apply_reached(fill, select_value, shared)
             return self._rounds
 
         def reached_count(self) -> int:
