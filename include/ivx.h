@@ -165,6 +165,13 @@ typedef struct ivx_mc_params {
 int ivx_dev_mc_scratch_bytes(const ivx_mc_params *p, size_t *nbytes);
 /* classify + per-row-group triangle counts + scan; *ntris (host) receives the total */
 int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch, int64_t *ntris, void *stream);
+/* Queue-only forms: nothing comes back to the host, so ivx_dev_mc_emit can be queued right behind them with the
+ * CAPACITY of `tris` as max_tris (the emit kernel reads the real count, and the iso-0 / iso-1 split, on the device and
+ * writes min(count, max_tris) triangles).  ivx_dev_mc_total then fetches the count: if it exceeds the capacity, grow the
+ * buffer and call ivx_dev_mc_emit again. */
+int ivx_dev_mc_count_async(const ivx_mc_params *p, const void *a, void *scratch, void *stream);
+int ivx_dev_mc_count_bits_async(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch, void *stream);
+int ivx_dev_mc_total(const ivx_mc_params *p, void *scratch, int64_t *ntris, void *stream);
 /* same, from an inside plane (value >= iso[0]) the caller already holds; niso must be 1 */
 int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch, int64_t *ntris,
                           void *stream);

@@ -382,16 +382,24 @@ __global__ __launch_bounds__(256) void k_mc_list(const uint64_t *__restrict__ bi
 // 4b. emit: a flat, regular kernel -- one lane per triangle of the list, 256 consecutive triangles per workgroup.
 //     Nothing but the 9-KB staging buffer in LDS, so eight workgroups share a CU and hide each other's gather latency.
 template <typename T>
-__global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g, double iso,
-                                                 const uint64_t *__restrict__ list, uint64_t ntris,
+__global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g, double iso0, double iso1,
+                                                 const uint64_t *__restrict__ split_dev,
+                                                 const uint64_t *__restrict__ total_dev,
+                                                 const uint64_t *__restrict__ list, uint64_t cap,
                                                  float *__restrict__ tris) {
     __shared__ uint8_t s_tri[256 * 16];
     __shared__ float s_out[256 * 9];
     const int tid = threadIdx.x;
+    // The grid covers the output CAPACITY; how many triangles there really are (and where iso 1's begin) is read from
+    // the scan's result on the device, so the host can queue this kernel before it knows the count.
+    const uint64_t total = *total_dev, split = *split_dev;
+    const uint64_t ntris = total < cap ? total : cap;
+    const uint64_t T0 = (uint64_t)blockIdx.x * 256;
+    if (T0 >= ntris) return;
 #pragma unroll
     for (int q = 0; q < 15; q++) s_tri[tid * 16 + q] = MC_TRI[tid][q];
-    const uint64_t T0 = (uint64_t)blockIdx.x * 256;
     const uint64_t T_ = T0 + tid;
+    const double iso = T_ < split ? iso0 : iso1;
     const bool live = T_ < ntris;
     const uint64_t d = live ? list[T_] : 0ull;
     __syncthreads();
@@ -480,15 +488,9 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     int rc = ivx::ws_get_s(ivx::WS_MCLIST, st, (size_t)max_tris * 8 + 64, &d_list);
     if (rc) return rc;
     // iso 1's triangles follow iso 0's: boff is one scan over [iso0 blocks | iso1 blocks], so both list passes write
-    // disjoint ranges of ONE list and a single flat emit per iso covers [first, last) of that iso
-    // triangle ranges per iso: [0, split) and [split, total); `split` was read by ivx_dev_mc_count through the mailbox
-    uint64_t hb[3] = {0, (uint64_t)max_tris, (uint64_t)max_tris};
-    if (p->niso == 2) {
-        std::lock_guard<std::mutex> lk(g_split_mu);
-        auto it = g_split.find(scratch);
-        IVX_REQUIRE(it != g_split.end(), IVX_EINVAL, "mc: ivx_dev_mc_emit must follow ivx_dev_mc_count on the same scratch");
-        hb[1] = it->second;
-    }
+    // disjoint ranges of ONE list and one flat emit covers all of it; the kernel reads the total (boff[nb]) and the
+    // iso-0 / iso-1 split (boff[nblocks]) on the device
+    const size_t nb = s.nblocks * (size_t)p->niso;
     for (int q = 0; q < p->niso; q++) {
         const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
         const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
@@ -496,14 +498,10 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
                            boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
         IVX_LAUNCH_CHECK();
     }
-    for (int q = 0; q < p->niso; q++) {
-        const uint64_t first = hb[q], last = hb[q + 1] < (uint64_t)max_tris ? hb[q + 1] : (uint64_t)max_tris;
-        if (last <= first) continue;
-        const uint64_t n = last - first;
-        hipLaunchKernelGGL((k_mc_emit<T>), dim3((unsigned)ivx::cdiv((int64_t)n, 256)), dim3(256), 0, st, (const T *)a, g,
-                           p->iso[q], (const uint64_t *)d_list + first, n, tris + first * 9);
-        IVX_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL((k_mc_emit<T>), dim3((unsigned)ivx::cdiv(max_tris, (int64_t)256)), dim3(256), 0, st, (const T *)a, g,
+                       p->iso[0], p->iso[1], boff + (p->niso == 2 ? s.nblocks : nb), boff + nb, (const uint64_t *)d_list,
+                       (uint64_t)max_tris, tris);
+    IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
 
@@ -705,11 +703,9 @@ extern "C" int ivx_dev_mc_scratch_bytes(const ivx_mc_params *p, size_t *nbytes) 
     return IVX_OK;
 }
 
-// classify + count + scan over the inside planes already sitting in scratch
-static int mc_count_planes(const ivx_mc_params *p, const Geom &g, const Scratch &s, void *scratch_, int64_t *ntris,
-                           hipStream_t st) {
+// classify + count + scan over the inside planes already sitting in scratch (queued, nothing comes back to the host)
+static int mc_queue_count(const ivx_mc_params *p, const Geom &g, const Scratch &s, void *scratch_, hipStream_t st) {
     char *scratch = (char *)scratch_;
-    int rc;
     uint32_t *bsum = (uint32_t *)(scratch + s.off_bsum);
     uint64_t *boff = (uint64_t *)(scratch + s.off_boff);
     for (int q = 0; q < p->niso; q++) {
@@ -722,8 +718,16 @@ static int mc_count_planes(const ivx_mc_params *p, const Geom &g, const Scratch 
     const size_t nb = s.nblocks * (size_t)p->niso;
     hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, st, bsum, nb, boff);
     IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+// the scan's total (and the iso-0 / iso-1 split) through the mailbox
+static int mc_read_total(const ivx_mc_params *p, const Scratch &s, void *scratch_, int64_t *ntris, hipStream_t st) {
+    char *scratch = (char *)scratch_;
+    int rc;
+    uint64_t *boff = (uint64_t *)(scratch + s.off_boff);
+    const size_t nb = s.nblocks * (size_t)p->niso;
     uint32_t seq, tw[2];
-    if (p->niso == 2) { // also fetch where iso 0's triangles end (= boff[nblocks])
+    if (p->niso == 2) { // also fetch where iso 0's triangles end (= boff[nblocks]): the indexed-mesh path needs it
         uint32_t seq0, t0[2];
         if ((rc = ivx::mailbox_publish(boff + s.nblocks, 2, st, &seq0))) return rc;
         if ((rc = ivx::mailbox_wait(seq0, st, t0, 2))) return rc;
@@ -736,7 +740,8 @@ static int mc_count_planes(const ivx_mc_params *p, const Geom &g, const Scratch 
     return IVX_OK;
 }
 
-extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch_, int64_t *ntris, void *stream) {
+static int mc_count_impl(const ivx_mc_params *p, const void *a, void *scratch_, int64_t *ntris, void *stream,
+                         bool ntris_wanted) {
     Geom g;
     int rc = make_geom(p, &g);
     if (rc) return rc;
@@ -752,14 +757,34 @@ extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scr
     default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
     }
     if (rc) return rc;
-    return mc_count_planes(p, g, s, scratch_, ntris, st);
+    if ((rc = mc_queue_count(p, g, s, scratch_, st))) return rc;
+    return ntris_wanted ? mc_read_total(p, s, scratch_, ntris, st) : IVX_OK;
+}
+
+extern "C" int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch_, int64_t *ntris, void *stream) {
+    return mc_count_impl(p, a, scratch_, ntris, stream, true);
+}
+// queue the counting passes only; ivx_dev_mc_emit may follow at once with the CAPACITY of `tris` as max_tris (it reads
+// the real count on the device); ivx_dev_mc_total fetches the count afterwards
+extern "C" int ivx_dev_mc_count_async(const ivx_mc_params *p, const void *a, void *scratch_, void *stream) {
+    int64_t unused = 0;
+    return mc_count_impl(p, a, scratch_, &unused, stream, false);
+}
+extern "C" int ivx_dev_mc_total(const ivx_mc_params *p, void *scratch_, int64_t *ntris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    const Scratch s = make_scratch(g, p->niso);
+    *ntris = 0;
+    if (s.nwords == 0) return IVX_OK;
+    return mc_read_total(p, s, scratch_, ntris, ivx::S(stream));
 }
 
 // Same, with the inside plane (value >= iso[0], source coordinates, the layout of the region-growing planes) handed in
 // instead of being derived from the voxels: a resident pipeline that already holds it (ivx_dev_threshold_i16_bits)
 // skips the pass over the volume.  One iso-value only.
-extern "C" int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch_, int64_t *ntris,
-                                     void *stream) {
+static int mc_count_bits_impl(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch_, int64_t *ntris,
+                              void *stream, bool ntris_wanted) {
     Geom g;
     int rc = make_geom(p, &g);
     if (rc) return rc;
@@ -771,7 +796,16 @@ extern "C" int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *ins
     IVX_REQUIRE(s.nblocks < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
     if (s.bits_words)
         IVX_HIP(hipMemcpyAsync((char *)scratch_ + s.off_bits, inside_bits, s.bits_words * 8, hipMemcpyDeviceToDevice, st));
-    return mc_count_planes(p, g, s, scratch_, ntris, st);
+    if ((rc = mc_queue_count(p, g, s, scratch_, st))) return rc;
+    return ntris_wanted ? mc_read_total(p, s, scratch_, ntris, st) : IVX_OK;
+}
+extern "C" int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch_, int64_t *ntris,
+                                     void *stream) {
+    return mc_count_bits_impl(p, inside_bits, scratch_, ntris, stream, true);
+}
+extern "C" int ivx_dev_mc_count_bits_async(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch_, void *stream) {
+    int64_t unused = 0;
+    return mc_count_bits_impl(p, inside_bits, scratch_, &unused, stream, false);
 }
 
 extern "C" int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *tris,

@@ -373,20 +373,37 @@ class DeviceVolume:
                 and p.nx == self.dx):
             plane = self._mbits.at(z0 * self.dy * ((self.dx + 63) // 64) * 8)
         n = ctypes.c_int64(0)
-        with self.timer.span("mc_count"):
-            if plane is not None:
-                L.check(lib.ivx_dev_mc_count_bits(ctypes.byref(p), plane, self._mc_scratch.ptr, ctypes.byref(n), self.stream),
-                        "mc_count")
-            else:
-                L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_count")
-        nt = n.value
-        if self._tris is None or self._tris.nbytes < nt * 36:
-            if self._tris is not None:
+        if self._tris is not None:
+            # steady state: the triangle buffer of the previous call gives a capacity, so count, list and emit are queued
+            # back to back and the count is read afterwards (no host round trip between the two halves)
+            cap = self._tris.nbytes // 36
+            with self.timer.span("mc_count"):
+                if plane is not None:
+                    L.check(lib.ivx_dev_mc_count_bits_async(ctypes.byref(p), plane, self._mc_scratch.ptr, self.stream), "mc_count")
+                else:
+                    L.check(lib.ivx_dev_mc_count_async(ctypes.byref(p), src, self._mc_scratch.ptr, self.stream), "mc_count")
+            with self.timer.span("mc_emit"):
+                L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(cap), self.stream),
+                        "mc_emit")
+            L.check(lib.ivx_dev_mc_total(ctypes.byref(p), self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_total")
+            nt = n.value
+            if nt > cap:  # the surface outgrew the buffer: emit again into a larger one
                 self._tris.close()
+                self._tris = DeviceBuffer(int(nt * 36 * 1.25) + 4096)
+                L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(nt), self.stream),
+                        "mc_emit")
+        else:
+            with self.timer.span("mc_count"):
+                if plane is not None:
+                    L.check(lib.ivx_dev_mc_count_bits(ctypes.byref(p), plane, self._mc_scratch.ptr, ctypes.byref(n), self.stream),
+                            "mc_count")
+                else:
+                    L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_count")
+            nt = n.value
             self._tris = DeviceBuffer(int(nt * 36 * 1.25) + 4096)
-        with self.timer.span("mc_emit"):
-            L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(nt), self.stream),
-                    "mc_emit")
+            with self.timer.span("mc_emit"):
+                L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(nt), self.stream),
+                        "mc_emit")
         if download:
             self.sync()
             return self._tris.download((nt, 3, 3), np.float32)
