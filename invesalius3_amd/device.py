@@ -153,7 +153,8 @@ class DeviceVolume:
         # outside this class's own kernels (their .ptr / upload / zero) drops the corresponding note.
         self._mbits_valid = False   # self._mbits == (mask >= 127), the inside plane marching cubes needs at iso 127
         self._mbits_range = None    # (lo, hi) while additionally _mbits == (lo <= image <= hi)
-        self._out_zero = False      # out_mask is all zero
+        self._out_bytes_zero = False  # the BYTES of out_mask are all zero
+        self._out_pending = None      # fill value of a deferred `out_mask[reached] = fill` (self.reached still holds it)
         self._fuse = os.environ.get("IVX_NO_FUSE", "") == ""
         self.image = TrackedBuffer(self.n * 2, self._image_touched)
         self.mask = TrackedBuffer(self.n, self._mask_touched)       # dense interior of mask.matrix[1:,1:,1:]
@@ -186,13 +187,30 @@ class DeviceVolume:
         self._mbits_valid = False
         self._mbits_range = None
 
+    # out_mask is the reference's throw-away `np.zeros_like` of styles.py:3190: the flood writes `fill` into it and the
+    # caller turns it into `mask[out_mask.astype(bool)] = 254`.  The pipeline keeps it as what the flood really produces
+    # -- the reached bit plane -- and writes the bytes only when somebody looks at them: `_out_pending` remembers a
+    # deferred `out_mask[reached] = fill` over bytes that are known to be zero.  Zeroing it again is then free, and the
+    # next flood does not have to read it.  Every path that reads or exposes the bytes calls _materialize_out() first.
+    def _out_logically_zero(self) -> bool:
+        return self._out_bytes_zero and self._out_pending is None
+
+    def _materialize_out(self):
+        if self._out_pending is not None:
+            L.check(L.lib().ivx_dev_flood_apply(ctypes.byref(self.plan), self.reached.ptr, L.U8, self.out_mask.raw,
+                                                ctypes.c_double(self._out_pending), self.stream))
+            self._out_pending = None
+            self._out_bytes_zero = False
+
     def _out_touched(self):
-        self._out_zero = False
+        self._materialize_out()
+        self._out_bytes_zero = False
 
     def zero_out_mask(self):
-        """out_mask = zeros (the np.zeros of styles.py:3190), remembered so that region growing can skip reading it"""
-        L.check(L.lib().ivx_memset(self.out_mask.raw, 0, ctypes.c_size_t(self.n), self.stream))
-        self._out_zero = True
+        """out_mask = zeros (the np.zeros of styles.py:3190)"""
+        if not self._out_bytes_zero:
+            L.check(L.lib().ivx_memset(self.out_mask.raw, 0, ctypes.c_size_t(self.n), self.stream))
+        self._out_bytes_zero, self._out_pending = True, None
 
     def sync(self):
         L.check(L.lib().ivx_stream_synchronize(self.stream))
@@ -211,6 +229,7 @@ class DeviceVolume:
         return self.mask.download(self.shape, np.uint8)
 
     def download_out_mask(self) -> np.ndarray:
+        self._materialize_out()
         self.sync()
         return self.out_mask.download(self.shape, np.uint8)
 
@@ -254,6 +273,7 @@ class DeviceVolume:
         p = ctypes.byref(self.plan)
         st = self.stream
         t0, t1 = float(int(t0)), float(int(t1))  # wrapper int() truncation for integer images
+        self._before_flood()
         L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
         cand, shared = self._candidate_plane(image, t0, t1, fill)
         L.check(lib.ivx_dev_flood_seed(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
@@ -265,11 +285,15 @@ class DeviceVolume:
         self._apply_reached(fill, select_value, shared)
         return rounds.value
 
+    def _before_flood(self):
+        """the reached plane is about to be cleared: a deferred out_mask write that is still wanted must land first"""
+        self._materialize_out()
+
     def _candidate_plane(self, image, t0, t1, fill):
         """The flood's candidate plane: in range AND out_mask != fill.  With out_mask known to be zero (fill != 0) and
         the mask's plane known to be "image in [t0, t1]", the plane the threshold pass left behind is exactly that and
         no pass over the volume is needed.  Returns (buffer, shared?)."""
-        shared = (image is None and self._mbits_valid and self._out_zero and int(fill) != 0
+        shared = (image is None and self._mbits_valid and self._out_logically_zero() and int(fill) != 0
                   and self._mbits_range == (int(t0), int(t1)))
         if shared:
             return self._mbits, True
@@ -282,17 +306,23 @@ class DeviceVolume:
     def _apply_reached(self, fill, select_value, shared):
         """out_mask[reached] = fill and, when asked, mask[reached] = select_value; keeps the notes in step."""
         lib, p, st = L.lib(), ctypes.byref(self.plan), self.stream
-        self._out_zero = False
-        if select_value is not None:
+        defer = self._out_logically_zero() and int(fill) != 0
+        if defer:
+            self._out_pending = int(fill)  # bytes stay zero; self.reached carries the result until it is needed
+            if select_value is not None:
+                L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.mask.raw, ctypes.c_double(int(select_value)), st))
+        elif select_value is not None:
             L.check(lib.ivx_dev_flood_apply2(p, self.reached.ptr, self.out_mask.raw, int(fill), self.mask.raw,
                                              int(select_value), st))
-            if self._mbits_valid and not (shared and int(select_value) >= 127):
-                # mask[reached] = select_value: keep the inside plane in step (reached is a subset of a shared plane)
-                L.check(lib.ivx_dev_bits_combine(self._mbits.ptr, self.reached.ptr, c64(self._plane_words),
-                                                 0 if int(select_value) >= 127 else 1, st))
-                self._mbits_range = None
+            self._out_bytes_zero = False
         else:
             L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.raw, ctypes.c_double(fill), st))
+            self._out_bytes_zero = False
+        if select_value is not None and self._mbits_valid and not (shared and int(select_value) >= 127):
+            # mask[reached] = select_value: keep the inside plane in step (reached is a subset of a shared plane)
+            L.check(lib.ivx_dev_bits_combine(self._mbits.ptr, self.reached.ptr, c64(self._plane_words),
+                                             0 if int(select_value) >= 127 else 1, st))
+            self._mbits_range = None
 
     def region_grow_confidence(self, seed_xyz, strct, confid_mult=2.5, confid_iters=3, select_value=254,
                                image: DeviceBuffer | None = None):
@@ -318,8 +348,10 @@ class DeviceVolume:
             std = float(np.sqrt(var))
             t0, t1 = mean - std * confid_mult, mean + std * confid_mult
             rounds += self.region_grow([(x, y, z)], t0, t1, strct, fill=1, select_value=None, image=image)
+            self._materialize_out()
             L.check(lib.ivx_dev_or_equal_u8(d_sel.ptr, self.out_mask.raw, c64(self.n), 1, self.stream))
         if select_value is not None:
+            self._materialize_out()
             L.check(lib.ivx_dev_flood_apply_where(self.mask.ptr, self.out_mask.raw, c64(self.n), 1, int(select_value),
                                                   self.stream))  # mask.ptr: drops the inside-plane note
         self.sync()

@@ -252,6 +252,7 @@ def _make_slab_volume():
             self.plan.strct_bits = bits.value
             p, st = ctypes.byref(self.plan), self.stream
             t0, t1 = float(int(t0)), float(int(t1))
+            self._before_flood()
             L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
             # same shortcut as the single-GPU pipeline: the plane the threshold pass left behind, when it provably IS
             # the candidate plane of this slab (halo slices included: they were thresholded with the slab)

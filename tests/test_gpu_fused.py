@@ -90,7 +90,7 @@ def test_outside_writes_drop_the_shortcuts(ivxlib, oracle):
     s1 = (int(xs[0]), int(ys[0]), int(zs[0]))
     vol.zero_out_mask()
     vol.region_grow([s1], lo, hi, S26, fill=1, select_value=None)
-    assert not vol._out_zero
+    assert not vol._out_logically_zero()
     s2 = (int(xs[-1]), int(ys[-1]), int(zs[-1]))
     vol.region_grow([s2], lo, hi, S26, fill=1, select_value=None)
     out0 = np.zeros(img.shape, np.uint8)
@@ -115,4 +115,52 @@ def test_outside_writes_drop_the_shortcuts(ivxlib, oracle):
     assert np.array_equal(v2.download_mask(), m2)
     assert np.array_equal(v2.marching_cubes(download=True), _soup(oracle, m2, (1.0, 1.0, 1.0)))
     v2.close()
+    vol.close()
+
+
+def test_out_mask_is_materialised_whenever_it_is_looked_at(ivxlib, oracle):
+    """out_mask lives as the reached bit plane until its bytes are needed: downloads, outside pointers, the next
+    flood's barrier and the confidence loop must all see the bytes the reference would have written"""
+    import ctypes
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceVolume, c64
+    img = synth_volume((18, 24, 64), seed=45)
+    lo, hi = 100, 3071
+    cand = (img >= lo) & (img <= hi)
+    zs, ys, xs = np.nonzero(cand)
+    s1 = (int(xs[0]), int(ys[0]), int(zs[0]))
+    s2 = (int(xs[-1]), int(ys[-1]), int(zs[-1]))
+    out1 = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold(img, [s1], lo, hi, 1, S26, out1)
+    vol = DeviceVolume(img)
+    vol.threshold(lo, hi)
+    vol.zero_out_mask()
+    vol.region_grow([s1], lo, hi, S26, fill=1, select_value=254)
+    assert vol._out_pending == 1 and vol._out_bytes_zero
+    # 1. an outside kernel reads out_mask through its pointer: the bytes must be there by then
+    tgt = np.zeros(img.shape, np.uint8)
+    from invesalius3_amd.device import DeviceBuffer
+    d = DeviceBuffer(img.size)
+    d.upload(tgt)
+    L.check(L.lib().ivx_dev_flood_apply_where(d.ptr, vol.out_mask.ptr, c64(img.size), 1, 77, vol.stream))
+    vol.sync()
+    assert np.array_equal(d.download(img.shape, np.uint8), out1 * 77)
+    assert vol._out_pending is None and not vol._out_bytes_zero
+    assert np.array_equal(vol.download_out_mask(), out1)
+    # 2. zero, flood, zero again without anybody looking: nothing is ever written, and it reads back as zeros
+    vol.zero_out_mask()
+    vol.region_grow([s1], lo, hi, S26, fill=1, select_value=None)
+    vol.zero_out_mask()
+    assert not vol.download_out_mask().any()
+    # 3. flood twice into the same out_mask (no zeroing in between): the first result is the second one's barrier
+    vol.region_grow([s1], lo, hi, S26, fill=1, select_value=None)
+    vol.region_grow([s2], lo, hi, S26, fill=1, select_value=None)
+    both = out1.copy()
+    oracle.floodfill_threshold(img, [s2], lo, hi, 1, S26, both)
+    assert np.array_equal(vol.download_out_mask(), both)
+    # 4. fill = 7 is what lands in the bytes
+    vol.zero_out_mask()
+    vol.region_grow([s1], lo, hi, S26, fill=7, select_value=None)
+    assert np.array_equal(vol.download_out_mask(), out1 * 7)
+    d.close()
     vol.close()
