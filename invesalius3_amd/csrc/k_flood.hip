@@ -746,14 +746,38 @@ extern "C" int ivx_dev_flood_seed(const ivx_flood_plan *p, int dtype, const void
     return IVX_OK;
 }
 
+// one launch instead of three memsets: reached plane = 0, scratch head (dirty flags, counters, queue) = 0, ring = EMPTY
+__global__ __launch_bounds__(256) void k_flood_clear(uint4 *__restrict__ reached, int64_t n16, uint4 *__restrict__ head,
+                                                     int64_t h16, uint4 *__restrict__ ring, int64_t r16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u), e = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16 + h16 + r16; i += stride) {
+        if (i < n16) reached[i] = z;
+        else if (i < n16 + h16) head[i - n16] = z;
+        else ring[i - n16 - h16] = e;
+    }
+}
+
 extern "C" int ivx_dev_flood_clear(const ivx_flood_plan *p, uint64_t *reached, void *scratch, void *stream) {
     Tiles t;
     int rc = make_tiles(p, &t);
     if (rc) return rc;
     const FScratch s = make_fscratch(t);
-    IVX_HIP(hipMemsetAsync(reached, 0, (size_t)(t.dz * t.dy * t.wx) * 8, ivx::S(stream)));
-    IVX_HIP(hipMemsetAsync(scratch, 0, s.off_seeds, ivx::S(stream)));
-    IVX_HIP(hipMemsetAsync((char *)scratch + s.off_ring, 0xff, (size_t)s.qcap * 4, ivx::S(stream)));
+    const size_t nb = (size_t)(t.dz * t.dy * t.wx) * 8, rb = (size_t)s.qcap * 4;
+    if ((nb | s.off_seeds | rb | (uintptr_t)reached | (uintptr_t)scratch | s.off_ring) & 15) { // odd sizes: plain memsets
+        IVX_HIP(hipMemsetAsync(reached, 0, nb, ivx::S(stream)));
+        IVX_HIP(hipMemsetAsync(scratch, 0, s.off_seeds, ivx::S(stream)));
+        IVX_HIP(hipMemsetAsync((char *)scratch + s.off_ring, 0xff, rb, ivx::S(stream)));
+    } else {
+        const int64_t total = (int64_t)((nb + s.off_seeds + rb) / 16);
+        if (total) {
+            const int64_t blocks = ivx::cdiv(total, 256);
+            hipLaunchKernelGGL(k_flood_clear, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, ivx::S(stream),
+                               (uint4 *)reached, (int64_t)(nb / 16), (uint4 *)scratch, (int64_t)(s.off_seeds / 16),
+                               (uint4 *)((char *)scratch + s.off_ring), (int64_t)(rb / 16));
+            IVX_LAUNCH_CHECK();
+        }
+    }
     ivx::ccl_invalidate(scratch);
     return IVX_OK;
 }
