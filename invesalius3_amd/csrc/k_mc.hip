@@ -400,6 +400,18 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
     for (int q = 0; q < 15; q++) s_tri[tid * 16 + q] = MC_TRI[tid][q];
     const uint64_t T_ = T0 + tid;
     const double iso = T_ < split ? iso0 : iso1;
+    // per-edge constants, once per workgroup: voxel offsets of the edge's two end points relative to the cell's corner
+    // (0,0,0) (dy runs against the source rows: the Y flip) and the end point / axis codes.  |offset| <= ny*nx + nx + 1.
+    __shared__ int s_e0[12], s_e1[12], s_ec[12];
+    const int plane32 = (int)(g.ny * g.nx), nx32 = (int)g.nx;
+    if (tid < 12) {
+        int ax, bx, by, bz;
+        edge_decode(tid, ax, bx, by, bz);
+        const int o0 = bz * plane32 - by * nx32 + bx;
+        s_e0[tid] = o0;
+        s_e1[tid] = o0 + (ax == 2 ? plane32 : (ax == 1 ? -nx32 : 1));
+        s_ec[tid] = ax | (bx << 2) | (by << 3) | (bz << 4);
+    }
     const bool live = T_ < ntris;
     const uint64_t d = live ? list[T_] : 0ull;
     __syncthreads();
@@ -410,36 +422,43 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
         const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
         const int32_t k = (int32_t)(row / (uint32_t)(g.NY - 1)), j = (int32_t)(row - (uint32_t)k * (uint32_t)(g.NY - 1));
         const int32_t i = (int32_t)w * 64 + b;
-        const int64_t ka = k - g.pb, ja = (g.NY - 1 - j) - g.pxy; // source row of corner (dy=0, dz=0)
-        const int32_t ia = i - g.pxy;
-        const bool fast = ka >= 0 && ka + 1 < g.nz && ja - 1 >= 0 && ja < g.ny && ia >= 0 && ia + 1 < g.nx;
-        const int64_t plane = g.ny * g.nx;
-        const T *cell = a + (fast ? (ka * g.ny + ja) * g.nx + ia : 0); // corner (0,0,0); dy -> -nx (flipped), dz -> +plane
+        const int32_t ka = k - (int32_t)g.pb, ja = ((int32_t)g.NY - 1 - j) - (int32_t)g.pxy; // source row of corner (dy=0, dz=0)
+        const int32_t ia = i - (int32_t)g.pxy;
+        const bool fast = ka >= 0 && ka + 1 < (int32_t)g.nz && ja - 1 >= 0 && ja < (int32_t)g.ny && ia >= 0 &&
+                          ia + 1 < (int32_t)g.nx;
         float *o = s_out + tid * 9;
         double s0[3], s1[3];
-        int ax[3], bx[3], by[3], bz[3];
+        int ec[3];
 #pragma unroll
-        for (int v = 0; v < 3; v++) { // issue the six gathers of the triangle back to back
-            const int e = s_tri[idx * 16 + 3 * rel + v];
-            edge_decode(e, ax[v], bx[v], by[v], bz[v]);
-            if (fast) {
-                const int64_t o0 = (int64_t)bz[v] * plane - (int64_t)by[v] * g.nx + bx[v];
-                const int64_t o1 = o0 + (ax[v] == 2 ? plane : (ax[v] == 1 ? -g.nx : 1));
-                s0[v] = (double)cell[o0];
-                s1[v] = (double)cell[o1];
-            } else {
-                s0[v] = mc_at(a, g, k + bz[v], j + by[v], i + bx[v]);
-                s1[v] = mc_at(a, g, k + bz[v] + (ax[v] == 2), j + by[v] + (ax[v] == 1), i + bx[v] + (ax[v] == 0));
+        for (int v = 0; v < 3; v++) ec[v] = s_tri[idx * 16 + 3 * rel + v];
+        if (fast) { // interior cell: one base pointer, six byte/short gathers at table offsets, issued back to back
+            const T *cell = a + ((int64_t)ka * g.ny + ja) * g.nx + ia;
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                s0[v] = (double)cell[s_e0[ec[v]]];
+                s1[v] = (double)cell[s_e1[ec[v]]];
+            }
+#pragma unroll
+            for (int v = 0; v < 3; v++) ec[v] = s_ec[ec[v]];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                const int c = s_ec[ec[v]];
+                const int ax = c & 3, bx = (c >> 2) & 1, by = (c >> 3) & 1, bz = (c >> 4) & 1;
+                s0[v] = mc_at(a, g, k + bz, j + by, i + bx);
+                s1[v] = mc_at(a, g, k + bz + (ax == 2), j + by + (ax == 1), i + bx + (ax == 0));
+                ec[v] = c;
             }
         }
 #pragma unroll
         for (int v = 0; v < 3; v++) {
+            const int ax = ec[v] & 3, bx = (ec[v] >> 2) & 1, by = (ec[v] >> 3) & 1, bz = (ec[v] >> 4) & 1;
             const double tt = (iso - s0[v]) / (s1[v] - s0[v]);
-            double p0 = (double)(i + bx[v] - g.pxy);
-            double p1 = (double)(j + by[v] - (int32_t)g.yoff);
-            double p2 = (double)(k + bz[v] + g.zoff);
-            if (ax[v] == 0) p0 += tt;
-            else if (ax[v] == 1) p1 += tt;
+            double p0 = (double)(i + bx - (int32_t)g.pxy);
+            double p1 = (double)(j + by - (int32_t)g.yoff);
+            double p2 = (double)(k + bz + g.zoff);
+            if (ax == 0) p0 += tt;
+            else if (ax == 1) p1 += tt;
             else p2 += tt;
             o[3 * v + 0] = (float)(g.sx * p0);
             o[3 * v + 1] = (float)(g.sy * p1);
