@@ -1,6 +1,7 @@
 """Times the surface stages after marching cubes on the bench volume: indexed mesh (point merge), keep-largest,
-mass properties, context-aware smoothing -- device-resident, events on the volume's stream -- and the CPU oracle's
-smoothing on the same mesh for scale.  python tools/bench_mesh.py [n] [--cpu]"""
+mass properties, context-aware smoothing -- device-resident, events on the volume's stream.
+python tools/bench_mesh.py [n]   (the CPU side of the comparison lives in tests/test_gpu_smooth.py, where the oracle may
+be used)"""
 import ctypes
 import json
 import sys
@@ -26,7 +27,6 @@ def timed(vol, fn, reps=5):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
-    cpu = "--cpu" in sys.argv
     img = synth_v512((n, n, n))
     vol = DeviceVolume(img, spacing=(0.5, 0.5, 0.5))
     vol.threshold(226, 3071)
@@ -75,17 +75,6 @@ def main():
     out["smooth_setup_ms"] = t0  # copy + topology + seeds + weights
     out["smooth_10_steps_ms"] = t10 - t0
     out["smooth_halfstep_us"] = (t10 - t0) / 20 * 1e3
-    if cpu:
-        from oracle import oracle
-        nrm_h = nrm.download((nt, 3), np.float64)
-        f4 = np.concatenate([np.full((nt, 1), 3), faces0], axis=1).astype(np.int64)
-        want = verts0.copy()
-        t = time.perf_counter()
-        oracle.context_aware_smoothing(want, f4, nrm_h, 0.7, 3.0, 0.5, 10)
-        out["cpu_oracle_smooth_s"] = time.perf_counter() - t
-        smooth(10)()
-        vol.sync()
-        out["smooth_equals_oracle"] = bool(np.array_equal(work.download((nv, 3), np.float32), want))
     print(json.dumps(out))
 
 
