@@ -282,6 +282,26 @@ int ivx_count_regions(int ldtype, const void *labels, const int64_t shape[3], co
                       int64_t number_regions, uint32_t *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * convolve_non_zero and the mask-area measurement built on it
+ *   ivx_*_convolve_non_zero  replaces convolve_non_zero  invesalius_rs/src/transforms_py.rs:51-93
+ *                            (float64 volume and kernel; correlation, outside = cval (an int16), zero where the
+ *                            volume is zero; every output value bit-identical to the reference's (k, j, i) sum)
+ *   ivx_*_mask_area          replaces Slice.calc_image_area  invesalius/data/slice_.py:2296-2322  (mask > 127, the
+ *                            7-point exposed-face kernel of the spacing, cval = 1, summed) without materialising
+ *                            the float64 volume; spacing = (sx, sy, sz)
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_convolve_non_zero(const double *volume, int64_t sz, int64_t sy, int64_t sx, const double *kernel, int64_t skz,
+                              int64_t sky, int64_t skx, int cval, double *out, void *stream);
+int ivx_mask_area_scratch_bytes(int64_t sz, int64_t sy, int64_t sx, size_t *nbytes);
+/* kernel27_dev: the 27 doubles of the kernel on the device; area_dev: one double on the device */
+int ivx_dev_mask_area_u8(const uint8_t *mask, int64_t sz, int64_t sy, int64_t sx, const double *kernel27_dev,
+                         double *scratch, double *area_dev, void *stream);
+int ivx_convolve_non_zero(const double *volume, const int64_t shape[3], const int64_t vol_strides[3], const double *kernel,
+                          const int64_t kshape[3], int cval, double *out);
+int ivx_mask_area(const uint8_t *mask, const int64_t shape[3], const int64_t mask_strides[3], const double spacing_xyz[3],
+                  double *area);
+
+/* ------------------------------------------------------------------------------------------------
  * seeded region growing
  *   replaces generic_floodfill_threshold          invesalius_rs/src/floodfill.rs:96-166
  *            generic_floodfill_threshold_inplace  invesalius_rs/src/floodfill.rs:168-237

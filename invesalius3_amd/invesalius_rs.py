@@ -350,3 +350,22 @@ def count_regions(image, number_regions):
                                       L.i64(image.strides), ctypes.c_int64(int(number_regions)), L.ptr(out)),
             "count_regions")  # IVX_ERANGE -> IndexError
     return out
+
+
+def convolve_non_zero(volume, kernel, cval):
+    """transforms_py.rs:51-93: float64 (d,h,w) volume correlated with a float64 kernel where the volume is non-zero
+    (zero elsewhere); samples outside the volume count as ``cval`` (an i16 in the reference).  Returns a new array."""
+    if not isinstance(volume, np.ndarray) or volume.dtype != np.float64 or volume.ndim != 3:
+        raise TypeError("volume must be a 3-D float64 array")
+    if not isinstance(kernel, np.ndarray) or kernel.dtype != np.float64 or kernel.ndim != 3:
+        raise TypeError("kernel must be a 3-D float64 array")
+    if isinstance(cval, float) and not float(cval).is_integer():
+        raise TypeError("cval must be an integer (i16)")
+    cval = int(cval)
+    if not -32768 <= cval <= 32767:
+        raise OverflowError("cval does not fit an i16")
+    k = np.ascontiguousarray(kernel)
+    out = np.zeros(volume.shape, np.float64)
+    L.check(L.lib().ivx_convolve_non_zero(L.ptr(volume), L.i64(volume.shape), L.i64(volume.strides), L.ptr(k), L.i64(k.shape),
+                                          ctypes.c_int(cval), L.ptr(out)), "convolve_non_zero")
+    return out

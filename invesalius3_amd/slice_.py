@@ -89,3 +89,17 @@ def project(slab: np.ndarray, axis: int, projection: int) -> np.ndarray:
     L.check(L.lib().ivx_mip_reduce(code, L.ptr(slab), L.i64(slab.shape), L.i64(slab.strides), int(axis), int(op),
                                    L.ptr(out), L.i64(out.strides)), "project")
     return out
+
+
+def calc_image_area(mask_matrix: np.ndarray, spacing) -> float:
+    """Slice.calc_image_area (invesalius/data/slice_.py:2296-2322) after its threshold step: the exposed-face area of
+    ``mask_matrix[1:,1:,1:] > 127`` for ``spacing = (sx, sy, sz)``.  Computed from the uint8 mask on the GPU (the
+    reference builds ``bin_img * 1.0`` and calls convolve_non_zero(..., cval=1).sum()); per-voxel terms are identical,
+    the final sum is a tree sum instead of numpy's pairwise one (differs by rounding only)."""
+    if mask_matrix.dtype != np.uint8 or mask_matrix.ndim != 3:
+        raise TypeError("mask matrix must be a 3-D uint8 array")
+    inner = mask_matrix[1:, 1:, 1:]
+    sp = (ctypes.c_double * 3)(*[float(v) for v in spacing])
+    area = ctypes.c_double(0.0)
+    L.check(L.lib().ivx_mask_area(L.ptr(inner), L.i64(inner.shape), L.i64(inner.strides), sp, ctypes.byref(area)), "mask_area")
+    return float(area.value)

@@ -542,3 +542,34 @@ def count_regions(image, number_regions):
     if rc == -1:
         raise IndexError("label out of range")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# convolve_non_zero (invesalius_rs/src/transforms_py.rs:51-93) and Slice.calc_image_area (slice_.py:2296-2322)
+# ---------------------------------------------------------------------------------------------------------------------
+def convolve_non_zero(volume, kernel, cval):
+    """term-by-term restatement in numpy: the (k, j, i) accumulation order is kept by adding one shifted plane at a time"""
+    v = np.asarray(volume, np.float64)
+    k = np.asarray(kernel, np.float64)
+    pz, py, px = (s // 2 for s in k.shape)
+    pad = np.pad(v, ((pz, k.shape[0] - 1 - pz), (py, k.shape[1] - 1 - py), (px, k.shape[2] - 1 - px)), constant_values=float(int(cval)))
+    acc = np.zeros(v.shape, np.float64)
+    for a in range(k.shape[0]):
+        for b in range(k.shape[1]):
+            for c in range(k.shape[2]):
+                acc = acc + pad[a:a + v.shape[0], b:b + v.shape[1], c:c + v.shape[2]] * k[a, b, c]
+    return np.where(v != 0.0, acc, 0.0)
+
+
+def calc_image_area(mask_matrix, spacing):
+    sx, sy, sz = (float(s) for s in spacing)
+    kernel = np.zeros((3, 3, 3))
+    kernel[1, 1, 1] = 2 * sx * sy + 2 * sx * sz + 2 * sy * sz
+    kernel[0, 1, 1] = -(sx * sy)
+    kernel[2, 1, 1] = -(sx * sy)
+    kernel[1, 0, 1] = -(sx * sz)
+    kernel[1, 2, 1] = -(sx * sz)
+    kernel[1, 1, 0] = -(sy * sz)
+    kernel[1, 1, 2] = -(sy * sz)
+    bin_img = mask_matrix[1:, 1:, 1:] > 127
+    return float(convolve_non_zero(bin_img * 1.0, kernel, 1).sum())

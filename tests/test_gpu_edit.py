@@ -122,3 +122,36 @@ def test_count_regions_matches_oracle(ivxlib, oracle, dtype):
         rs.count_regions(neg, nreg)
     with pytest.raises(TypeError):
         rs.count_regions(lab.astype(np.uint8), nreg)
+
+
+def test_convolve_non_zero_matches_oracle_bit_for_bit(ivxlib, oracle):
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(12)
+    for shape, kshape, cval in (((9, 10, 33), (3, 3, 3), 1), ((5, 6, 7), (1, 3, 5), -7), ((4, 4, 4), (2, 2, 2), 0)):
+        vol = rng.normal(size=shape) * (rng.random(shape) < 0.5)
+        ker = rng.normal(size=kshape)
+        got = rs.convolve_non_zero(vol, ker, cval)
+        assert got.dtype == np.float64 and np.array_equal(got, oracle.convolve_non_zero(vol, ker, cval))
+        assert np.array_equal(got == 0, (vol == 0) | (got == 0))
+    # a strided view, as bin_img * 1.0 of a larger array would be
+    big = rng.normal(size=(6, 8, 20))
+    view = big[::2, 1:, ::3]
+    assert np.array_equal(rs.convolve_non_zero(view, np.ones((3, 3, 3)), 2), oracle.convolve_non_zero(view, np.ones((3, 3, 3)), 2))
+    with pytest.raises(TypeError):
+        rs.convolve_non_zero(vol.astype(np.float32), ker, 0)
+    with pytest.raises(OverflowError):
+        rs.convolve_non_zero(vol, ker, 40000)
+
+
+def test_mask_area_matches_the_reference_formula(ivxlib, oracle):
+    from invesalius3_amd import slice_ as sl
+    rng = np.random.default_rng(13)
+    m = np.zeros((20, 24, 70), np.uint8)
+    m[1:, 1:, 1:] = rng.choice(np.array([0, 1, 127, 128, 254, 255], np.uint8), size=(19, 23, 69))
+    for sp in ((1.0, 1.0, 1.0), (0.4785156, 0.4785156, 2.0)):
+        got = sl.calc_image_area(m, sp)
+        assert got == pytest.approx(oracle.calc_image_area(m, sp), rel=1e-12)
+    box = np.zeros((12, 13, 14), np.uint8)
+    box[3:6, 4:9, 5:12] = 255
+    assert sl.calc_image_area(box, (0.5, 0.75, 2.0)) == pytest.approx(2 * 35 * 0.375 + 2 * 21 * 1.0 + 2 * 15 * 1.5, rel=1e-12)
+    assert sl.calc_image_area(np.zeros((3, 3, 3), np.uint8), (1, 1, 1)) == 0.0

@@ -99,3 +99,26 @@ def test_count_regions(oracle):
         oracle.count_regions(lab, 5)
     with pytest.raises(IndexError):
         oracle.count_regions(lab - 1, 6)
+
+
+def test_convolve_non_zero_and_area_anchors(oracle):
+    from scipy import ndimage
+    rng = np.random.default_rng(4)
+    vol = rng.normal(size=(7, 8, 9)) * (rng.random((7, 8, 9)) < 0.6)
+    ker = rng.normal(size=(3, 3, 3))
+    got = oracle.convolve_non_zero(vol, ker, -3)
+    ref = np.where(vol != 0, ndimage.correlate(vol, ker, mode="constant", cval=-3.0), 0.0)
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-12)
+    # even-sized kernel: centre offset is size // 2, like scipy's origin 0
+    ker2 = rng.normal(size=(2, 4, 3))
+    got2 = oracle.convolve_non_zero(vol, ker2, 0)
+    ref2 = np.where(vol != 0, ndimage.correlate(vol, ker2, mode="constant", cval=0.0), 0.0)
+    assert np.allclose(got2, ref2, rtol=1e-12, atol=1e-12)
+    # area of an a x b x c voxel box: its exposed faces (cval = 1: the volume border does not count as exposed)
+    m = np.zeros((12, 13, 14), np.uint8)
+    m[3:6, 4:9, 5:12] = 255  # 3 (z) x 5 (y) x 7 (x) voxels
+    sx, sy, sz = 0.5, 0.75, 2.0
+    area = oracle.calc_image_area(m, (sx, sy, sz))
+    nz, ny, nx = 3, 5, 7   # mask_matrix[1:,1:,1:] shifts the box, not its size
+    want = 2 * (nx * ny) * (sx * sy) + 2 * (nx * nz) * (sx * sz) + 2 * (ny * nz) * (sy * sz)
+    assert area == pytest.approx(want, rel=1e-12)
