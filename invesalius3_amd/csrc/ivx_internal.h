@@ -78,6 +78,7 @@ int download_strided2(void *dst, const int64_t shape[2], const int64_t strides[2
                       int hslot);
 
 // run-based union-find flood (k_ccl.hip)
+void ccl_forget_stream(void *stream);
 void ccl_invalidate(const void *scratch);
 bool ccl_supported(uint32_t strct_bits);
 int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, const void *scratch_key, hipStream_t st);

@@ -296,7 +296,21 @@ int ivx_stream_create(void **stream) {
     return IVX_OK;
 }
 int ivx_stream_destroy(void *stream) {
-    if (stream) IVX_HIP(hipStreamDestroy(S(stream)));
+    if (!stream) return IVX_OK;
+    IVX_HIP(hipStreamSynchronize(S(stream)));
+    { // the stream's private workspaces go with it (a later stream may be handed the same handle value)
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto it = g_ws_stream.begin(); it != g_ws_stream.end();) {
+            if (it->first.second == S(stream)) {
+                if (it->second.p) (void)hipFree(it->second.p);
+                it = g_ws_stream.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    ccl_forget_stream(stream);
+    IVX_HIP(hipStreamDestroy(S(stream)));
     return IVX_OK;
 }
 int ivx_stream_synchronize(void *stream) {

@@ -410,6 +410,14 @@ void ccl_invalidate(const void *scratch) {
     g_state[scratch] = CclState();
 }
 
+void ccl_forget_stream(void *stream) {
+    std::lock_guard<std::mutex> lk(g_state_mu);
+    auto it = g_tab_owner.find((hipStream_t)stream);
+    if (it == g_tab_owner.end()) return;
+    g_state.erase(it->second); // its tables lived in the stream's workspaces, which are being freed
+    g_tab_owner.erase(it);
+}
+
 bool ccl_supported(uint32_t strct_bits) {
     const uint32_t s = strct_bits | (1u << 13);
     for (int k = 0; k < 27; k++)
