@@ -216,6 +216,11 @@ class DeviceVolume:
         L.check(L.lib().ivx_stream_synchronize(self.stream))
 
     def close(self):
+        if getattr(self, "stream", None) is None:
+            return  # already closed (or never fully built)
+        self._out_pending = None
+        for b in (self.image, self.mask, self.out_mask):
+            b._on_touch = None  # freeing is not "somebody looked at the contents"
         for b in (self.image, self.mask, self.out_mask, self.cand, self.reached, self._mbits, self.flood_scratch,
                   self._mc_scratch, self._tris, self._verts, self._faces):
             if b is not None:
@@ -223,6 +228,18 @@ class DeviceVolume:
         if self.stream is not None:
             L.lib().ivx_stream_destroy(self.stream)
             self.stream = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def download_mask(self) -> np.ndarray:
         self.sync()
