@@ -251,8 +251,14 @@ __device__ __forceinline__ Corner8 load_corners(const uint64_t *__restrict__ bit
 }
 __device__ __forceinline__ int case_of(const uint64_t *c, int b) {
     int idx = 0;
+    if (b != 63) {
+        // c[2q+1] is c[2q] moved down by one cell, so bits b and b+1 of the even words ARE the corner pairs (2q, 2q+1)
 #pragma unroll
-    for (int q = 0; q < 8; q++) idx |= (int)((c[q] >> b) & 1ull) << q;
+        for (int q = 0; q < 4; q++) idx |= (int)((c[2 * q] >> b) & 3ull) << (2 * q);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) idx |= (int)((c[q] >> 63) & 1ull) << q;
+    }
     return idx;
 }
 
