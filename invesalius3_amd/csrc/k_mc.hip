@@ -226,18 +226,53 @@ struct Corner8 {
     uint64_t c[8];
     uint64_t active;
 };
+// The eight corner words of cell word (k, j, w).  Same view as padded_pair, specialised: of the following word only
+// bit 0 is ever needed (corner x+1 of cell 63), so each of the four rows costs two loads instead of three and one mask
+// instead of two, and the masks that depend only on w are computed once for all four rows.
 __device__ __forceinline__ Corner8 load_corners(const uint64_t *__restrict__ bits, const Geom &g, int64_t k,
                                                 int64_t j, int64_t w, uint64_t pbits) {
     Corner8 r;
+    const auto clampi = [](int64_t v, int64_t n) { return v >= n ? (n > 0 ? n - 1 : 0) : (v < 0 ? 0 : v); };
+    const int64_t rem = g.NX - w * 64; // padded points in this word
+    const uint64_t exist = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    uint64_t srcm = exist; // ... of which backed by source voxels (when the row is a source row)
+    if (g.pxy && w == 0) srcm &= ~1ull;
+    const int64_t top = g.pxy + g.nx - w * 64;
+    srcm &= top >= 64 ? ~0ull : (top <= 0 ? 0ull : ((1ull << top) - 1ull));
+    const int64_t x1 = (w + 1) * 64;              // padded x of the next word's first point
+    const bool exist1 = x1 < g.NX;
+    const bool src1 = x1 - g.pxy < g.nx;          // (x1 - pxy >= 0 always)
+    const bool has_m = w - 1 >= 0 && w - 1 < g.ws, has_c = w < g.ws, has_p = w + 1 < g.ws;
+    const int64_t wm = clampi(w - 1, g.ws), wc = clampi(w, g.ws), wp = clampi(w + 1, g.ws);
+    uint64_t a0[4], a1[4];
+    bool rin[4];
 #pragma unroll
-    for (int dz = 0; dz < 2; dz++)
+    for (int q = 0; q < 4; q++) { // issue the eight loads back to back
+        const int64_t ja = (g.NY - 1 - (j + (q & 1))) - g.pxy, ka = k + (q >> 1) - g.pb;
+        rin[q] = ja >= 0 && ja < g.ny && ka >= 0 && ka < g.nz;
+        const uint64_t *row = bits + (clampi(ka, g.nz) * g.ny + clampi(ja, g.ny)) * g.ws;
+        a0[q] = row[wc];
+        a1[q] = g.pxy ? row[wm] : row[wp];
+    }
 #pragma unroll
-        for (int dy = 0; dy < 2; dy++) {
-            uint64_t lo, nx;
-            padded_pair(bits, g, k + dz, j + dy, w, pbits, lo, nx);
-            r.c[4 * dz + 2 * dy] = lo;
-            r.c[4 * dz + 2 * dy + 1] = (lo >> 1) | (nx << 63);
+    for (int q = 0; q < 4; q++) {
+        const uint64_t sc = (rin[q] && has_c) ? a0[q] : 0ull;
+        uint64_t v0, raw1;
+        if (g.pxy) {
+            const uint64_t sm = (rin[q] && has_m) ? a1[q] : 0ull;
+            v0 = (sc << 1) | (sm >> 63);
+            raw1 = sc >> 63;
+        } else {
+            const uint64_t sp = (rin[q] && has_p) ? a1[q] : 0ull;
+            v0 = sc;
+            raw1 = sp & 1ull;
         }
+        const uint64_t src = rin[q] ? srcm : 0ull;
+        const uint64_t lo = (v0 & src) | (pbits & exist & ~src);
+        const uint64_t nb = exist1 ? ((rin[q] && src1) ? raw1 : (pbits & 1ull)) : 0ull;
+        r.c[2 * q] = lo;
+        r.c[2 * q + 1] = (lo >> 1) | (nb << 63);
+    }
     uint64_t any = 0, all = ~0ull;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
