@@ -332,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
                                                   uint64_t *__restrict__ boff) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
-    constexpr int PER = 8; // consecutive elements per lane: 8192 per pass
+    constexpr int PER = 16; // consecutive elements per lane: 16384 per pass (one pass for a 512^3 piece)
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
