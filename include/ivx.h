@@ -372,6 +372,14 @@ int ivx_dev_fill_holes(uint8_t *mask, const uint32_t *labels, int64_t n, uint32_
 int ivx_fill_holes_automatically(uint8_t *mask, const int64_t shape[3], const int64_t mask_strides[3],
                                  const uint32_t *labels, const int64_t label_strides[3], uint32_t nlabels,
                                  uint32_t max_size, int *modified);
+/* Mask.fill_holes_auto (invesalius/data/mask.py:519-562) in one call: imask = ~(mask > 127), connected components of
+ * imask under `strct` (what scipy.ndimage.label computes there), then the rule above -- without a label volume: the
+ * result depends on the labels only through the component sizes.  strct: generate_binary_structure(3, 1|2|3) or a
+ * (1,3,3) 4-/8-neighbour element for a (1,h,w) slice.  *modified = the bool the reference's call returns. */
+int ivx_dev_fill_holes_auto(uint8_t *mask, int64_t dz, int64_t dy, int64_t dx, const uint8_t *strct, const int64_t sshape[3],
+                            uint32_t max_size, int *modified, void *stream);
+int ivx_fill_holes_auto(uint8_t *mask, const int64_t shape[3], const int64_t mask_strides[3], const uint8_t *strct,
+                        const int64_t sshape[3], uint32_t max_size, int *modified);
 
 /* ------------------------------------------------------------------------------------------------
  * watershed pre- and post-processing (the deterministic parts of do_watershed,

@@ -54,7 +54,7 @@ static inline size_t dtype_size(int dt) {
 }
 
 // Cached device workspaces for the host-level entry points (grow-only, freed by ivx_release_workspace).
-enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_CCL0, WS_CCL1, WS_MCLIST, WS_MCV, WS_MESH, WS_MESH2, WS_COUNT };
+enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_CCL0, WS_CCL1, WS_MCLIST, WS_MCV, WS_MESH, WS_MESH2, WS_HOLES, WS_COUNT };
 int ws_get(int slot, size_t nbytes, void **dptr);
 // Same, but private to `stream`: the device-level entry points keep their internal scratch (MC triangle list, MIP
 // partials, union-find tables, ...) per stream, so several resident volumes can run concurrently from different
@@ -80,6 +80,8 @@ int download_strided2(void *dst, const int64_t shape[2], const int64_t strides[2
 // run-based union-find flood (k_ccl.hip)
 void ccl_forget_stream(void *stream);
 void ccl_invalidate(const void *scratch);
+int ccl_small_components(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *out, uint32_t max_size, int *any_small,
+                         const void *scratch_key, hipStream_t st);
 bool ccl_supported(uint32_t strct_bits);
 int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, const void *scratch_key, hipStream_t st);
 

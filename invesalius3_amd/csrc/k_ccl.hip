@@ -387,6 +387,47 @@ __global__ __launch_bounds__(256) void k_ccl_paint(const unsigned long long *__r
     }
 }
 
+// voxels per component: every run adds its length to its root.  The wave first agrees on the root its first lane's run
+// has (background components own most runs of a wave) and adds that part with ONE atomic.
+__global__ __launch_bounds__(256) void k_ccl_sizes(const unsigned long long *__restrict__ cand,
+                                                   const uint32_t *__restrict__ wbase, int64_t nwords,
+                                                   const uint32_t *__restrict__ parent, uint32_t *__restrict__ sizes) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < nwords; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        const unsigned long long c = i < nwords ? cand[i] : 0ull;
+        unsigned long long rest = c;
+        uint32_t id = i < nwords ? wbase[i] : 0u;
+        const unsigned long long havem = __ballot(c != 0ull);
+        if (!havem) continue;
+        const uint32_t hot = __shfl(c ? parent[id] : 0u, __builtin_ctzll(havem), 64); // root of the wave's first run
+        uint32_t hot_add = 0;
+        while (rest) {
+            const int a = __builtin_ctzll(rest);
+            const int b = run_end_at(c, a);
+            const unsigned long long rm = (b - a == 63) ? ~0ull : (((1ull << (b - a + 1)) - 1ull) << a);
+            rest &= ~rm;
+            const uint32_t root = parent[id];
+            if (root == hot) hot_add += (uint32_t)(b - a + 1);
+            else atomicAdd(&sizes[root], (uint32_t)(b - a + 1));
+            id++;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hot_add += __shfl_xor(hot_add, o, 64);
+        if ((threadIdx.x & 63) == 0 && hot_add) atomicAdd(&sizes[hot], hot_add);
+    }
+}
+__global__ __launch_bounds__(256) void k_ccl_flag_small(const uint32_t *__restrict__ sizes, uint32_t nruns, uint32_t max_size,
+                                                        uint8_t *__restrict__ flag, int *__restrict__ any_small) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nruns; i += stride) {
+        const uint32_t s = sizes[i]; // non-zero only at roots
+        const bool small = s > 0 && s <= max_size;
+        flag[i] = small ? 1 : 0;
+        if (small) *any_small = 1; // benign race: all write 1
+    }
+}
+
 // host-side state per scratch buffer: is the component table valid for the current candidate plane?
 struct CclState {
     bool built = false;
@@ -425,9 +466,18 @@ bool ccl_supported(uint32_t strct_bits) {
     return (s >> 12 & 1u) && (s >> 14 & 1u);                      // x neighbours in the centre row: runs are connected
 }
 
-// reached := union of the candidate components that hold a reached bit.  Builds the component table on first use.
-int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, const void *scratch_key, hipStream_t st) {
+struct CclTables {
     CGeom g;
+    uint32_t *wbase = nullptr, *parent = nullptr;
+    uint8_t *flag = nullptr;
+    uint32_t nruns = 0;
+};
+
+// Component table of the candidate plane (run ids per word, flattened union-find), built on first use per scratch key.
+// extra_per_run: additional bytes per run reserved behind parent[] and flag[] (the caller's own per-run arrays).
+static int ccl_prepare(const ivx_flood_plan *p, const uint64_t *cand, const void *scratch_key, hipStream_t st, CclTables *t,
+                       size_t extra_per_run = 0) {
+    CGeom &g = t->g;
     g.dz = p->dz; g.dy = p->dy; g.dx = p->dx; g.wx = p->wx;
     g.nwords = p->dz * p->dy * p->wx;
     g.strct = p->strct_bits | (1u << 13);
@@ -463,15 +513,19 @@ int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, co
         state.nruns = tot;
         IVX_REQUIRE(tot < 0xfffffff0u, IVX_EINVAL, "flood: too many runs for 32-bit ids");
     }
+    t->wbase = wbase;
+    t->nruns = state.nruns;
     if (state.nruns == 0) {
         std::lock_guard<std::mutex> lk(g_state_mu);
         state.built = true;
         g_state[scratch_key] = state;
         return IVX_OK;
     }
-    if ((rc = ws_get_s(WS_CCL1, st, (size_t)state.nruns * 5 + 64, &d_tab))) return rc;
+    if ((rc = ws_get_s(WS_CCL1, st, (size_t)state.nruns * (5 + extra_per_run) + 256, &d_tab))) return rc;
     uint32_t *parent = (uint32_t *)d_tab;
     uint8_t *flag = (uint8_t *)(parent + state.nruns);
+    t->parent = parent;
+    t->flag = flag;
     if (!state.built) {
         hipLaunchKernelGGL(k_ccl_init, dim3(grid_for(state.nruns)), dim3(256), 0, st, parent, flag, state.nruns);
         IVX_LAUNCH_CHECK();
@@ -487,12 +541,45 @@ int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, co
         state.built = true;
         g_state[scratch_key] = state;
     }
-    hipLaunchKernelGGL(k_ccl_activate, dim3(grid_for(g.nwords)), dim3(256), 0, st, c, (const unsigned long long *)reached,
-                       wbase, g.nwords, parent, flag);
+    return IVX_OK;
+}
+
+// reached := union of the candidate components that hold a reached bit.  Builds the component table on first use.
+int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, const void *scratch_key, hipStream_t st) {
+    CclTables t;
+    int rc = ccl_prepare(p, cand, scratch_key, st, &t);
+    if (rc) return rc;
+    if (t.g.nwords == 0 || t.nruns == 0) return IVX_OK;
+    const unsigned long long *c = (const unsigned long long *)cand;
+    hipLaunchKernelGGL(k_ccl_activate, dim3(grid_for(t.g.nwords)), dim3(256), 0, st, c, (const unsigned long long *)reached,
+                       t.wbase, t.g.nwords, t.parent, t.flag);
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ccl_paint, dim3(grid_for(g.nwords)), dim3(256), 0, st, c, (unsigned long long *)reached, wbase,
-                       g.nwords, parent, flag);
+    hipLaunchKernelGGL(k_ccl_paint, dim3(grid_for(t.g.nwords)), dim3(256), 0, st, c, (unsigned long long *)reached, t.wbase,
+                       t.g.nwords, t.parent, t.flag);
     IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+// out := the voxels of every candidate component of at most max_size voxels (out must be zeroed by the caller);
+// *any_small (device int) is raised when there is one.  The component sizes are the sums of the run lengths per root.
+int ccl_small_components(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *out, uint32_t max_size, int *any_small,
+                         const void *scratch_key, hipStream_t st) {
+    CclTables t;
+    ccl_invalidate(scratch_key); // the flags are reused with another meaning: never trust a table built for a flood
+    int rc = ccl_prepare(p, cand, scratch_key, st, &t, 4);
+    if (rc) return rc;
+    if (t.g.nwords == 0 || t.nruns == 0) return IVX_OK;
+    uint32_t *sizes = (uint32_t *)(((uintptr_t)(t.flag + t.nruns) + 15) & ~(uintptr_t)15);
+    const unsigned long long *c = (const unsigned long long *)cand;
+    IVX_HIP(hipMemsetAsync(sizes, 0, (size_t)t.nruns * 4, st));
+    hipLaunchKernelGGL(k_ccl_sizes, dim3(grid_for(t.g.nwords)), dim3(256), 0, st, c, t.wbase, t.g.nwords, t.parent, sizes);
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ccl_flag_small, dim3(grid_for(t.nruns)), dim3(256), 0, st, sizes, t.nruns, max_size, t.flag, any_small);
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ccl_paint, dim3(grid_for(t.g.nwords)), dim3(256), 0, st, c, (unsigned long long *)out, t.wbase,
+                       t.g.nwords, t.parent, t.flag);
+    IVX_LAUNCH_CHECK();
+    ccl_invalidate(scratch_key);
     return IVX_OK;
 }
 

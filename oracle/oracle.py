@@ -573,3 +573,31 @@ def calc_image_area(mask_matrix, spacing):
     kernel[1, 1, 2] = -(sy * sz)
     bin_img = mask_matrix[1:, 1:, 1:] > 127
     return float(convolve_non_zero(bin_img * 1.0, kernel, 1).sum())
+
+
+def mask_fill_holes_auto(matrix, target, conn, orientation, index, size):
+    """Mask.fill_holes_auto (invesalius/data/mask.py:519-562) minus the history: scipy.ndimage.label (the third-party
+    function the reference calls) + the fill_holes_automatically restatement.  In place; returns the bool."""
+    from scipy import ndimage
+    if target == "3D":
+        view = matrix[1:, 1:, 1:]
+        bstruct = ndimage.generate_binary_structure(3, {6: 1, 18: 2, 26: 3}[conn])
+    else:
+        view = {"AXIAL": lambda: matrix[index + 1, 1:, 1:], "CORONAL": lambda: matrix[1:, index + 1, 1:],
+                "SAGITAL": lambda: matrix[1:, 1:, index + 1]}[orientation]()
+        bstruct = ndimage.generate_binary_structure(2, {4: 1, 8: 2}[conn])
+    imask = ~(view > 127)
+    labels, nlabels = ndimage.label(imask, bstruct, output=np.uint32)
+    labels = np.asarray(labels, dtype=np.uint32, order="C")
+    if nlabels == 0:
+        return False
+    if target != "3D":
+        labels = labels.reshape(1, labels.shape[0], labels.shape[1])
+        work = np.ascontiguousarray(view).reshape(1, view.shape[0], view.shape[1])
+        ret = fill_holes_automatically(work, labels, nlabels, size)
+        view[...] = work[0]
+        return ret
+    work = np.ascontiguousarray(view)
+    ret = fill_holes_automatically(work, labels, nlabels, size)
+    view[...] = work
+    return ret
