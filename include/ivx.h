@@ -282,6 +282,22 @@ int ivx_count_regions(int ldtype, const void *labels, const int64_t shape[3], co
                       int64_t number_regions, uint32_t *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * whole-mask numpy expressions of invesalius/data/slice_.py
+ *   ivx_*_mask_boolean        Slice.do_boolean_op slice_.py:1906-1916: out = 255 where op(m1 > 2, m2 > 2) else 0;
+ *                             op = 1 union, 2 diff (m1 and not m2), 3 intersection, 4 xor (constants.py:818-821)
+ *   ivx_*_masked_density_i16  Slice.calc_image_density slice_.py:2284-2297: count / sum / sum of squares (exact
+ *                             integers) / min / max of the int16 image where mask > 127; mean and std are formed
+ *                             from them in float64 by the caller
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_mask_boolean(int op, const uint8_t *m1, const uint8_t *m2, uint8_t *out, int64_t n, void *stream);
+/* acc5: 32 bytes on the device: int64 count, sum, sum of squares, then int32 min, max */
+int ivx_dev_masked_density_i16(const int16_t *img, const uint8_t *mask, int64_t n, void *acc5, void *stream);
+int ivx_mask_boolean(int op, const uint8_t *m1, const int64_t st1[3], const uint8_t *m2, const int64_t st2[3], uint8_t *out,
+                     const int64_t sto[3], const int64_t shape[3]);
+int ivx_masked_density_i16(const int16_t *img, const int64_t img_strides[3], const uint8_t *mask,
+                           const int64_t mask_strides[3], const int64_t shape[3], double *out5);
+
+/* ------------------------------------------------------------------------------------------------
  * convolve_non_zero and the mask-area measurement built on it
  *   ivx_*_convolve_non_zero  replaces convolve_non_zero  invesalius_rs/src/transforms_py.rs:51-93
  *                            (float64 volume and kernel; correlation, outside = cval (an int16), zero where the

@@ -11,6 +11,8 @@
 //
 // All are HBM streaming passes (bytes per voxel in DESIGN.md section 3); no LDS tiling is needed except for the
 // gradient, whose 27 taps are served by L1/L2 (each row is re-read by its y/z neighbours while still cached).
+#include <cstring>
+
 #include "ivx_internal.h"
 
 namespace {
@@ -157,6 +159,63 @@ __global__ __launch_bounds__(256) void k_masked_stats(const int16_t *__restrict_
         atomicAdd(&acc[2], (unsigned long long)s2);
     }
 }
+// count, sum, sum of squares, min, max of img where mask > 127 (Slice.calc_image_density, slice_.py:2284-2297)
+__global__ __launch_bounds__(256) void k_density(const int16_t *__restrict__ img, const uint8_t *__restrict__ mask, int64_t n,
+                                                 unsigned long long *__restrict__ acc, int *__restrict__ mm) {
+    long long cnt = 0, s = 0, s2 = 0;
+    int lo = 32767, hi = -32768;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (mask[i] > 127) {
+            const int v = img[i];
+            cnt++;
+            s += v;
+            s2 += (long long)v * v;
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, 64);
+        s += __shfl_xor(s, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+        const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&acc[0], (unsigned long long)cnt);
+        atomicAdd(&acc[1], (unsigned long long)s);
+        atomicAdd(&acc[2], (unsigned long long)s2);
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+// Slice.do_boolean_op (slice_.py:1906-1916): "selected" here means > 2, the result is 0 / 255
+typedef unsigned char bool16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned char bool_op(int op, unsigned char a, unsigned char b) {
+    const bool x = a > 2, y = b > 2;
+    const bool r = op == 1 ? (x || y) : op == 2 ? (x != (x && y)) : op == 3 ? (x && y) : (x != y);
+    return r ? 255 : 0;
+}
+__global__ __launch_bounds__(256) void k_mask_boolean(int op, const uint8_t *__restrict__ m1, const uint8_t *__restrict__ m2,
+                                                      uint8_t *__restrict__ out, int64_t n, int vec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t nc = n / 16;
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += stride) {
+            const bool16_t a = reinterpret_cast<const bool16_t *>(m1)[c], b = reinterpret_cast<const bool16_t *>(m2)[c];
+            bool16_t r;
+#pragma unroll
+            for (int i = 0; i < 16; i++) r[i] = bool_op(op, a[i], b[i]);
+            reinterpret_cast<bool16_t *>(out)[c] = r;
+        }
+    }
+    for (int64_t i = (vec ? (n / 16) * 16 : 0) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = bool_op(op, m1[i], m2[i]);
+}
+
 __global__ __launch_bounds__(256) void k_set_where(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t n,
                                                    int value, int fill) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -334,4 +393,78 @@ extern "C" int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const 
     if ((rc = ivx_dev_watershed_merge((uint8_t *)d_m, (const uint8_t *)d_t, n, overwrite, nullptr))) return rc;
     IVX_HIP(hipDeviceSynchronize());
     return download_strided(mask, shape, mst, d_m, 1, WS_OUT);
+}
+
+
+extern "C" int ivx_dev_mask_boolean(int op, const uint8_t *m1, const uint8_t *m2, uint8_t *out, int64_t n, void *stream) {
+    IVX_REQUIRE(op >= 1 && op <= 4, IVX_EINVAL, "mask_boolean: op must be 1 (union), 2 (diff), 3 (and) or 4 (xor)");
+    IVX_REQUIRE(n >= 0, IVX_EINVAL, "mask_boolean: negative size");
+    if (n == 0) return IVX_OK;
+    const int vec = ((((uintptr_t)m1 | (uintptr_t)m2 | (uintptr_t)out) & 15) == 0) && n >= 16;
+    hipLaunchKernelGGL(k_mask_boolean, dim3(grid_for(n, 16)), dim3(256), 0, ivx::S(stream), op, m1, m2, out, n, vec);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+// acc5 (device): count, sum, sum of squares (int64), then min and max as two int32 packed behind them (40 bytes total)
+extern "C" int ivx_dev_masked_density_i16(const int16_t *img, const uint8_t *mask, int64_t n, void *acc5, void *stream) {
+    IVX_REQUIRE(n >= 0, IVX_EINVAL, "masked_density: negative size");
+    hipStream_t st = ivx::S(stream);
+    IVX_HIP(hipMemsetAsync(acc5, 0, 24, st));
+    const int init[2] = {32767, -32768};
+    IVX_HIP(hipMemcpyAsync((char *)acc5 + 24, init, 8, hipMemcpyHostToDevice, st));
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_density, dim3(grid_for(n, 8)), dim3(256), 0, st, img, mask, n, (unsigned long long *)acc5,
+                       (int *)((char *)acc5 + 24));
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+// host forms ---------------------------------------------------------------------------------------------------------
+extern "C" int ivx_mask_boolean(int op, const uint8_t *m1, const int64_t st1[3], const uint8_t *m2, const int64_t st2[3],
+                                uint8_t *out, const int64_t sto[3], const int64_t shape[3]) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    IVX_REQUIRE(shape[0] >= 0 && shape[1] >= 0 && shape[2] >= 0, IVX_EINVAL, "mask_boolean: negative shape");
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+    if (n == 0) return IVX_OK;
+    void *d1, *d2, *d3;
+    int rc;
+    if ((rc = ws_get(WS_IN, n, &d1))) return rc;
+    if ((rc = ws_get(WS_AUX0, n, &d2))) return rc;
+    if ((rc = ws_get(WS_OUT, n, &d3))) return rc;
+    if ((rc = upload_strided(d1, m1, shape, st1, 1, WS_IN))) return rc;
+    if ((rc = upload_strided(d2, m2, shape, st2, 1, WS_AUX0))) return rc;
+    if ((rc = ivx_dev_mask_boolean(op, (const uint8_t *)d1, (const uint8_t *)d2, (uint8_t *)d3, (int64_t)n, nullptr))) return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    return download_strided(out, shape, sto, d3, 1, WS_OUT);
+}
+
+// out5: count, sum, sum of squares (as doubles: exact below 2^53), min, max
+extern "C" int ivx_masked_density_i16(const int16_t *img, const int64_t ist[3], const uint8_t *mask, const int64_t mst[3],
+                                      const int64_t shape[3], double *out5) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    IVX_REQUIRE(shape[0] >= 0 && shape[1] >= 0 && shape[2] >= 0, IVX_EINVAL, "masked_density: negative shape");
+    for (int q = 0; q < 5; q++) out5[q] = 0.0;
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+    if (n == 0) return IVX_OK;
+    void *d_i, *d_m, *d_a;
+    int rc;
+    if ((rc = ws_get(WS_IN, n * 2, &d_i))) return rc;
+    if ((rc = ws_get(WS_AUX0, n, &d_m))) return rc;
+    if ((rc = ws_get(WS_SMALL, 64, &d_a))) return rc;
+    if ((rc = upload_strided(d_i, img, shape, ist, 2, WS_IN))) return rc;
+    if ((rc = upload_strided(d_m, mask, shape, mst, 1, WS_AUX0))) return rc;
+    if ((rc = ivx_dev_masked_density_i16((const int16_t *)d_i, (const uint8_t *)d_m, (int64_t)n, d_a, nullptr))) return rc;
+    long long h[4];
+    IVX_HIP(hipMemcpy(h, d_a, 32, hipMemcpyDeviceToHost));
+    int mm[2];
+    memcpy(mm, &h[3], 8);
+    out5[0] = (double)h[0];
+    out5[1] = (double)h[1];
+    out5[2] = (double)h[2];
+    out5[3] = h[0] ? (double)mm[0] : 0.0;
+    out5[4] = h[0] ? (double)mm[1] : 0.0;
+    return IVX_OK;
 }

@@ -103,3 +103,41 @@ def calc_image_area(mask_matrix: np.ndarray, spacing) -> float:
     area = ctypes.c_double(0.0)
     L.check(L.lib().ivx_mask_area(L.ptr(inner), L.i64(inner.shape), L.i64(inner.strides), sp, ctypes.byref(area)), "mask_area")
     return float(area.value)
+
+
+BOOLEAN_UNION, BOOLEAN_DIFF, BOOLEAN_AND, BOOLEAN_XOR = 1, 2, 3, 4  # invesalius/constants.py:818-821
+
+
+def do_boolean_op(op: int, m1_matrix: np.ndarray, m2_matrix: np.ndarray) -> np.ndarray:
+    """Slice.do_boolean_op (slice_.py:1878-1923), the array part: a new padded mask matrix filled with 1 (flags
+    "thresholded"), interior = 255 where op(m1 > 2, m2 > 2).  Both inputs are padded (dz+1, dy+1, dx+1) matrices that
+    the caller has brought up to date (the reference calls do_threshold_to_all_slices on both first)."""
+    if m1_matrix.shape != m2_matrix.shape or m1_matrix.dtype != np.uint8 or m2_matrix.dtype != np.uint8:
+        raise TypeError("two uint8 mask matrices of the same shape")
+    if op not in (BOOLEAN_UNION, BOOLEAN_DIFF, BOOLEAN_AND, BOOLEAN_XOR):
+        raise ValueError("unknown boolean operation %r" % (op,))
+    out = np.ones(m1_matrix.shape, np.uint8)
+    a, b, m = m1_matrix[1:, 1:, 1:], m2_matrix[1:, 1:, 1:], out[1:, 1:, 1:]
+    L.check(L.lib().ivx_mask_boolean(int(op), L.ptr(a), L.i64(a.strides), L.ptr(b), L.i64(b.strides), L.ptr(m),
+                                     L.i64(m.strides), L.i64(m.shape)), "mask_boolean")
+    return out
+
+
+def calc_image_density(image: np.ndarray, mask_matrix: np.ndarray):
+    """Slice.calc_image_density (slice_.py:2284-2297): (min, max, mean, std) of ``image[mask[1:,1:,1:] > 127]``, or
+    four zeros when the mask selects nothing.  min / max are exact; mean and std come from exact integer sums, formed
+    in float64 (numpy's two-pass std differs from sqrt(E[x^2] - mean^2) by rounding only)."""
+    if image.dtype != np.int16 or image.ndim != 3:
+        raise TypeError("image must be a 3-D int16 array")
+    inner = mask_matrix[1:, 1:, 1:]
+    if inner.shape != image.shape or mask_matrix.dtype != np.uint8:
+        raise TypeError("mask matrix must be uint8 and one voxel larger than the image on every axis")
+    out = np.zeros(5, np.float64)
+    L.check(L.lib().ivx_masked_density_i16(L.ptr(image), L.i64(image.strides), L.ptr(inner), L.i64(inner.strides),
+                                           L.i64(image.shape), L.ptr(out)), "masked_density")
+    cnt, s1, s2, lo, hi = out
+    if cnt == 0:
+        return 0, 0, 0, 0
+    mean = s1 / cnt
+    var = max(s2 / cnt - mean * mean, 0.0)
+    return int(lo), int(hi), float(mean), float(np.sqrt(var))

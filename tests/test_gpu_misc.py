@@ -177,3 +177,35 @@ def test_dynamic_and_confidence_region_growing_on_lut_image(ivxlib, oracle):
     assert np.array_equal(vol.download_out_mask(), oracle.do_rg_confidence(lut, seed, strct, 2.5, 3))
     d_lut.close()
     vol.close()
+
+
+@pytest.mark.parametrize("op", [1, 2, 3, 4])
+def test_mask_boolean_is_the_references_numpy_expression(ivxlib, op):
+    """Slice.do_boolean_op, slice_.py:1906-1916"""
+    from invesalius3_amd import slice_ as sl
+    rng = np.random.default_rng(op)
+    vals = np.array([0, 1, 2, 3, 127, 253, 254, 255], np.uint8)
+    m1 = rng.choice(vals, size=(12, 21, 70))
+    m2 = rng.choice(vals, size=(12, 21, 70))
+    a, b = m1[1:, 1:, 1:], m2[1:, 1:, 1:]
+    want = {1: ((a > 2) + (b > 2)) * 255, 2: ((a > 2) ^ ((a > 2) & (b > 2))) * 255, 3: ((a > 2) & (b > 2)) * 255,
+            4: np.logical_xor((a > 2), (b > 2)) * 255}[op].astype(np.uint8)
+    got = sl.do_boolean_op(op, m1, m2)
+    assert got.shape == m1.shape and np.array_equal(got[1:, 1:, 1:], want)
+    assert (got[0] == 1).all() and (got[:, 0] == 1).all() and (got[:, :, 0] == 1).all()  # future_mask.matrix[:] = 1
+    with pytest.raises(ValueError):
+        sl.do_boolean_op(9, m1, m2)
+
+
+def test_calc_image_density_matches_numpy(ivxlib):
+    """Slice.calc_image_density, slice_.py:2284-2297"""
+    from invesalius3_amd import slice_ as sl
+    img = synth_volume((20, 33, 65), seed=71)
+    rng = np.random.default_rng(2)
+    m = np.zeros((21, 34, 66), np.uint8)
+    m[1:, 1:, 1:] = rng.choice(np.array([0, 127, 128, 254, 255], np.uint8), size=img.shape)
+    vals = img[m[1:, 1:, 1:] > 127]
+    lo, hi, mean, std = sl.calc_image_density(img, m)
+    assert (lo, hi) == (int(vals.min()), int(vals.max()))
+    assert mean == pytest.approx(float(vals.mean()), rel=1e-13) and std == pytest.approx(float(vals.std()), rel=1e-10)
+    assert sl.calc_image_density(img, np.zeros_like(m)) == (0, 0, 0, 0)
