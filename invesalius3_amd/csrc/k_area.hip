@@ -44,18 +44,18 @@ __global__ __launch_bounds__(256) void k_convolve_non_zero(const double *__restr
 // per-voxel value of convolve_non_zero(bin * 1.0, K, 1) for the 3x3x3 kernel K, straight from the uint8 mask
 __device__ __forceinline__ double area_term(const uint8_t *__restrict__ m, int64_t z, int64_t y, int64_t x, int64_t sz,
                                             int64_t sy, int64_t sx, const double *__restrict__ K) {
+    // Only the seven axis taps of this kernel are non-zero.  The other twenty contribute v * (+0.0) = +0.0 for v in {0, 1},
+    // which never changes a float64 sum, so they are skipped; the seven are added in the reference's (k, j, i) order.
+    const int8_t tap[7][3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}, {1, 1, 1}, {1, 1, 2}, {1, 2, 1}, {2, 1, 1}};
     double sum = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const int64_t kz = z - 1 + k, ky = y - 1 + j, kx = x - 1 + i;
-                const bool in = kz >= 0 && kz < sz && ky >= 0 && ky < sy && kx >= 0 && kx < sx;
-                const double v = in ? (m[(kz * sy + ky) * sx + kx] > 127 ? 1.0 : 0.0) : 1.0; // cval = 1
-                sum += v * K[(k * 3 + j) * 3 + i];
-            }
+    for (int q = 0; q < 7; q++) {
+        const int k = tap[q][0], j = tap[q][1], i = tap[q][2];
+        const int64_t kz = z - 1 + k, ky = y - 1 + j, kx = x - 1 + i;
+        const bool in = kz >= 0 && kz < sz && ky >= 0 && ky < sy && kx >= 0 && kx < sx;
+        const double v = in ? (m[(kz * sy + ky) * sx + kx] > 127 ? 1.0 : 0.0) : 1.0; // cval = 1
+        sum += v * K[(k * 3 + j) * 3 + i];
+    }
     return sum;
 }
 

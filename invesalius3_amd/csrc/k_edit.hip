@@ -136,9 +136,20 @@ __global__ __launch_bounds__(256) void k_polygon2mask(uint8_t *__restrict__ out,
     }
 }
 
+// Histogram of the labels.  Up to LBINS labels are counted in a per-workgroup LDS histogram (the wave's most common
+// label -- the one its first lane holds, usually the background -- goes in with ONE add, the rest with LDS atomics) and
+// flushed with one global atomic per non-empty bin; larger label spaces fall back to global atomics.  A first version
+// with one global atomic per voxel-that-differs-from-lane-0 took 160 ms at 512^3 on salt-like labels.
+constexpr int LBINS = 4096;
 template <typename T>
 __global__ __launch_bounds__(256) void k_count_hist(const T *__restrict__ labels, int64_t n, int64_t nreg,
                                                     uint32_t *__restrict__ counts, int *__restrict__ status) {
+    __shared__ uint32_t s_h[LBINS];
+    const bool lds = nreg < LBINS;
+    if (lds) {
+        for (int b = threadIdx.x; b < LBINS; b += 256) s_h[b] = 0u;
+        __syncthreads();
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
         const int64_t i = base + threadIdx.x;
@@ -152,8 +163,19 @@ __global__ __launch_bounds__(256) void k_count_hist(const T *__restrict__ labels
         if (!livem) continue;
         const int64_t first = __shfl(l, __builtin_ctzll(livem), 64);
         const unsigned long long same = __ballot(live && l == first);
-        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(same)) atomicAdd(&counts[first], (uint32_t)__popcll(same));
-        if (live && l != first) atomicAdd(&counts[l], 1u);
+        const bool lead = (threadIdx.x & 63) == (unsigned)__builtin_ctzll(same);
+        if (lds) {
+            if (lead) atomicAdd(&s_h[first], (uint32_t)__popcll(same));
+            if (live && l != first) atomicAdd(&s_h[l], 1u);
+        } else {
+            if (lead) atomicAdd(&counts[first], (uint32_t)__popcll(same));
+            if (live && l != first) atomicAdd(&counts[l], 1u);
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (int b = threadIdx.x; b <= (int)nreg; b += 256)
+            if (s_h[b]) atomicAdd(&counts[b], s_h[b]);
     }
 }
 template <typename T>
@@ -271,7 +293,7 @@ extern "C" int ivx_dev_count_regions(int ldtype, const void *labels, int64_t n, 
     IVX_HIP(hipMemsetAsync(status, 0, 4, st));
     if (n == 0) return IVX_OK;
 #define IVX_CR(T)                                                                                                    \
-    hipLaunchKernelGGL((k_count_hist<T>), dim3(grid_for(n, 4)), dim3(256), 0, st, (const T *)labels, n, number_regions, \
+    hipLaunchKernelGGL((k_count_hist<T>), dim3(std::min(grid_for(n, 4), 2048u)), dim3(256), 0, st, (const T *)labels, n, number_regions, \
                        counts, status);                                                                              \
     IVX_LAUNCH_CHECK();                                                                                              \
     hipLaunchKernelGGL((k_count_gather<T>), dim3(grid_for(n, 4)), dim3(256), 0, st, (const T *)labels, n,             \
