@@ -93,7 +93,8 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
             tris = vol.marching_cubes(from_binary=True, download=True)
             lay = vol.lay
             proj = {(ax, op): vol.project_global(ax, op) for ax in (0, 1, 2) for op in ("max", "min", "mean")}
-            res[rank] = dict(proj=proj, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
+            piece_mesh = vol.marching_cubes_indexed(from_binary=True, download=True)
+            res[rank] = dict(proj=proj, mesh=piece_mesh, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
                              mask=vol.download_mask()[lay.first_interior:lay.last_interior + 1], tris=tris,
                              count=vol.reached_count())
             vol.close()
@@ -118,6 +119,11 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
     cat = np.concatenate([res[r]["tris"] for r in range(world)])
     key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
     assert len(cat) == len(whole) and np.array_equal(key(cat), key(whole))
+    # cross-slab stitch of the ranks' indexed pieces == the merged whole-volume surface
+    from invesalius3_amd.parallel import stitch_piece_meshes
+    sv, sf = stitch_piece_meshes([res[r]["mesh"] for r in range(world)])
+    assert len(sv) == len(np.unique(whole.reshape(-1, 3), axis=0)) == len(np.unique(sv, axis=0))
+    assert np.array_equal(key(sv[sf]), key(whole))
     # projections of the whole volume, identical on every rank and equal to numpy on the unsharded array
     for r in range(world):
         for (ax, op), img in res[r]["proj"].items():

@@ -83,3 +83,35 @@ def test_mesh_oracle_anchors(oracle):
     e = np.concatenate([f2[:, [0, 1]], f2[:, [0, 2]]])
     g = coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(len(v2), len(v2)))
     assert connected_components(g, directed=False)[0] == 3
+
+
+def test_stitch_piece_meshes_merges_the_shared_planes(oracle):
+    """cross-slab stitch: rank pieces (indexed) -> one mesh with every vertex once, same triangles as the whole volume"""
+    from conftest import synth_volume
+    from invesalius3_amd import parallel as par
+    img = synth_volume((30, 24, 40), seed=3)
+    mask = np.where(img > 100, 255, 0).astype(np.uint8)
+
+    def index(soup):
+        u, inv = np.unique(soup.reshape(-1, 3), axis=0, return_inverse=True)
+        return u.astype(np.float32), inv.reshape(-1, 3).astype(np.int32)
+
+    world, nz, pieces = 3, 10, []
+    for r in range(world):
+        lay = par.slab_layout(r, world, nz)
+        a = par.slab_mc_args(lay)
+        lo = lay.z_global0 - lay.hb
+        piece = mask[lo: lo + lay.local_dz][a["z0"]: a["z1"]]
+        pieces.append(index(oracle.marching_cubes(piece, (0.5, 0.5, 2.0), [127.0], a["roi_start"], True, a["pad_bottom"],
+                                                  a["pad_top"], 0.0, int(a["pad_bottom"]))))
+    v, f = par.stitch_piece_meshes(pieces)
+    whole = oracle.marching_cubes(mask, (0.5, 0.5, 2.0), [127.0], 0, True, True, True, 0.0, 1)
+    assert len(v) == len(np.unique(whole.reshape(-1, 3), axis=0)) == len(np.unique(v, axis=0))
+    assert len(v) < sum(len(p[0]) for p in pieces)  # something was merged
+    key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
+    assert f.dtype == np.int32 and np.array_equal(key(v[f]), key(whole))
+    # degenerate inputs
+    ev, ef = par.stitch_piece_meshes([])
+    assert ev.shape == (0, 3) and ef.shape == (0, 3)
+    one_v, one_f = par.stitch_piece_meshes([pieces[0]])
+    assert np.array_equal(one_v, pieces[0][0]) and np.array_equal(one_f, pieces[0][1])
