@@ -63,24 +63,8 @@ __global__ __launch_bounds__(256) void k_fill_small(uint8_t *__restrict__ mask, 
 
 // ---- window / level LUT -------------------------------------------------------------------------------------
 // np.piecewise on an int16 array: result dtype int16, the float64 expression is truncated toward zero.
-template <typename O>
-__global__ __launch_bounds__(256) void k_lut_u16(const int16_t *__restrict__ img, int64_t n, double window, double level,
-                                                 double top, O *__restrict__ out) {
-    const double lo = level - 0.5 - (window - 1.0) / 2.0;
-    const double hi = level - 0.5 + (window - 1.0) / 2.0;
-    const int16_t topv = (int16_t)top;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double d = (double)img[i];
-        int16_t r;
-        if (d <= lo) r = 0;
-        else if (d > hi) r = topv;
-        else r = (int16_t)(((d - (level - 0.5)) / (window - 1.0) + 0.5) * top);
-        out[i] = (O)r; // int16 as np.piecewise leaves it, or .astype("uint16")
-    }
-}
 // The input is int16, so the whole float64 expression has only 65536 possible arguments: evaluate it once per value into
-// a 128 KiB table (exactly the arithmetic above, so exactly the same results) and turn the volume pass into a gather
+// a 128 KiB table and turn the volume pass into a gather
 // from L1/L2 -- the per-voxel float64 division made the direct form ALU-bound (0.15 ms at 512^3 instead of ~0.1).
 __global__ __launch_bounds__(256) void k_lut_table(double window, double level, double top, int16_t *__restrict__ tab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // 0..65535 = the uint16 reinterpretation of the sample
