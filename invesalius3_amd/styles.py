@@ -1,0 +1,69 @@
+"""Host mirror of the array work behind the 3-D region-growing tool,
+FloodFillSegmentInteractorStyle.do_3d_seg + do_rg_confidence (invesalius/data/styles.py:3151-3251): everything between
+the mouse click and `save_history`, on the GPU.  The GUI parts (picker, progress dialog, undo history) stay with the
+caller; the function takes what they produce -- the clicked voxel and the dialog's configuration -- and edits the mask
+matrix in place."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+from . import slice_ as sl
+from .device import DeviceVolume
+from .mask import CON3D, _structure
+
+
+def do_3d_seg(image: np.ndarray, mask_matrix: np.ndarray, seed_xyz, method: str = "dynamic", con_3d: int = 6,
+              fill_value: int = 254, t0=None, t1=None, dev_min=25, dev_max=25, use_ww_wl: bool = False, ww=None, wl=None,
+              confid_mult: float = 2.5, confid_iters: int = 3, threshold_range=None) -> bool:
+    """``image`` (dz,dy,dx) int16, ``mask_matrix`` the padded uint8 matrix of the current mask, ``seed_xyz`` the picked
+    voxel.  method "threshold" (t0, t1 given), "dynamic" (seed value -dev_min / +dev_max, optionally on the
+    get_LUT_value_255 image) or "confidence".  ``threshold_range`` = the mask's threshold range, for the
+    do_threshold_to_all_slices() the reference runs first (slices whose flag is 0 are (re)thresholded).
+    Returns False when the click is rejected (seed outside [t0, t1], styles.py:3178), True after editing the mask."""
+    if image.dtype != np.int16 or image.ndim != 3:
+        raise TypeError("image must be a 3-D int16 array")
+    if mask_matrix.dtype != np.uint8 or mask_matrix.shape != tuple(s + 1 for s in image.shape):
+        raise TypeError("mask matrix must be uint8 and one voxel larger than the image on every axis")
+    if method not in ("threshold", "dynamic", "confidence"):
+        raise ValueError("method must be threshold, dynamic or confidence")
+    x, y, z = (int(v) for v in seed_xyz)
+    if not (0 <= z < image.shape[0] and 0 <= y < image.shape[1] and 0 <= x < image.shape[2]):
+        raise IndexError("seed outside the volume")
+    strct = _structure(3, CON3D[con_3d])
+    with DeviceVolume(np.ascontiguousarray(image)) as vol:
+        flood_image = None
+        if use_ww_wl and method in ("dynamic", "confidence"):
+            flood_image = vol.lut_image_255(ww, wl)  # get_LUT_value_255(image, ww, wl), int16
+        if method != "confidence":
+            if method == "threshold":
+                lo, hi = t0, t1
+                v = int(image[z, y, x])
+            else:
+                if flood_image is not None:
+                    one = np.zeros(1, np.int16)
+                    L.check(L.lib().ivx_memcpy_d2h(L.ptr(one), flood_image.at(((z * image.shape[1] + y) * image.shape[2] + x) * 2),
+                                                   ctypes.c_size_t(2)))
+                    v = int(one[0])
+                else:
+                    v = int(image[z, y, x])
+                lo, hi = v - dev_min, v + dev_max
+            if v < lo or v > hi:
+                if flood_image is not None:
+                    flood_image.close()
+                return False
+        if threshold_range is not None:
+            sl.do_threshold_to_all_slices(mask_matrix, image, threshold_range)
+        vol.mask.upload(np.ascontiguousarray(mask_matrix[1:, 1:, 1:]))
+        vol.zero_out_mask()
+        if method == "confidence":
+            vol.region_grow_confidence((x, y, z), strct, confid_mult, confid_iters, select_value=int(fill_value),
+                                       image=flood_image)
+        else:
+            vol.region_grow([(x, y, z)], lo, hi, strct, fill=1, select_value=int(fill_value), image=flood_image)
+        mask_matrix[1:, 1:, 1:] = vol.download_mask()
+        if flood_image is not None:
+            flood_image.close()
+    return True

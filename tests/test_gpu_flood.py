@@ -203,3 +203,41 @@ def test_all_flood_engines_agree(ivxlib, oracle, mode):
     env = dict(os.environ, IVX_FLOOD_MODE=mode)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "engines-ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("method,use_ww_wl", [("threshold", False), ("dynamic", False), ("dynamic", True), ("confidence", False),
+                                               ("confidence", True)])
+def test_do_3d_seg_mirror_matches_the_reference_recipe(ivxlib, oracle, method, use_ww_wl):
+    """styles.py:3151-3251 end to end: thresholds per method, do_threshold_to_all_slices, flood, mask[out] = fill_value"""
+    from scipy.ndimage import generate_binary_structure
+    from invesalius3_amd import styles as st
+    img = synth_volume((20, 40, 64), seed=91)
+    ww, wl = 1500.0, 300.0
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    seed = (int(x), int(y), int(z))
+    mask = np.zeros(tuple(s + 1 for s in img.shape), np.uint8)
+    rng = (100, 3071)
+    want = mask.copy()
+    flood_img = oracle.get_LUT_value_255(img, ww, wl) if use_ww_wl else img
+    bstruct = generate_binary_structure(3, 2).astype(np.uint8)
+    oracle.do_threshold_to_all_slices(want, img, rng)
+    if method == "confidence":
+        out = oracle.do_rg_confidence(flood_img, seed, bstruct, 2.5, 3)
+    else:
+        if method == "threshold":
+            t0, t1 = 200, 2500
+        else:
+            v = int(flood_img[z, y, x])
+            t0, t1 = v - 40, v + 60
+        out = np.zeros(img.shape, np.uint8)
+        oracle.floodfill_threshold(flood_img, [seed], t0, t1, 1, bstruct, out)
+    want[1:, 1:, 1:][out.astype(bool)] = 254
+    ok = st.do_3d_seg(img, mask, seed, method=method, con_3d=18, fill_value=254, t0=200, t1=2500, dev_min=40, dev_max=60,
+                      use_ww_wl=use_ww_wl, ww=ww, wl=wl, threshold_range=rng)
+    assert ok and np.array_equal(mask, want)
+    assert (mask == 254).sum() == int(out.sum()) > 0
+    # a click outside the range is rejected before anything is touched (styles.py:3178)
+    if method == "threshold":
+        m2 = np.zeros_like(mask)
+        assert st.do_3d_seg(img, m2, (0, 0, 0), method="threshold", t0=2000, t1=2500, threshold_range=rng) is False
+        assert not m2.any()
