@@ -33,6 +33,8 @@ def main():
     lib = L.lib()
     out = {"n": n}
     out["soup_ms"], nt = timed(vol, vol.marching_cubes)
+    t_img, nt_img = timed(vol, lambda: vol.marching_cubes(from_binary=False, min_value=226, max_value=3071))
+    out["soup_image_two_iso_ms"], out["tris_image_two_iso"] = t_img, nt_img  # the "Default" surface: raw image at both thresholds
     out["indexed_ms"], (nv, nt) = timed(vol, vol.marching_cubes_indexed)
     out["verts"], out["tris"] = nv, nt
     c64 = ctypes.c_int64
