@@ -128,6 +128,12 @@ int ivx_dev_mida(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx,
                  int *status /* device int, set to IVX_EDOM on cast failure */, void *stream);
 int ivx_dev_lmip(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, double tmin,
                  double tmax, void *out, void *stream);
+/* Z-sharded volumes, rays along Z: one slab's share of every ray.  state = 5 doubles per output pixel
+ * (dy*dx*5), NULL state_in on the first slab, NULL state_out on the last one (which writes `out`).  kind 0 = LMIP
+ * (p0, p1 = tmin, tmax), 1 = MIDA (p0, p1 = wl, ww; minmax2 = min / max of the WHOLE volume, device float32[2]). */
+int ivx_dev_rays_z_slab(int kind, int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, double p0, double p1,
+                        const float *minmax2, const double *state_in, double *state_out, int out_dtype, void *out,
+                        int *status, void *stream);
 int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
                        void *tmp /* same dtype/shape */, int *status, void *stream);
 int ivx_mida(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,

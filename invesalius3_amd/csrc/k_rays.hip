@@ -118,7 +118,8 @@ __device__ __forceinline__ void finish(const LmipRay<T> &lr, const MidaRay &mr, 
 template <typename T, typename U, int MODE>
 __global__ __launch_bounds__(256) void k_rays_strided(const T *__restrict__ vol, RayGeom g, double p0, double p1,
                                                       const float *__restrict__ minmax, U *__restrict__ out,
-                                                      int *__restrict__ status) {
+                                                      int *__restrict__ status, const double *__restrict__ state_in,
+                                                      double *__restrict__ state_out) {
     const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= g.nr * g.nc) return;
     const int64_t r = pix / g.nc, c = pix - r * g.nc;
@@ -132,6 +133,22 @@ __global__ __launch_bounds__(256) void k_rays_strided(const T *__restrict__ vol,
         mr.init(minmax[0], range, (float)p0, (float)p1);
     }
     bool done = false;
+    // A ray that continues from the previous Z-slab (sharded volumes, rays along the sharding axis) resumes from the
+    // state that slab left: five doubles per pixel (every state variable is exactly representable in one).
+    if (state_in) {
+        const double *si = state_in + pix * 5;
+        if (MODE == 0) {
+            lr.maxv = (T)si[0];
+            lr.start = si[1] != 0.0;
+            lr.first = si[2] != 0.0;
+        } else {
+            mr.fmax = (float)si[0];
+            mr.alpha_p = (float)si[1];
+            mr.colour_p = (float)si[2];
+            mr.final_colour = (float)si[3];
+        }
+        done = si[4] != 0.0;
+    }
     // software pipeline: the 8 loads of the NEXT block are in flight while the current block's 8 samples are
     // composited (the walk is a serial dependence chain, the loads are not); one wave vote per block for early exit
     constexpr int B = 16; // samples per block: up to 2 x 16 loads in flight per lane
@@ -150,6 +167,22 @@ __global__ __launch_bounds__(256) void k_rays_strided(const T *__restrict__ vol,
         if (__all(done)) break; // the whole wave's rays have terminated
 #pragma unroll
         for (int k = 0; k < B; k++) cur[k] = nxt[k];
+    }
+    if (state_out) { // more slabs follow: hand the ray over instead of finishing it
+        double *so = state_out + pix * 5;
+        if (MODE == 0) {
+            so[0] = (double)lr.maxv;
+            so[1] = lr.start ? 1.0 : 0.0;
+            so[2] = lr.first ? 1.0 : 0.0;
+            so[3] = 0.0;
+        } else {
+            so[0] = (double)mr.fmax;
+            so[1] = (double)mr.alpha_p;
+            so[2] = (double)mr.colour_p;
+            so[3] = (double)mr.final_colour;
+        }
+        so[4] = done ? 1.0 : 0.0;
+        return;
     }
     finish<T, U, MODE>(lr, mr, range, out + pix, status);
 }
@@ -361,7 +394,8 @@ __global__ __launch_bounds__(256) void k_fcm_volume_i16x8(const int16_t *__restr
 
 template <typename T, typename U, int MODE>
 static int launch_rays(const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, double p0, double p1,
-                       const float *minmax, void *out, int *status, hipStream_t st) {
+                       const float *minmax, void *out, int *status, hipStream_t st, const double *state_in = nullptr,
+                       double *state_out = nullptr) {
     const RayGeom g = ray_geom(axis, dz, dy, dx);
     const int64_t npix = g.nr * g.nc;
     if (npix == 0) return IVX_OK;
@@ -370,7 +404,7 @@ static int launch_rays(const void *vol, int64_t dz, int64_t dy, int64_t dx, int 
                            (const T *)vol, npix, g.len, p0, p1, minmax, (U *)out, status);
     } else {
         hipLaunchKernelGGL((k_rays_strided<T, U, MODE>), dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st,
-                           (const T *)vol, g, p0, p1, minmax, (U *)out, status);
+                           (const T *)vol, g, p0, p1, minmax, (U *)out, status, state_in, state_out);
     }
     IVX_LAUNCH_CHECK();
     return IVX_OK;
@@ -428,6 +462,34 @@ extern "C" int ivx_dev_lmip(int dtype, const void *vol, int64_t dz, int64_t dy, 
     case IVX_F64: return launch_rays<double, double, 0>(vol, dz, dy, dx, axis, tmin, tmax, nullptr, out, nullptr, st);
     }
     ivx::set_error("lmip: unsupported dtype %d", dtype);
+    return IVX_EINVAL;
+}
+
+// Rays along Z through ONE slab of a Z-sharded volume (axis 0 only): resume from `state_in` (NULL on the first slab),
+// leave the state in `state_out` (NULL on the last slab, which writes `out` instead).  kind 0 = LMIP (p0, p1 = tmin,
+// tmax), 1 = MIDA (p0, p1 = wl, ww; minmax2 = the min / max of the WHOLE volume as float32, on the device).
+extern "C" int ivx_dev_rays_z_slab(int kind, int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, double p0, double p1,
+                                   const float *minmax2, const double *state_in, double *state_out, int out_dtype, void *out,
+                                   int *status, void *stream) {
+    hipStream_t st = ivx::S(stream);
+    IVX_REQUIRE(kind == 0 || kind == 1, IVX_EINVAL, "rays_z_slab: kind must be 0 (lmip) or 1 (mida)");
+    IVX_REQUIRE(dz > 0 && dy >= 0 && dx >= 0, IVX_EINVAL, "rays_z_slab: empty slab");
+    IVX_REQUIRE(state_out || out, IVX_EINVAL, "rays_z_slab: the last slab needs an output image");
+    if (kind == 0) {
+        switch (dtype) {
+        case IVX_I16: return launch_rays<int16_t, int16_t, 0>(vol, dz, dy, dx, 0, p0, p1, nullptr, out, nullptr, st, state_in, state_out);
+        case IVX_U8: return launch_rays<uint8_t, uint8_t, 0>(vol, dz, dy, dx, 0, p0, p1, nullptr, out, nullptr, st, state_in, state_out);
+        case IVX_F64: return launch_rays<double, double, 0>(vol, dz, dy, dx, 0, p0, p1, nullptr, out, nullptr, st, state_in, state_out);
+        }
+    } else {
+        if (dtype == IVX_I16 && out_dtype == IVX_I16)
+            return launch_rays<int16_t, int16_t, 1>(vol, dz, dy, dx, 0, p0, p1, minmax2, out, status, st, state_in, state_out);
+        if (dtype == IVX_U8 && out_dtype == IVX_U8)
+            return launch_rays<uint8_t, uint8_t, 1>(vol, dz, dy, dx, 0, p0, p1, minmax2, out, status, st, state_in, state_out);
+        if (dtype == IVX_F64 && out_dtype == IVX_U8)
+            return launch_rays<double, uint8_t, 1>(vol, dz, dy, dx, 0, p0, p1, minmax2, out, status, st, state_in, state_out);
+    }
+    ivx::set_error("rays_z_slab: unsupported dtype pair (in %d, out %d)", dtype, out_dtype);
     return IVX_EINVAL;
 }
 

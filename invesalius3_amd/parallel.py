@@ -139,6 +139,26 @@ class TorchComm:
                                     "sum": self.dist.ReduceOp.SUM}[op])
         return t.cpu().numpy().astype(a.dtype)
 
+    def _bytes_tensor(self, a: np.ndarray):
+        t = self.torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+        return t.to(self.device) if self.device != "cpu" else t
+
+    def send_array(self, a: np.ndarray, to: int):
+        """Blocking point-to-point send of a host array (a ray-state hand-over between Z-neighbours)."""
+        self.dist.send(self._bytes_tensor(a), dst=to)
+
+    def recv_array(self, shape, dtype, frm: int) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        t = self._bytes_tensor(out)
+        self.dist.recv(t, src=frm)
+        return t.cpu().numpy().view(dtype).reshape(shape)
+
+    def bcast_array(self, a: np.ndarray | None, shape, dtype, root: int) -> np.ndarray:
+        buf = np.ascontiguousarray(a, dtype=dtype) if self.rank == root else np.empty(shape, dtype)
+        t = self._bytes_tensor(buf)
+        self.dist.broadcast(t, src=root)
+        return t.cpu().numpy().view(dtype).reshape(shape)
+
     def allgather_rows(self, a: np.ndarray, rows_per_rank) -> np.ndarray:
         """Concatenate every rank's rows (axis 0) in rank order; ranks may own different numbers of rows."""
         torch = self.torch
@@ -295,6 +315,72 @@ def _make_slab_volume():
                 return partial.astype(np.float64) / float(nint) if code == L.MIP_SUM else partial
             rows = [lay.nz] * lay.world
             return slab_project_combine(partial, self.comm, axis, op, rows, lay.nz * lay.world, gather)
+
+        def rays_global(self, kind: str, axis: int, p0, p1, gather: bool = True) -> np.ndarray:
+            """LMIP ("lmip": p0, p1 = tmin, tmax) or MIDA ("mida": p0, p1 = wl, ww) of the WHOLE volume along `axis`
+            (invesalius_rs lmip / mida, mips.rs:7-168).  Rays inside a slice (axis 1, 2) are rank-local rows, gathered.
+            Rays along Z are order-dependent: the slabs are walked front to back, each rank resumes every ray from the
+            state its lower neighbour hands over (5 doubles per pixel) and the last rank's image is broadcast.  MIDA
+            normalises by the min / max of the whole volume: one all-reduce of two numbers first."""
+            lay = self.lay
+            code = {"lmip": 0, "mida": 1}[kind]
+            nint = lay.nz
+            src = self.image.raw_at(lay.first_interior * self.dy * self.dx * 2)
+            lib = L.lib()
+            mm = DeviceBuffer(64)
+            status = DeviceBuffer(64)
+            status.zero(self.stream)
+            if code == 1:
+                L.check(lib.ivx_dev_minmax_f32(L.I16, src, c64(nint * self.dy * self.dx), mm.ptr, self.stream))
+                self.sync()
+                local = mm.download((2,), np.float32).astype(np.float64)
+                if lay.world > 1:
+                    lo = self.comm.allreduce_array(local[:1], "min")
+                    hi = self.comm.allreduce_array(local[1:], "max")
+                    mm.upload(np.array([lo[0], hi[0]], np.float32))
+            p0, p1 = float(int(p0)), float(int(p1))  # the wrappers' int() truncation (invesalius_rs/__init__.py:91-95)
+            if axis != 0:
+                oshape = (nint, self.dx) if axis == 1 else (nint, self.dy)
+                out = DeviceBuffer(int(np.prod(oshape)) * 2 + 16)
+                if code == 0:
+                    L.check(lib.ivx_dev_lmip(L.I16, src, c64(nint), c64(self.dy), c64(self.dx), int(axis), ctypes.c_double(p0),
+                                             ctypes.c_double(p1), out.ptr, self.stream), "lmip")
+                else:
+                    L.check(lib.ivx_dev_mida(L.I16, src, c64(nint), c64(self.dy), c64(self.dx), int(axis), ctypes.c_float(p0),
+                                             ctypes.c_float(p1), mm.ptr, L.I16, out.ptr, status.ptr, self.stream), "mida")
+                self.sync()
+                rows = out.download(oshape, np.int16)
+                bad = status.download((1,), np.int32)[0]
+                for b in (out, mm, status):
+                    b.close()
+                if bad:
+                    raise ValueError("mida: a result does not fit the output dtype (the reference's NumCast panics)")
+                if lay.world == 1 or not gather:
+                    return rows
+                return self.comm.allgather_rows(rows, [lay.nz] * lay.world)
+            npix = self.dy * self.dx
+            state = DeviceBuffer(npix * 5 * 8 + 16)
+            out = DeviceBuffer(npix * 2 + 16)
+            first, last = lay.rank == 0, lay.rank == lay.world - 1
+            if not first:
+                state.upload(self.comm.recv_array((npix * 5,), np.float64, lay.rank - 1))
+            L.check(lib.ivx_dev_rays_z_slab(code, L.I16, src, c64(nint), c64(self.dy), c64(self.dx), ctypes.c_double(p0),
+                                            ctypes.c_double(p1), mm.ptr, None if first else state.ptr, None if last else state.ptr,
+                                            L.I16, out.ptr, status.ptr, self.stream), "rays_z_slab")
+            self.sync()
+            if not last:
+                self.comm.send_array(state.download((npix * 5,), np.float64), lay.rank + 1)
+            img = out.download((self.dy, self.dx), np.int16) if last else None
+            bad = int(status.download((1,), np.int32)[0]) if last else 0
+            for b in (state, out, mm, status):
+                b.close()
+            if lay.world > 1:
+                flag = self.comm.bcast_array(np.array([bad], np.int32) if last else None, (1,), np.int32, lay.world - 1)
+                bad = int(flag[0])
+                img = self.comm.bcast_array(img, (self.dy, self.dx), np.int16, lay.world - 1)
+            if bad:
+                raise ValueError("mida: a result does not fit the output dtype (the reference's NumCast panics)")
+            return img
 
         def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
             a = slab_mc_args(self.lay, fill_border_holes)

@@ -81,6 +81,13 @@ def main():
                 partial = getattr(own, op)(axis=ax)
             img = par.slab_project_combine(partial, comm, ax, op, [nz] * world, nz * world)
             np.save(os.path.join(outdir, "proj_%d_%d_%s.npy" % (rank, ax, op)), img)
+    # the hand-over primitives of the Z-ray pipeline: a token walks up the ranks, the last one's value is broadcast
+    tok = np.arange(7, dtype=np.float64) if rank == 0 else comm.recv_array((7,), np.float64, rank - 1)
+    tok = tok + rank
+    if rank < world - 1:
+        comm.send_array(tok, rank + 1)
+    final = comm.bcast_array(tok if rank == world - 1 else None, (7,), np.float64, world - 1)
+    np.save(os.path.join(outdir, "token_%d.npy" % rank), final)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -20,6 +20,8 @@ class LoopbackWorld:
         self.barrier = threading.Barrier(world)
         self.box = {}
         self.acc = [0] * world
+        self.p2p = {}
+        self.cv = threading.Condition()
 
     def comm(self, rank):
         return LoopbackComm(self, rank)
@@ -63,6 +65,27 @@ class LoopbackComm:
         w.barrier.wait()
         return out
 
+    def send_array(self, a, to):
+        w = self.w
+        with w.cv:
+            w.p2p[(self.rank, to)] = np.array(a)
+            w.cv.notify_all()
+
+    def recv_array(self, shape, dtype, frm):
+        w = self.w
+        with w.cv:
+            w.cv.wait_for(lambda: (frm, self.rank) in w.p2p, timeout=120)
+            return w.p2p.pop((frm, self.rank)).reshape(shape)
+
+    def bcast_array(self, a, shape, dtype, root):
+        w = self.w
+        if self.rank == root:
+            w.box[("bcast", root)] = np.array(a, dtype=dtype)
+        w.barrier.wait()
+        out = w.box[("bcast", root)].copy()
+        w.barrier.wait()
+        return out
+
     def allgather_rows(self, a, rows_per_rank):
         w = self.w
         w.box[(self.rank, "rows")] = np.array(a)
@@ -94,7 +117,9 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
             lay = vol.lay
             proj = {(ax, op): vol.project_global(ax, op) for ax in (0, 1, 2) for op in ("max", "min", "mean")}
             piece_mesh = vol.marching_cubes_indexed(from_binary=True, download=True)
-            res[rank] = dict(proj=proj, mesh=piece_mesh, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
+            rays = {(kind, ax): vol.rays_global(kind, ax, *par) for kind, par in (("lmip", (-300, 900)), ("mida", (300.0, 1200.0)))
+                    for ax in (0, 1, 2)}
+            res[rank] = dict(proj=proj, mesh=piece_mesh, rays=rays, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
                              mask=vol.download_mask()[lay.first_interior:lay.last_interior + 1], tris=tris,
                              count=vol.reached_count())
             vol.close()
@@ -124,6 +149,16 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
     sv, sf = stitch_piece_meshes([res[r]["mesh"] for r in range(world)])
     assert len(sv) == len(np.unique(whole.reshape(-1, 3), axis=0)) == len(np.unique(sv, axis=0))
     assert np.array_equal(key(sv[sf]), key(whole))
+    # LMIP / MIDA of the whole volume: rays along Z are handed from slab to slab, the others are rank-local rows
+    for (kind, ax), img in res[0]["rays"].items():
+        oshape = tuple(s for i, s in enumerate(full.shape) if i != ax)
+        want = np.zeros(oshape, np.int16)
+        if kind == "lmip":
+            oracle.lmip(full, ax, -300, 900, want)
+        else:
+            oracle.mida(full, ax, 300, 1200, want)
+        for r in range(world):
+            assert np.array_equal(res[r]["rays"][(kind, ax)], want), (kind, ax, r)
     # projections of the whole volume, identical on every rank and equal to numpy on the unsharded array
     for r in range(world):
         for (ax, op), img in res[r]["proj"].items():

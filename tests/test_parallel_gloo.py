@@ -58,6 +58,9 @@ def test_slab_region_grow_and_mc_match_single_volume(tmp_path, oracle, world, co
     cat = np.concatenate([np.load(tmp_path / ("tris_%d.npy" % r)) for r in range(world)])
     key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
     assert len(cat) == len(whole) and np.array_equal(key(cat), key(whole))
+    # ray-state hand-over primitives (send / recv up the ranks, broadcast from the last)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("token_%d.npy" % r)), np.arange(7.0) + sum(range(world)))
     # sharded MaxIP / MinIP / MeanIP: every rank ends with numpy's result on the whole volume
     for r in range(world):
         for ax in (0, 1, 2):
