@@ -296,7 +296,7 @@ def _make_slab_volume():
                                                 ctypes.byref(n), self.stream))
             return n.value
 
-        def project_global(self, axis: int, op: str, gather: bool = True) -> np.ndarray:
+        def project_global(self, axis: int, op: str, gather: bool = True, source=None) -> np.ndarray:
             """MaxIP ("max") / MinIP ("min") / MeanIP ("mean") of the WHOLE volume along `axis`, from every rank's
             resident slab: local reduce over the interior slices on the GPU, then slab_project_combine."""
             lay = self.lay
@@ -305,7 +305,8 @@ def _make_slab_volume():
             oshape = (self.dy, self.dx) if axis == 0 else ((nint, self.dx) if axis == 1 else (nint, self.dy))
             odt = np.int64 if code == L.MIP_SUM else (np.float64 if code == L.MIP_MEAN else np.int16)
             out = DeviceBuffer(int(np.prod(oshape)) * np.dtype(odt).itemsize + 16)
-            src = self.image.raw_at(lay.first_interior * self.dy * self.dx * 2)
+            off = lay.first_interior * self.dy * self.dx * 2
+            src = self.image.raw_at(off) if source is None else source.at(off)  # `source`: another resident int16 slab
             L.check(L.lib().ivx_dev_mip_reduce(L.I16, src, c64(nint), c64(self.dy), c64(self.dx), int(axis), int(code), out.ptr,
                                                self.stream), "project")
             self.sync()
@@ -316,7 +317,7 @@ def _make_slab_volume():
             rows = [lay.nz] * lay.world
             return slab_project_combine(partial, self.comm, axis, op, rows, lay.nz * lay.world, gather)
 
-        def rays_global(self, kind: str, axis: int, p0, p1, gather: bool = True) -> np.ndarray:
+        def rays_global(self, kind: str, axis: int, p0, p1, gather: bool = True, source=None) -> np.ndarray:
             """LMIP ("lmip": p0, p1 = tmin, tmax) or MIDA ("mida": p0, p1 = wl, ww) of the WHOLE volume along `axis`
             (invesalius_rs lmip / mida, mips.rs:7-168).  Rays inside a slice (axis 1, 2) are rank-local rows, gathered.
             Rays along Z are order-dependent: the slabs are walked front to back, each rank resumes every ray from the
@@ -325,7 +326,8 @@ def _make_slab_volume():
             lay = self.lay
             code = {"lmip": 0, "mida": 1}[kind]
             nint = lay.nz
-            src = self.image.raw_at(lay.first_interior * self.dy * self.dx * 2)
+            off = lay.first_interior * self.dy * self.dx * 2
+            src = self.image.raw_at(off) if source is None else source.at(off)
             lib = L.lib()
             mm = DeviceBuffer(64)
             status = DeviceBuffer(64)
@@ -381,6 +383,35 @@ def _make_slab_volume():
             if bad:
                 raise ValueError("mida: a result does not fit the output dtype (the reference's NumCast panics)")
             return img
+
+        def fast_countour_mip_global(self, n: float, axis: int, wl, ww, tmip: int) -> np.ndarray:
+            """fast_countour_mip (mips.rs:215-279) of the whole volume: the contour volume is computed on the stored
+            slices -- the halo slices give every owned voxel its true z neighbours, the clamped differences at the ends
+            of the volume are the unsharded ones -- and then projected like any other volume (tmip 0 = MaxIP,
+            1 = LMIP(700, 3033), 2 = MIDA)."""
+            tmp, status = DeviceBuffer(self.n * 2 + 16), DeviceBuffer(64)
+            status.zero(self.stream)
+            L.check(L.lib().ivx_dev_fcm_volume(L.I16, self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), ctypes.c_float(n),
+                                               int(axis), tmp.ptr, status.ptr, self.stream), "fcm_volume")
+            self.sync()
+            bad = int(status.download((1,), np.int32)[0])
+            if self.lay.world > 1:
+                bad = int(self.comm.allreduce_array(np.array([bad], np.int64), "max")[0])
+            if bad:
+                tmp.close()
+                status.close()
+                raise ValueError("fast_countour_mip: a contour value does not fit the image dtype (the reference's NumCast panics)")
+            try:
+                if tmip == 0:
+                    return self.project_global(axis, "max", source=tmp)
+                if tmip == 1:
+                    return self.rays_global("lmip", axis, 700, 3033, source=tmp)
+                if tmip == 2:
+                    return self.rays_global("mida", axis, wl, ww, source=tmp)
+                raise ValueError("tmip must be 0, 1 or 2")
+            finally:
+                tmp.close()
+                status.close()
 
         def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
             a = slab_mc_args(self.lay, fill_border_holes)

@@ -119,7 +119,8 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
             piece_mesh = vol.marching_cubes_indexed(from_binary=True, download=True)
             rays = {(kind, ax): vol.rays_global(kind, ax, *par) for kind, par in (("lmip", (-300, 900)), ("mida", (300.0, 1200.0)))
                     for ax in (0, 1, 2)}
-            res[rank] = dict(proj=proj, mesh=piece_mesh, rays=rays, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
+            fcm = {(tm, ax): vol.fast_countour_mip_global(2.0, ax, 300, 1200, tm) for tm in (0, 1, 2) for ax in (0, 1, 2)}
+            res[rank] = dict(proj=proj, mesh=piece_mesh, rays=rays, fcm=fcm, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
                              mask=vol.download_mask()[lay.first_interior:lay.last_interior + 1], tris=tris,
                              count=vol.reached_count())
             vol.close()
@@ -159,6 +160,12 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
             oracle.mida(full, ax, 300, 1200, want)
         for r in range(world):
             assert np.array_equal(res[r]["rays"][(kind, ax)], want), (kind, ax, r)
+    # contour MIP: the contour volume needs the z neighbours across the slab boundary (halo slices)
+    for (tm, ax), img in res[0]["fcm"].items():
+        want = np.zeros(tuple(s for i, s in enumerate(full.shape) if i != ax), np.int16)
+        oracle.fast_countour_mip(full, 2.0, ax, 300, 1200, tm, want)
+        for r in range(world):
+            assert np.array_equal(res[r]["fcm"][(tm, ax)], want), (tm, ax, r)
     # projections of the whole volume, identical on every rank and equal to numpy on the unsharded array
     for r in range(world):
         for (ax, op), img in res[r]["proj"].items():
