@@ -1,6 +1,8 @@
 /*
  * ivx.h -- C ABI of libivx.so: the MI355X (gfx950) implementation of the InVesalius dense-voxel
- * hot path (threshold / region growing / watershed masks, MIP-family projections, marching cubes).
+ * hot path (threshold / region growing / watershed masks, MIP-family projections, marching cubes)
+ * and of the stages SURVEY.md 8(f) ranks next to it (indexed surface, largest region, area / volume,
+ * context-aware smoothing, view-matrix resampling, 3-D mask editing, mask measurements).
  *
  * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain pointers, sizes and
  * byte strides (no torch / numpy / VTK types) and returns an int status (IVX_OK or a negative
@@ -44,8 +46,8 @@ extern "C" {
 #define IVX_I16 1
 #define IVX_F64 2
 #define IVX_U16 3
-#define IVX_F32 4
-#define IVX_I32 5
+#define IVX_F32 4 /* mesh vertices */
+#define IVX_I32 5 /* label volumes (LabelsTypes3) */
 #define IVX_I64 6
 
 /* projection ops for ivx_*mip_reduce (numpy .max/.min/.mean, invesalius/data/slice_.py:885-889) */
