@@ -308,9 +308,10 @@ __global__ __launch_bounds__(256) void k_mc_count(const uint64_t *__restrict__ b
     const size_t wid = (size_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t n = 0;
     if (wid < nwords) {
-        const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
-        const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
-        const Corner8 r = load_corners(bits, g, k, j, w, pbits);
+        // nwords < 2^32 (checked on the host): 32-bit divisions instead of two 64-bit ones per lane
+        const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
+        const uint32_t k = row / (uint32_t)(g.NY - 1), j = row - k * (uint32_t)(g.NY - 1);
+        const Corner8 r = load_corners(bits, g, (int64_t)k, (int64_t)j, (int64_t)w, pbits);
         uint64_t act = r.active;
         while (act) {
             const int b = __builtin_ctzll(act);
@@ -403,9 +404,9 @@ __global__ __launch_bounds__(256) void k_mc_list(const uint64_t *__restrict__ bi
     for (int q = 0; q < wv; q++) wbase += s_wave[q];
     uint64_t pos = boff[blockIdx.x] + wbase + inc - n;
     if (pos + n > max_tris) return; // never write past the list the caller sized from the count
-    const int64_t row = (int64_t)(wid / (size_t)g.WC), w = (int64_t)(wid - (size_t)row * g.WC);
-    const int64_t k = row / (g.NY - 1), j = row - k * (g.NY - 1);
-    const Corner8 r = load_corners(bits, g, k, j, w, pbits);
+    const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
+    const uint32_t k = row / (uint32_t)(g.NY - 1), j = row - k * (uint32_t)(g.NY - 1);
+    const Corner8 r = load_corners(bits, g, (int64_t)k, (int64_t)j, (int64_t)w, pbits);
     uint64_t act = r.active;
     while (act) {
         const int b = __builtin_ctzll(act);
@@ -811,6 +812,7 @@ static int mc_count_impl(const ivx_mc_params *p, const void *a, void *scratch_, 
     *ntris = 0;
     if (s.nwords == 0) return IVX_OK;
     IVX_REQUIRE(s.nblocks * (size_t)p->niso < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
+    IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
     switch (p->dtype) {
     case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
     case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
@@ -853,7 +855,7 @@ static int mc_count_bits_impl(const ivx_mc_params *p, const uint64_t *inside_bit
     hipStream_t st = ivx::S(stream);
     *ntris = 0;
     if (s.nwords == 0) return IVX_OK;
-    IVX_REQUIRE(s.nblocks < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
+    IVX_REQUIRE(s.nblocks < 0x7fffffffull && s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for one launch");
     if (s.bits_words)
         IVX_HIP(hipMemcpyAsync((char *)scratch_ + s.off_bits, inside_bits, s.bits_words * 8, hipMemcpyDeviceToDevice, st));
     if ((rc = mc_queue_count(p, g, s, scratch_, st))) return rc;
