@@ -115,3 +115,20 @@ def test_stitch_piece_meshes_merges_the_shared_planes(oracle):
     assert ev.shape == (0, 3) and ef.shape == (0, 3)
     one_v, one_f = par.stitch_piece_meshes([pieces[0]])
     assert np.array_equal(one_v, pieces[0][0]) and np.array_equal(one_f, pieces[0][1])
+
+
+def test_structure_helper_is_scipys_generate_binary_structure():
+    from scipy.ndimage import generate_binary_structure
+    from invesalius3_amd.mask import CON2D, CON3D, _structure
+    for conn, c in CON3D.items():
+        assert np.array_equal(_structure(3, c), generate_binary_structure(3, c)) and _structure(3, c).sum() == conn + 1
+    for conn, c in CON2D.items():
+        assert np.array_equal(_structure(2, c), generate_binary_structure(2, c)) and _structure(2, c).sum() == conn + 1
+
+
+def test_headless_argument_parsing():
+    from invesalius3_amd import headless
+    with pytest.raises(SystemExit):
+        headless.main(["case.inv3", "--seed", "1", "2"])          # seeds come in triples
+    with pytest.raises(SystemExit):
+        headless.main(["case.inv3", "--threshold", "1", "2", "--mask", "0"])  # either a new threshold or a saved mask
