@@ -131,4 +131,4 @@ def test_headless_argument_parsing():
     with pytest.raises(SystemExit):
         headless.main(["case.inv3", "--seed", "1", "2"])          # seeds come in triples
     with pytest.raises(SystemExit):
-        headless.main(["case.inv3", "--threshold", "1", "2", "--mask", "0"])  # either a new threshold or a saved mask
+        headless.main(["case.inv3", "--threshold", "1", "2", "--mask", "1"])  # either a new threshold or a saved mask
