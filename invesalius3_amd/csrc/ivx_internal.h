@@ -90,5 +90,12 @@ int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, co
 // (~5 us instead of ~40 us).  Falls back to hipStreamSynchronize if the word does not arrive in time.
 int mailbox_publish(const void *dsrc, int ndwords, hipStream_t st, uint32_t *seq_out);
 int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords);
+// Progress line: 64 B of pinned, host-coherent memory per stream that the kernels of a running chain store to directly
+// (no publishing kernel) while the host polls it.  Every call hands out a fresh 8-bit tag (never 0) for bits 63..56 of
+// the words the chain stores, so values left behind by an earlier chain on the same stream -- kernels that were queued
+// ahead and still run after their host loop returned -- are recognised and ignored; on one stream the newest chain
+// always writes last.
+int progress_line(hipStream_t stream, volatile unsigned long long **line, uint32_t *tag);
+void progress_forget_stream(void *stream);
 
 } // namespace ivx

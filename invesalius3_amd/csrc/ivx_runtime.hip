@@ -213,6 +213,42 @@ int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords) {
     return IVX_OK;
 }
 
+// ---- progress lines ----------------------------------------------------------------------------------------
+static unsigned long long *g_pl = nullptr; // 64 lines x 8 qwords (one 64-B line each)
+static hipStream_t g_pl_owner[64];
+static uint8_t g_pl_used[64], g_pl_tag[64];
+
+int progress_line(hipStream_t st, volatile unsigned long long **line, uint32_t *tag) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_pl) {
+        void *p = nullptr;
+        IVX_HIP(hipHostMalloc(&p, 64 * 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(p, 0, 64 * 64);
+        g_pl = (unsigned long long *)p;
+    }
+    int idx = -1, free_idx = -1;
+    for (int i = 0; i < 64; i++) {
+        if (g_pl_used[i] && g_pl_owner[i] == st) { idx = i; break; }
+        if (!g_pl_used[i] && free_idx < 0) free_idx = i;
+    }
+    if (idx < 0) {
+        IVX_REQUIRE(free_idx >= 0, IVX_EHIP, "progress: more than 64 streams are being watched at once");
+        idx = free_idx;
+        g_pl_used[idx] = 1;
+        g_pl_owner[idx] = st;
+    }
+    if (++g_pl_tag[idx] == 0) g_pl_tag[idx] = 1;
+    *tag = g_pl_tag[idx];
+    *line = g_pl + (size_t)idx * 8;
+    return IVX_OK;
+}
+
+void progress_forget_stream(void *stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < 64; i++)
+        if (g_pl_used[i] && g_pl_owner[i] == (hipStream_t)stream) g_pl_used[i] = 0; // the tag counter lives on
+}
+
 } // namespace ivx
 
 using namespace ivx;
@@ -310,6 +346,7 @@ int ivx_stream_destroy(void *stream) {
         }
     }
     ccl_forget_stream(stream);
+    progress_forget_stream(stream);
     IVX_HIP(hipStreamDestroy(S(stream)));
     return IVX_OK;
 }

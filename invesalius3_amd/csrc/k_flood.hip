@@ -22,9 +22,12 @@
 //                           ((C + R) ^ C) & C  (and its bit-reversed twin), i.e. a 64-voxel run fills in one step,
 //                         - one s_barrier per iteration (wave ballot + LDS flag vote).
 //                       A tile whose boundary changed enlists exactly the neighbour tiles that can see the change
-//                       (byte flags de-duplicate); the host launches rounds in batches of 8 and reads the per-round
-//                       list lengths through a pinned mailbox.  Global rounds are bounded by the number of TILES on
-//                       the longest path, not voxels; past 48 rounds the union-find engine (k_ccl.hip) takes over.
+//                       (byte flags de-duplicate); every round reports its list length to a pinned progress line as it
+//                       starts and the host keeps a few rounds queued ahead of the newest one it has seen.  Global
+//                       rounds are bounded by the number of TILES on the longest path, not voxels; past 48 rounds the
+//                       union-find engine (k_ccl.hip) takes over.
+//   k_flood_coarse      before the rounds: tiles that are ALL candidate are flooded as units on the tile graph (one
+//                       workgroup, rows of tile bits), so the solid interior of a region costs no rounds at all.
 //   k_flood_persistent  the same tile update in ONE launch with a device-side ticket queue (opt-in, measured slower).
 //   k_flood_apply(2)    reached bits -> out[v] = fill (only words with reached bits touch memory).
 #include <math.h>
@@ -76,7 +79,8 @@ static int make_tiles(const ivx_flood_plan *p, Tiles *t) {
 constexpr size_t SEED_CHUNK = 4096;
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FScratch {
-    size_t off_dirty0, off_dirty1, off_cnt, off_queue, off_queued, off_seeds, off_status, off_ring, off_list0, off_list1, total;
+    size_t off_dirty0, off_dirty1, off_cnt, off_queue, off_queued, off_seeds, off_status, off_ring, off_list0, off_list1;
+    size_t off_full, off_whole, total;
     uint32_t qcap;
 };
 // persistent-frontier queue header (device)
@@ -102,7 +106,9 @@ static FScratch make_fscratch(const Tiles &t) {
     s.qcap = q;
     s.off_list0 = al256(s.off_ring + (size_t)q * 4);
     s.off_list1 = al256(s.off_list0 + (size_t)t.ntiles * 4);
-    s.total = al256(s.off_list1 + (size_t)t.ntiles * 4);
+    s.off_full = al256(s.off_list1 + (size_t)t.ntiles * 4); // coarse pass: one word per row of tiles, all-candidate / wholly reached
+    s.off_whole = al256(s.off_full + (size_t)(t.nty * t.ntz) * 8);
+    s.total = al256(s.off_whole + (size_t)(t.nty * t.ntz) * 8);
     return s;
 }
 
@@ -412,14 +418,24 @@ __global__ void k_flood_build_list(Tiles t, const uint8_t *__restrict__ dirty, u
     if (i < t.ntiles && dirty[i]) list[atomicAdd(count, 1u)] = (unsigned int)i;
 }
 
-__global__ __launch_bounds__(NT) void k_flood_round_list(Tiles t, const unsigned long long *__restrict__ cand,
-                                                          unsigned long long *reached, const unsigned int *__restrict__ list_cur,
-                                                          const unsigned int *__restrict__ n_cur, uint8_t *dirty_cur,
-                                                          uint8_t *dirty_next, unsigned int *list_next,
-                                                          unsigned int *n_next, unsigned int *n_clear) {
+// `line` (pinned host memory, ivx::progress_line): word 0 = tag | round + 1 | tiles on this round's list, stored as the
+// round STARTS (everything before it in the stream is complete, so the count is final); word 1 = tag | round + 1 of the
+// last round that had any work.  The host polls word 0, keeps a few rounds queued ahead of the newest one it has seen
+// start, and stops when a round starts with an empty list.
+__global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsigned long long *__restrict__ cand,
+                                                             unsigned long long *reached, const unsigned int *__restrict__ list_cur,
+                                                             const unsigned int *__restrict__ n_cur, uint8_t *dirty_cur,
+                                                             uint8_t *dirty_next, unsigned int *list_next,
+                                                             unsigned int *n_next, unsigned int *n_clear,
+                                                             unsigned long long *line, unsigned int tag_round) {
     __shared__ TileLds L;
     const unsigned int n = *n_cur;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_clear = 0u; // the counter the round AFTER the next one appends to
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *n_clear = 0u; // the counter the round AFTER the next one appends to
+        const unsigned long long hi = (unsigned long long)tag_round << 32;
+        __hip_atomic_store(&line[0], hi | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (n) __hip_atomic_store(&line[1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (unsigned int li = blockIdx.x; li < n; li += gridDim.x) {
         const int64_t tile = list_cur[li];
         if (threadIdx.x == 0) {
@@ -546,6 +562,167 @@ __global__ void k_flood_mark(Tiles t, int64_t tz0, int64_t tz1, uint8_t *dirty) 
     if (i < n) dirty[tz0 * per + i] = 1;
 }
 
+// ---- coarse pass: whole tiles at once ---------------------------------------------------------------
+// A tile whose in-bounds voxels are ALL candidates is connected in itself under every structuring element that
+// contains the six face offsets, so one reached voxel in it means the whole tile is reached, and two such tiles that
+// touch (by a face; by an edge for 18/26; by a corner for 26) reach each other.  The interior of a solid region is made
+// of such tiles, and crossing it voxel-tile by voxel-tile costs one ~11 us round per tile hop.  The coarse pass floods
+// the TILE graph instead: flags (k_flood_tile_flags) -> fix-point over rows of tile bits in ONE workgroup
+// (k_flood_coarse: a row of tiles along x is one 64-bit word, the same dilate / carry-fill update as the voxel tiles)
+// -> reached = cand for the tiles it reached and a dirty mark on their other neighbours (k_flood_coarse_apply).
+// The ordinary rounds then only have the boundary shell left.  Result bits are identical with or without it.
+constexpr int CT = 1024, CRP = 8, CROWS_MAX = 7680; // coarse workgroup size, rows per lane, LDS rows incl. halo (60 KB)
+constexpr unsigned int ENLISTED = 0x80u;             // dirty-byte bit: "already on the round-0 list" (coarse pass only)
+
+// A row of tiles along x (tile row index g = tzi * nty + tyi) is described by two words, bit = tile x index:
+//   rowF[g]  the tile is all-candidate,   rowW[g]  the tile is wholly reached (seeded by this kernel, closed by k_flood_coarse).
+// One workgroup per tile row: the 16 rows of a slice are contiguous, so the loads coalesce across the row's tiles.
+__global__ __launch_bounds__(256) void k_flood_tile_flags(Tiles t, const unsigned long long *__restrict__ cand,
+                                                          const unsigned long long *__restrict__ reached,
+                                                          const uint8_t *__restrict__ dirty,
+                                                          unsigned long long *__restrict__ rowF,
+                                                          unsigned long long *__restrict__ rowW,
+                                                          unsigned int *__restrict__ cnt, int ncnt) {
+    __shared__ unsigned int s_bad[64], s_has[64];
+    const int64_t tyi = blockIdx.x % t.nty, tzi = blockIdx.x / t.nty;
+    if (threadIdx.x < 64) {
+        s_bad[threadIdx.x] = 0u;
+        s_has[threadIdx.x] = 0u;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ncnt) cnt[threadIdx.x] = 0u; // the round counters (k_flood_coarse_apply appends)
+    __syncthreads();
+    const int wx = (int)t.wx, per_z = TY * wx, nw = TZ * per_z;
+    const unsigned long long last = (t.dx & 63) ? (1ull << (t.dx & 63)) - 1ull : ~0ull;
+    const int64_t tile0 = (int64_t)blockIdx.x * t.wx;
+    for (int i = threadIdx.x; i < nw; i += 256) {
+        const int tz = i / per_z, rem = i - tz * per_z, ty = rem / wx, txi = rem - ty * wx;
+        const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
+        if (z >= t.dz || y >= t.dy) continue;
+        const int64_t w = (z * t.dy + y) * t.wx + txi;
+        if (cand[w] != (txi == wx - 1 ? last : ~0ull)) s_bad[txi] = 1u;
+        else if (dirty[tile0 + txi] && reached[w]) s_has[txi] = 1u; // only freshly seeded / marked tiles start a coarse flood
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const bool in = (int)threadIdx.x < wx;
+        const unsigned long long f = __ballot(in && !s_bad[threadIdx.x]);
+        const unsigned long long h = __ballot(in && s_has[threadIdx.x]);
+        if (threadIdx.x == 0) {
+            rowF[blockIdx.x] = f;
+            rowW[blockIdx.x] = f & h;
+        }
+    }
+}
+
+template <int CONN>
+__global__ __launch_bounds__(CT) void k_flood_coarse(Tiles t, const unsigned long long *__restrict__ rowF,
+                                                     unsigned long long *__restrict__ rowW) {
+    __shared__ unsigned long long sR[CROWS_MAX];
+    __shared__ unsigned int vote[2];
+    const int nty = (int)t.nty, ntz = (int)t.ntz, hy = nty + 2;
+    const int nrows = nty * ntz, nh = hy * (ntz + 2);
+    unsigned long long F[CRP], R[CRP];
+    int me[CRP];
+#pragma unroll
+    for (int k = 0; k < CRP; k++) { // issue the loads before the LDS clear
+        const int j = threadIdx.x + k * CT;
+        F[k] = j < nrows ? rowF[j] : 0ull;
+        R[k] = j < nrows ? rowW[j] : 0ull;
+        me[k] = j < nrows ? (j / nty + 1) * hy + (j % nty) + 1 : 0;
+    }
+    for (int i = threadIdx.x; i < nh; i += CT) sR[i] = 0ull;
+    if (threadIdx.x == 0) vote[0] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CRP; k++)
+        if (R[k]) {
+            R[k] = fill_runs(R[k], F[k]);
+            sR[me[k]] = R[k];
+        }
+    __syncthreads();
+    for (int it = 0; it < 65536; it++) {
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < CRP; k++) {
+            if (!(F[k] & ~R[k])) continue; // nothing left to gain in this row (also skips the unused slots)
+            unsigned long long nb = 0;
+#pragma unroll
+            for (int kk = -1; kk <= 1; kk++)
+#pragma unroll
+                for (int jj = -1; jj <= 1; jj++) {
+                    const int nz = (kk != 0) + (jj != 0);
+                    const bool wide = CONN == 26 || (CONN == 18 && nz <= 1) || (CONN == 6 && nz == 0);
+                    const bool mid = (CONN == 18 && nz == 2) || (CONN == 6 && nz == 1);
+                    if (!wide && !mid) continue;
+                    const unsigned long long n = sR[me[k] + kk * hy + jj];
+                    nb |= wide ? (n | (n << 1) | (n >> 1)) : n;
+                }
+            const unsigned long long nr = fill_runs(R[k] | (nb & F[k]), F[k]);
+            if (nr != R[k]) {
+                R[k] = nr;
+                sR[me[k]] = nr;
+                changed = true;
+            }
+        }
+        if (__any(changed) && (threadIdx.x & 63) == 0) vote[it & 1] = 1u;
+        if (threadIdx.x == 0) vote[(it + 1) & 1] = 0u;
+        __syncthreads();
+        if (!vote[it & 1]) break;
+    }
+#pragma unroll
+    for (int k = 0; k < CRP; k++) {
+        const int j = threadIdx.x + k * CT;
+        if (j < nrows) rowW[j] = R[k];
+    }
+}
+
+// reached = cand for the wholly reached tiles; their not-wholly-reached neighbours (and the seeded tiles that are not
+// whole) go straight onto the round-0 list: a dirty byte is enlisted by whoever sets its ENLISTED bit first.
+__device__ __forceinline__ void coarse_enlist(uint8_t *dirty, int64_t tile, unsigned int *list, unsigned int *count) {
+    unsigned int *wp = (unsigned int *)(dirty + (tile & ~(int64_t)3));
+    const unsigned int bit = ENLISTED << (8 * (unsigned int)(tile & 3));
+    if (!(atomicOr(wp, bit) & bit)) list[atomicAdd(count, 1u)] = (unsigned int)tile;
+}
+
+__global__ __launch_bounds__(256) void k_flood_coarse_apply(Tiles t, const unsigned long long *__restrict__ cand,
+                                                            unsigned long long *__restrict__ reached,
+                                                            const unsigned long long *__restrict__ rowW, uint8_t *dirty,
+                                                            unsigned int *__restrict__ list, unsigned int *count) {
+    __shared__ unsigned int s_chg[64];
+    const int64_t tyi = blockIdx.x % t.nty, tzi = blockIdx.x / t.nty;
+    const int wx = (int)t.wx, per_z = TY * wx, nw = TZ * per_z;
+    const int64_t tile0 = (int64_t)blockIdx.x * t.wx;
+    const unsigned long long whole = rowW[blockIdx.x];
+    if (threadIdx.x < 64) s_chg[threadIdx.x] = 0u;
+    if ((int)threadIdx.x < wx && dirty[tile0 + threadIdx.x]) {
+        if (whole >> threadIdx.x & 1ull) dirty[tile0 + threadIdx.x] = 0; // final: a wholly reached tile has nothing to gain
+        else coarse_enlist(dirty, tile0 + threadIdx.x, list, count);
+    }
+    if (!whole) return; // uniform
+    __syncthreads();
+    for (int i = threadIdx.x; i < nw; i += 256) {
+        const int tz = i / per_z, rem = i - tz * per_z, ty = rem / wx, txi = rem - ty * wx;
+        if (!(whole >> txi & 1ull)) continue;
+        const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
+        if (z >= t.dz || y >= t.dy) continue;
+        const int64_t w = (z * t.dy + y) * t.wx + txi;
+        const unsigned long long c = cand[w];
+        if (reached[w] != c) { // the tile gained voxels: its neighbours must look again
+            reached[w] = c;
+            s_chg[txi] = 1u;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * wx; i += 256) {
+        const int txi = i / 27, d = i - txi * 27;
+        if (d == 13 || !s_chg[txi]) continue;
+        const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
+        if (nz < 0 || nz >= t.ntz || ny < 0 || ny >= t.nty || nx < 0 || nx >= t.wx) continue;
+        if (rowW[nz * t.nty + ny] >> nx & 1ull) continue;
+        coarse_enlist(dirty, (nz * t.nty + ny) * t.wx + nx, list, count);
+    }
+}
+
 // ---- apply: out[v] = fill where reached ---------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_flood_apply(Tiles t, const uint8_t *__restrict__ reached, T *__restrict__ out,
@@ -553,11 +730,16 @@ __global__ __launch_bounds__(256) void k_flood_apply(Tiles t, const uint8_t *__r
     const int64_t bpr = t.wx * 8;
     const int64_t total = t.dz * t.dy * bpr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool aligned8 = ((uintptr_t)out & 7) == 0 && (t.dx & 7) == 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const unsigned m = reached[i];
         if (!m) continue;
         const int64_t row = i / bpr, q = i - row * bpr;
         T *o = out + row * t.dx + q * 8;
+        if (sizeof(T) == 1 && m == 0xffu && aligned8) { // inside a filled region: one 8-byte store
+            *reinterpret_cast<unsigned long long *>(o) = 0x0101010101010101ull * (unsigned long long)(uint8_t)fill;
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 8; e++)
             if (m >> e & 1u) o[e] = fill; // reached bits never exist beyond dx
@@ -851,60 +1033,97 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
     unsigned int *list[2] = {(unsigned int *)(scr + s.off_list0), (unsigned int *)(scr + s.off_list1)};
     // Counters live in a ring of RING dwords indexed by the round number: round r reads cnt[r % RING] (entries of its
     // list), appends to cnt[(r+1) % RING] and clears cnt[(r+2) % RING] for the round after -- no host-side resets, so
-    // batches can be queued back to back.  The host stays ONE batch ahead of what it has seen: it queues batch k+1
-    // before it waits for batch k's counters (a kernel snapshot of the ring into the pinned mailbox), because the wait
-    // + re-launch round trip cost 35-45 us of idle GPU per batch; a batch that turns out to be unnecessary is a handful
-    // of empty launches that later work simply queues behind.
+    // rounds can be queued back to back.  Every round reports the length of its list to a pinned progress line as it
+    // starts; the host keeps `ahead` rounds queued beyond the newest round it has seen start (a wait + re-launch round
+    // trip would leave the GPU idle for 35-45 us) and stops at the first round that starts empty.  The rounds queued
+    // ahead at that point find empty lists: a few ~2 us launches that later work simply queues behind.
     constexpr int RING = 2 * BATCH;
-    static const int batch_rounds = [] {
+    static const int ahead = [] {
         const char *e = getenv("IVX_FLOOD_BATCH");
-        const int v = e ? atoi(e) : 4;
-        return v < 2 ? 2 : (v > BATCH ? BATCH : v & ~1); // even, so every batch starts on list[0] / dirty[0]
+        const int v = e ? atoi(e) : 3;
+        return v < 1 ? 1 : (v > BATCH ? BATCH : v);
     }();
-    IVX_HIP(hipMemsetAsync(cnt, 0, RING * 4, st));
-    hipLaunchKernelGGL(k_flood_build_list, dim3((unsigned)ivx::cdiv(t.ntiles, 256)), dim3(256), 0, st, t, dirty[0], list[0], cnt);
-    IVX_LAUNCH_CHECK();
-    const unsigned grid = (unsigned)(t.ntiles < 1024 ? t.ntiles : 1024);
-    int64_t next_round = 0; // absolute number of the next round to queue
-    auto queue_batch = [&](uint32_t *seq) -> int {
-        for (int b = 0; b < batch_rounds; b++, next_round++) {
-            const int r = (int)(next_round % RING), cur = (int)(next_round & 1);
-            hipLaunchKernelGGL(k_flood_round_list, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
-                               (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
-                               cnt + (r + 1) % RING, cnt + (r + 2) % RING);
-            IVX_LAUNCH_CHECK();
-        }
-        return ivx::mailbox_publish(cnt, RING, st, seq);
+    static const bool coarse_on = [] {
+        const char *e = getenv("IVX_FLOOD_COARSE");
+        return !(e && e[0] == '0');
+    }();
+    // coarse pass (see k_flood_coarse): standard structures only, tile grid small enough for one workgroup's LDS
+    if (coarse_on && t.conn != 0 && t.wx <= 64 && (t.nty + 2) * (t.ntz + 2) <= CROWS_MAX &&
+        t.nty * t.ntz <= (int64_t)CT * CRP) {
+        unsigned long long *rowF = (unsigned long long *)(scr + s.off_full), *rowW = (unsigned long long *)(scr + s.off_whole);
+        const unsigned groups = (unsigned)(t.nty * t.ntz);
+        hipLaunchKernelGGL(k_flood_tile_flags, dim3(groups), dim3(256), 0, st, t, (const unsigned long long *)cand,
+                           (const unsigned long long *)reached, dirty[0], rowF, rowW, cnt, RING);
+        IVX_LAUNCH_CHECK();
+        if (t.conn == 26) hipLaunchKernelGGL(k_flood_coarse<26>, dim3(1), dim3(CT), 0, st, t, rowF, rowW);
+        else if (t.conn == 18) hipLaunchKernelGGL(k_flood_coarse<18>, dim3(1), dim3(CT), 0, st, t, rowF, rowW);
+        else hipLaunchKernelGGL(k_flood_coarse<6>, dim3(1), dim3(CT), 0, st, t, rowF, rowW);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_flood_coarse_apply, dim3(groups), dim3(256), 0, st, t, (const unsigned long long *)cand,
+                           (unsigned long long *)reached, rowW, dirty[0], list[0], cnt);
+        IVX_LAUNCH_CHECK();
+    } else {
+        IVX_HIP(hipMemsetAsync(cnt, 0, RING * 4, st));
+        hipLaunchKernelGGL(k_flood_build_list, dim3((unsigned)ivx::cdiv(t.ntiles, 256)), dim3(256), 0, st, t, dirty[0], list[0], cnt);
+        IVX_LAUNCH_CHECK();
+    }
+    volatile unsigned long long *line = nullptr;
+    uint32_t tag = 0;
+    if ((rc = ivx::progress_line(st, &line, &tag))) return rc;
+    const unsigned grid = (unsigned)(t.ntiles < 1536 ? t.ntiles : 1536); // 6 workgroups per CU are resident (80 VGPRs)
+    int64_t queued = 0; // rounds launched so far
+    auto queue_round = [&]() -> int {
+        const int r = (int)(queued % RING), cur = (int)(queued & 1);
+        hipLaunchKernelGGL(k_flood_round_list, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+                           (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
+                           cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line,
+                           (unsigned int)(tag << 24) | (unsigned int)((queued + 1) & 0xffffff));
+        IVX_LAUNCH_CHECK();
+        queued++;
+        return IVX_OK;
     };
-    uint32_t seq_cur = 0, seq_next = 0;
-    if ((rc = queue_batch(&seq_cur))) return rc;
-    for (int64_t first = 0;; first += batch_rounds) { // `first` = first round of the batch being waited for
-        if ((rc = queue_batch(&seq_next))) return rc; // stay one batch ahead
-        unsigned int h2[RING], h[BATCH];
-        if ((rc = ivx::mailbox_wait(seq_cur, st, h2, RING))) return rc;
-        for (int b = 0; b < batch_rounds; b++) h[b] = h2[(first + b + 1) % RING]; // tiles enlisted BY round first+b
-        static const bool trace = getenv("IVX_FLOOD_TRACE") != nullptr;
-        if (trace) {
-            fprintf(stderr, "ivx flood: tiles enlisted by rounds %d..%d:", total_rounds + 1, total_rounds + batch_rounds);
-            for (int b = 0; b < batch_rounds; b++) fprintf(stderr, " %u", h[b]);
-            fprintf(stderr, "  (of %lld tiles)\n", (long long)t.ntiles);
+    static const bool trace = getenv("IVX_FLOOD_TRACE") != nullptr;
+    int64_t seen = 0; // rounds seen starting
+    for (;;) {
+        while (queued < seen + 1 + ahead)
+            if ((rc = queue_round())) return rc;
+        // wait for a round beyond `seen` to report
+        unsigned long long v = 0;
+        bool got = false;
+        for (long spins = 0; spins < 20000000L; spins++) {
+            v = __atomic_load_n((const unsigned long long *)line, __ATOMIC_ACQUIRE);
+            if ((uint32_t)(v >> 56) == tag && (int64_t)((v >> 32) & 0xffffffull) > seen) { got = true; break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
         }
-        int used = batch_rounds;
-        for (int b = 0; b < batch_rounds; b++)
-            if (h[b] == 0) { used = b + 1; break; }
-        total_rounds += used;
-        if (h[batch_rounds - 1] == 0) break; // converged; the batch queued ahead finds empty lists
+        if (!got) { // a few hundred ms without news: take the safe path once
+            IVX_HIP(hipStreamSynchronize(st));
+            v = __atomic_load_n((const unsigned long long *)line, __ATOMIC_ACQUIRE);
+            IVX_REQUIRE((uint32_t)(v >> 56) == tag && (int64_t)((v >> 32) & 0xffffffull) > seen, IVX_EHIP,
+                        "flood: the queued rounds never reported");
+        }
+        seen = (int64_t)((v >> 32) & 0xffffffull);
+        const unsigned int n_list = (unsigned int)(v & 0xffffffffull);
+        if (trace) fprintf(stderr, "ivx flood: round %lld starts with %u of %lld tiles (%lld queued)\n", (long long)seen, n_list,
+                           (long long)t.ntiles, (long long)queued);
+        if (n_list == 0) { // converged: word 1 holds the last round that had work (if any, and if it is ours)
+            const unsigned long long u = __atomic_load_n((const unsigned long long *)line + 1, __ATOMIC_ACQUIRE);
+            total_rounds = (uint32_t)(u >> 56) == tag ? (int)((u >> 32) & 0xffffffull) : 0;
+            break;
+        }
+        total_rounds = (int)seen;
         if (total_rounds >= CCL_ESCAPE_ROUNDS && ivx::ccl_supported(p->strct_bits)) {
             // long, thin region: stop paying one launch per tile hop -- every reached bit so far is correct, the
-            // union-find path completes the components they belong to in one flat pass
+            // union-find path completes the components they belong to in one flat pass (the rounds already queued
+            // keep flooding until then, which is harmless)
             IVX_HIP(hipMemsetAsync(dirty[0], 0, (size_t)t.ntiles, st));
             IVX_HIP(hipMemsetAsync(dirty[1], 0, (size_t)t.ntiles, st));
             if ((rc = ivx::ccl_run(p, cand, reached, scratch_, st))) return rc;
             total_rounds += 1;
             break;
         }
-        IVX_REQUIRE(total_rounds < (1 << 24), IVX_EHIP, "flood: did not converge");
-        seq_cur = seq_next;
+        IVX_REQUIRE(total_rounds < (1 << 24) - 64, IVX_EHIP, "flood: did not converge");
     }
     if (rounds) *rounds = total_rounds;
     return IVX_OK;
