@@ -180,7 +180,9 @@ int ivx_dev_mc_count(const ivx_mc_params *p, const void *a, void *scratch, int64
 int ivx_dev_mc_count_async(const ivx_mc_params *p, const void *a, void *scratch, void *stream);
 int ivx_dev_mc_count_bits_async(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch, void *stream);
 int ivx_dev_mc_total(const ivx_mc_params *p, void *scratch, int64_t *ntris, void *stream);
-/* same, from an inside plane (value >= iso[0]) the caller already holds; niso must be 1 */
+/* same, from an inside plane (value >= iso[0]) the caller already holds; niso must be 1.  The plane is read IN PLACE by
+ * this call and by the ivx_dev_mc_emit / ivx_dev_mc_indexed_* calls that follow on the same scratch: keep it unchanged
+ * until they have run. */
 int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, void *scratch, int64_t *ntris,
                           void *stream);
 /* emit; must follow ivx_dev_mc_count with the same params/scratch */

@@ -746,6 +746,33 @@ __global__ __launch_bounds__(256) void k_flood_apply(Tiles t, const uint8_t *__r
     }
 }
 
+// byte targets with dx % 64 == 0 (rows are whole words, the bit volume is one flat array): one lane = 16 voxels =
+// two bytes of reached bits -> one 16-byte store (a read-modify-write of the lane's own 16 bytes on a partial chunk)
+__global__ __launch_bounds__(256) void k_flood_apply16(const uint16_t *__restrict__ reached, int64_t nchunks,
+                                                       uint4 *__restrict__ out, uint8_t fill) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const unsigned int f4 = 0x01010101u * fill;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const unsigned int m = reached[i];
+        if (!m) continue;
+        uint4 v = make_uint4(f4, f4, f4, f4);
+        if (m != 0xffffu) {
+            const uint4 o = out[i];
+            // bit e of m -> byte e: spread 4 bits to 4 byte masks
+            auto blend = [&](unsigned int old, unsigned int bits4) {
+                const unsigned int sel = ((bits4 & 1u) * 0xffu) | ((bits4 >> 1 & 1u) * 0xff00u) |
+                                         ((bits4 >> 2 & 1u) * 0xff0000u) | ((bits4 >> 3 & 1u) * 0xff000000u);
+                return (old & ~sel) | (f4 & sel);
+            };
+            v.x = blend(o.x, m & 15u);
+            v.y = blend(o.y, m >> 4 & 15u);
+            v.z = blend(o.z, m >> 8 & 15u);
+            v.w = blend(o.w, m >> 12 & 15u);
+        }
+        out[i] = v;
+    }
+}
+
 // out[v] = fill AND mask[v] = select where reached: floodfill_threshold's `out` plus the caller's
 // `mask[out_mask.astype(bool)] = 254` (styles.py:3214) in one pass over the reached bits
 __global__ __launch_bounds__(256) void k_flood_apply2(Tiles t, const uint8_t *__restrict__ reached, uint8_t *__restrict__ out,
@@ -1155,6 +1182,14 @@ extern "C" int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reac
     const int g = grid_for(total);
     hipStream_t st = ivx::S(stream);
     const uint8_t *r = (const uint8_t *)reached;
+    if (dtype == IVX_U8 && t.dx % 64 == 0 && ((uintptr_t)target & 15) == 0) {
+        const int64_t nchunks = t.dz * t.dy * t.dx / 16;
+        const int64_t blocks = ivx::cdiv(nchunks, 256);
+        hipLaunchKernelGGL(k_flood_apply16, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st,
+                           (const uint16_t *)reached, nchunks, (uint4 *)target, (uint8_t)fill);
+        IVX_LAUNCH_CHECK();
+        return IVX_OK;
+    }
     switch (dtype) {
     case IVX_U8: hipLaunchKernelGGL(k_flood_apply<uint8_t>, dim3(g), dim3(256), 0, st, t, r, (uint8_t *)target, (uint8_t)fill); break;
     case IVX_I16: hipLaunchKernelGGL(k_flood_apply<int16_t>, dim3(g), dim3(256), 0, st, t, r, (int16_t *)target, (int16_t)fill); break;

@@ -516,6 +516,18 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
 static std::map<const void *, uint64_t> g_split; // scratch -> number of iso-0 triangles (two-iso pieces)
 static std::map<const void *, uint32_t> g_vsplit; // scratch -> number of iso-0 vertices (indexed mesh)
 static std::mutex g_split_mu;
+// scratch -> inside plane handed in by ivx_dev_mc_count_bits (read in place by the later list / indexed passes of the
+// same piece instead of being copied into the scratch); an ivx_dev_mc_count on the same scratch forgets it
+static std::map<const void *, const uint64_t *> g_ext_bits;
+
+static const uint64_t *mc_bits_ptr(const void *scratch, const Scratch &s, int q) {
+    if (q == 0) {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        auto it = g_ext_bits.find(scratch);
+        if (it != g_ext_bits.end()) return it->second;
+    }
+    return (const uint64_t *)((const char *)scratch + s.off_bits) + (size_t)q * s.bits_words;
+}
 
 static inline uint64_t pad_bits(const ivx_mc_params *p, int q) { return p->pad_value >= p->iso[q] ? ~0ull : 0ull; }
 
@@ -553,7 +565,7 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     // iso-0 / iso-1 split (boff[nblocks]) on the device
     const size_t nb = s.nblocks * (size_t)p->niso;
     for (int q = 0; q < p->niso; q++) {
-        const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
+        const uint64_t *bits = mc_bits_ptr(scratch, s, q);
         const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
         hipLaunchKernelGGL(k_mc_list, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q), counts,
                            boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
@@ -770,7 +782,7 @@ static int mc_queue_count(const ivx_mc_params *p, const Geom &g, const Scratch &
     uint32_t *bsum = (uint32_t *)(scratch + s.off_bsum);
     uint64_t *boff = (uint64_t *)(scratch + s.off_boff);
     for (int q = 0; q < p->niso; q++) {
-        const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
+        const uint64_t *bits = mc_bits_ptr(scratch, s, q);
         uint16_t *counts = (uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
         hipLaunchKernelGGL(k_mc_count, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q),
                            counts, bsum + (size_t)q * s.nblocks);
@@ -813,6 +825,10 @@ static int mc_count_impl(const ivx_mc_params *p, const void *a, void *scratch_, 
     if (s.nwords == 0) return IVX_OK;
     IVX_REQUIRE(s.nblocks * (size_t)p->niso < 0x7fffffffull, IVX_EINVAL, "mc: piece too large for one launch");
     IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        g_ext_bits.erase(scratch_); // this piece's planes are derived into the scratch
+    }
     switch (p->dtype) {
     case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
     case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
@@ -856,8 +872,10 @@ static int mc_count_bits_impl(const ivx_mc_params *p, const uint64_t *inside_bit
     *ntris = 0;
     if (s.nwords == 0) return IVX_OK;
     IVX_REQUIRE(s.nblocks < 0x7fffffffull && s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for one launch");
-    if (s.bits_words)
-        IVX_HIP(hipMemcpyAsync((char *)scratch_ + s.off_bits, inside_bits, s.bits_words * 8, hipMemcpyDeviceToDevice, st));
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        g_ext_bits[scratch_] = inside_bits; // read in place until the next count on this scratch
+    }
     if ((rc = mc_queue_count(p, g, s, scratch_, st))) return rc;
     return ntris_wanted ? mc_read_total(p, s, scratch_, ntris, st) : IVX_OK;
 }
@@ -939,7 +957,7 @@ extern "C" int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, c
     for (int q = 0; q < p->niso; q++) {
         uint32_t *vbase = (uint32_t *)((char *)d_v + m.off_v + (size_t)q * m.per_iso);
         uint32_t *bsum = vbase + m.npw, *d_total = bsum + m.nsb;
-        const uint64_t *bits = (const uint64_t *)((const char *)scratch_ + s.off_bits) + (size_t)q * s.bits_words;
+        const uint64_t *bits = mc_bits_ptr(scratch_, s, q);
         const uint64_t *qb = (const uint64_t *)d_v + (size_t)q * s.bits_words;
         const int64_t blocks = ivx::cdiv(m.npw, 256);
         hipLaunchKernelGGL(k_mci_count, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, bits, qb, g,
@@ -982,7 +1000,7 @@ static int run_indexed(const ivx_mc_params *p, const Geom &g, const Scratch &s, 
         }
     }
     for (int q = 0; q < p->niso; q++) {
-        const uint64_t *bits = (const uint64_t *)(scratch + s.off_bits) + (size_t)q * s.bits_words;
+        const uint64_t *bits = mc_bits_ptr(scratch, s, q);
         const uint64_t *qb = (const uint64_t *)d_v + (size_t)q * s.bits_words;
         const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
         const uint32_t *vbase = (const uint32_t *)((const char *)d_v + m.off_v + (size_t)q * m.per_iso);

@@ -94,6 +94,18 @@ class Timer:
         self.stream = stream
         self.spans = []  # (name, ev0, ev1)
         self._pool = []
+        # Names to record (None = all).  A recorded event is a barrier packet in the stream: ~4 us of idle GPU each, so
+        # a caller timing whole steps by the wall clock brackets only what it needs.
+        self.only = None
+
+    class _Off:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *a):
+            return False
+
+    _OFF = _Off()
 
     def _ev(self):
         if self._pool:
@@ -116,6 +128,8 @@ class Timer:
             self.t.spans.append((self.name, self.e0, e1))
 
     def span(self, name):
+        if self.only is not None and name not in self.only:
+            return Timer._OFF
         return Timer._Span(self, name)
 
     def collect(self) -> dict:
@@ -154,6 +168,7 @@ class DeviceVolume:
         self._mbits_valid = False   # self._mbits == (mask >= 127), the inside plane marching cubes needs at iso 127
         self._mbits_range = None    # (lo, hi) while additionally _mbits == (lo <= image <= hi)
         self._out_bytes_zero = False  # the BYTES of out_mask are all zero
+        self._mc_params_cache = {}
         self._out_pending = None      # fill value of a deferred `out_mask[reached] = fill` (self.reached still holds it)
         self._fuse = os.environ.get("IVX_NO_FUSE", "") == ""
         self.image = TrackedBuffer(self.n * 2, self._image_touched)
@@ -384,6 +399,11 @@ class DeviceVolume:
     def _mc_params(self, from_binary, min_value, max_value, fill_border_holes=True, z0=0, z1=None, roi_start=None,
                    pad_bottom=None, pad_top=None) -> L.McParams:
         z1 = self.dz if z1 is None else z1
+        key = (bool(from_binary), min_value, max_value, bool(fill_border_holes), z0, z1, roi_start, pad_bottom, pad_top,
+               tuple(self.spacing))
+        hit = self._mc_params_cache.get(key)
+        if hit is not None:
+            return hit
         p = L.McParams()
         pb = (z0 == 0) if pad_bottom is None else pad_bottom
         pt = (z1 >= self.dz) if pad_top is None else pad_top
@@ -400,6 +420,8 @@ class DeviceVolume:
         else:
             p.dtype, p.niso, p.pad_value = L.I16, 2, float(np.iinfo(np.int16).min)
             p.iso[:] = [float(min_value), float(max_value)]
+        if len(self._mc_params_cache) < 64:
+            self._mc_params_cache[key] = p  # callers treat the struct as read-only
         return p
 
     def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False,
