@@ -594,13 +594,25 @@ __global__ __launch_bounds__(256) void k_flood_tile_flags(Tiles t, const unsigne
     const int wx = (int)t.wx, per_z = TY * wx, nw = TZ * per_z;
     const unsigned long long last = (t.dx & 63) ? (1ull << (t.dx & 63)) - 1ull : ~0ull;
     const int64_t tile0 = (int64_t)blockIdx.x * t.wx;
-    for (int i = threadIdx.x; i < nw; i += 256) {
-        const int tz = i / per_z, rem = i - tz * per_z, ty = rem / wx, txi = rem - ty * wx;
-        const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
-        if (z >= t.dz || y >= t.dy) continue;
-        const int64_t w = (z * t.dy + y) * t.wx + txi;
-        if (cand[w] != (txi == wx - 1 ? last : ~0ull)) s_bad[txi] = 1u;
-        else if (dirty[tile0 + txi] && reached[w]) s_has[txi] = 1u; // only freshly seeded / marked tiles start a coarse flood
+    for (int i0 = threadIdx.x; i0 < nw; i0 += 4 * 256) { // four loads in flight per lane: the kernel is latency-bound
+        unsigned long long cv[4];
+        int64_t wi[4];
+        int tx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 256;
+            const int tz = i / per_z, rem = i - tz * per_z, ty = rem / wx;
+            tx[u] = rem - ty * wx;
+            const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
+            wi[u] = (i < nw && z < t.dz && y < t.dy) ? (z * t.dy + y) * t.wx + tx[u] : -1;
+            cv[u] = wi[u] >= 0 ? cand[wi[u]] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (wi[u] < 0) continue;
+            if (cv[u] != (tx[u] == wx - 1 ? last : ~0ull)) s_bad[tx[u]] = 1u;
+            else if (dirty[tile0 + tx[u]] && reached[wi[u]]) s_has[tx[u]] = 1u; // only freshly seeded / marked tiles start a coarse flood
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -625,12 +637,12 @@ __global__ __launch_bounds__(CT) void k_flood_coarse(Tiles t, const unsigned lon
     int me[CRP];
 #pragma unroll
     for (int k = 0; k < CRP; k++) { // issue the loads before the LDS clear
-        const int j = threadIdx.x + k * CT;
+        const int j = threadIdx.x + k * (int)blockDim.x;
         F[k] = j < nrows ? rowF[j] : 0ull;
         R[k] = j < nrows ? rowW[j] : 0ull;
         me[k] = j < nrows ? (j / nty + 1) * hy + (j % nty) + 1 : 0;
     }
-    for (int i = threadIdx.x; i < nh; i += CT) sR[i] = 0ull;
+    for (int i = threadIdx.x; i < nh; i += blockDim.x) sR[i] = 0ull;
     if (threadIdx.x == 0) vote[0] = 0u;
     __syncthreads();
 #pragma unroll
@@ -671,7 +683,7 @@ __global__ __launch_bounds__(CT) void k_flood_coarse(Tiles t, const unsigned lon
     }
 #pragma unroll
     for (int k = 0; k < CRP; k++) {
-        const int j = threadIdx.x + k * CT;
+        const int j = threadIdx.x + k * (int)blockDim.x;
         if (j < nrows) rowW[j] = R[k];
     }
 }
@@ -700,17 +712,26 @@ __global__ __launch_bounds__(256) void k_flood_coarse_apply(Tiles t, const unsig
     }
     if (!whole) return; // uniform
     __syncthreads();
-    for (int i = threadIdx.x; i < nw; i += 256) {
-        const int tz = i / per_z, rem = i - tz * per_z, ty = rem / wx, txi = rem - ty * wx;
-        if (!(whole >> txi & 1ull)) continue;
-        const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
-        if (z >= t.dz || y >= t.dy) continue;
-        const int64_t w = (z * t.dy + y) * t.wx + txi;
-        const unsigned long long c = cand[w];
-        if (reached[w] != c) { // the tile gained voxels: its neighbours must look again
-            reached[w] = c;
-            s_chg[txi] = 1u;
+    for (int i0 = threadIdx.x; i0 < nw; i0 += 4 * 256) { // four word pairs in flight per lane
+        unsigned long long cv[4], rv[4];
+        int64_t wi[4];
+        int tx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 256;
+            const int tz = i / per_z, rem = i - tz * per_z, ty = rem / wx;
+            tx[u] = rem - ty * wx;
+            const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
+            wi[u] = (i < nw && (whole >> tx[u] & 1ull) && z < t.dz && y < t.dy) ? (z * t.dy + y) * t.wx + tx[u] : -1;
+            cv[u] = wi[u] >= 0 ? cand[wi[u]] : 0ull;
+            rv[u] = wi[u] >= 0 ? reached[wi[u]] : 0ull;
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (wi[u] >= 0 && rv[u] != cv[u]) { // the tile gained voxels: its neighbours must look again
+                reached[wi[u]] = cv[u];
+                s_chg[tx[u]] = 1u;
+            }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 27 * wx; i += 256) {
@@ -1082,9 +1103,11 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
         hipLaunchKernelGGL(k_flood_tile_flags, dim3(groups), dim3(256), 0, st, t, (const unsigned long long *)cand,
                            (const unsigned long long *)reached, dirty[0], rowF, rowW, cnt, RING);
         IVX_LAUNCH_CHECK();
-        if (t.conn == 26) hipLaunchKernelGGL(k_flood_coarse<26>, dim3(1), dim3(CT), 0, st, t, rowF, rowW);
-        else if (t.conn == 18) hipLaunchKernelGGL(k_flood_coarse<18>, dim3(1), dim3(CT), 0, st, t, rowF, rowW);
-        else hipLaunchKernelGGL(k_flood_coarse<6>, dim3(1), dim3(CT), 0, st, t, rowF, rowW);
+        int ct = 64; // one row of tiles per lane up to 1024 lanes, then up to CRP rows per lane (128..1024 lanes measured equal)
+        while (ct < CT && ct < t.nty * t.ntz) ct *= 2;
+        if (t.conn == 26) hipLaunchKernelGGL(k_flood_coarse<26>, dim3(1), dim3(ct), 0, st, t, rowF, rowW);
+        else if (t.conn == 18) hipLaunchKernelGGL(k_flood_coarse<18>, dim3(1), dim3(ct), 0, st, t, rowF, rowW);
+        else hipLaunchKernelGGL(k_flood_coarse<6>, dim3(1), dim3(ct), 0, st, t, rowF, rowW);
         IVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_flood_coarse_apply, dim3(groups), dim3(256), 0, st, t, (const unsigned long long *)cand,
                            (unsigned long long *)reached, rowW, dirty[0], list[0], cnt);

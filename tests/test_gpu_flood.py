@@ -273,3 +273,41 @@ def test_solid_bodies_cross_whole_tiles(ivxlib, oracle, conn, shape):
     floodfill.floodfill_threshold(img, seeds2, 400, 600, 2, strct, out_g)
     oracle.floodfill_threshold(img, seeds2, 400, 600, 2, strct, out_r)
     assert np.array_equal(out_g, out_r)
+
+
+def test_concurrent_floods_on_separate_streams(ivxlib, oracle):
+    """Four resident volumes, each on its own stream and host thread, flood repeatedly at the same time: every stream
+    watches its own progress line, and rounds left queued by one flood must not end the next one early."""
+    import threading
+
+    from invesalius3_amd.device import DeviceVolume
+    strct = generate_binary_structure(3, 3)
+    vols, refs, seeds = [], [], []
+    for i in range(4):
+        img = synth_volume((40 + 8 * i, 48, 128), seed=90 + i)
+        z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+        sd = [(int(x), int(y), int(z))]
+        ref = np.zeros(img.shape, np.uint8)
+        oracle.floodfill_threshold(img, sd, -700, 3071, 1, strct, ref)
+        vols.append(DeviceVolume(img))
+        refs.append(ref)
+        seeds.append(sd)
+    errs = []
+
+    def run(i):
+        try:
+            for rep in range(12):
+                vols[i].zero_out_mask()
+                vols[i].region_grow(seeds[i], -700, 3071, strct, fill=1, select_value=None)
+                if rep % 4 == 3 and not np.array_equal(vols[i].download_out_mask(), refs[i]):
+                    errs.append((i, rep))
+        except Exception as e:  # pragma: no cover
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for v in vols:
+        v.close()
+    assert not errs, errs
+    assert all(r.sum() > 1000 for r in refs)
