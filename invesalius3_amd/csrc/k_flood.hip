@@ -49,6 +49,7 @@ struct Tiles {
     int64_t dz, dy, dx, wx;
     int64_t nty, ntz, ntiles;
     uint32_t strct;
+    int itcap; // local iterations per tile visit before the tile re-enlists itself
     int conn; // 6 / 18 / 26 when strct is exactly scipy's generate_binary_structure(3, 1|2|3), else 0 (generic path)
 };
 
@@ -71,6 +72,16 @@ static int make_tiles(const ivx_flood_plan *p, Tiles *t) {
         t->conn = sb == m26 ? 26 : sb == m18 ? 18 : sb == m6 ? 6 : 0;
     }
     if (getenv("IVX_FLOOD_DBG")) t->strct |= 1u << 30;
+    // One tile crossing (TY = TZ = 16 rows) per visit: a tile that is still changing after that re-enlists itself and
+    // carries on in the next round, when its neighbours have already started on what it has published so far -- the
+    // rounds pipeline instead of waiting for the slowest tile's local fix-point (measured 0.240 -> 0.232 ms on the bench
+    // volume; below 16 a straight crossing needs two visits and the round count doubles).
+    static const int itcap = [] {
+        const char *e = getenv("IVX_FLOOD_ITCAP");
+        const int v = e ? atoi(e) : TY;
+        return v < 1 ? 1 : v;
+    }();
+    t->itcap = itcap;
     IVX_REQUIRE(t->ntiles < 0x7fffffffll, IVX_EINVAL, "flood: too many tiles");
     return IVX_OK;
 }
@@ -309,7 +320,7 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     const uint32_t st = t.strct;
     const bool xrun = (st >> 12 & 1) && (st >> 14 & 1); // both x neighbours of the centre row present
     bool exhausted = true;
-    for (int it = 0; it < 2048; it++) {
+    for (int it = 0; it < t.itcap; it++) {
       bool changed = false;
       // SUB gather/update steps per vote: LDS is coherent inside the workgroup and bits are only OR'ed in, so steps need
       // no barrier between them -- a wave always sees its own rows' previous step (program order), other waves' rows
@@ -498,6 +509,8 @@ __global__ __launch_bounds__(NT) void k_flood_persistent(Tiles t, const unsigned
     __shared__ TileLds L;
     __shared__ int s_tile;
     unsigned int my_visits = 0;
+    // nothing was enqueued (the counter is final: the enqueue kernel has completed): nobody would ever set `done`
+    if (blockIdx.x == 0 && threadIdx.x == 0 && AT_LOAD(&q->pending) == 0u) AT_STORE(&q->done, 1u);
     for (;;) {
         if (threadIdx.x == 0) {
             int tile = -1;
