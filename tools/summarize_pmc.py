@@ -50,7 +50,9 @@ def main():
         open(sys.argv[2], "w").write(out + "\n")
     if len(sys.argv) > 4:  # <traffic.json> <steps of the kernel-trace run incl. warmup>
         import json
-        nsteps = int(sys.argv[4])
+        # steps of the kernel-trace run (warm-up + timed + the bench's instrumented extra steps); "auto" = the call count
+        # of a kernel that runs exactly once per step
+        nsteps = stats["k_flood_clear<unsigned int, 4u>"][0] if sys.argv[4] == "auto" else int(sys.argv[4])
         stage_of = lambda k: ("threshold" if k.startswith("k_threshold") else "marching_cubes" if k.startswith("k_mc_")
                               else "region_grow" if k.startswith(("k_flood_", "k_ccl_", "k_scan_")) and not k.startswith("k_flood_count")
                               else None)
