@@ -368,6 +368,11 @@ int ivx_dev_flood_mark_slab(const ivx_flood_plan *p, void *scratch, int64_t z0, 
 int ivx_dev_bits_combine(uint64_t *dst, const uint64_t *src, int64_t nwords, int op, void *stream);
 int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z,
                            const uint64_t *plane, void *scratch, int *changed, void *stream);
+/* both halo planes of a slab in one call (either plane may be NULL): same update per plane, the tiles of the words that
+ * gained bits are marked dirty on the device, ONE read-back: *changed (host) = words that gained bits in either plane */
+int ivx_dev_flood_or_planes(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
+                            const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch, int *changed,
+                            void *stream);
 /* out[v] = fill where reached (uint8 out), or data[v] = fill (in-place form, dtype of data) */
 int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reached, int dtype, void *target,
                         double fill, void *stream);

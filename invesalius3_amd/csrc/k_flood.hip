@@ -1272,16 +1272,24 @@ extern "C" int ivx_dev_flood_count(const ivx_flood_plan *p, const uint64_t *reac
 }
 
 // ---- multi-GPU halo: OR a neighbour's reached plane into slice z; counts words that gained bits -------------
+// MARK: the tile of every word that gained bits is flagged dirty by the kernel itself (instead of the host marking the
+// whole tile layer of z after reading the count back)
+template <bool MARK>
 __global__ __launch_bounds__(256) void k_flood_or_plane(unsigned long long *__restrict__ dst,
                                                         const unsigned long long *__restrict__ src,
                                                         const unsigned long long *__restrict__ cand, int64_t nwords,
-                                                        unsigned int *__restrict__ changed) {
+                                                        unsigned int *__restrict__ changed, Tiles t, int64_t z,
+                                                        uint8_t *__restrict__ dirty) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nwords) return;
     const unsigned long long add = src[i] & cand[i] & ~dst[i];
     if (add) {
         dst[i] |= add;
         atomicAdd(changed, 1u);
+        if (MARK) {
+            const int64_t y = i / t.wx, txi = i - y * t.wx;
+            dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + txi] = 1;
+        }
     }
 }
 
@@ -1315,15 +1323,48 @@ extern "C" int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *c
     hipStream_t st = ivx::S(stream);
     unsigned int *d_chg = (unsigned int *)((char *)scratch_ + s.off_status);
     IVX_HIP(hipMemsetAsync(d_chg, 0, 4, st));
-    hipLaunchKernelGGL(k_flood_or_plane, dim3((unsigned)ivx::cdiv(nw, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_flood_or_plane<false>, dim3((unsigned)ivx::cdiv(nw, 256)), dim3(256), 0, st,
                        (unsigned long long *)reached + z * nw, (const unsigned long long *)plane,
-                       (const unsigned long long *)cand + z * nw, nw, d_chg);
+                       (const unsigned long long *)cand + z * nw, nw, d_chg, t, z, (uint8_t *)nullptr);
     IVX_LAUNCH_CHECK();
     unsigned int h = 0;
     IVX_HIP(hipMemcpyAsync(&h, d_chg, 4, hipMemcpyDeviceToHost, st));
     IVX_HIP(hipStreamSynchronize(st));
     *changed = (int)h;
     if (h) return ivx_dev_flood_mark_slab(p, scratch_, z, z + 1, stream);
+    return IVX_OK;
+}
+
+// Both halo planes of a slab in one call (either may be NULL): reached[z] |= plane & cand[z] for each, the tiles of the
+// words that gained bits are marked dirty on the device, and ONE read-back returns the number of such words.
+extern "C" int ivx_dev_flood_or_planes(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
+                                       const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch_,
+                                       int *changed, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    const FScratch s = make_fscratch(t);
+    const int64_t nw = t.dy * t.wx;
+    *changed = 0;
+    if (!nw || (!plane_a && !plane_b)) return IVX_OK;
+    hipStream_t st = ivx::S(stream);
+    unsigned int *d_chg = (unsigned int *)((char *)scratch_ + s.off_status);
+    uint8_t *dirty = (uint8_t *)((char *)scratch_ + s.off_dirty0);
+    IVX_HIP(hipMemsetAsync(d_chg, 0, 4, st));
+    const int64_t zs[2] = {z_a, z_b};
+    const uint64_t *pl[2] = {plane_a, plane_b};
+    for (int q = 0; q < 2; q++) {
+        if (!pl[q]) continue;
+        IVX_REQUIRE(zs[q] >= 0 && zs[q] < t.dz, IVX_ERANGE, "flood: plane %lld outside slab", (long long)zs[q]);
+        hipLaunchKernelGGL(k_flood_or_plane<true>, dim3((unsigned)ivx::cdiv(nw, 256)), dim3(256), 0, st,
+                           (unsigned long long *)reached + zs[q] * nw, (const unsigned long long *)pl[q],
+                           (const unsigned long long *)cand + zs[q] * nw, nw, d_chg, t, zs[q], dirty);
+        IVX_LAUNCH_CHECK();
+    }
+    uint32_t seq, h = 0;
+    if ((rc = ivx::mailbox_publish(d_chg, 1, st, &seq))) return rc;
+    if ((rc = ivx::mailbox_wait(seq, st, &h, 1))) return rc;
+    *changed = (int)h;
     return IVX_OK;
 }
 

@@ -124,9 +124,24 @@ class TorchComm:
         return from_down, from_up
 
     def allreduce_sum(self, value: int) -> int:
-        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.device)
+        if self.device == "cpu":
+            t = self.torch.tensor([int(value)], dtype=self.torch.int64)
+        else:  # one resident word, filled by a kernel: no pageable host-to-device copy per vote
+            if getattr(self, "_vote", None) is None:
+                self._vote = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+            t = self._vote
+            t.fill_(int(value))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
+
+    def plane_buffer(self, nbytes: int, slot: int):
+        """A resident uint8 CUDA tensor the volume exports a boundary plane into directly (slot 0 = down, 1 = up): RCCL
+        sends it as it is, no staging copy per exchange."""
+        bufs = self.__dict__.setdefault("_planes", {})
+        t = bufs.get(slot)
+        if t is None or t.numel() != nbytes:
+            t = bufs[slot] = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+        return t
 
     def allreduce_array(self, a: np.ndarray, op: str) -> np.ndarray:
         """Element-wise max / min / sum of one small host array per rank (a projection image)."""
@@ -185,11 +200,14 @@ def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
         down = backend.export_plane(lay.first_interior) if lay.hb else None
         up = backend.export_plane(lay.last_interior) if lay.ht else None
         from_down, from_up = comm.exchange(down, up)
-        changed = 0
-        if from_down is not None:
-            changed += backend.or_plane(0, from_down)
-        if from_up is not None:
-            changed += backend.or_plane(lay.local_dz - 1, from_up)
+        if hasattr(backend, "or_planes"):  # both planes, one read-back
+            changed = backend.or_planes(from_down, from_up)
+        else:
+            changed = 0
+            if from_down is not None:
+                changed += backend.or_plane(0, from_down)
+            if from_up is not None:
+                changed += backend.or_plane(lay.local_dz - 1, from_up)
         rounds += 1
         if comm.allreduce_sum(changed) == 0:
             return rounds
@@ -249,11 +267,28 @@ def _make_slab_volume():
             self._rounds += r.value
 
         def export_plane(self, z: int):
-            b = self._send[0 if z == self.lay.first_interior else 1]
-            L.check(L.lib().ivx_memcpy_d2d(b.ptr, self.reached.at(z * self.plane_words * 8),
-                                           ctypes.c_size_t(self.plane_words * 8), self.stream))
-            self.sync()  # the plane must be complete before the communicator (RCCL runs on torch's stream) reads it
-            return DevPlane(b.ptr.value, self.plane_words * 8, keep=b)
+            slot = 0 if z == self.lay.first_interior else 1
+            nb = self.plane_words * 8
+            if hasattr(self.comm, "plane_buffer") and self.comm.device != "cpu":
+                # straight into the tensor RCCL sends (TorchComm): one device copy, one stream wait
+                t = self.comm.plane_buffer(nb, slot)
+                L.check(L.lib().ivx_memcpy_d2d(ctypes.c_void_p(t.data_ptr()), self.reached.at(z * nb), ctypes.c_size_t(nb),
+                                               self.stream))
+                self.sync()  # complete before the communicator (RCCL runs on torch's stream) reads it
+                return t
+            b = self._send[slot]
+            L.check(L.lib().ivx_memcpy_d2d(b.ptr, self.reached.at(z * nb), ctypes.c_size_t(nb), self.stream))
+            self.sync()
+            return DevPlane(b.ptr.value, nb, keep=b)
+
+        def or_planes(self, from_down, from_up) -> int:
+            chg = ctypes.c_int(0)
+            pd = ctypes.c_void_p(from_down.data_ptr()) if from_down is not None else None
+            pu = ctypes.c_void_p(from_up.data_ptr()) if from_up is not None else None
+            L.check(L.lib().ivx_dev_flood_or_planes(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr, c64(0), pd,
+                                                    c64(self.lay.local_dz - 1), pu, self.flood_scratch.ptr,
+                                                    ctypes.byref(chg), self.stream), "flood_or_planes")
+            return chg.value
 
         def or_plane(self, z: int, tensor) -> int:
             chg = ctypes.c_int(0)
