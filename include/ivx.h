@@ -382,6 +382,27 @@ int ivx_dev_flood_apply2(const ivx_flood_plan *p, const uint64_t *reached, uint8
                          int select, void *stream);
 /* number of reached voxels */
 int ivx_dev_flood_count(const ivx_flood_plan *p, const uint64_t *reached, int64_t *count, void *stream);
+/* directed floods (floodfill_auto_threshold): six edge planes (+x, -x, +y, -y, +z, -z; bit = SOURCE voxel, layout of the
+ * candidate plane, packed back to back) instead of a candidate plane.  ivx_dev_flood_edges_auto builds them for
+ * floodfill_py.rs:32-35: from a voxel of value v the flood may step to a neighbour whose value lies in
+ * [ceil(v(1-p)), floor(v(1+p))] (f32 products, `as i16`) and whose `out` byte is not `fill`. */
+int ivx_flood_edges_bytes(const ivx_flood_plan *p, size_t *nbytes);
+int ivx_dev_flood_edges_auto(const ivx_flood_plan *p, const int16_t *data, const uint8_t *out, float pfrac, int fill,
+                             uint64_t *edges, void *stream);
+/* seeds set unconditionally (floodfill.rs:21, floodfill_py.rs:30); cand may be NULL */
+int ivx_dev_flood_seed_forced(const ivx_flood_plan *p, const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand,
+                              uint64_t *reached, void *scratch, void *stream);
+/* ivx_dev_flood_run over edge planes */
+int ivx_dev_flood_run_edges(const ivx_flood_plan *p, const uint64_t *edges, uint64_t *reached, void *scratch, int *rounds,
+                            void *stream);
+/* Host forms.  floodfill (invesalius_rs/__init__.py:10 = floodfill_py.rs:88-135, floodfill.rs:5-49): 6-neighbour
+ * component of data == v around (x, y, z), the seed filled whatever its value.  floodfill_auto_threshold
+ * (invesalius_rs/__init__.py:57-65 = floodfill_py.rs:12-85): int16 data, seeds as (x, y, z) triples. */
+int ivx_floodfill(int dtype, const void *data, const int64_t shape[3], const int64_t strides[3], int64_t x, int64_t y,
+                  int64_t z, double v, int fill, uint8_t *out, const int64_t out_strides[3]);
+int ivx_floodfill_auto_threshold(const int16_t *data, const int64_t shape[3], const int64_t strides[3],
+                                 const int64_t *seeds_xyz, int64_t nseeds, float pfrac, int fill, uint8_t *out,
+                                 const int64_t out_strides[3]);
 int ivx_floodfill_threshold(int dtype, const void *data, const int64_t shape[3], const int64_t strides[3],
                             const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1, int fill,
                             const uint8_t *strct, const int64_t sshape[3], uint8_t *out,

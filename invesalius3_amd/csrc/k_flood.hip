@@ -412,6 +412,91 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
     if ((threadIdx.x & 63) == 0 && dirs) atomicOr(&L.dirs, dirs);
 }
 
+// ---- directed tile update (floodfill_auto_threshold) -------------------------------------------------------------
+// The admissible range of a step depends on the voxel it LEAVES (floodfill_py.rs:32-35), so reachability is directed:
+// six edge planes say, per source voxel, whether the step to its +x / -x / +y / -y / +z / -z neighbour is allowed
+// (k_flood_edges_auto folds "the target is not a barrier" into them).  Same tile, same relaxation, same votes as
+// tile_update; a lane gathers  reached(neighbour row) & edge(neighbour row -> me)  for its four row neighbours (the edge
+// words are loaded once per visit), and closes x-chains inside its word with the carry trick along the edge bits:
+// (E + (R & E)) ^ E  sets every bit a run of consecutive edges carries a reached bit to (bit-reversed twin for -x).
+__device__ __forceinline__ void tile_update_dir(const Tiles &t, const unsigned long long *__restrict__ edges,
+                                                unsigned long long *reached, int64_t tile, TileLds &L) {
+    const int64_t txi = tile % t.wx, r1 = tile / t.wx;
+    const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+    const int64_t z0 = tzi * TZ, y0 = tyi * TY;
+    const int64_t plane = t.dz * t.dy * t.wx; // words per edge plane
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int idx = threadIdx.x + pass * NT;
+        if (idx < HZ * HY) {
+            const int yy = idx % HY, zz = idx / HY;
+            const int64_t z = z0 + zz - 1, y = y0 + yy - 1;
+            L.sN[idx] = (z >= 0 && z < t.dz && y >= 0 && y < t.dy) ? reached[(z * t.dy + y) * t.wx + txi] : 0ull;
+        }
+    }
+    const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> TY_LOG;
+    const int64_t z = z0 + tz, y = y0 + ty;
+    const bool inside = z < t.dz && y < t.dy;
+    const int64_t me_w = (z * t.dy + y) * t.wx + txi;
+    unsigned long long exp = 0, bexm = 0, e_ym = 0, e_yp = 0, e_zm = 0, e_zp = 0, carry = 0;
+    if (inside) {
+        exp = edges[me_w];
+        bexm = __brevll(edges[plane + me_w]);
+        if (y > 0) e_ym = edges[2 * plane + me_w - t.wx];                  // row y-1 stepping +y
+        if (y + 1 < t.dy) e_yp = edges[3 * plane + me_w + t.wx];           // row y+1 stepping -y
+        if (z > 0) e_zm = edges[4 * plane + me_w - t.dy * t.wx];           // slice z-1 stepping +z
+        if (z + 1 < t.dz) e_zp = edges[5 * plane + me_w + t.dy * t.wx];    // slice z+1 stepping -z
+        // steps across the word boundary come from the x-neighbour tiles: constant during this visit
+        if (txi > 0) carry |= (reached[me_w - 1] & edges[me_w - 1]) >> 63;
+        if (txi + 1 < t.wx) carry |= (reached[me_w + 1] & edges[plane + me_w + 1] & 1ull) << 63;
+    }
+    if (threadIdx.x == 0) L.vote[0] = 0u;
+    __syncthreads();
+    const int me = (tz + 1) * HY + (ty + 1);
+    const unsigned long long r_in = L.sN[me];
+    unsigned long long r = r_in;
+    bool exhausted = true;
+    for (int it = 0; it < t.itcap; it++) {
+        unsigned long long nr = r | carry | (L.sN[me - 1] & e_ym) | (L.sN[me + 1] & e_yp) | (L.sN[me - HY] & e_zm) |
+                                (L.sN[me + HY] & e_zp);
+        nr |= (exp + (nr & exp)) ^ exp;
+        unsigned long long rn = __brevll(nr);
+        rn |= (bexm + (rn & bexm)) ^ bexm;
+        nr = __brevll(rn);
+        if (!inside) nr = 0ull;
+        const bool ch = nr != r;
+        if (ch) {
+            r = nr;
+            L.sN[me] = r;
+        }
+        if (__any(ch) && (threadIdx.x & 63) == 0) L.vote[it & 1] = 1u;
+        if (threadIdx.x == 0) L.vote[(it + 1) & 1] = 0u;
+        __syncthreads();
+        if (!L.vote[it & 1]) {
+            exhausted = false;
+            break;
+        }
+    }
+    const unsigned long long chg = r ^ r_in;
+    unsigned dirs = 0;
+    if (chg) {
+        reached[me_w] = r;
+        const bool zlo = tz == 0, zhi = tz == TZ - 1, ylo = ty == 0, yhi = ty == TY - 1;
+        const bool xlo = chg & 1ull, xhi = chg >> 63;
+        // face neighbours only: every step moves along one axis
+        if (zlo) dirs |= 1u << 4;
+        if (zhi) dirs |= 1u << 22;
+        if (ylo) dirs |= 1u << 10;
+        if (yhi) dirs |= 1u << 16;
+        if (xlo) dirs |= 1u << 12;
+        if (xhi) dirs |= 1u << 14;
+        if (exhausted) dirs |= 1u << 13;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dirs |= __shfl_xor(dirs, o, 64);
+    if ((threadIdx.x & 63) == 0 && dirs) atomicOr(&L.dirs, dirs);
+}
+
 // diagnostic only (not part of include/ivx.h): cycle stamps written under IVX_FLOOD_DBG=1, see tools/dbg_tile.py
 extern "C" int ivx_debug_read(unsigned long long *out16) {
     IVX_HIP(hipDeviceSynchronize());
@@ -433,6 +518,7 @@ __global__ void k_flood_build_list(Tiles t, const uint8_t *__restrict__ dirty, u
 // round STARTS (everything before it in the stream is complete, so the count is final); word 1 = tag | round + 1 of the
 // last round that had any work.  The host polls word 0, keeps a few rounds queued ahead of the newest one it has seen
 // start, and stops when a round starts with an empty list.
+template <bool DIRECTED> // DIRECTED: `cand` holds the six edge planes of k_flood_edges_auto instead of a candidate plane
 __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsigned long long *__restrict__ cand,
                                                              unsigned long long *reached, const unsigned int *__restrict__ list_cur,
                                                              const unsigned int *__restrict__ n_cur, uint8_t *dirty_cur,
@@ -456,7 +542,8 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
         __syncthreads();
         const bool dbg = (t.strct >> 30 & 1u) && li == 0; // IVX_FLOOD_DBG: cycle stamps of the first tile (tools/dbg_tile.py)
         if (dbg && threadIdx.x == 0) g_dbg[0] = __builtin_readcyclecounter();
-        if (dbg) tile_update<false, 26, true>(t, cand, reached, tile, L);
+        if (DIRECTED) tile_update_dir(t, cand, reached, tile, L);
+        else if (dbg) tile_update<false, 26, true>(t, cand, reached, tile, L);
         else if (t.conn == 26) tile_update<false, 26>(t, cand, reached, tile, L);
         else if (t.conn == 18) tile_update<false, 18>(t, cand, reached, tile, L);
         else if (t.conn == 6) tile_update<false, 6>(t, cand, reached, tile, L);
@@ -757,6 +844,64 @@ __global__ __launch_bounds__(256) void k_flood_coarse_apply(Tiles t, const unsig
     }
 }
 
+// ---- floodfill_auto_threshold: edge planes --------------------------------------------------------------------
+// floodfill_py.rs:32-35: a voxel of value v lets the flood step to a 6-neighbour whose value lies in
+// [ceil(v * (1 - p)), floor(v * (1 + p))], both f32 products cast to i16 the way Rust's `as` does (saturating, NaN -> 0),
+// provided that neighbour's `out` byte is not `fill` yet.  One lane per 8 source voxels -> one byte in each of the six
+// planes (+x, -x, +y, -y, +z, -z; bit = SOURCE voxel).
+__device__ __forceinline__ int sat_i16(float f) {
+    if (f != f) return 0;
+    if (f <= -32768.0f) return -32768;
+    if (f >= 32767.0f) return 32767;
+    return (int)f;
+}
+__global__ __launch_bounds__(256) void k_flood_edges_auto(const int16_t *__restrict__ data, const uint8_t *__restrict__ out,
+                                                          Tiles t, float p, uint8_t fill, uint8_t *__restrict__ edges) {
+    const int64_t bpr = t.wx * 8, rows = t.dz * t.dy, total = rows * bpr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float lo_f = 1.0f - p, hi_f = 1.0f + p;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / bpr, q = i - row * bpr;
+        const int64_t z = row / t.dy, y = row - z * t.dy;
+        unsigned m[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        const int64_t base = row * t.dx;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int64_t x = q * 8 + e;
+            if (x >= t.dx) break;
+            const float val = (float)data[base + x];
+            const int t0 = sat_i16(ceilf(val * lo_f)), t1 = sat_i16(floorf(val * hi_f));
+            const int64_t off[6] = {1, -1, t.dx, -t.dx, t.dy * t.dx, -t.dy * t.dx};
+            const bool ok[6] = {x + 1 < t.dx, x > 0, y + 1 < t.dy, y > 0, z + 1 < t.dz, z > 0};
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                if (!ok[d]) continue;
+                const int64_t n = base + x + off[d];
+                const int nv = data[n];
+                if (out[n] != fill && nv >= t0 && nv <= t1) m[d] |= 1u << e;
+            }
+        }
+        const int64_t plane = total;
+#pragma unroll
+        for (int d = 0; d < 6; d++) edges[d * plane + i] = (uint8_t)m[d];
+    }
+}
+
+// seeds whose bits are set no matter what the data says (floodfill.rs:21, floodfill_py.rs:30: `out[seed] = fill` and the
+// seed is expanded unconditionally); `cand` may be NULL (directed floods have no candidate plane)
+__global__ void k_flood_seed_forced(Tiles t, const int64_t *__restrict__ seeds, int64_t nseeds,
+                                    unsigned long long *__restrict__ cand, unsigned long long *__restrict__ reached,
+                                    uint8_t *__restrict__ dirty) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nseeds) return;
+    const int64_t x = seeds[3 * n], y = seeds[3 * n + 1], z = seeds[3 * n + 2];
+    const int64_t w = (z * t.dy + y) * t.wx + (x >> 6);
+    const unsigned long long bit = 1ull << (x & 63);
+    if (cand) atomicOr(&cand[w], bit);
+    atomicOr(&reached[w], bit);
+    dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + (x >> 6)] = 1;
+}
+
 // ---- apply: out[v] = fill where reached ---------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_flood_apply(Tiles t, const uint8_t *__restrict__ reached, T *__restrict__ out,
@@ -1025,8 +1170,10 @@ extern "C" int ivx_dev_flood_clear(const ivx_flood_plan *p, uint64_t *reached, v
     return IVX_OK;
 }
 
-extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch_,
-                                 int *rounds, void *stream) {
+// directed: `cand` = the six edge planes of ivx_dev_flood_edges_auto (rounds engine only: the coarse pass, the
+// union-find escape and the persistent frontier all rely on symmetric adjacency)
+static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool directed, uint64_t *reached, void *scratch_,
+                          int *rounds, void *stream) {
     Tiles t;
     int rc = make_tiles(p, &t);
     if (rc) return rc;
@@ -1041,12 +1188,13 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
     // when a flood needs more than CCL_ESCAPE_ROUNDS rounds (serpentine / maze-like regions); "ccl" = run-based
     // union-find from the start (k_ccl.hip; no frontier, flat cost); "persistent" = tile frontier, single launch +
     // device queue.  Measured at 512^3 on the bench blob (20 rounds): rounds 0.74 ms, ccl 0.86 ms, persistent 1.4 ms.
-    static const int mode = [] {
+    static const int mode_env = [] {
         const char *e = getenv("IVX_FLOOD_MODE");
         if (e && !strcmp(e, "ccl")) return 0;
         if (e && !strcmp(e, "persistent")) return 2;
         return 1;
     }();
+    const int mode = directed ? 1 : mode_env;
     constexpr int CCL_ESCAPE_ROUNDS = 48;
     if (mode == 0 && ivx::ccl_supported(p->strct_bits)) {
         if (rounds) *rounds = 1;
@@ -1109,7 +1257,7 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
         return !(e && e[0] == '0');
     }();
     // coarse pass (see k_flood_coarse): standard structures only, tile grid small enough for one workgroup's LDS
-    if (coarse_on && t.conn != 0 && t.wx <= 64 && (t.nty + 2) * (t.ntz + 2) <= CROWS_MAX &&
+    if (coarse_on && !directed && t.conn != 0 && t.wx <= 64 && (t.nty + 2) * (t.ntz + 2) <= CROWS_MAX &&
         t.nty * t.ntz <= (int64_t)CT * CRP) {
         unsigned long long *rowF = (unsigned long long *)(scr + s.off_full), *rowW = (unsigned long long *)(scr + s.off_whole);
         const unsigned groups = (unsigned)(t.nty * t.ntz);
@@ -1137,10 +1285,15 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
     int64_t queued = 0; // rounds launched so far
     auto queue_round = [&]() -> int {
         const int r = (int)(queued % RING), cur = (int)(queued & 1);
-        hipLaunchKernelGGL(k_flood_round_list, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
-                           (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
-                           cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line,
-                           (unsigned int)(tag << 24) | (unsigned int)((queued + 1) & 0xffffff));
+        const unsigned int tr = (unsigned int)(tag << 24) | (unsigned int)((queued + 1) & 0xffffff);
+        if (directed)
+            hipLaunchKernelGGL(k_flood_round_list<true>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+                               (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
+                               cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr);
+        else
+            hipLaunchKernelGGL(k_flood_round_list<false>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+                               (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
+                               cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr);
         IVX_LAUNCH_CHECK();
         queued++;
         return IVX_OK;
@@ -1176,7 +1329,7 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
             break;
         }
         total_rounds = (int)seen;
-        if (total_rounds >= CCL_ESCAPE_ROUNDS && ivx::ccl_supported(p->strct_bits)) {
+        if (!directed && total_rounds >= CCL_ESCAPE_ROUNDS && ivx::ccl_supported(p->strct_bits)) {
             // long, thin region: stop paying one launch per tile hop -- every reached bit so far is correct, the
             // union-find path completes the components they belong to in one flat pass (the rounds already queued
             // keep flooding until then, which is harmless)
@@ -1189,6 +1342,66 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
         IVX_REQUIRE(total_rounds < (1 << 24) - 64, IVX_EHIP, "flood: did not converge");
     }
     if (rounds) *rounds = total_rounds;
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch_,
+                                 int *rounds, void *stream) {
+    return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream);
+}
+extern "C" int ivx_dev_flood_run_edges(const ivx_flood_plan *p, const uint64_t *edges, uint64_t *reached, void *scratch_,
+                                       int *rounds, void *stream) {
+    return flood_run_impl(p, edges, true, reached, scratch_, rounds, stream);
+}
+
+extern "C" int ivx_flood_edges_bytes(const ivx_flood_plan *p, size_t *nbytes) {
+    size_t one;
+    int rc = ivx_flood_bits_bytes(p, &one);
+    if (rc) return rc;
+    *nbytes = 6 * one;
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_edges_auto(const ivx_flood_plan *p, const int16_t *data, const uint8_t *out, float pfrac, int fill,
+                                        uint64_t *edges, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    IVX_REQUIRE(data && out && edges, IVX_EINVAL, "flood_edges_auto: NULL argument");
+    const int64_t total = t.dz * t.dy * t.wx * 8;
+    if (!total) return IVX_OK;
+    // the six planes are packed back to back, dz * dy * wx words each (ivx_flood_edges_bytes leaves room for that)
+    hipLaunchKernelGGL(k_flood_edges_auto, dim3((unsigned)grid_for(total)), dim3(256), 0, ivx::S(stream), data, out, t, pfrac,
+                       (uint8_t)fill, (uint8_t *)edges);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_seed_forced(const ivx_flood_plan *p, const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand,
+                                         uint64_t *reached, void *scratch_, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    for (int64_t n = 0; n < nseeds; n++) {
+        const int64_t x = seeds_xyz[3 * n], y = seeds_xyz[3 * n + 1], z = seeds_xyz[3 * n + 2];
+        IVX_REQUIRE(x >= 0 && y >= 0 && z >= 0 && x < t.dx && y < t.dy && z < t.dz, IVX_ERANGE,
+                    "flood: seed (%lld,%lld,%lld) outside volume (%lld,%lld,%lld) [x,y,z]", (long long)x, (long long)y,
+                    (long long)z, (long long)t.dx, (long long)t.dy, (long long)t.dz);
+    }
+    if (nseeds == 0) return IVX_OK;
+    const FScratch s = make_fscratch(t);
+    char *scr = (char *)scratch_;
+    hipStream_t st = ivx::S(stream);
+    ivx::ccl_invalidate(scratch_);
+    int64_t *d_seeds = (int64_t *)(scr + s.off_seeds);
+    for (int64_t b = 0; b < nseeds; b += (int64_t)SEED_CHUNK) {
+        const int64_t m = nseeds - b < (int64_t)SEED_CHUNK ? nseeds - b : (int64_t)SEED_CHUNK;
+        IVX_HIP(hipMemcpyAsync(d_seeds, seeds_xyz + 3 * b, (size_t)m * 24, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_flood_seed_forced, dim3((unsigned)ivx::cdiv(m, 256)), dim3(256), 0, st, t, d_seeds, m,
+                           (unsigned long long *)cand, (unsigned long long *)reached, (uint8_t *)(scr + s.off_dirty0));
+        IVX_LAUNCH_CHECK();
+        IVX_HIP(hipStreamSynchronize(st)); // d_seeds is reused by the next chunk; seeds_xyz is pageable host memory
+    }
     return IVX_OK;
 }
 
@@ -1433,4 +1646,85 @@ extern "C" int ivx_floodfill_threshold_inplace(int dtype, void *data, const int6
                                                double fill, const uint8_t *strct, const int64_t sshape[3]) {
     ivx::HostCallGuard host_guard__;
     return flood_host(dtype, data, shape, strides, seeds_xyz, nseeds, t0, t1, fill, strct, sshape, nullptr, strides, 1);
+}
+
+// floodfill_internal (floodfill.rs:5-49): 6-neighbour component of `data == v` around (x, y, z); the seed itself is
+// filled and expanded whatever its value; voxels whose `out` byte already equals `fill` are barriers.
+extern "C" int ivx_floodfill(int dtype, const void *data, const int64_t shape[3], const int64_t strides[3], int64_t x,
+                             int64_t y, int64_t z, double v, int fill, uint8_t *out, const int64_t out_strides[3]) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    const size_t isz = dtype_size(dtype);
+    IVX_REQUIRE(isz, IVX_EINVAL, "floodfill: unsupported dtype %d", dtype);
+    IVX_REQUIRE(x >= 0 && y >= 0 && z >= 0 && x < shape[2] && y < shape[1] && z < shape[0], IVX_ERANGE,
+                "floodfill: seed (%lld,%lld,%lld) outside volume", (long long)x, (long long)y, (long long)z);
+    ivx_flood_plan plan;
+    plan.dz = shape[0]; plan.dy = shape[1]; plan.dx = shape[2];
+    plan.wx = cdiv(shape[2], 64);
+    plan.strct_bits = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 13) | (1u << 14) | (1u << 16) | (1u << 22); // 6 faces
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+    size_t bb, sb;
+    int rc;
+    if ((rc = ivx_flood_bits_bytes(&plan, &bb))) return rc;
+    if ((rc = ivx_flood_scratch_bytes(&plan, &sb))) return rc;
+    void *d_data, *d_out, *d_cand, *d_reach, *d_scr;
+    if ((rc = ws_get(WS_IN, n * isz, &d_data))) return rc;
+    if ((rc = ws_get(WS_OUT, n, &d_out))) return rc;
+    if ((rc = ws_get(WS_AUX0, bb, &d_cand))) return rc;
+    if ((rc = ws_get(WS_AUX1, bb, &d_reach))) return rc;
+    if ((rc = ws_get(WS_AUX2, sb, &d_scr))) return rc;
+    if ((rc = upload_strided(d_data, data, shape, strides, isz, WS_IN))) return rc;
+    if ((rc = upload_strided(d_out, out, shape, out_strides, 1, WS_OUT))) return rc;
+    const double fl = (double)(uint8_t)fill;
+    const int64_t seed[3] = {x, y, z};
+    if ((rc = ivx_dev_flood_clear(&plan, (uint64_t *)d_reach, d_scr, nullptr))) return rc;
+    if ((rc = ivx_dev_flood_candidates(&plan, dtype, d_data, v, v, (const uint8_t *)d_out, 1, fl, (uint64_t *)d_cand, nullptr)))
+        return rc;
+    if ((rc = ivx_dev_flood_seed_forced(&plan, seed, 1, (uint64_t *)d_cand, (uint64_t *)d_reach, d_scr, nullptr))) return rc;
+    if ((rc = ivx_dev_flood_run(&plan, (const uint64_t *)d_cand, (uint64_t *)d_reach, d_scr, nullptr, nullptr))) return rc;
+    if ((rc = ivx_dev_flood_apply(&plan, (const uint64_t *)d_reach, IVX_U8, d_out, fl, nullptr))) return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    return download_strided(out, shape, out_strides, d_out, 1, WS_OUT);
+}
+
+// floodfill_auto_threshold (floodfill_py.rs:12-85): int16 data, uint8 out; every seed is filled and expanded
+// unconditionally, a step from a voxel of value v reaches 6-neighbours in [ceil(v(1-p)), floor(v(1+p))] (f32, as i16).
+extern "C" int ivx_floodfill_auto_threshold(const int16_t *data, const int64_t shape[3], const int64_t strides[3],
+                                            const int64_t *seeds_xyz, int64_t nseeds, float pfrac, int fill, uint8_t *out,
+                                            const int64_t out_strides[3]) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    ivx_flood_plan plan;
+    plan.dz = shape[0]; plan.dy = shape[1]; plan.dx = shape[2];
+    plan.wx = cdiv(shape[2], 64);
+    plan.strct_bits = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 13) | (1u << 14) | (1u << 16) | (1u << 22);
+    for (int64_t n = 0; n < nseeds; n++) {
+        const int64_t x = seeds_xyz[3 * n], y = seeds_xyz[3 * n + 1], z = seeds_xyz[3 * n + 2];
+        IVX_REQUIRE(x >= 0 && y >= 0 && z >= 0 && x < shape[2] && y < shape[1] && z < shape[0], IVX_ERANGE,
+                    "floodfill_auto_threshold: seed (%lld,%lld,%lld) outside volume", (long long)x, (long long)y, (long long)z);
+    }
+    const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+    if (n == 0 || nseeds == 0) return IVX_OK;
+    size_t bb, eb, sb;
+    int rc;
+    if ((rc = ivx_flood_bits_bytes(&plan, &bb))) return rc;
+    if ((rc = ivx_flood_edges_bytes(&plan, &eb))) return rc;
+    if ((rc = ivx_flood_scratch_bytes(&plan, &sb))) return rc;
+    void *d_data, *d_out, *d_edges, *d_reach, *d_scr;
+    if ((rc = ws_get(WS_IN, n * 2, &d_data))) return rc;
+    if ((rc = ws_get(WS_OUT, n, &d_out))) return rc;
+    if ((rc = ws_get(WS_AUX0, eb, &d_edges))) return rc;
+    if ((rc = ws_get(WS_AUX1, bb, &d_reach))) return rc;
+    if ((rc = ws_get(WS_AUX2, sb, &d_scr))) return rc;
+    if ((rc = upload_strided(d_data, data, shape, strides, 2, WS_IN))) return rc;
+    if ((rc = upload_strided(d_out, out, shape, out_strides, 1, WS_OUT))) return rc;
+    if ((rc = ivx_dev_flood_clear(&plan, (uint64_t *)d_reach, d_scr, nullptr))) return rc;
+    if ((rc = ivx_dev_flood_edges_auto(&plan, (const int16_t *)d_data, (const uint8_t *)d_out, pfrac, fill, (uint64_t *)d_edges,
+                                       nullptr)))
+        return rc;
+    if ((rc = ivx_dev_flood_seed_forced(&plan, seeds_xyz, nseeds, nullptr, (uint64_t *)d_reach, d_scr, nullptr))) return rc;
+    if ((rc = ivx_dev_flood_run_edges(&plan, (const uint64_t *)d_edges, (uint64_t *)d_reach, d_scr, nullptr, nullptr))) return rc;
+    if ((rc = ivx_dev_flood_apply(&plan, (const uint64_t *)d_reach, IVX_U8, d_out, (double)(uint8_t)fill, nullptr))) return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    return download_strided(out, shape, out_strides, d_out, 1, WS_OUT);
 }

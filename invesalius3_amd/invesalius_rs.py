@@ -66,6 +66,43 @@ def floodfill_threshold_inplace(data, seeds, t0, t1, fill, strct):
         "floodfill_threshold_inplace")
 
 
+def floodfill(data, i, j, k, v, fill, out):
+    """floodfill (invesalius_rs/__init__.py:10 -> floodfill_py.rs:88-135 -> floodfill_internal floodfill.rs:5-49):
+    the 6-neighbour component of ``data == v`` around the seed (i, j, k) = (x, y, z) receives `fill` in `out`; the seed
+    itself is filled and expanded whatever its value, and voxels of `out` that already hold `fill` are barriers.
+    dtype pairs of the binding: int16 / uint8 / float64 data with a uint8 `out`; `v` and `fill` must fit their dtype
+    (``v.extract::<i16>()``, ``fill.extract::<u8>()``)."""
+    if data.ndim != 3 or out.ndim != 3 or tuple(data.shape) != tuple(out.shape):
+        raise TypeError("data and out must be 3-D arrays of the same shape")
+    if out.dtype != np.uint8:
+        raise TypeError("out must be uint8")
+    code = L.dtype_code(data, (L.U8, L.I16, L.F64))
+    if data.dtype.kind in "iu" and not isinstance(v, (int, np.integer)):
+        raise TypeError("v must be an integer for %s data" % data.dtype)
+    v = _fits(v, data.dtype, "v")
+    fill = _fits(fill, np.dtype(np.uint8), "fill")
+    L.check(L.lib().ivx_floodfill(code, L.ptr(data), L.i64(data.shape), L.i64(data.strides), ctypes.c_int64(int(i)),
+                                  ctypes.c_int64(int(j)), ctypes.c_int64(int(k)), ctypes.c_double(v), ctypes.c_int(fill),
+                                  L.ptr(out), L.i64(out.strides)), "floodfill")
+
+
+def floodfill_auto_threshold(data, seeds, p, fill, out):
+    """floodfill_auto_threshold (invesalius_rs/__init__.py:57-65 -> floodfill_py.rs:12-85): int16 data, uint8 out.
+    Every seed (x, y, z) is filled and expanded; from a voxel of value v the flood steps to the 6-neighbours whose
+    value lies in [ceil(v * (1 - p)), floor(v * (1 + p))] (float32 products, cast to int16 the way Rust's ``as`` does)
+    and whose `out` byte is not `fill` yet.  The result does not depend on the order of the queue: it is the set of
+    voxels reachable from the seeds along such steps."""
+    if data.ndim != 3 or out.ndim != 3 or tuple(data.shape) != tuple(out.shape):
+        raise TypeError("data and out must be 3-D arrays of the same shape")
+    if data.dtype != np.int16 or out.dtype != np.uint8:
+        raise TypeError("data must be int16 and out uint8")
+    fill = _fits(fill, np.dtype(np.uint8), "fill")
+    s = _seeds(seeds)
+    L.check(L.lib().ivx_floodfill_auto_threshold(
+        L.ptr(data), L.i64(data.shape), L.i64(data.strides), L.ptr(s), ctypes.c_int64(len(s)), ctypes.c_float(float(p)),
+        ctypes.c_int(fill), L.ptr(out), L.i64(out.strides)), "floodfill_auto_threshold")
+
+
 def _proj_out_shape(image, axis):
     a = 2 if axis not in (0, 1, 2) else axis
     return tuple(d for i, d in enumerate(image.shape) if i != a)

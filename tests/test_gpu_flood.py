@@ -311,3 +311,73 @@ def test_concurrent_floods_on_separate_streams(ivxlib, oracle):
         v.close()
     assert not errs, errs
     assert all(r.sum() > 1000 for r in refs)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint8, np.float64])
+def test_floodfill_equal_value_matches_oracle(ivxlib, oracle, dtype):
+    """invesalius_rs.floodfill (floodfill.rs:5-49): 6-neighbour component of data == v, seed filled unconditionally."""
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(11)
+    shape = (21, 37, 131)
+    data = (rng.random(shape) < 0.62).astype(dtype) * (7 if dtype != np.float64 else 7.5)
+    v = 7 if dtype != np.float64 else 7.5
+    idx = np.argwhere(data == v)
+    for n, seed_on_value in enumerate((True, False)):
+        z, y, x = idx[rng.integers(len(idx))] if seed_on_value else np.argwhere(data != v)[rng.integers(100)]
+        og = (rng.random(shape) < 0.03).astype(np.uint8) * 9  # pre-filled voxels: barriers
+        orf = og.copy()
+        rs.floodfill(data, int(x), int(y), int(z), v, 9, og)
+        oracle.floodfill(data, int(x), int(y), int(z), v, 9, orf)
+        assert np.array_equal(og, orf)
+        assert og[z, y, x] == 9
+        if seed_on_value:
+            assert (og == 9).sum() > (orf == 9).sum() * 0 + 1000
+    with pytest.raises(IndexError):
+        rs.floodfill(data, shape[2], 0, 0, v, 1, np.zeros(shape, np.uint8))
+    with pytest.raises(OverflowError):
+        rs.floodfill(data, 0, 0, 0, v, 256, np.zeros(shape, np.uint8))
+    with pytest.raises(TypeError):
+        rs.floodfill(data, 0, 0, 0, v, 1, np.zeros(shape, np.int16))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.03, 0.2, 1.5, -0.1])
+@pytest.mark.parametrize("shape", [(24, 40, 70), (5, 33, 200), (40, 64, 128)])
+def test_floodfill_auto_threshold_matches_oracle(ivxlib, oracle, p, shape):
+    """invesalius_rs.floodfill_auto_threshold (floodfill_py.rs:12-85): directed reachability, float32 range arithmetic,
+    saturating casts; positive, negative and near-saturation values, pre-filled barriers, several seeds (one of them
+    on a pre-filled voxel)."""
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(int(abs(p) * 100) + shape[0])
+    zz, yy, xx = np.meshgrid(*(np.linspace(-1, 1, s, dtype=np.float32) for s in shape), indexing="ij")
+    f = 900.0 * np.exp(-(zz ** 2 + yy ** 2 + xx ** 2) * 2.0) + 120.0 * np.sin(5 * xx) * np.cos(4 * yy) - 60.0
+    f += rng.standard_normal(shape).astype(np.float32) * 6.0
+    data = f.astype(np.int16)
+    data[:, :4, :] = np.where(rng.random((shape[0], 4, shape[2])) < 0.5, 32000, 32767).astype(np.int16)  # saturation band
+    data[:, -3:, :] = -30000
+    z, y, x = np.unravel_index(int(np.argmax(f)), shape)
+    seeds = [(int(x), int(y), int(z)), (0, 0, 0), (shape[2] - 1, shape[1] - 1, shape[0] - 1), (3, 20, 2)]
+    og = (rng.random(shape) < 0.02).astype(np.uint8)   # fill = 1: these are barriers
+    og[rng.random(shape) < 0.02] = 5                    # other values are not
+    og[2, 20, 3] = 1                                     # a seed on a pre-filled voxel is still expanded
+    orf = og.copy()
+    rs.floodfill_auto_threshold(data, seeds, p, 1, og)
+    oracle.floodfill_auto_threshold(data, seeds, p, 1, orf)
+    assert np.array_equal(og, orf)
+    if p == 0.2:
+        assert (og == 1).sum() > 0.02 * og.size + 1000
+
+
+def test_floodfill_auto_threshold_on_strided_views_and_errors(ivxlib, oracle):
+    from invesalius3_amd import invesalius_rs as rs
+    rng = np.random.default_rng(2)
+    big = (rng.integers(97, 106, (30, 41, 90))).astype(np.int16)  # steps of up to 8 against a range of about +-4
+    data = big[1:, 1:, 1:]
+    out_big = np.zeros((30, 41, 90), np.uint8)
+    og, orf = out_big[1:, 1:, 1:], np.zeros(data.shape, np.uint8)
+    rs.floodfill_auto_threshold(data, [[5, 5, 5]], 0.04, 200, og)
+    oracle.floodfill_auto_threshold(np.ascontiguousarray(data), [(5, 5, 5)], 0.04, 200, orf)
+    assert np.array_equal(og, orf) and out_big[0].sum() == 0 and (og == 200).sum() > 100
+    with pytest.raises(TypeError):
+        rs.floodfill_auto_threshold(data.astype(np.uint8), [(0, 0, 0)], 0.1, 1, og)
+    with pytest.raises(IndexError):
+        rs.floodfill_auto_threshold(data, [(0, 0, 29)], 0.1, 1, og)

@@ -200,3 +200,40 @@ def test_view_transform_trilinear_matches_scipy_map_coordinates(oracle):
     oracle.apply_view_matrix_transform(vol, (1.0, 1.0, 1.0), M, 5, "AXIAL", 0, -1e9, outn)
     qi = q[:3].astype(int).reshape(3, *out.shape)
     assert np.array_equal(outn[inside], vol[qi[0][inside], qi[1][inside], qi[2][inside]])
+
+
+def test_floodfill_equal_value_and_auto_threshold_hand_cases(oracle):
+    """floodfill.rs:5-49 and floodfill_py.rs:12-85 have no test in the reference tree (parity unpinned: the restatement
+    is checked against cases worked out by hand from the Rust source)."""
+    # floodfill: component of data == v; the seed is filled whatever its value; out == fill is a barrier
+    d = np.array([[[5, 7, 7, 7, 9, 7]]], np.int16)
+    o = np.zeros(d.shape, np.uint8)
+    oracle.floodfill(d, 0, 0, 0, 7, 3, o)            # seed holds 5, not 7: still filled and expanded
+    assert o.tolist() == [[[3, 3, 3, 3, 0, 0]]]
+    o = np.zeros(d.shape, np.uint8)
+    o[0, 0, 2] = 3                                   # pre-filled voxel stops the walk
+    oracle.floodfill(d, 1, 0, 0, 7, 3, o)
+    assert o.tolist() == [[[0, 3, 3, 0, 0, 0]]]
+    # auto threshold, p = 0.05: a step leaves a voxel of value v into [ceil(0.95 v), floor(1.05 v)]
+    d = np.array([[[100, 104, 109, 120, 121]]], np.int16)
+    o = np.zeros(d.shape, np.uint8)
+    oracle.floodfill_auto_threshold(d, [(0, 0, 0)], 0.05, 1, o)
+    assert o.tolist() == [[[1, 1, 1, 0, 0]]]         # 100 -> 104 -> 109, but 109 -> 120 is out of [104, 114]
+    # the relation is directed: 200 -> 190 is allowed ([190, 210]), 190 -> 200 is not ([181, 199])
+    d = np.array([[[200, 190]]], np.int16)
+    o = np.zeros(d.shape, np.uint8)
+    oracle.floodfill_auto_threshold(d, [(0, 0, 0)], 0.05, 1, o)
+    assert o.tolist() == [[[1, 1]]]
+    o = np.zeros(d.shape, np.uint8)
+    oracle.floodfill_auto_threshold(d, [(1, 0, 0)], 0.05, 1, o)
+    assert o.tolist() == [[[0, 1]]]
+    # negative values flip the products: v = -100 -> [ceil(-95), floor(-105)] = [-95, -105] is empty
+    d = np.array([[[-100, -100]]], np.int16)
+    o = np.zeros(d.shape, np.uint8)
+    oracle.floodfill_auto_threshold(d, [(0, 0, 0)], 0.05, 1, o)
+    assert o.tolist() == [[[1, 0]]]
+    # `as i16` saturates: 30000 * 1.5 = 45000 -> 32767
+    d = np.array([[[30000, 32767, 14000]]], np.int16)
+    o = np.zeros(d.shape, np.uint8)
+    oracle.floodfill_auto_threshold(d, [(0, 0, 0)], 0.5, 1, o)
+    assert o.tolist() == [[[1, 1, 0]]]               # 32767 -> 14000 is below ceil(16383.5)
