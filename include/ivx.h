@@ -403,6 +403,14 @@ int ivx_floodfill(int dtype, const void *data, const int64_t shape[3], const int
 int ivx_floodfill_auto_threshold(const int16_t *data, const int64_t shape[3], const int64_t strides[3],
                                  const int64_t *seeds_xyz, int64_t nseeds, float pfrac, int fill, uint8_t *out,
                                  const int64_t out_strides[3]);
+/* jump_flooding (invesalius_rs/__init__.py:76-80 = floodfill_py.rs:262-275, floodfill.rs:298-507): Voronoi owners (int32,
+ * 1-based site index, 0 = none) and float32 distance to the owning site, floor(log2(max dim)) double-buffered passes of
+ * 26 taps; normalize != 0: sites move to their cells' integer centroids, distances are recomputed and divided by the
+ * cell maximum.  sites = nsites rows of (z, y, x) int32 in HOST memory.  Device form: dense arrays, in place. */
+int ivx_dev_jump_flooding(float *dist, int32_t *owners, const int64_t shape[3], const int32_t *sites_host, int64_t nsites,
+                          int normalize, void *stream);
+int ivx_jump_flooding(float *dist, const int64_t dist_strides[3], int32_t *owners, const int64_t owner_strides[3],
+                      const int64_t shape[3], const int32_t *sites, int64_t nsites, int normalize);
 int ivx_floodfill_threshold(int dtype, const void *data, const int64_t shape[3], const int64_t strides[3],
                             const int64_t *seeds_xyz, int64_t nseeds, double t0, double t1, int fill,
                             const uint8_t *strct, const int64_t sshape[3], uint8_t *out,

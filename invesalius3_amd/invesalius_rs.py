@@ -103,6 +103,26 @@ def floodfill_auto_threshold(data, seeds, p, fill, out):
         ctypes.c_int(fill), L.ptr(out), L.i64(out.strides)), "floodfill_auto_threshold")
 
 
+def jump_flooding(distance_map, map_owners, sites, normalize):
+    """jump_flooding (invesalius_rs/__init__.py:76-80 -> floodfill_py.rs:262-275 -> jump_flooding_internal
+    floodfill.rs:298-507): 3-D jump flooding.  `distance_map` (float32) and `map_owners` (int32; 1-based index into
+    `sites`, 0 = no owner) are updated in place; `sites` is an (n, 3) int32 array of (z, y, x) rows; with `normalize`
+    every site moves to the integer centroid of its cell and the distances are divided by the cell's maximum."""
+    if distance_map.ndim != 3 or map_owners.ndim != 3 or tuple(distance_map.shape) != tuple(map_owners.shape):
+        raise TypeError("distance_map and map_owners must be 3-D arrays of the same shape")
+    if distance_map.dtype != np.float32 or map_owners.dtype != np.int32:
+        raise TypeError("distance_map must be float32 and map_owners int32")
+    sites = np.asarray(sites)
+    if sites.dtype != np.int32 or sites.ndim != 2:
+        raise TypeError("sites must be a 2-D int32 array")
+    if sites.shape[0] and sites.shape[1] < 3:
+        raise IndexError("sites rows need (z, y, x)")  # the Rust code indexes columns 0..2
+    s = np.ascontiguousarray(sites[:, :3])
+    L.check(L.lib().ivx_jump_flooding(L.ptr(distance_map), L.i64(distance_map.strides), L.ptr(map_owners),
+                                      L.i64(map_owners.strides), L.i64(distance_map.shape), L.ptr(s),
+                                      ctypes.c_int64(len(s)), ctypes.c_int(1 if normalize else 0)), "jump_flooding")
+
+
 def _proj_out_shape(image, axis):
     a = 2 if axis not in (0, 1, 2) else axis
     return tuple(d for i, d in enumerate(image.shape) if i != a)

@@ -159,3 +159,106 @@ int orc_count_regions(const int64_t *labels, int64_t n, int64_t number_regions, 
     free(counts);
     return 0;
 }
+
+/* jump_flooding_internal                   invesalius_rs/src/floodfill.rs:298-507
+ * 3-D jump flooding (Voronoi owners + distance to the owning site) with floor(log2(max_dim)) passes whose 26 taps sit at
+ * offsets (size / 2) / 2^pass per axis; every pass reads the previous pass's arrays only (the Rust code double-buffers), so
+ * the result does not depend on any traversal order.  Taps are visited z-major (zi, yi, xi ascending) and a tap wins
+ * only with a strictly smaller distance -- or unconditionally while the voxel has no owner yet.  normalize: sites move to
+ * the (integer) centroid of their cells, distances are recomputed to the new sites and divided by the cell's maximum.
+ * Arrays are dense C-order [z][y][x]; sites are (z, y, x) int32 triples.  Test infrastructure only. */
+int orc_jump_flooding(float *dist, int32_t *owners, const int64_t shape[3], const int32_t *sites, int64_t nsites,
+                      int normalize) {
+    const int64_t sz = shape[0], sy = shape[1], sx = shape[2];
+    if (nsites == 0 || sz == 0 || sy == 0 || sx == 0) return 0;
+    const size_t n = (size_t)sz * sy * sx;
+    int32_t *oc = (int32_t *)malloc(n * 4), *on = (int32_t *)malloc(n * 4);
+    float *dc = (float *)malloc(n * 4), *dn = (float *)malloc(n * 4);
+    if (!oc || !on || !dc || !dn) { free(oc); free(on); free(dc); free(dn); return -3; }
+    memcpy(oc, owners, n * 4);
+    memcpy(dc, dist, n * 4);
+    for (int64_t i = 0; i < nsites; i++) {
+        const int32_t z = sites[3 * i], y = sites[3 * i + 1], x = sites[3 * i + 2];
+        if (z < 0 || y < 0 || x < 0 || z >= sz || y >= sy || x >= sx) continue;
+        oc[((size_t)z * sy + y) * sx + x] = (int32_t)i + 1;
+        dc[((size_t)z * sy + y) * sx + x] = 0.0f;
+    }
+    int64_t max_dim = sx > sy ? sx : sy;
+    if (sz > max_dim) max_dim = sz;
+    int n_steps = 0;
+    if (max_dim > 1)
+        while ((max_dim >> (n_steps + 1)) > 0) n_steps++;
+    int64_t ox = sx / 2, oy = sy / 2, oz = sz / 2;
+    memcpy(on, oc, n * 4);
+    memcpy(dn, dc, n * 4);
+    for (int s = 0; s < n_steps; s++) {
+        for (int64_t z = 0; z < sz; z++)
+            for (int64_t y = 0; y < sy; y++)
+                for (int64_t x = 0; x < sx; x++) {
+                    const size_t v = ((size_t)z * sy + y) * sx + x;
+                    int32_t idx0 = oc[v];
+                    float best = dc[v];
+                    for (int zi = -1; zi <= 1; zi++)
+                        for (int yi = -1; yi <= 1; yi++)
+                            for (int xi = -1; xi <= 1; xi++) {
+                                if (!xi && !yi && !zi) continue;
+                                const int64_t tz = z + zi * oz, ty = y + yi * oy, tx = x + xi * ox;
+                                if (tz < 0 || ty < 0 || tx < 0 || tz >= sz || ty >= sy || tx >= sx) continue;
+                                const int32_t idx1 = oc[((size_t)tz * sy + ty) * sx + tx];
+                                if (idx1 <= 0) continue;
+                                const int64_t si = (int64_t)idx1 - 1;
+                                if (si >= nsites) continue;
+                                const float z1 = (float)sites[3 * si], y1 = (float)sites[3 * si + 1], x1 = (float)sites[3 * si + 2];
+                                const float dz = (float)z - z1, dy = (float)y - y1, dx = (float)x - x1;
+                                const float d1 = sqrtf(dz * dz + dy * dy + dx * dx);
+                                if (idx0 > 0) {
+                                    if (d1 < best) { idx0 = idx1; best = d1; }
+                                } else { idx0 = idx1; best = d1; }
+                            }
+                    on[v] = idx0;
+                    dn[v] = best;
+                }
+        { int32_t *t = oc; oc = on; on = t; }
+        { float *t = dc; dc = dn; dn = t; }
+        ox /= 2; oy /= 2; oz /= 2;
+    }
+    if (normalize) {
+        uint32_t *cnt = (uint32_t *)calloc((size_t)nsites, 4);
+        int64_t *sum = (int64_t *)calloc((size_t)nsites * 3, 8);
+        int32_t *ns = (int32_t *)calloc((size_t)nsites * 3, 4);
+        float *mx = (float *)calloc((size_t)nsites, 4);
+        if (!cnt || !sum || !ns || !mx) { free(cnt); free(sum); free(ns); free(mx); free(oc); free(on); free(dc); free(dn); return -3; }
+        for (int64_t z = 0; z < sz; z++)
+            for (int64_t y = 0; y < sy; y++)
+                for (int64_t x = 0; x < sx; x++) {
+                    const int32_t o = oc[((size_t)z * sy + y) * sx + x];
+                    if (o <= 0 || (int64_t)o - 1 >= nsites) continue;
+                    cnt[o - 1]++;
+                    sum[3 * (o - 1)] += z; sum[3 * (o - 1) + 1] += y; sum[3 * (o - 1) + 2] += x;
+                }
+        for (int64_t i = 0; i < nsites; i++)
+            if (cnt[i]) for (int q = 0; q < 3; q++) ns[3 * i + q] = (int32_t)(sum[3 * i + q] / (int64_t)cnt[i]);
+        for (int64_t z = 0; z < sz; z++)
+            for (int64_t y = 0; y < sy; y++)
+                for (int64_t x = 0; x < sx; x++) {
+                    const size_t v = ((size_t)z * sy + y) * sx + x;
+                    const int32_t o = oc[v];
+                    if (o <= 0 || (int64_t)o - 1 >= nsites) continue;
+                    const float dz = (float)z - (float)ns[3 * (o - 1)], dy = (float)y - (float)ns[3 * (o - 1) + 1],
+                                dx = (float)x - (float)ns[3 * (o - 1) + 2];
+                    const float d = sqrtf(dz * dz + dy * dy + dx * dx);
+                    dc[v] = d;
+                    if (d > mx[o - 1]) mx[o - 1] = d;
+                }
+        for (size_t v = 0; v < n; v++) {
+            const int32_t o = oc[v];
+            if (o <= 0 || (int64_t)o - 1 >= nsites) continue;
+            if (mx[o - 1] > 0.0f) dc[v] /= mx[o - 1];
+        }
+        free(cnt); free(sum); free(ns); free(mx);
+    }
+    memcpy(owners, oc, n * 4);
+    memcpy(dist, dc, n * 4);
+    free(oc); free(on); free(dc); free(dn);
+    return 0;
+}

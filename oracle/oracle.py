@@ -601,3 +601,14 @@ def mask_fill_holes_auto(matrix, target, conn, orientation, index, size):
     ret = fill_holes_automatically(work, labels, nlabels, size)
     view[...] = work
     return ret
+
+
+def jump_flooding(distance_map, map_owners, sites, normalize):
+    """jump_flooding_internal floodfill.rs:298-507 (wrapper invesalius_rs/__init__.py:76-80): float32 distances and int32
+    owners (1-based site index, 0 = none) updated in place; sites = (n, 3) int32 rows of (z, y, x)."""
+    assert distance_map.dtype == np.float32 and map_owners.dtype == np.int32
+    assert distance_map.flags.c_contiguous and map_owners.flags.c_contiguous and distance_map.shape == map_owners.shape
+    s = np.ascontiguousarray(sites, dtype=np.int32).reshape(-1, 3)
+    rc = lib().orc_jump_flooding(_p(distance_map), _p(map_owners), _i64(distance_map.shape), _p(s),
+                                 ctypes.c_int64(len(s)), ctypes.c_int(1 if normalize else 0))
+    _check(rc)

@@ -237,3 +237,20 @@ def test_floodfill_equal_value_and_auto_threshold_hand_cases(oracle):
     o = np.zeros(d.shape, np.uint8)
     oracle.floodfill_auto_threshold(d, [(0, 0, 0)], 0.5, 1, o)
     assert o.tolist() == [[[1, 1, 0]]]               # 32767 -> 14000 is below ceil(16383.5)
+
+
+def test_jump_flooding_is_the_voronoi_diagram_on_a_small_grid(oracle):
+    """floodfill.rs:298-507 has no test in the reference tree (parity unpinned); on an 8^3 grid with two sites the passes
+    reach every voxel, so the restatement must reproduce the brute-force Voronoi diagram and distances."""
+    shape = (8, 8, 8)
+    d = np.full(shape, -1, np.float32)
+    o = np.zeros(shape, np.int32)
+    sites = np.array([[1, 1, 1], [6, 6, 6]], np.int32)
+    oracle.jump_flooding(d, o, sites, False)
+    zz, yy, xx = np.meshgrid(*[np.arange(8)] * 3, indexing="ij")
+    d1 = np.sqrt(((zz - 1) ** 2 + (yy - 1) ** 2 + (xx - 1) ** 2).astype(np.float32))
+    d2 = np.sqrt(((zz - 6) ** 2 + (yy - 6) ** 2 + (xx - 6) ** 2).astype(np.float32))
+    assert np.array_equal(o, np.where(d1 <= d2, 1, 2))
+    assert np.array_equal(d, np.minimum(d1, d2).astype(np.float32))
+    oracle.jump_flooding(d, o, sites, True)          # normalised: 1.0 at the farthest voxel of each cell
+    assert abs(float(d[o == 1].max()) - 1.0) < 1e-6 and abs(float(d[o == 2].max()) - 1.0) < 1e-6
