@@ -3,6 +3,8 @@
 // Reference semantics (bit-exact):
 //   generic_floodfill_threshold          invesalius_rs/src/floodfill.rs:96-166
 //   generic_floodfill_threshold_inplace  invesalius_rs/src/floodfill.rs:168-237
+//   floodfill_internal                   invesalius_rs/src/floodfill.rs:5-49       (data == v, forced seed: ivx_floodfill)
+//   floodfill_auto_threshold             invesalius_rs/src/floodfill_py.rs:12-85   (directed: edge planes, tile_update_dir)
 // The reference walks a LIFO stack; the set it fills does not depend on the visiting order:
 //   filled = connected component (under `strct`) of the in-range seeds inside
 //            C = { v : t0 <= data[v] <= t1  and  barrier[v] != fill }   (+ the in-range seeds themselves),
@@ -42,7 +44,7 @@ namespace {
 constexpr int TY_LOG = 4, TY = 1 << TY_LOG, TZ = 16; // tile rows / slices (tile is one 64-voxel word wide)
 constexpr int NT = TY * TZ;           // lanes per tile workgroup (one per word)
 constexpr int HY = TY + 2, HZ = TZ + 2;
-constexpr int BATCH = 8;              // rounds launched between host checks
+constexpr int BATCH = 8;              // most rounds the host may keep queued ahead (the counter ring has 2 * BATCH entries)
 constexpr int SUB = 1;                // gather/update steps per termination vote (measured: 4 doubles the tile time)
 
 struct Tiles {
@@ -86,7 +88,7 @@ static int make_tiles(const ivx_flood_plan *p, Tiles *t) {
     return IVX_OK;
 }
 
-// scratch: dirty[2][ntiles] u8 | counters[BATCH] u32 | seed staging
+// scratch: dirty[2][ntiles] u8 | counter ring | persistent-frontier queue | seed staging | round lists | coarse-pass row words
 constexpr size_t SEED_CHUNK = 4096;
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FScratch {
