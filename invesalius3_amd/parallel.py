@@ -124,6 +124,8 @@ class TorchComm:
         return from_down, from_up
 
     def allreduce_sum(self, value: int) -> int:
+        if self.world == 1:
+            return int(value)
         if self.device == "cpu":
             t = self.torch.tensor([int(value)], dtype=self.torch.int64)
         else:  # one resident word, filled by a kernel: no pageable host-to-device copy per vote
@@ -195,8 +197,10 @@ def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
     flood_run(), export_plane(z) -> tensor, or_plane(z, tensor) -> int (words/voxels that gained bits).
     Returns the number of exchange rounds."""
     rounds = 0
+    gained = True  # the first pass floods from the seeds; later ones only where a neighbour's plane brought new bits
     while True:
-        backend.flood_run()
+        if gained:
+            backend.flood_run()
         down = backend.export_plane(lay.first_interior) if lay.hb else None
         up = backend.export_plane(lay.last_interior) if lay.ht else None
         from_down, from_up = comm.exchange(down, up)
@@ -209,6 +213,7 @@ def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
             if from_up is not None:
                 changed += backend.or_plane(lay.local_dz - 1, from_up)
         rounds += 1
+        gained = changed > 0
         if comm.allreduce_sum(changed) == 0:
             return rounds
 
