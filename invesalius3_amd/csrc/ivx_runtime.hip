@@ -7,6 +7,7 @@
 #include <unistd.h>
 
 #include <map>
+#include <vector>
 #include <mutex>
 
 #include "ivx_internal.h"
@@ -214,39 +215,43 @@ int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords) {
 }
 
 // ---- progress lines ----------------------------------------------------------------------------------------
-static unsigned long long *g_pl = nullptr; // 64 lines x 8 qwords (one 64-B line each)
-static hipStream_t g_pl_owner[64];
-static uint8_t g_pl_used[64], g_pl_tag[64];
+// one 64-B line per stream, carved from pinned chunks of 64 lines; a line is handed back when its stream is destroyed
+struct ProgressLine {
+    unsigned long long *p;
+    uint8_t tag;
+};
+static std::map<hipStream_t, ProgressLine> g_pl;
+static std::vector<unsigned long long *> g_pl_free;
 
 int progress_line(hipStream_t st, volatile unsigned long long **line, uint32_t *tag) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_pl) {
-        void *p = nullptr;
-        IVX_HIP(hipHostMalloc(&p, 64 * 64, hipHostMallocMapped | hipHostMallocCoherent));
-        memset(p, 0, 64 * 64);
-        g_pl = (unsigned long long *)p;
+    auto it = g_pl.find(st);
+    if (it == g_pl.end()) {
+        if (g_pl_free.empty()) {
+            void *p = nullptr;
+            IVX_HIP(hipHostMalloc(&p, 64 * 64, hipHostMallocMapped | hipHostMallocCoherent));
+            memset(p, 0, 64 * 64);
+            for (int i = 63; i >= 0; i--) g_pl_free.push_back((unsigned long long *)p + (size_t)i * 8);
+        }
+        ProgressLine l = {g_pl_free.back(), 0};
+        g_pl_free.pop_back();
+        it = g_pl.insert(std::make_pair(st, l)).first;
     }
-    int idx = -1, free_idx = -1;
-    for (int i = 0; i < 64; i++) {
-        if (g_pl_used[i] && g_pl_owner[i] == st) { idx = i; break; }
-        if (!g_pl_used[i] && free_idx < 0) free_idx = i;
-    }
-    if (idx < 0) {
-        IVX_REQUIRE(free_idx >= 0, IVX_EHIP, "progress: more than 64 streams are being watched at once");
-        idx = free_idx;
-        g_pl_used[idx] = 1;
-        g_pl_owner[idx] = st;
-    }
-    if (++g_pl_tag[idx] == 0) g_pl_tag[idx] = 1;
-    *tag = g_pl_tag[idx];
-    *line = g_pl + (size_t)idx * 8;
+    if (++it->second.tag == 0) it->second.tag = 1;
+    *tag = it->second.tag;
+    *line = it->second.p;
     return IVX_OK;
 }
 
 void progress_forget_stream(void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int i = 0; i < 64; i++)
-        if (g_pl_used[i] && g_pl_owner[i] == (hipStream_t)stream) g_pl_used[i] = 0; // the tag counter lives on
+    auto it = g_pl.find((hipStream_t)stream);
+    if (it == g_pl.end()) return;
+    // the stream has been synchronised by the caller: nothing can still write to the line.  The next owner starts from
+    // a clean line, so the tag may start over.
+    memset(it->second.p, 0, 64);
+    g_pl_free.push_back(it->second.p);
+    g_pl.erase(it);
 }
 
 } // namespace ivx

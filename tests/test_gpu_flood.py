@@ -441,3 +441,21 @@ def test_jump_flooding_many_sites_normalised(ivxlib, oracle):
     oracle.jump_flooding(dr, orf, sites, True)
     assert np.array_equal(og, orf)
     assert np.array_equal(dg.view(np.uint32), dr.view(np.uint32))
+
+
+def test_more_than_64_resident_volumes_can_flood(ivxlib, oracle):
+    """every resident volume owns a stream and every stream a progress line: the pool of lines grows on demand"""
+    from invesalius3_amd.device import DeviceVolume
+    strct = generate_binary_structure(3, 1)
+    img = synth_volume((8, 16, 64), seed=5)
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    ref = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold(img, [(int(x), int(y), int(z))], -900, 3071, 1, strct, ref)
+    vols = [DeviceVolume(img) for _ in range(70)]
+    try:
+        for v in vols:
+            v.region_grow([(int(x), int(y), int(z))], -900, 3071, strct, fill=1, select_value=None)
+        assert all(np.array_equal(v.download_out_mask(), ref) for v in vols[::7])
+    finally:
+        for v in vols:
+            v.close()
