@@ -36,7 +36,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 def synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
     """V512 of SURVEY.md 8(d): 6 Gaussian 'bone' blobs (peak 1800) + low-frequency sinusoid + N(0,25) noise,
-    offset -1000, clipped to [-1024, 3071].  Built separably, slab by slab, in float32."""
+    offset -1000, clipped to [-1024, 3071].  Built separably, slab by slab, in float32.
+
+    Weak scaling (z_total > shape[0]): the taller volume is V512 repeated along Z -- every rank's slab holds the same six
+    blobs at the same places of ITS slab, plus what the blobs of the slabs directly below and above contribute across
+    the shared faces (so regions do join their neighbours' and the halo exchange has real work), and its own noise.
+    Per-GPU work is therefore the single-GPU work, which is what "weak" means; at one GPU this is V512 itself."""
     dz, dy, dx = shape
     z_total = z_total or dz
     rng = np.random.default_rng(seed)
@@ -44,9 +49,12 @@ def synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
     cy = rng.uniform(0.15, 0.85, 6)
     cx = rng.uniform(0.15, 0.85, 6)
     sg = rng.uniform(0.12, 0.28, 6)
-    zz = ((np.arange(dz) + z_offset) / max(z_total - 1, 1)).astype(np.float32)
+    zz = (np.arange(dz) / max(dz - 1, 1)).astype(np.float32)  # this slab's own normalised z
     yy = (np.arange(dy) / max(dy - 1, 1)).astype(np.float32)
     xx = (np.arange(dx) / max(dx - 1, 1)).astype(np.float32)
+    rank, world = z_offset // dz, max(z_total // dz, 1)
+    pitch = dz / max(dz - 1, 1)  # one slab further, in normalised z
+    shifts = [0.0] + ([-pitch] if rank > 0 else []) + ([pitch] if rank + 1 < world else [])
     out = np.empty(shape, np.int16)
     nrng = np.random.default_rng(seed + 1 + z_offset)
     step = 32
@@ -54,7 +62,7 @@ def synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
         z1 = min(dz, z0 + step)
         f = np.zeros((z1 - z0, dy, dx), np.float32)
         for b in range(6):
-            gz = np.exp(-((zz[z0:z1] - cz[b]) ** 2) / (2 * sg[b] ** 2))
+            gz = sum(np.exp(-((zz[z0:z1] - cz[b] - sh) ** 2) / (2 * sg[b] ** 2)) for sh in shifts)
             gy = np.exp(-((yy - cy[b]) ** 2) / (2 * sg[b] ** 2))
             gx = np.exp(-((xx - cx[b]) ** 2) / (2 * sg[b] ** 2))
             f += 1800.0 * gz[:, None, None] * gy[None, :, None] * gx[None, None, :]
