@@ -1,18 +1,18 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof_v9
+mkdir -p $R/gpurun_out/prof_v10
 cd $R
-timeout -k 5 400 python -m pytest tests -m gpu -q < /dev/null 2>&1 | tail -4 > gpurun_out/prof_v9/gpu_tests.txt
-timeout -k 5 200 python bench.py < /dev/null > gpurun_out/prof_v9/bench.json 2> gpurun_out/prof_v9/bench.err
-timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v9 -o kt -- python bench.py --steps 5 --warmup 1 --cpu-slices 0 < /dev/null > gpurun_out/prof_v9/kt.log 2>&1
-timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_v9 -o fetch -- python bench.py --steps 3 --warmup 1 --cpu-slices 0 < /dev/null > /dev/null 2>&1
-timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_v9 -o write -- python bench.py --steps 3 --warmup 1 --cpu-slices 0 < /dev/null > /dev/null 2>&1
-find gpurun_out/prof_v9 -name "*.csv" | head -20
-D=$(dirname $(find gpurun_out/prof_v9 -name "kt_kernel_stats.csv" | head -1))
+timeout -k 5 400 python -m pytest tests -m gpu -q < /dev/null 2>&1 | tail -4 > gpurun_out/prof_v10/gpu_tests.txt
+timeout -k 5 200 python bench.py < /dev/null > gpurun_out/prof_v10/bench.json 2> gpurun_out/prof_v10/bench.err
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v10 -o kt -- python bench.py --steps 5 --warmup 1 --cpu-slices 0 < /dev/null > gpurun_out/prof_v10/kt.log 2>&1
+timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_v10 -o fetch -- python bench.py --steps 3 --warmup 1 --cpu-slices 0 < /dev/null > /dev/null 2>&1
+timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_v10 -o write -- python bench.py --steps 3 --warmup 1 --cpu-slices 0 < /dev/null > /dev/null 2>&1
+find gpurun_out/prof_v10 -name "*.csv" | head -20
+D=$(dirname $(find gpurun_out/prof_v10 -name "kt_kernel_stats.csv" | head -1))
 echo "D=$D"
-for f in fetch_counter_collection.csv write_counter_collection.csv; do s=$(find gpurun_out/prof_v9 -name $f | head -1); [ -n "$s" ] && [ "$(dirname $s)" != "$D" ] && cp $s $D/; done
-python tools/summarize_pmc.py $D gpurun_out/prof_v9/kernels_pmc.md gpurun_out/prof_v9/pmc_traffic.json auto < /dev/null | head -30
-timeout -k 5 100 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v9 -o mesh -- python tools/bench_mesh.py 512 < /dev/null > gpurun_out/prof_v9/mesh.log 2>&1
-tail -1 gpurun_out/prof_v9/mesh.log | cut -c1-900
-cat gpurun_out/prof_v9/gpu_tests.txt
-cat gpurun_out/prof_v9/bench.json
+for f in fetch_counter_collection.csv write_counter_collection.csv; do s=$(find gpurun_out/prof_v10 -name $f | head -1); [ -n "$s" ] && [ "$(dirname $s)" != "$D" ] && cp $s $D/; done
+python tools/summarize_pmc.py $D gpurun_out/prof_v10/kernels_pmc.md gpurun_out/prof_v10/pmc_traffic.json auto < /dev/null | head -30
+timeout -k 5 100 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v10 -o mesh -- python tools/bench_mesh.py 512 < /dev/null > gpurun_out/prof_v10/mesh.log 2>&1
+tail -1 gpurun_out/prof_v10/mesh.log | cut -c1-900
+cat gpurun_out/prof_v10/gpu_tests.txt
+cat gpurun_out/prof_v10/bench.json
