@@ -123,6 +123,37 @@ class TorchComm:
                 torch.cuda.current_stream().synchronize()
         return from_down, from_up
 
+    def exchange_and_vote(self, to_down, to_up, changed: int):
+        """The neighbour exchange and the vote in one collective: every rank contributes [changed | plane to the rank
+        below | plane to the rank above] to an all-gather; returns (from_down, from_up, sum of everybody's `changed`).
+        The planes are a few tens of KB, so gathering all of them costs nothing next to a second collective's latency."""
+        torch, dist = self.torch, self.dist
+        to_down, to_up = self._as_tensor(to_down), self._as_tensor(to_up)
+        if self.world == 1:
+            return None, None, int(changed)
+        ref = to_down if to_down is not None else to_up
+        if ref.dtype != torch.uint8:
+            raise TypeError("exchange_and_vote: planes must be uint8 tensors")
+        nb = int(ref.numel())
+        rec = 16 + 2 * nb  # 16-byte header keeps the planes 16-byte aligned
+        st = self.__dict__.setdefault("_gather", {})
+        if st.get("nb") != nb:
+            st["nb"] = nb
+            st["send"] = torch.zeros(rec, dtype=torch.uint8, device=ref.device)
+            st["recv"] = torch.empty(rec * self.world, dtype=torch.uint8, device=ref.device)
+        send, recv = st["send"], st["recv"]
+        send[:8].view(torch.int64).fill_(int(changed))  # a fill kernel, not a pageable host-to-device copy
+        if to_down is not None:
+            send[16:16 + nb] = to_down.reshape(-1)
+        if to_up is not None:
+            send[16 + nb:16 + 2 * nb] = to_up.reshape(-1)
+        dist.all_gather_into_tensor(recv, send)
+        recs = recv.view(self.world, rec)
+        total = int(recs[:, :8].contiguous().view(torch.int64).sum().item())  # also waits for the gather to land
+        from_down = recs[self.rank - 1, 16 + nb:16 + 2 * nb].reshape(ref.shape) if self.rank > 0 else None  # its "up" plane
+        from_up = recs[self.rank + 1, 16:16 + nb].reshape(ref.shape) if self.rank < self.world - 1 else None  # its "down" plane
+        return from_down, from_up, total
+
     def allreduce_sum(self, value: int) -> int:
         if self.world == 1:
             return int(value)
@@ -194,16 +225,31 @@ class TorchComm:
 
 def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
     """Iterate local fix-point + halo exchange to the global fix-point.  `backend` provides
-    flood_run(), export_plane(z) -> tensor, or_plane(z, tensor) -> int (words/voxels that gained bits).
-    Returns the number of exchange rounds."""
+    flood_run(), export_plane(z) -> tensor, or_plane(z, tensor) -> int (words/voxels that gained bits) and optionally
+    or_planes(from_down, from_up) -> int.  Returns the number of exchange rounds.
+
+    With a communicator that offers `exchange_and_vote` the "did anybody gain anything" vote of round k travels with the
+    planes of round k+1 -- ONE collective per round instead of a neighbour exchange plus an all-reduce: the loop ends
+    when a round reports that nobody gained anything in the round before (nobody flooded since, so the planes just
+    exchanged are the ones everybody already had)."""
     rounds = 0
     gained = True  # the first pass floods from the seeds; later ones only where a neighbour's plane brought new bits
+    merged = hasattr(comm, "exchange_and_vote")
+    prev_changed = 1  # "something happened before round 1": the seeds
+    down = up = None
     while True:
         if gained:
             backend.flood_run()
-        down = backend.export_plane(lay.first_interior) if lay.hb else None
-        up = backend.export_plane(lay.last_interior) if lay.ht else None
-        from_down, from_up = comm.exchange(down, up)
+        if gained or rounds == 0:  # otherwise the planes exported last round are still current
+            down = backend.export_plane(lay.first_interior) if lay.hb else None
+            up = backend.export_plane(lay.last_interior) if lay.ht else None
+        if merged:
+            from_down, from_up, total_prev = comm.exchange_and_vote(down, up, prev_changed)
+            rounds += 1
+            if total_prev == 0:
+                return rounds
+        else:
+            from_down, from_up = comm.exchange(down, up)
         if hasattr(backend, "or_planes"):  # both planes, one read-back
             changed = backend.or_planes(from_down, from_up)
         else:
@@ -212,8 +258,11 @@ def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
                 changed += backend.or_plane(0, from_down)
             if from_up is not None:
                 changed += backend.or_plane(lay.local_dz - 1, from_up)
-        rounds += 1
         gained = changed > 0
+        if merged:
+            prev_changed = changed
+            continue
+        rounds += 1
         if comm.allreduce_sum(changed) == 0:
             return rounds
 
