@@ -241,8 +241,11 @@ def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
         if gained:
             backend.flood_run()
         if gained or rounds == 0:  # otherwise the planes exported last round are still current
-            down = backend.export_plane(lay.first_interior) if lay.hb else None
-            up = backend.export_plane(lay.last_interior) if lay.ht else None
+            if hasattr(backend, "export_planes"):  # both planes, one stream wait
+                down, up = backend.export_planes()
+            else:
+                down = backend.export_plane(lay.first_interior) if lay.hb else None
+                up = backend.export_plane(lay.last_interior) if lay.ht else None
         if merged:
             from_down, from_up, total_prev = comm.exchange_and_vote(down, up, prev_changed)
             rounds += 1
@@ -334,6 +337,28 @@ def _make_slab_volume():
             L.check(L.lib().ivx_memcpy_d2d(b.ptr, self.reached.at(z * nb), ctypes.c_size_t(nb), self.stream))
             self.sync()
             return DevPlane(b.ptr.value, nb, keep=b)
+
+        def export_planes(self):
+            """(plane for the rank below, plane for the rank above), None at the ends; ONE stream wait for both"""
+            nb = self.plane_words * 8
+            direct = hasattr(self.comm, "plane_buffer") and self.comm.device != "cpu"
+            out = []
+            for slot, (have, z) in enumerate(((self.lay.hb, self.lay.first_interior), (self.lay.ht, self.lay.last_interior))):
+                if not have:
+                    out.append(None)
+                    continue
+                if direct:
+                    t = self.comm.plane_buffer(nb, slot)
+                    dst = ctypes.c_void_p(t.data_ptr())
+                    out.append(t)
+                else:
+                    b = self._send[slot]
+                    dst = b.ptr
+                    out.append(DevPlane(b.ptr.value, nb, keep=b))
+                L.check(L.lib().ivx_memcpy_d2d(dst, self.reached.at(z * nb), ctypes.c_size_t(nb), self.stream))
+            if out[0] is not None or out[1] is not None:
+                self.sync()  # complete before the communicator (RCCL runs on torch's stream) reads them
+            return out[0], out[1]
 
         def or_planes(self, from_down, from_up) -> int:
             chg = ctypes.c_int(0)
