@@ -72,12 +72,15 @@ int ivx_memcpy_h2d(void *dst, const void *src, size_t nbytes);
 int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes);
 int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
 int ivx_stream_create(void **stream);
+int ivx_stream_create_low_priority(void **stream); /* yields to default-priority streams when both have work */
 int ivx_stream_destroy(void *stream);
 int ivx_stream_synchronize(void *stream);
 /* HIP events on the stream the kernels are launched on (bench.py roofline timing) */
 int ivx_event_create(void **event);
+int ivx_event_create_sync(void **event); /* for ordering streams (record + ivx_stream_wait_event), not for timing */
 int ivx_event_destroy(void *event);
 int ivx_event_record(void *event, void *stream);
+int ivx_stream_wait_event(void *stream, void *event); /* work queued on `stream` after this call waits for `event` */
 int ivx_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 /* free the cached device workspaces the host-level entry points keep between calls */
 int ivx_release_workspace(void);
@@ -188,6 +191,9 @@ int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, v
 /* emit; must follow ivx_dev_mc_count with the same params/scratch */
 int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *tris, int64_t max_tris,
                     void *stream);
+/* the list pass of ivx_dev_mc_emit on its own (it needs the counts, not the voxels): queue it early, on the stream the
+ * emit will use; the emit that follows with max_tris <= this max_tris skips its own list pass */
+int ivx_dev_mc_list(const ivx_mc_params *p, const void *scratch, int64_t max_tris, void *stream);
 /* Host form: strided piece in, soup out.  tris == NULL -> count only.  Returns count in *ntris. */
 int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *tris,
                        int64_t max_tris, int64_t *ntris);
@@ -360,6 +366,13 @@ int ivx_dev_flood_seed(const ivx_flood_plan *p, int dtype, const void *data, dou
 /* grow `reached` inside `cand` to the fix-point; *rounds (host, may be NULL) = global rounds used */
 int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch,
                       int *rounds, void *stream);
+/* Gate for background work (e.g. the next stage's mask-independent passes on a second, low-priority stream): the next
+ * ivx_dev_flood_run on `scratch` stores `value` to the device word `word` from the first round that starts with fewer
+ * than `below_tiles` tiles -- its throughput-bound head is over -- or when it returns, if no round did.
+ * ivx_dev_gate_wait parks `stream` behind a one-wave kernel polling the word; it gives up after `timeout_us`. */
+int ivx_dev_flood_arm_gate(const void *scratch, uint32_t *word, uint32_t value, uint32_t below_tiles);
+int ivx_dev_gate_wait(const uint32_t *word, uint32_t value, uint32_t timeout_us, void *stream);
+int ivx_dev_gate_open(uint32_t *word, uint32_t value, void *stream); /* open it by hand (no flood came) */
 /* mark every tile of the plan whose z-range touches [z0,z1) dirty (multi-GPU halo re-seeding) */
 int ivx_dev_flood_mark_slab(const ivx_flood_plan *p, void *scratch, int64_t z0, int64_t z1, void *stream);
 /* multi-GPU slab halo: reached[z] |= plane & cand[z] (plane = the Z-neighbour's boundary plane, dy*wx words);

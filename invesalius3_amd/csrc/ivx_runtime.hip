@@ -336,6 +336,16 @@ int ivx_stream_create(void **stream) {
     *stream = (void *)s;
     return IVX_OK;
 }
+// a stream whose work yields to the default-priority streams' when both have workgroups waiting (background work that
+// should fill idle CUs without slowing the main stream down)
+int ivx_stream_create_low_priority(void **stream) {
+    int least = 0, greatest = 0;
+    IVX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s;
+    IVX_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+    *stream = (void *)s;
+    return IVX_OK;
+}
 int ivx_stream_destroy(void *stream) {
     if (!stream) return IVX_OK;
     IVX_HIP(hipStreamSynchronize(S(stream)));
@@ -367,12 +377,23 @@ int ivx_event_create(void **event) {
     *event = (void *)e;
     return IVX_OK;
 }
+// an event for ORDERING streams (ivx_event_record + ivx_stream_wait_event), not for timing: full fence, no timestamps
+int ivx_event_create_sync(void **event) {
+    hipEvent_t e;
+    IVX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void *)e;
+    return IVX_OK;
+}
 int ivx_event_destroy(void *event) {
     if (event) IVX_HIP(hipEventDestroy((hipEvent_t)event));
     return IVX_OK;
 }
 int ivx_event_record(void *event, void *stream) {
     IVX_HIP(hipEventRecord((hipEvent_t)event, S(stream)));
+    return IVX_OK;
+}
+int ivx_stream_wait_event(void *stream, void *event) {
+    IVX_HIP(hipStreamWaitEvent(S(stream), (hipEvent_t)event, 0));
     return IVX_OK;
 }
 int ivx_event_elapsed_ms(void *start, void *stop, float *ms) {

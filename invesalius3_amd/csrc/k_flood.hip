@@ -33,6 +33,8 @@
 //   k_flood_persistent  the same tile update in ONE launch with a device-side ticket queue (opt-in, measured slower).
 //   k_flood_apply(2)    reached bits -> out[v] = fill (only words with reached bits touch memory).
 #include <math.h>
+#include <map>
+#include <mutex>
 #include <stdlib.h>
 
 #include "ivx_internal.h"
@@ -526,10 +528,14 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
                                                              const unsigned int *__restrict__ n_cur, uint8_t *dirty_cur,
                                                              uint8_t *dirty_next, unsigned int *list_next,
                                                              unsigned int *n_next, unsigned int *n_clear,
-                                                             unsigned long long *line, unsigned int tag_round) {
+                                                             unsigned long long *line, unsigned int tag_round,
+                                                             unsigned int *gate, unsigned int gate_val,
+                                                             unsigned int gate_below) {
     __shared__ TileLds L;
     const unsigned int n = *n_cur;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // a short list: the busy rounds are over, let background work gated on this word start (ivx_dev_flood_arm_gate)
+        if (gate && n < gate_below) __hip_atomic_store(gate, gate_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *n_clear = 0u; // the counter the round AFTER the next one appends to
         const unsigned long long hi = (unsigned long long)tag_round << 32;
         __hip_atomic_store(&line[0], hi | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1172,6 +1178,30 @@ extern "C" int ivx_dev_flood_clear(const ivx_flood_plan *p, uint64_t *reached, v
     return IVX_OK;
 }
 
+// ---- gate: background work that should start once the flood's busy rounds are over --------------------------------------
+// ivx_dev_flood_arm_gate(scratch, word, value, below): in the next flood on `scratch` the first round that starts with
+// fewer than `below` tiles stores `value` to the device word `word` (and so does the end of the flood, if no round did).  ivx_dev_gate_wait(word, value, timeout, stream) parks `stream` behind a one-wave
+// kernel that polls the word (bounded: it gives up after `timeout_us`).  Together: work queued on a second, low-priority
+// stream runs under the latency-bound tail of the flood instead of competing with its throughput-bound head.
+struct GateArm {
+    unsigned int *word;
+    unsigned int value, below;
+};
+static std::map<const void *, GateArm> g_gates;
+static std::mutex g_gates_mu;
+
+__global__ void k_gate_wait(const unsigned int *word, unsigned int value, unsigned long long timeout_ticks) {
+    if (threadIdx.x) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) {
+        if (wall_clock64() - t0 > timeout_ticks) break; // never hang: start late rather than never
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+__global__ void k_gate_set(unsigned int *word, unsigned int value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // directed: `cand` = the six edge planes of ivx_dev_flood_edges_auto (rounds engine only: the coarse pass, the
 // union-find escape and the persistent frontier all rely on symmetric adjacency)
 static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool directed, uint64_t *reached, void *scratch_,
@@ -1180,10 +1210,27 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
     int rc = make_tiles(p, &t);
     if (rc) return rc;
     if (rounds) *rounds = 0;
+    hipStream_t st = ivx::S(stream);
+    GateArm arm = {nullptr, 0u, 0u};
+    {
+        std::lock_guard<std::mutex> lk(g_gates_mu);
+        auto it = g_gates.find(scratch_);
+        if (it != g_gates.end()) {
+            arm = it->second;
+            g_gates.erase(it);
+        }
+    }
+    // whatever path the flood takes, the gate opens at the latest when it returns
+    struct GateGuard {
+        GateArm &a;
+        hipStream_t st;
+        ~GateGuard() {
+            if (a.word) hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, st, a.word, a.value);
+        }
+    } gate_guard = {arm, st};
     if (t.ntiles == 0) return IVX_OK;
     const FScratch s = make_fscratch(t);
     char *scr = (char *)scratch_;
-    hipStream_t st = ivx::S(stream);
     uint8_t *dirty[2] = {(uint8_t *)(scr + s.off_dirty0), (uint8_t *)(scr + s.off_dirty1)};
     unsigned int *cnt = (unsigned int *)(scr + s.off_cnt);
     // IVX_FLOOD_MODE: "rounds" (default) = tile frontier, one launch per round, with an escape to the union-find path
@@ -1288,14 +1335,15 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
     auto queue_round = [&]() -> int {
         const int r = (int)(queued % RING), cur = (int)(queued & 1);
         const unsigned int tr = (unsigned int)(tag << 24) | (unsigned int)((queued + 1) & 0xffffff);
+        unsigned int *gw = arm.word; // every round carries the gate: the first one with a short list opens it
         if (directed)
             hipLaunchKernelGGL(k_flood_round_list<true>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
                                (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
-                               cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr);
+                               cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr, gw, arm.value, arm.below);
         else
             hipLaunchKernelGGL(k_flood_round_list<false>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
                                (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
-                               cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr);
+                               cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr, gw, arm.value, arm.below);
         IVX_LAUNCH_CHECK();
         queued++;
         return IVX_OK;
@@ -1325,6 +1373,7 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
         const unsigned int n_list = (unsigned int)(v & 0xffffffffull);
         if (trace) fprintf(stderr, "ivx flood: round %lld starts with %u of %lld tiles (%lld queued)\n", (long long)seen, n_list,
                            (long long)t.ntiles, (long long)queued);
+        if (n_list < arm.below) arm.word = nullptr; // that round has opened the gate: nothing left for the guard to do
         if (n_list == 0) { // converged: word 1 holds the last round that had work (if any, and if it is ours)
             const unsigned long long u = __atomic_load_n((const unsigned long long *)line + 1, __ATOMIC_ACQUIRE);
             total_rounds = (uint32_t)(u >> 56) == tag ? (int)((u >> 32) & 0xffffffull) : 0;
@@ -1404,6 +1453,25 @@ extern "C" int ivx_dev_flood_seed_forced(const ivx_flood_plan *p, const int64_t 
         IVX_LAUNCH_CHECK();
         IVX_HIP(hipStreamSynchronize(st)); // d_seeds is reused by the next chunk; seeds_xyz is pageable host memory
     }
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_flood_arm_gate(const void *scratch, uint32_t *word, uint32_t value, uint32_t below_tiles) {
+    IVX_REQUIRE(scratch && word, IVX_EINVAL, "flood_arm_gate: NULL argument");
+    std::lock_guard<std::mutex> lk(g_gates_mu);
+    g_gates[scratch] = GateArm{word, value, below_tiles};
+    return IVX_OK;
+}
+extern "C" int ivx_dev_gate_open(uint32_t *word, uint32_t value, void *stream) {
+    IVX_REQUIRE(word, IVX_EINVAL, "gate_open: NULL argument");
+    hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, ivx::S(stream), word, value);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+extern "C" int ivx_dev_gate_wait(const uint32_t *word, uint32_t value, uint32_t timeout_us, void *stream) {
+    IVX_REQUIRE(word, IVX_EINVAL, "gate_wait: NULL argument");
+    hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, ivx::S(stream), word, value, (unsigned long long)timeout_us * 100ull);
+    IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
 

@@ -519,6 +519,25 @@ static std::mutex g_split_mu;
 // scratch -> inside plane handed in by ivx_dev_mc_count_bits (read in place by the later list / indexed passes of the
 // same piece instead of being copied into the scratch); an ivx_dev_mc_count on the same scratch forgets it
 static std::map<const void *, const uint64_t *> g_ext_bits;
+// ivx_dev_mc_list: scratch -> (list buffer, capacity) of a triangle list built ahead of the emit, valid until the next
+// count on that scratch; list buffer (a per-stream workspace shared by every piece on that stream) -> the scratch whose
+// descriptors it currently holds
+struct ListBuilt {
+    const void *list;
+    int64_t max_tris;
+};
+static std::map<const void *, ListBuilt> g_list_built;
+static std::map<const void *, const void *> g_list_owner;
+// may the list pass be skipped: was this very buffer filled for `scratch`, with room for all the caller will read?
+static bool list_ready(const void *scratch, const void *d_list, int64_t max_tris) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_list_built.find(scratch);
+    auto ow = g_list_owner.find(d_list);
+    const bool ok = it != g_list_built.end() && it->second.list == d_list && max_tris <= it->second.max_tris &&
+                    ow != g_list_owner.end() && ow->second == scratch;
+    if (!ok) g_list_owner[d_list] = nullptr; // the caller is about to overwrite it
+    return ok;
+}
 
 static const uint64_t *mc_bits_ptr(const void *scratch, const Scratch &s, int q) {
     if (q == 0) {
@@ -551,6 +570,19 @@ static int run_bits(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     return IVX_OK;
 }
 
+static int run_list(const ivx_mc_params *p, const Geom &g, const Scratch &s, const char *scratch, void *d_list,
+                    int64_t max_tris, hipStream_t st) {
+    const uint64_t *boff = (const uint64_t *)(scratch + s.off_boff);
+    for (int q = 0; q < p->niso; q++) {
+        const uint64_t *bits = mc_bits_ptr(scratch, s, q);
+        const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
+        hipLaunchKernelGGL(k_mc_list, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q), counts,
+                           boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
+        IVX_LAUNCH_CHECK();
+    }
+    return IVX_OK;
+}
+
 template <typename T>
 static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, const char *scratch,
                     float *tris, int64_t max_tris, hipStream_t st) {
@@ -564,13 +596,8 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     // disjoint ranges of ONE list and one flat emit covers all of it; the kernel reads the total (boff[nb]) and the
     // iso-0 / iso-1 split (boff[nblocks]) on the device
     const size_t nb = s.nblocks * (size_t)p->niso;
-    for (int q = 0; q < p->niso; q++) {
-        const uint64_t *bits = mc_bits_ptr(scratch, s, q);
-        const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
-        hipLaunchKernelGGL(k_mc_list, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q), counts,
-                           boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
-        IVX_LAUNCH_CHECK();
-    }
+    if (!list_ready(scratch, d_list, max_tris)) // not built ahead by ivx_dev_mc_list
+        if ((rc = run_list(p, g, s, scratch, d_list, max_tris, st))) return rc;
     hipLaunchKernelGGL((k_mc_emit<T>), dim3((unsigned)ivx::cdiv(max_tris, (int64_t)256)), dim3(256), 0, st, (const T *)a, g,
                        p->iso[0], p->iso[1], boff + (p->niso == 2 ? s.nblocks : nb), boff + nb, (const uint64_t *)d_list,
                        (uint64_t)max_tris, tris);
@@ -779,6 +806,10 @@ extern "C" int ivx_dev_mc_scratch_bytes(const ivx_mc_params *p, size_t *nbytes) 
 // classify + count + scan over the inside planes already sitting in scratch (queued, nothing comes back to the host)
 static int mc_queue_count(const ivx_mc_params *p, const Geom &g, const Scratch &s, void *scratch_, hipStream_t st) {
     char *scratch = (char *)scratch_;
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        g_list_built.erase(scratch_); // new counts: a list built from the old ones is void
+    }
     uint32_t *bsum = (uint32_t *)(scratch + s.off_bsum);
     uint64_t *boff = (uint64_t *)(scratch + s.off_boff);
     for (int q = 0; q < p->niso; q++) {
@@ -903,6 +934,26 @@ extern "C" int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void
     }
 }
 
+// The list pass of ivx_dev_mc_emit on its own: it needs the counts only, not the voxels, so a pipeline can queue it (on
+// the stream the emit will use: the list lives in that stream's workspace) before the values the emit interpolates are
+// final.  The emit that follows with max_tris <= this max_tris skips its own list pass.
+extern "C" int ivx_dev_mc_list(const ivx_mc_params *p, const void *scratch, int64_t max_tris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    const Scratch s = make_scratch(g, p->niso);
+    if (s.nwords == 0 || s.nblocks == 0 || max_tris <= 0) return IVX_OK;
+    IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
+    hipStream_t st = ivx::S(stream);
+    void *d_list;
+    if ((rc = ivx::ws_get_s(ivx::WS_MCLIST, st, (size_t)max_tris * 8 + 64, &d_list))) return rc;
+    if ((rc = run_list(p, g, s, (const char *)scratch, d_list, max_tris, st))) return rc;
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    g_list_built[scratch] = ListBuilt{d_list, max_tris};
+    g_list_owner[d_list] = scratch;
+    return IVX_OK;
+}
+
 extern "C" int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *tris,
                                   int64_t max_tris, int64_t *ntris) {
     ivx::HostCallGuard host_guard__;
@@ -985,6 +1036,7 @@ static int run_indexed(const ivx_mc_params *p, const Geom &g, const Scratch &s, 
     int rc;
     if ((rc = ivx::ws_get_s(ivx::WS_MCV, st, m.total, &d_v))) return rc;
     if ((rc = ivx::ws_get_s(ivx::WS_MCLIST, st, (size_t)max_tris * 8 + 64, &d_list))) return rc;
+    const bool have_list = list_ready(scratch, d_list, max_tris); // else: marks the buffer as about to be overwritten
     const uint64_t *boff = (const uint64_t *)(scratch + s.off_boff);
     uint64_t tb[3] = {0, (uint64_t)max_tris, (uint64_t)max_tris};
     uint32_t vsplit = 0;
@@ -1005,9 +1057,11 @@ static int run_indexed(const ivx_mc_params *p, const Geom &g, const Scratch &s, 
         const uint16_t *counts = (const uint16_t *)(scratch + s.off_counts) + (size_t)q * s.nwords;
         const uint32_t *vbase = (const uint32_t *)((const char *)d_v + m.off_v + (size_t)q * m.per_iso);
         const uint32_t id0 = q == 0 ? 0u : vsplit;
-        hipLaunchKernelGGL(k_mc_list, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q), counts,
-                           boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
-        IVX_LAUNCH_CHECK();
+        if (!have_list) {
+            hipLaunchKernelGGL(k_mc_list, dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, g, s.nwords, pad_bits(p, q), counts,
+                               boff + (size_t)q * s.nblocks, (uint64_t *)d_list, (uint64_t)max_tris);
+            IVX_LAUNCH_CHECK();
+        }
         const int64_t blocks = ivx::cdiv(m.npw, 256);
         hipLaunchKernelGGL((k_mci_vertices<T>), dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st,
                            (const T *)a, bits, qb, g, m.npw, pad_bits(p, q), pad_qbits(p, q), p->iso[q], vbase, id0, verts,

@@ -169,6 +169,14 @@ class DeviceVolume:
         self._mbits_range = None    # (lo, hi) while additionally _mbits == (lo <= image <= hi)
         self._out_bytes_zero = False  # the BYTES of out_mask are all zero
         self._mc_params_cache = {}
+        # surface_prefetch: marching cubes' count + list queued on a second stream under the region growing
+        self._stream2 = None
+        self._sync_events = []
+        self._prefetch = None     # (params, z0, capacity, plane version) of the outstanding prefetch
+        self._gate = None         # device word the flood opens once its busy rounds are over
+        self._gate_epoch = 0
+        self._gate_armed = False  # armed and no flood has run since (so nobody will open it)
+        self._mbits_version = 0   # bumped whenever the inside plane is rewritten
         self._out_pending = None      # fill value of a deferred `out_mask[reached] = fill` (self.reached still holds it)
         self._fuse = os.environ.get("IVX_NO_FUSE", "") == ""
         self.image = TrackedBuffer(self.n * 2, self._image_touched)
@@ -201,6 +209,7 @@ class DeviceVolume:
     def _mask_touched(self):
         self._mbits_valid = False
         self._mbits_range = None
+        self._mbits_version += 1
 
     # out_mask is the reference's throw-away `np.zeros_like` of styles.py:3190: the flood writes `fill` into it and the
     # caller turns it into `mask[out_mask.astype(bool)] = 254`.  The pipeline keeps it as what the flood really produces
@@ -234,10 +243,17 @@ class DeviceVolume:
         if getattr(self, "stream", None) is None:
             return  # already closed (or never fully built)
         self._out_pending = None
+        self._prefetch = None
+        if self._stream2 is not None:
+            L.lib().ivx_stream_destroy(self._stream2)  # synchronises it first
+            self._stream2 = None
+        for e in self._sync_events:
+            L.lib().ivx_event_destroy(e)
+        self._sync_events = []
         for b in (self.image, self.mask, self.out_mask):
             b._on_touch = None  # freeing is not "somebody looked at the contents"
         for b in (self.image, self.mask, self.out_mask, self.cand, self.reached, self._mbits, self.flood_scratch,
-                  self._mc_scratch, self._tris, self._verts, self._faces):
+                  self._mc_scratch, self._tris, self._verts, self._faces, self._gate):
             if b is not None:
                 b.close()
         if self.stream is not None:
@@ -272,7 +288,9 @@ class DeviceVolume:
         more): it IS the candidate plane of a region growing with the same thresholds into a zero out_mask, and the
         inside plane of marching cubes at iso 127 -- both then skip their own pass over the volume."""
         lib = L.lib()
+        self._join_prefetch()  # a count still reading the plane must not see it change
         if self._fuse and not preserve and self.dx % 64 == 0:
+            self._mbits_version += 1
             L.check(lib.ivx_dev_threshold_i16_bits(self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(lo), int(hi),
                                                    self.mask.raw, self._mbits.ptr, self.stream), "threshold")
             self._mbits_valid, self._mbits_range = True, (int(lo), int(hi))
@@ -314,6 +332,7 @@ class DeviceVolume:
         rounds = ctypes.c_int(0)
         L.check(lib.ivx_dev_flood_run(p, cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
                                       st), "region_grow")
+        self._gate_armed = False  # an armed gate has been opened by this flood
         self._apply_reached(fill, select_value, shared)
         return rounds.value
 
@@ -352,6 +371,8 @@ class DeviceVolume:
             self._out_bytes_zero = False
         if select_value is not None and self._mbits_valid and not (shared and int(select_value) >= 127):
             # mask[reached] = select_value: keep the inside plane in step (reached is a subset of a shared plane)
+            self._join_prefetch()
+            self._mbits_version += 1
             L.check(lib.ivx_dev_bits_combine(self._mbits.ptr, self.reached.ptr, c64(self._plane_words),
                                              0 if int(select_value) >= 127 else 1, st))
             self._mbits_range = None
@@ -424,25 +445,121 @@ class DeviceVolume:
             self._mc_params_cache[key] = p  # callers treat the struct as read-only
         return p
 
-    def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False,
-                       params: L.McParams | None = None, z0: int = 0):
-        """count + emit on the resident mask (from_binary, iso 127) or image (two iso-values).  Returns the triangle
-        count, or the (T,3,3) float32 soup when download=True."""
-        lib = L.lib()
-        p = params if params is not None else self._mc_params(from_binary, min_value, max_value, fill_border_holes)
+    # -- marching cubes -----------------------------------------------------------------------------------------------
+    def _surface_params(self, from_binary, min_value, max_value, fill_border_holes):
+        """(piece parameters, first slice) of this volume's surface call; SlabVolume answers with its slab's piece"""
+        return self._mc_params(from_binary, min_value, max_value, fill_border_holes), 0
+
+    def _mc_setup(self, p, z0):
+        """scratch of the right size, the voxel source and -- when the pipeline still holds it -- the inside plane"""
         nb = ctypes.c_size_t(0)
-        L.check(lib.ivx_dev_mc_scratch_bytes(ctypes.byref(p), ctypes.byref(nb)))
+        L.check(L.lib().ivx_dev_mc_scratch_bytes(ctypes.byref(p), ctypes.byref(nb)))
         if self._mc_scratch is None or self._mc_scratch.nbytes < nb.value:
+            self._join_prefetch()
             if self._mc_scratch is not None:
                 self._mc_scratch.close()
             self._mc_scratch = DeviceBuffer(nb.value)
         isz = 1 if p.dtype == L.U8 else 2
         src = (self.mask if p.dtype == L.U8 else self.image).raw_at(z0 * self.dy * self.dx * isz)
-        # the mask's inside plane at iso 127, if the pipeline still holds it: skip the pass over the voxels
         plane = None
         if (p.dtype == L.U8 and p.niso == 1 and p.iso[0] == 127.0 and self._mbits_valid and p.ny == self.dy
                 and p.nx == self.dx):
             plane = self._mbits.at(z0 * self.dy * ((self.dx + 63) // 64) * 8)
+        return src, plane
+
+    def _second_stream(self):
+        if self._stream2 is None:
+            s = ctypes.c_void_p()
+            if os.environ.get("IVX_PREFETCH_PRIORITY", "low") == "low":
+                L.check(L.lib().ivx_stream_create_low_priority(ctypes.byref(s)))  # fills idle CUs, yields to the flood
+            else:
+                L.check(L.lib().ivx_stream_create(ctypes.byref(s)))
+            self._stream2 = s
+            for _ in range(2):
+                e = ctypes.c_void_p()
+                L.check(L.lib().ivx_event_create_sync(ctypes.byref(e)))
+                self._sync_events.append(e)
+        return self._stream2
+
+    def _join_prefetch(self):
+        """an outstanding prefetch is about to lose its inputs (or its scratch): let it finish, then forget it"""
+        if self._prefetch is not None:
+            if self._gate_armed:
+                L.check(L.lib().ivx_dev_gate_open(self._gate.ptr, ctypes.c_uint32(self._gate_epoch), self.stream))
+                self._gate_armed = False
+            L.check(L.lib().ivx_stream_synchronize(self._stream2))
+            self._prefetch = None
+
+    def surface_prefetch(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True,
+                         behind_flood: bool = True) -> bool:
+        """Queue the part of the coming `marching_cubes(...)` call (same arguments) that depends on the mask's inside
+        plane only -- count, scan and triangle list -- on a second stream, NOW: it then runs under whatever follows on
+        the main stream (typically the region growing, whose `mask[reached] = 254` changes values the emit
+        interpolates but not which side of iso 127 a voxel is on).  Needs the plane the threshold pass left behind
+        and a triangle buffer from an earlier call (its size is the capacity); returns False, doing nothing, otherwise.
+        Any change to the plane in between simply voids the prefetch.  `behind_flood`: hold the prefetched passes back
+        until the next region growing has left its throughput-bound first rounds (they would slow each other down;
+        its latency-bound tail leaves most of the GPU idle) -- or for 300 us at most, if no region growing follows."""
+        if not from_binary or not self._fuse or self._tris is None or not self._mbits_valid:
+            return False
+        self._join_prefetch()
+        p, z0 = self._surface_params(from_binary, min_value, max_value, fill_border_holes)
+        src, plane = self._mc_setup(p, z0)
+        if plane is None:
+            return False
+        lib, s2 = L.lib(), self._second_stream()
+        cap = self._tris.nbytes // 36
+        L.check(lib.ivx_event_record(self._sync_events[0], self.stream))   # the plane is complete at this point
+        L.check(lib.ivx_stream_wait_event(s2, self._sync_events[0]))
+        if behind_flood:
+            if self._gate is None:
+                self._gate = DeviceBuffer(64)
+                self._gate.zero(self.stream)
+                self.sync()
+            self._gate_epoch = (self._gate_epoch % 0x7fffffff) + 1
+            L.check(lib.ivx_dev_flood_arm_gate(self.flood_scratch.ptr, self._gate.ptr, ctypes.c_uint32(self._gate_epoch),
+                                               ctypes.c_uint32(512)))
+            L.check(lib.ivx_dev_gate_wait(self._gate.ptr, ctypes.c_uint32(self._gate_epoch), ctypes.c_uint32(300), s2))
+            self._gate_armed = True
+        L.check(lib.ivx_dev_mc_count_bits_async(ctypes.byref(p), plane, self._mc_scratch.ptr, s2), "mc_count")
+        L.check(lib.ivx_dev_mc_list(ctypes.byref(p), self._mc_scratch.ptr, c64(cap), s2), "mc_list")
+        self._prefetch = (p, z0, cap, self._mbits_version)
+        return True
+
+    def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False,
+                       params: L.McParams | None = None, z0: int = 0):
+        """count + emit on the resident mask (from_binary, iso 127) or image (two iso-values).  Returns the triangle
+        count, or the (T,3,3) float32 soup when download=True."""
+        lib = L.lib()
+        if params is not None:
+            p = params
+        else:
+            p, z0 = self._surface_params(from_binary, min_value, max_value, fill_border_holes)
+        pf, n = self._prefetch, ctypes.c_int64(0)
+        if pf is not None:
+            ok = (pf[0] is p and pf[1] == z0 and self._tris is not None and pf[2] == self._tris.nbytes // 36
+                  and pf[3] == self._mbits_version and self._mbits_valid)
+            if not ok:
+                self._join_prefetch()
+            else:
+                # count and list are done or running on the second stream; the emit needs the mask's final bytes
+                src, plane = self._mc_setup(p, z0)
+                s2, cap = self._stream2, pf[2]
+                if self._gate_armed:  # no flood came in between: open the gate by hand instead of waiting it out
+                    L.check(lib.ivx_dev_gate_open(self._gate.ptr, ctypes.c_uint32(self._gate_epoch), self.stream))
+                    self._gate_armed = False
+                L.check(lib.ivx_event_record(self._sync_events[1], self.stream))
+                L.check(lib.ivx_stream_wait_event(s2, self._sync_events[1]))
+                L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(cap), s2), "mc_emit")
+                L.check(lib.ivx_dev_mc_total(ctypes.byref(p), self._mc_scratch.ptr, ctypes.byref(n), s2), "mc_total")
+                self._prefetch = None  # the host has seen the total: everything on the second stream has finished
+                nt = n.value
+                if nt <= cap:
+                    if download:
+                        return self._tris.download((nt, 3, 3), np.float32)
+                    return nt
+                # the surface outgrew the buffer: take the ordinary path below (it re-counts and re-emits)
+        src, plane = self._mc_setup(p, z0)
         n = ctypes.c_int64(0)
         if self._tris is not None:
             # steady state: the triangle buffer of the previous call gives a capacity, so count, list and emit are queued
@@ -485,20 +602,12 @@ class DeviceVolume:
         """Same surface with coincident points merged (ivx.h "indexed surface").  Returns (n_verts, n_tris), or the
         (V,3) float32 / (T,3) int32 arrays when download=True; the device buffers stay in self._verts / self._faces."""
         lib = L.lib()
-        p = params if params is not None else self._mc_params(from_binary, min_value, max_value, fill_border_holes)
-        nb = ctypes.c_size_t(0)
-        L.check(lib.ivx_dev_mc_scratch_bytes(ctypes.byref(p), ctypes.byref(nb)))
-        if self._mc_scratch is None or self._mc_scratch.nbytes < nb.value:
-            if self._mc_scratch is not None:
-                self._mc_scratch.close()
-            self._mc_scratch = DeviceBuffer(nb.value)
-        isz = 1 if p.dtype == L.U8 else 2
-        src = (self.mask if p.dtype == L.U8 else self.image).raw_at(z0 * self.dy * self.dx * isz)
-        # the mask's inside plane at iso 127, if the pipeline still holds it: skip the pass over the voxels
-        plane = None
-        if (p.dtype == L.U8 and p.niso == 1 and p.iso[0] == 127.0 and self._mbits_valid and p.ny == self.dy
-                and p.nx == self.dx):
-            plane = self._mbits.at(z0 * self.dy * ((self.dx + 63) // 64) * 8)
+        if params is not None:
+            p = params
+        else:
+            p, z0 = self._surface_params(from_binary, min_value, max_value, fill_border_holes)
+        self._join_prefetch()  # same scratch
+        src, plane = self._mc_setup(p, z0)
         nt, nv = ctypes.c_int64(0), ctypes.c_int64(0)
         with self.timer.span("mc_count"):
             if plane is not None:

@@ -399,6 +399,7 @@ def _make_slab_volume():
                                                self.flood_scratch.ptr, st), "region_grow")
             self._rounds = 0
             slab_region_grow(self, self.comm, self.lay)
+            self._gate_armed = False  # an armed gate has been opened by the first local flood
             self._apply_reached(fill, select_value, shared)
             return self._rounds
 
@@ -527,21 +528,20 @@ def _make_slab_volume():
                 tmp.close()
                 status.close()
 
-        def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
+        def _surface_params(self, from_binary, min_value, max_value, fill_border_holes):
+            """this rank's piece: its cell layers plus the one slice of the upper neighbour (the reference's o_piece = 1)"""
             a = slab_mc_args(self.lay, fill_border_holes)
             p = self._mc_params(from_binary, min_value, max_value, fill_border_holes, z0=a["z0"], z1=a["z1"],
                                 roi_start=a["roi_start"], pad_bottom=a["pad_bottom"], pad_top=a["pad_top"])
-            return super().marching_cubes(from_binary, min_value, max_value, fill_border_holes, download, params=p,
-                                          z0=a["z0"])
+            return p, a["z0"]
+
+        def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
+            return super().marching_cubes(from_binary, min_value, max_value, fill_border_holes, download)
 
         def marching_cubes_indexed(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
             """This rank's piece as an indexed mesh.  Vertices on the plane shared with the next rank exist on both
             sides; `stitch_piece_meshes` merges them (the vtkCleanPolyData step of join_process_surface)."""
-            a = slab_mc_args(self.lay, fill_border_holes)
-            p = self._mc_params(from_binary, min_value, max_value, fill_border_holes, z0=a["z0"], z1=a["z1"],
-                                roi_start=a["roi_start"], pad_bottom=a["pad_bottom"], pad_top=a["pad_top"])
-            return super().marching_cubes_indexed(from_binary, min_value, max_value, fill_border_holes, download, params=p,
-                                                  z0=a["z0"])
+            return super().marching_cubes_indexed(from_binary, min_value, max_value, fill_border_holes, download)
 
     return SlabVolume
 

@@ -164,3 +164,60 @@ def test_out_mask_is_materialised_whenever_it_is_looked_at(ivxlib, oracle):
     assert np.array_equal(vol.download_out_mask(), out1 * 7)
     d.close()
     vol.close()
+
+
+def test_surface_prefetch_gives_the_same_surface_and_is_voided_by_plane_changes(ivxlib, oracle):
+    """DeviceVolume.surface_prefetch: count + list on a second stream under the region growing.  Same soup as the plain
+    sequence and as the oracle; a prefetch whose plane changed before the surface call (select_value < 127 clears bits,
+    a new threshold rewrites it) is dropped, not used."""
+    from invesalius3_amd.device import DeviceVolume
+    img = synth_volume((40, 48, 128), seed=31)
+    strct = generate_binary_structure(3, 3)
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    seed = (int(x), int(y), int(z))
+
+    def reference(select):
+        mask = np.zeros(tuple(s + 1 for s in img.shape), np.uint8)
+        oracle.set_mask_threshold_volume(mask, img, (226, 3071))
+        out = np.zeros(img.shape, np.uint8)
+        oracle.floodfill_threshold(img, [seed], 226, 3071, 1, strct, out)
+        mask[1:, 1:, 1:][out.astype(bool)] = select
+        return oracle.create_surface_piece(None, mask, slice(0, img.shape[0]), (1.0, 1.0, 1.0), 0, 0, True)
+
+    with DeviceVolume(img) as vol:
+        assert vol.surface_prefetch() is False               # no plane, no triangle buffer yet: nothing happens
+        vol.threshold(226, 3071)
+        vol.region_grow([seed], 226, 3071, strct, fill=1, select_value=254)
+        plain = vol.marching_cubes(from_binary=True, download=True)
+        assert np.array_equal(plain, reference(254))
+        for _ in range(3):                                   # steady state: prefetch, flood, emit
+            vol.zero_out_mask()
+            vol.threshold(226, 3071)
+            assert vol.surface_prefetch() is True
+            vol.region_grow([seed], 226, 3071, strct, fill=1, select_value=254)
+            assert vol._prefetch is not None
+            got = vol.marching_cubes(from_binary=True, download=True)
+            assert vol._prefetch is None and np.array_equal(got, plain)
+        # select_value 100 takes the region OUT of the inside plane: the prefetched list is for another surface
+        vol.zero_out_mask()
+        vol.threshold(226, 3071)
+        assert vol.surface_prefetch() is True
+        vol.region_grow([seed], 226, 3071, strct, fill=1, select_value=100)
+        assert vol._prefetch is None
+        got = vol.marching_cubes(from_binary=True, download=True)
+        assert np.array_equal(got, reference(100))
+        # no region growing between the prefetch and the surface call: the gate is opened by hand
+        vol.zero_out_mask()
+        vol.threshold(226, 3071)
+        assert vol.surface_prefetch() is True
+        direct = vol.marching_cubes(from_binary=True, download=True)
+        vol.threshold(226, 3071)
+        assert np.array_equal(direct, vol.marching_cubes(from_binary=True, download=True))
+        # a prefetch that nobody collects is joined before the plane is rewritten
+        vol.zero_out_mask()
+        vol.threshold(226, 3071)
+        assert vol.surface_prefetch() is True
+        vol.threshold(300, 3071)
+        assert vol._prefetch is None
+        n_ref = vol.marching_cubes(from_binary=True)
+        assert n_ref > 0
