@@ -163,10 +163,12 @@ def main():
     nvox = img.size
 
     # Marching cubes' count, scan and triangle list depend on WHICH voxels are >= 127 only, and `mask[reached] = 254`
-    # does not change that: the timed steps queue them on a second stream right after the threshold pass, under the
-    # (latency-bound) region growing; the emit waits for the mask's final bytes.  IVX_NO_PREFETCH=1: strictly one
-    # stage after the other, which is also how the per-stage table is measured.
-    overlap = os.environ.get("IVX_NO_PREFETCH", "") == ""
+    # does not change that: with IVX_PREFETCH=1 the timed steps queue them on a second, low-priority stream right after
+    # the threshold pass, held back until the region growing's busy rounds are over; the emit waits for the mask's final
+    # bytes (DeviceVolume.surface_prefetch; measured 0.498 -> 0.466 ms per step, profiles/r01_bench_v11_overlap*).
+    # The default is strictly one stage after the other: the per-stage roofline figures then describe kernels that
+    # had the GPU to themselves, and every GPU count runs the same schedule.
+    overlap = os.environ.get("IVX_PREFETCH", "") == "1"
 
     def step(prefetch=False):
         with vol.timer.span("zero_out_mask"):
@@ -204,6 +206,9 @@ def main():
     dt = time.perf_counter() - t0
     spans_timed = vol.timer.collect()
     vol.timer.only = None
+    step()  # the sequential path's own one-time work (its triangle-list workspace) stays out of the table
+    barrier()
+    vol.timer.collect()
     for _ in range(max(1, min(args.steps, 5))):
         step()
     barrier()
