@@ -164,7 +164,11 @@ int orc_floodfill(int dt, const void *data_, const int64_t shape[3], const int64
     return ORC_OK;
 }
 
-/* floodfill_auto_threshold                invesalius_rs/src/floodfill_py.rs:12-85
+/* PARITY UNPINNED for floodfill_internal (above) and floodfill_auto_threshold (below): the reference tree holds no test
+ * or golden vector for either and the Rust source cannot be built here; both restatements are checked against cases
+ * worked out by hand from the Rust source (tests/test_oracle_golden.py).
+ *
+ * floodfill_auto_threshold                invesalius_rs/src/floodfill_py.rs:12-85
  * i16 only; 6-neighbour FIFO; the admissible range is recomputed from the
  * value of the voxel being expanded: [ceil(v(1-p)), floor(v(1+p))] as i16
  * (Rust `as i16` saturates). */

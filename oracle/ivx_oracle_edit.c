@@ -166,7 +166,9 @@ int orc_count_regions(const int64_t *labels, int64_t n, int64_t number_regions, 
  * the result does not depend on any traversal order.  Taps are visited z-major (zi, yi, xi ascending) and a tap wins
  * only with a strictly smaller distance -- or unconditionally while the voxel has no owner yet.  normalize: sites move to
  * the (integer) centroid of their cells, distances are recomputed to the new sites and divided by the cell's maximum.
- * Arrays are dense C-order [z][y][x]; sites are (z, y, x) int32 triples.  Test infrastructure only. */
+ * Arrays are dense C-order [z][y][x]; sites are (z, y, x) int32 triples.  Test infrastructure only.
+ * PARITY UNPINNED: the reference tree holds no test or golden vector for this function and its Rust source cannot be
+ * built here; the restatement is checked against a brute-force Voronoi diagram (tests/test_oracle_golden.py). */
 int orc_jump_flooding(float *dist, int32_t *owners, const int64_t shape[3], const int32_t *sites, int64_t nsites,
                       int normalize) {
     const int64_t sz = shape[0], sy = shape[1], sx = shape[2];
