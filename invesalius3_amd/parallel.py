@@ -79,7 +79,11 @@ class DevPlane:
 
 
 class TorchComm:
-    """Neighbour exchange + scalar all-reduce over torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+    """Neighbour exchange + scalar all-reduce over torch.distributed (RCCL on GPUs, gloo in the CPU tests).
+
+    On GPUs, initialise torch's device (``torch.cuda.set_device`` / ``init_process_group``) BEFORE the first call into
+    libivx: torch ships its own ROCm runtime and cannot find the GPU once the system runtime libivx links against has
+    come up first in the process."""
 
     def __init__(self, dist, rank: int, world: int, device="cpu"):
         import torch

@@ -171,3 +171,87 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
         for (ax, op), img in res[r]["proj"].items():
             want = getattr(full, op)(axis=ax)
             assert img.dtype == want.dtype and np.array_equal(img, want), (r, ax, op)
+
+
+_TORCH_PLANES = r"""
+import sys, threading
+import torch
+torch.cuda.init()                      # torch's HIP runtime first, as in bench.py: it cannot come up after libivx's
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from scipy.ndimage import generate_binary_structure
+from conftest import synth_volume
+from test_gpu_slab import LoopbackWorld, LoopbackComm
+from invesalius3_amd.parallel import SlabVolume
+from oracle import oracle
+oracle.build()
+
+
+class LoopbackTorchComm(LoopbackComm):
+    device = "cuda"
+
+    def plane_buffer(self, nbytes, slot):
+        bufs = self.__dict__.setdefault("_planes", {})
+        if slot not in bufs or bufs[slot].numel() != nbytes:
+            bufs[slot] = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        return bufs[slot]
+
+    def exchange(self, to_down, to_up):
+        if isinstance(to_down, np.ndarray) or isinstance(to_up, np.ndarray):  # the one-time image halo
+            return super().exchange(to_down, to_up)
+        for t in (to_down, to_up):
+            assert t is None or (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8)
+        # hand the peer a COPY, as a real exchange would (the sender's buffer is rewritten next round)
+        cd, cu = (None if to_down is None else to_down.clone()), (None if to_up is None else to_up.clone())
+        torch.cuda.current_stream().synchronize()  # as TorchComm.exchange does: the copies run on torch's stream
+        return super().exchange(cd, cu)
+
+
+world, nz = 3, 20
+full = synth_volume((world * nz, 48, 128), seed=79)
+t0, t1 = -850, 3071
+strct = generate_binary_structure(3, 3)
+z, y, x = np.unravel_index(int(np.argmax(full)), full.shape)
+seeds = [(int(x), int(y), int(z))]
+lw = LoopbackWorld(world)
+res, errs = {}, []
+
+
+def run(rank):
+    try:
+        vol = SlabVolume(full[rank * nz:(rank + 1) * nz], rank, world, comm=LoopbackTorchComm(lw, rank))
+        vol.threshold(t0, t1)
+        vol.region_grow(seeds, t0, t1, strct, fill=1, select_value=254)
+        lay = vol.lay
+        res[rank] = vol.download_out_mask()[lay.first_interior:lay.last_interior + 1]
+        vol.close()
+    except Exception as e:
+        import traceback
+        traceback.print_exc()
+        errs.append((rank, repr(e)))
+        lw.barrier.abort()
+
+
+th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+[t.start() for t in th]
+[t.join(timeout=300) for t in th]
+assert not errs, errs
+ref = np.zeros(full.shape, np.uint8)
+oracle.floodfill_threshold(full, seeds, t0, t1, 1, strct, ref)
+assert np.array_equal(np.concatenate([res[r] for r in range(world)]), ref)
+assert ref[:nz].any() and ref[-nz:].any()  # the region really crosses both slab faces
+print("torch-planes-ok")
+"""
+
+
+def test_slab_flood_through_cuda_tensor_planes(ivxlib):
+    """3 ranks on one GPU, planes exported straight into CUDA tensors (TorchComm.plane_buffer's role) and OR-ed in from
+    CUDA tensors: the plumbing RCCL traffic goes through.  In a fresh process, torch initialised first."""
+    pytest.importorskip("torch")
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", _TORCH_PLANES % (os.path.dirname(here), here)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "torch-planes-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
