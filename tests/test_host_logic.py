@@ -132,3 +132,59 @@ def test_headless_argument_parsing():
         headless.main(["case.inv3", "--seed", "1", "2"])          # seeds come in triples
     with pytest.raises(SystemExit):
         headless.main(["case.inv3", "--threshold", "1", "2", "--mask", "1"])  # either a new threshold or a saved mask
+
+
+def test_slab_region_grow_protocols_count_their_collectives():
+    """slab_region_grow against scripted stand-ins: with exchange_and_vote a flood that gains bits in k rounds costs k + 1
+    collectives (the vote of round k travels with round k + 1), a rank floods and re-exports only after a round in which
+    its halo gained something; without it (older communicators) every round is an exchange plus an all-reduce."""
+    from invesalius3_amd import parallel as par
+
+    class Backend:
+        def __init__(self, gains):
+            self.gains, self.floods, self.exports, self.ors = list(gains), 0, 0, 0
+
+        def flood_run(self):
+            self.floods += 1
+
+        def export_plane(self, z):
+            self.exports += 1
+            return "plane%d" % z
+
+        def or_planes(self, from_down, from_up):
+            self.ors += 1
+            return self.gains.pop(0) if self.gains else 0
+
+    class Merged:
+        """two ranks' worth of votes: `other` is what the peer reports for the same rounds"""
+        def __init__(self, other):
+            self.other, self.calls = list(other), 0
+
+        def exchange_and_vote(self, down, up, changed):
+            self.calls += 1
+            return "fd", "fu", changed + (self.other.pop(0) if self.other else 0)
+
+    lay = par.slab_layout(1, 3, 8)  # a middle rank: both neighbours exist
+    # this rank gains in rounds 1 and 2, the peer only in round 1: rounds 1, 2 productive, round 3 gains nothing, round 4
+    # learns that -> 4 collectives, 3 floods (initial + after the two productive rounds), 3 x 2 exports
+    be, comm = Backend([5, 2, 0]), Merged([1, 3, 0, 0])  # peer's "previous changed": seeds, then its gains
+    rounds = par.slab_region_grow(be, comm, lay)
+    assert (rounds, comm.calls, be.floods, be.ors, be.exports) == (4, 4, 3, 3, 6)
+    # nothing ever gained: one round to exchange, a second one to learn that nobody gained -> 2 collectives, 1 flood
+    be, comm = Backend([0]), Merged([1, 0])
+    assert par.slab_region_grow(be, comm, lay) == 2 and (comm.calls, be.floods, be.exports) == (2, 1, 2)
+
+    class Plain:
+        def __init__(self, other):
+            self.other, self.exchanges, self.votes = list(other), 0, 0
+
+        def exchange(self, down, up):
+            self.exchanges += 1
+            return "fd", "fu"
+
+        def allreduce_sum(self, v):
+            self.votes += 1
+            return v + (self.other.pop(0) if self.other else 0)
+
+    be, comm = Backend([5, 2, 0]), Plain([3, 0, 0])
+    assert par.slab_region_grow(be, comm, lay) == 3 and (comm.exchanges, comm.votes, be.floods) == (3, 3, 3)
