@@ -28,8 +28,8 @@ typedef struct ws_el {
 
 /* input: uint8 (idt=0) or uint16 (idt=3), C-contiguous, rank 3 (use shape[0]=1 for 2-D).
  * markers/output: int16 (mdt=1) or int8 (mdt=4), C-contiguous.  strct: 3x3x3 uint8. */
-int orc_watershed_ift(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
-                      const uint8_t *strct, void *output) {
+static int ws_ift_impl(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
+                       const uint8_t *strct, void *output, int64_t *ev) {
     const int64_t dims[3] = {shape[0], shape[1], shape[2]};
     const int64_t size = dims[0] * dims[1] * dims[2];
     const int64_t strides[3] = {dims[1] * dims[2], dims[2], 1};
@@ -74,6 +74,7 @@ int orc_watershed_ift(int idt, const void *input, const int64_t shape[3], int md
     for (int32_t jj = 0; jj <= maxval; jj++) {
         while (first[jj]) {
             ws_el *v = first[jj];
+            if (ev) { if (v->done) ev[2]++; else if (v->cost != jj) ev[1]++; }
             first[jj] = first[jj]->next;
             if (first[jj]) first[jj]->prev = NULL;
             v->prev = NULL; v->next = NULL;
@@ -102,6 +103,7 @@ int orc_watershed_ift(int idt, const void *input, const int64_t shape[3], int md
                     p->cost = max;
                     int32_t label = OUT(v_index);
                     SETOUT(p_index, label);
+                    if (ev && !(p->next || p->prev) && first[pcost] == p) ev[0]++;
                     if (p->next || p->prev) {
                         ws_el *prev = p->prev, *next = p->next;
                         if (first[pcost] == p) first[pcost] = next;
@@ -124,10 +126,27 @@ int orc_watershed_ift(int idt, const void *input, const int64_t shape[3], int md
             }
         }
     }
+    if (ev)
+        for (int64_t i = 0; i < size; i++) if (!temp[i].done && temp[i].cost <= maxval) ev[3]++;
     free(temp); free(first); free(last);
     return ORC_OK;
 #undef IN
 #undef MK
 #undef OUT
 #undef SETOUT
+}
+
+int orc_watershed_ift(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
+                      const uint8_t *strct, void *output) {
+    return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, NULL);
+}
+
+/* Same flood, plus what scipy's linked-list defect did on this input:
+ * ev[0] = a bucket's only element re-queued without being unlinked (the defect's trigger),
+ * ev[1] = elements popped from a bucket that is not their cost's (processed LATE: the only way the defect
+ *         changes labels), ev[2] = elements popped twice (harmless), ev[3] = reachable elements never popped. */
+int orc_watershed_ift_events(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
+                             const uint8_t *strct, void *output, int64_t ev[4]) {
+    ev[0] = ev[1] = ev[2] = ev[3] = 0;
+    return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, ev);
 }

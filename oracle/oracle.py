@@ -612,3 +612,39 @@ def jump_flooding(distance_map, map_owners, sites, normalize):
     rc = lib().orc_jump_flooding(_p(distance_map), _p(map_owners), _i64(distance_map.shape), _p(s),
                                  ctypes.c_int64(len(s)), ctypes.c_int(1 if normalize else 0))
     _check(rc)
+
+
+def _ws_args(image, markers, strct):
+    image = np.ascontiguousarray(image)
+    markers = np.ascontiguousarray(markers)
+    assert image.dtype in (np.uint8, np.uint16) and markers.dtype in (np.int8, np.int16)
+    s3 = np.zeros((3, 3, 3), np.uint8)
+    if image.ndim == 3:
+        s3[:] = np.asarray(strct, dtype=np.uint8)
+        shp = image.shape
+    else:
+        s3[1] = np.asarray(strct, dtype=np.uint8)
+        shp = (1,) + image.shape
+    return image, markers, s3, shp
+
+
+def watershed_ift_events(image, markers, strct):
+    """orc_watershed_ift (== live scipy) plus the event counts of scipy's linked-list defect:
+    (sole-element re-queues, late pops, double pops, never popped)."""
+    image, markers, s3, shp = _ws_args(image, markers, strct)
+    out = np.empty_like(markers)
+    ev = (ctypes.c_int64 * 4)()
+    _check(lib().orc_watershed_ift_events(0 if image.dtype == np.uint8 else 3, _p(image), _i64(shp),
+                                          1 if markers.dtype == np.int16 else 4, _p(markers), _p(s3), _p(out), ev))
+    return out, tuple(int(v) for v in ev)
+
+
+def watershed_ift_clean(image, markers, strct, want_cost=False):
+    """The algorithm watershed_ift documents, without the linked-list defect (ivx_oracle_wsz.c)."""
+    image, markers, s3, shp = _ws_args(image, markers, strct)
+    out = np.empty_like(markers)
+    cost = np.empty(image.shape, np.uint32) if want_cost else None
+    _check(lib().orc_watershed_ift_clean(0 if image.dtype == np.uint8 else 3, _p(image), _i64(shp),
+                                         1 if markers.dtype == np.int16 else 4, _p(markers), _p(s3), _p(out),
+                                         _p(cost) if want_cost else None))
+    return (out, cost) if want_cost else out
