@@ -49,6 +49,7 @@ extern "C" {
 #define IVX_F32 4 /* mesh vertices */
 #define IVX_I32 5 /* label volumes (LabelsTypes3) */
 #define IVX_I64 6
+#define IVX_I8 7 /* watershed markers (watershed_process.py:57 casts to int8) */
 
 /* projection ops for ivx_*mip_reduce (numpy .max/.min/.mean, invesalius/data/slice_.py:885-889) */
 #define IVX_MIP_MAX 0
@@ -478,6 +479,26 @@ int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3], const int6
                           double window, double level, const int gradient_size[3] /* NULL = none */, uint16_t *out);
 int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mask_strides[3], const uint8_t *tmp,
                         const int64_t tmp_strides[3], int overwrite);
+
+/* ------------------------------------------------------------------------------------------------
+ * the marker flood of do_watershed's IFT branch
+ *   replaces scipy.ndimage.watershed_ift(tmp_image, markers, bstruct) as called at
+ *            invesalius/data/watershed_process.py:44-46,54-57 (3-D) and invesalius/data/styles.py:1958-1983 (one slice,
+ *            shape (1, h, w) with the 3x3 structure in strct[9..17])
+ * cost: uint16 (the LUT / min-shifted image above), markers int16 or int8 (>= 0; the reference passes 0 / 1 / 2),
+ * strct: 3x3x3 uint8, symmetric (generate_binary_structure).  Labels come back in the markers' dtype (what scipy
+ * returns) and/or as uint8 (what `mask[:] = tmp_mask` stores, watershed_process.py:58).  Arc weight |I(p)-I(q)|, path
+ * cost = largest arc, LIFO inside a cost bucket, neighbours by linear index (row wrap-around like scipy): the
+ * defect-free statement of NI_WatershedIFT, see k_wsift.hip.  cost_out (optional): the minimax cost map.
+ * stats (optional, host): [0] relaxation rounds, [1] tile visits, [2] non-empty cost levels, [3] time stamps used,
+ * [4] marker voxels, [5] entry voxels, [6] tiles.  The host form uploads / downloads dense C-order arrays.
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_watershed_ift(const uint16_t *cost, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
+                          const uint8_t strct[27], void *out_labels /* markers' dtype, may be NULL */,
+                          uint8_t *out_u8 /* may be NULL */, uint16_t *cost_out /* may be NULL */, int64_t stats[8],
+                          void *stream);
+int ivx_watershed_ift(int idtype /* IVX_U8 | IVX_U16 */, const void *input, const int64_t shape[3], int mdtype,
+                      const void *markers, const uint8_t strct[27], void *output, uint16_t *cost_out, int64_t stats[8]);
 
 /* ------------------------------------------------------------------------------------------------
  * confidence-connected region growing support (do_rg_confidence, invesalius/data/styles.py:3220-3251):

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libivx.so")
 
 IVX_OK, IVX_EINVAL, IVX_ERANGE, IVX_ENOMEM, IVX_EDOM, IVX_EHIP = 0, -1, -2, -3, -4, -5
-U8, I16, F64, U16, F32, I32, I64 = 0, 1, 2, 3, 4, 5, 6
+U8, I16, F64, U16, F32, I32, I64, I8 = 0, 1, 2, 3, 4, 5, 6, 7
 DT = {np.dtype(np.uint8): U8, np.dtype(np.int16): I16, np.dtype(np.float64): F64, np.dtype(np.uint16): U16, np.dtype(np.float32): F32, np.dtype(np.int32): I32,
       np.dtype(np.int64): I64}
 MIP_MAX, MIP_MIN, MIP_MEAN, MIP_SUM = 0, 1, 2, 3

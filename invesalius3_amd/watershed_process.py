@@ -4,12 +4,10 @@
 [morphological gradient] -> marker flood (``skimage.segmentation.watershed`` or ``scipy.ndimage.watershed_ift``)
 -> uint8 labels, followed in the caller by the merge rule (styles.py:2147-2152).
 
-What runs in HIP kernels here: the LUT / min-shift, the 3x3x3 (or larger, odd) morphological gradient and the
-merge.  The marker flood itself is a strictly sequential priority flood whose tie-breaking (LIFO buckets in
-scipy, (value, age) heap in scikit-image) decides the labels on every plateau; a bit-exact parallel
-formulation is not built yet, so ``do_watershed`` hands the GPU-made cost image to the
-very same third-party function the reference calls.  That step is NOT part of libivx and is excluded from every
-parity / performance claim.
+Everything runs in HIP kernels: the LUT / min-shift, the 3x3x3 (or larger, odd) morphological gradient, the marker
+flood of the IFT branch (``watershed_ift`` below: csrc/k_wsift.hip, the zone formulation of scipy's serial bucket
+flood) and the merge.  The scikit-image branch (``algorithm == "Watershed"``: a (value, age) heap flood, FIFO ties) has
+no GPU flood yet and raises; there is no CPU path in this package.
 """
 from __future__ import annotations
 
@@ -51,31 +49,62 @@ def merge(mask: np.ndarray, tmp_mask: np.ndarray, overwrite: bool):
                                         int(bool(overwrite))), "watershed merge")
 
 
-def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_ww_wl, wl, ww, q=None, flood=None):
-    """Same signature and side effects as watershed_process.do_watershed (:19-60): writes the uint8 label volume to
-    the memmap `tfile` and signals ``q.put(1)``.  The cost image is made on the GPU.
-
-    The marker flood is NOT implemented in libivx (module docstring): by default this raises NotImplementedError --
-    there is no silent CPU path in this package.  Pass ``flood="third-party-cpu"`` to run, explicitly, the same
-    scipy / scikit-image call the reference makes on the GPU-made cost image."""
-    if flood != "third-party-cpu":
-        raise NotImplementedError(
-            "the watershed marker flood has no HIP implementation yet (bit-exact parallel tie-breaking is an open "
-            "problem, DESIGN.md section 6); pass flood='third-party-cpu' to use the reference's own scipy/skimage call")
-    from scipy import ndimage
-
-    mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")
-    if algorithm == "Watershed":
-        try:
-            from skimage.segmentation import watershed
-        except ImportError as e:  # scikit-image is not part of this environment
-            raise RuntimeError("algorithm 'Watershed' needs scikit-image for the flood step") from e
-        tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, mg_size)
-        tmp_mask = watershed(tmp_image, np.asarray(markers).astype("int16"), bstruct)
+def _strct27(strct, ndim):
+    s = np.asarray(strct)
+    if s.ndim != ndim or any(d != 3 for d in s.shape):
+        raise RuntimeError("structure and input must have equal rank")  # scipy's message
+    s3 = np.zeros((3, 3, 3), np.uint8)
+    if ndim == 3:
+        s3[:] = s.astype(bool)
     else:
-        tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, 0)
-        mk = np.asarray(markers).astype("int16" if use_ww_wl else "int8")  # watershed_process.py:45,57
-        tmp_mask = ndimage.watershed_ift(tmp_image, mk, bstruct)
+        s3[1] = s.astype(bool)
+    return s3
+
+
+def watershed_ift(image: np.ndarray, markers: np.ndarray, structure=None, want_cost=False, want_stats=False):
+    """``scipy.ndimage.watershed_ift(input, markers, structure)`` on the GPU (2-D or 3-D uint8 / uint16 input, int8 /
+    int16 markers >= 0), labels returned in the markers' dtype.  Same argument checks as scipy: TypeError for other
+    input dtypes, RuntimeError for shape mismatches."""
+    image = np.asarray(image)
+    markers = np.asarray(markers)
+    if image.dtype.type not in (np.uint8, np.uint16):
+        raise TypeError("only 8 and 16 unsigned inputs are supported")
+    if markers.dtype.type not in (np.int8, np.int16):
+        raise TypeError("markers must be int8 or int16 (the reference casts them: watershed_process.py:45,57)")
+    if image.ndim not in (2, 3) or markers.shape != image.shape:
+        raise RuntimeError("input and markers must have equal shape")
+    if structure is None:
+        from scipy.ndimage import generate_binary_structure
+        structure = generate_binary_structure(image.ndim, 1)
+    s3 = _strct27(structure, image.ndim)
+    img = np.ascontiguousarray(image)
+    mk = np.ascontiguousarray(markers)
+    shp = img.shape if img.ndim == 3 else (1,) + img.shape
+    out = np.empty(mk.shape, mk.dtype)
+    cost = np.empty(img.shape, np.uint16) if want_cost else None
+    stats = (ctypes.c_int64 * 8)()
+    L.check(L.lib().ivx_watershed_ift(L.U8 if img.dtype == np.uint8 else L.U16, L.ptr(img), L.i64(shp),
+                                      L.I16 if mk.dtype == np.int16 else L.I8, L.ptr(mk), L.ptr(s3), L.ptr(out),
+                                      L.ptr(cost) if want_cost else None, stats), "watershed_ift")
+    res = (out,)
+    if want_cost:
+        res += (cost,)
+    if want_stats:
+        res += (dict(zip(("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles"), stats)),)
+    return res[0] if len(res) == 1 else res
+
+
+def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_ww_wl, wl, ww, q=None):
+    """Same signature and side effects as watershed_process.do_watershed (:19-60): writes the uint8 label volume to
+    the memmap `tfile` and signals ``q.put(1)``.  Cost image and flood run on the GPU."""
+    if algorithm == "Watershed":
+        raise NotImplementedError(
+            "do_watershed(algorithm='Watershed'): the scikit-image (value, age)-heap flood has no HIP implementation; "
+            "use the 'Watershed IFT' algorithm (watershed_process.py:41-46,54-57)")
+    mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")
+    tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, 0)
+    mk = np.asarray(markers).astype("int16" if use_ww_wl else "int8")  # watershed_process.py:45,57
+    tmp_mask = watershed_ift(tmp_image, mk, bstruct)
     mask[:] = tmp_mask
     mask.flush()
     if q is not None:

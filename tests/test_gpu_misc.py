@@ -84,8 +84,8 @@ def test_watershed_merge_rule(ivxlib, oracle, overwrite):
 
 
 def test_do_watershed_ift_pipeline_matches_reference_calls(ivxlib, tmp_path):
-    """tests/test_segmentation_tools.py:170-213 analogue for the IFT branch: same memmap + queue protocol; the
-    GPU-made cost image feeds the same scipy call, so the labels equal the reference pipeline's."""
+    """tests/test_segmentation_tools.py:170-213 analogue for the IFT branch: same memmap + queue protocol, cost image
+    and marker flood on the GPU, labels equal the reference pipeline's (live scipy), with and without ww/wl."""
     import queue
     from invesalius3_amd import watershed_process as wp
     image = np.zeros((5, 5, 5), dtype=np.int16)
@@ -97,15 +97,21 @@ def test_do_watershed_ift_pipeline_matches_reference_calls(ivxlib, tmp_path):
     np.memmap(tfile, shape=image.shape, dtype="uint8", mode="w+").flush()
     q = queue.Queue()
     bstruct = generate_binary_structure(3, 1)
-    with pytest.raises(NotImplementedError):  # no silent CPU path: the flood must be requested explicitly
-        wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), False, 0, 0, q)
-    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), False, 0, 0, q,
-                    flood="third-party-cpu")
+    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), False, 0, 0, q)
     assert q.get() == 1
     got = np.array(np.memmap(tfile, shape=image.shape, dtype="uint8", mode="r"))
     exp = ndimage.watershed_ift((image - image.min()).astype("uint16"), markers.astype("int8"), bstruct)
     assert np.array_equal(got, exp.astype(np.uint8))
     assert (got == 1).sum() == 27 and (got == 2).sum() == 98  # SURVEY 8c golden counts
+    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed IFT", (3, 3, 3), True, 50, 120, q)
+    assert q.get() == 1
+    got = np.array(np.memmap(tfile, shape=image.shape, dtype="uint8", mode="r"))
+    lut = np.piecewise(image, [image <= (50 - 0.5 - (120 - 1) / 2.0), image > (50 - 0.5 + (120 - 1) / 2.0)],
+                       [0, 120, lambda v: ((v - (50 - 0.5)) / (120 - 1) + 0.5) * 120])
+    exp = ndimage.watershed_ift(lut.astype("uint16"), markers.astype("int16"), bstruct)
+    assert np.array_equal(got, exp.astype(np.uint8))
+    with pytest.raises(NotImplementedError):  # the scikit-image flood is not built and there is no CPU path
+        wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed", (3, 3, 3), False, 0, 0, q)
 
 
 def test_device_volume_pipeline_matches_oracle(ivxlib, oracle):
