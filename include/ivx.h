@@ -491,14 +491,15 @@ int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mas
  * cost = largest arc, LIFO inside a cost bucket, neighbours by linear index (row wrap-around like scipy): the
  * defect-free statement of NI_WatershedIFT, see k_wsift.hip.  cost_out (optional): the minimax cost map.
  * stats (optional, host): [0] relaxation rounds, [1] tile visits, [2] non-empty cost levels, [3] time stamps used,
- * [4] marker voxels, [5] entry voxels, [6] tiles.  The host form uploads / downloads dense C-order arrays.
+ * [4] marker voxels, [5] entry voxels, [6] tiles, [8..12] microseconds of: costs, zones, bucketing, level chain, labels.
+ * The host form uploads / downloads dense C-order arrays.
  * ---------------------------------------------------------------------------------------------- */
 int ivx_dev_watershed_ift(const uint16_t *cost, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
                           const uint8_t strct[27], void *out_labels /* markers' dtype, may be NULL */,
-                          uint8_t *out_u8 /* may be NULL */, uint16_t *cost_out /* may be NULL */, int64_t stats[8],
+                          uint8_t *out_u8 /* may be NULL */, uint16_t *cost_out /* may be NULL */, int64_t stats[16],
                           void *stream);
 int ivx_watershed_ift(int idtype /* IVX_U8 | IVX_U16 */, const void *input, const int64_t shape[3], int mdtype,
-                      const void *markers, const uint8_t strct[27], void *output, uint16_t *cost_out, int64_t stats[8]);
+                      const void *markers, const uint8_t strct[27], void *output, uint16_t *cost_out, int64_t stats[16]);
 
 /* ------------------------------------------------------------------------------------------------
  * confidence-connected region growing support (do_rg_confidence, invesalius/data/styles.py:3220-3251):

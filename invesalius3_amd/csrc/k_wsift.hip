@@ -59,8 +59,11 @@ struct WsState {
     uint32_t base;     // next free time stamp
     uint32_t overflow; // time stamps ran out of the table
     uint32_t neg;      // a negative marker was seen
-    uint32_t nlist;    // dirty tiles of the next round
-    uint32_t visits_lo, visits_hi, pad0, pad1;
+    uint32_t pad0;
+    uint32_t nlist;    // dirty tiles of the next round            } read by the host
+    uint32_t minrej;   // smallest cost refused by the gate so far } after every round
+    uint32_t assigned; // voxels that have a finite cost           } (one mailbox message)
+    uint32_t pad1;
 };
 
 template <int CONN> __device__ __forceinline__ bool has_off(uint32_t smask, int k) {
@@ -186,27 +189,37 @@ __global__ __launch_bounds__(256) void k_ws_build_list(int64_t ntiles, uint8_t *
     }
 }
 
-// one visit of a dirty tile: relax to the local fix-point, write the changed costs back, wake the tiles that read them
+// one visit of a dirty tile: relax to the local fix-point, write the changed costs back, wake the tiles that read them.
+// Sweeps after the first only re-evaluate voxels a neighbour of which changed (flag byte per z-column in LDS).
+// theta gates the flood: a cost above it is not accepted yet (the tile is parked in `pending`), so that below the level
+// where the bulk of the volume connects only final costs spread -- no wave of provisional costs to correct later.
 template <int CONN>
 __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__restrict__ I, uint16_t *C,
-                                                  const uint32_t *__restrict__ list, uint8_t *dirty) {
+                                                  const uint32_t *__restrict__ list, uint8_t *dirty, uint8_t *pending,
+                                                  WsState *st, uint32_t theta) {
     __shared__ uint32_t s[NCELL];
+    __shared__ uint32_t s_act[TY][TX];
+    __shared__ uint32_t s_new, s_rej;
     const int64_t tile = list[blockIdx.x];
     int z0, y0, x0;
     tile_origin(g, tile, z0, y0, x0);
     load_tile(g, z0, y0, x0, I, C, s);
-    __syncthreads();
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    s_act[ly][lx] = 0;
+    if (threadIdx.x == 0) { s_new = 0; s_rej = NONE; }
+    __syncthreads();
     const bool col = x0 + lx < g.w && y0 + ly < g.h;
     const int nz = min(TZ, (int)(g.d - z0));
-    uint32_t chg = 0;
+    uint32_t chg = 0, fresh = 0, rej = NONE;
     int it = 0;
     bool more = true;
     while (more && it < RELAX_ITCAP) {
         bool any = false;
         if (col) {
-            for (int q = 0; q < nz; q++) {
-                const int zz = (it & 1) ? nz - 1 - q : q; // alternate the sweep direction
+            uint32_t a = it == 0 ? (1u << nz) - 1u : atomicExch(&s_act[ly][lx], 0u);
+            while (a) {
+                const int zz = (it & 1) ? 31 - __clz(a) : __ffs(a) - 1; // alternate the sweep direction
+                a &= ~(1u << zz);
                 const int ci = ((zz + 1) * BY + (ly + 1)) * BX + (lx + 1);
                 const uint32_t cell = s[ci];
                 const uint32_t c = cell >> 16, iv = cell & 0xFFFFu;
@@ -220,10 +233,30 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
                     const uint32_t m = max(qv >> 16, absdiff(qv & 0xFFFFu, iv));
                     best = min(best, m);
                 }
-                if (best < c) {
-                    s[ci] = (best << 16) | iv;
-                    chg |= 1u << zz;
-                    any = true;
+                if (best >= c) continue;
+                if (best > theta) {
+                    rej = min(rej, best);
+                    continue;
+                }
+                s[ci] = (best << 16) | iv;
+                chg |= 1u << zz;
+                fresh += c == CINF;
+                any = true;
+                // the neighbours inside the tile have to look again
+#pragma unroll
+                for (int cy = -1; cy <= 1; cy++) {
+#pragma unroll
+                    for (int cx = -1; cx <= 1; cx++) {
+                        uint32_t m3 = 0;
+#pragma unroll
+                        for (int dz = -1; dz <= 1; dz++)
+                            if (has_off<CONN>(g.smask, (dz + 1) * 9 + (cy + 1) * 3 + (cx + 1))) m3 |= 1u << (dz + 1);
+                        if (!m3) continue;
+                        const int tx = lx + cx, ty = ly + cy;
+                        if ((unsigned)tx >= (unsigned)TX || (unsigned)ty >= (unsigned)TY) continue;
+                        const uint32_t bits = ((m3 << zz) >> 1) & ((1u << nz) - 1u);
+                        if (bits) atomicOr(&s_act[ty][tx], bits);
+                    }
                 }
             }
         }
@@ -231,8 +264,9 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
         it++;
     }
     if (more && threadIdx.x == 0) dirty[tile] = 1; // iteration cap: come back
-    if (!chg) return;
-    for (int zz = 0; zz < nz; zz++) {
+    if (rej != NONE) atomicMin(&s_rej, rej);
+    if (fresh) atomicAdd(&s_new, fresh);
+    for (int zz = 0; zz < nz && chg; zz++) {
         if (!((chg >> zz) & 1u)) continue;
         const int z = z0 + zz, y = y0 + ly, x = x0 + lx;
         C[(int64_t)z * g.hw + (int64_t)y * g.w + x] = (uint16_t)(s[((zz + 1) * BY + (ly + 1)) * BX + (lx + 1)] >> 16);
@@ -247,6 +281,24 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
             const int64_t t = owner_tile(g, Z, Y, X);
             if (t >= 0) dirty[t] = 1;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_rej != NONE) {
+            pending[tile] = 1;
+            atomicMin(&st->minrej, s_rej);
+        }
+        if (s_new) atomicAdd(&st->assigned, s_new);
+    }
+}
+
+// the gate moved up: every parked tile is dirty again
+__global__ __launch_bounds__(256) void k_ws_wake(int64_t ntiles, uint8_t *__restrict__ dirty, uint8_t *__restrict__ pending, WsState *st) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) st->minrej = NONE;
+    if (t < ntiles && pending[t]) {
+        pending[t] = 0;
+        dirty[t] = 1;
     }
 }
 
@@ -355,27 +407,54 @@ __global__ __launch_bounds__(256) void k_ws_flatten(int64_t n, uint32_t *comp) {
     comp[p] = ws_find(comp, c);
 }
 
-// entries (markers excluded) per level: histogram, then scatter into the level's segment of elist
+// entries (markers excluded) per level: histogram, then scatter into the level's segment of elist.  A workgroup owns
+// 16384 consecutive voxels and counts in LDS (levels below BK_LB; the rare higher ones go straight to global memory), so
+// the hot global counters see one atomic per workgroup and level instead of one per wave and level.
+constexpr int BK_LB = 4096, BK_CH = 64;
 template <typename MT, bool SCATTER>
 __global__ __launch_bounds__(256) void k_ws_bucket(int64_t n, const uint16_t *__restrict__ C, const MT *__restrict__ mk,
                                                    const uint32_t *__restrict__ comp, uint32_t *__restrict__ hist_or_cursor,
                                                    uint32_t *__restrict__ elist) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool e = p < n && comp[p] == ENTRY && mk[p] == 0;
-    const uint32_t c = e ? C[p] : 0;
-    unsigned long long act = __ballot(e);
+    __shared__ uint32_t sh[BK_LB];
+    for (int i = threadIdx.x; i < BK_LB; i += 256) sh[i] = 0;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
     const int lane = threadIdx.x & 63;
-    while (act) {
-        const int leader = __ffsll((long long)act) - 1;
-        const uint32_t lc = __shfl(c, leader, 64);
-        const unsigned long long same = __ballot(e && c == lc);
-        uint32_t off = 0;
-        if (lane == leader) off = atomicAdd(&hist_or_cursor[lc], (uint32_t)__popcll(same));
-        if (SCATTER) {
-            off = __shfl(off, leader, 64);
-            if (e && c == lc) elist[off + __popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)p;
+    for (int pass = 0; pass < (SCATTER ? 2 : 1); pass++) {
+        for (int j = 0; j < BK_CH; j++) {
+            const int64_t p = b0 + (int64_t)j * 256 + threadIdx.x;
+            const bool e = p < n && comp[p] == ENTRY && mk[p] == 0;
+            const uint32_t c = e ? C[p] : 0;
+            unsigned long long act = __ballot(e);
+            while (act) {
+                const int leader = __ffsll((long long)act) - 1;
+                const uint32_t lc = __shfl(c, leader, 64);
+                const unsigned long long same = __ballot(e && c == lc);
+                const uint32_t cnt = (uint32_t)__popcll(same);
+                uint32_t off = 0;
+                if (lane == leader) {
+                    if (lc < BK_LB) off = atomicAdd(&sh[lc], cnt);
+                    else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[lc], cnt);
+                }
+                if (SCATTER && pass == 1) {
+                    off = __shfl(off, leader, 64);
+                    if (e && c == lc) elist[off + __popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)p;
+                }
+                act &= ~same;
+            }
         }
-        act &= ~same;
+        __syncthreads();
+        if (pass == 0) {
+            // flush the counts (histogram) / turn them into this workgroup's base offsets (scatter)
+            for (int i = threadIdx.x; i < BK_LB; i += 256) {
+                const uint32_t v = sh[i];
+                if (v) {
+                    const uint32_t base = atomicAdd(&hist_or_cursor[i], v);
+                    if (SCATTER) sh[i] = base;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -423,44 +502,62 @@ __global__ __launch_bounds__(256) void k_ws_keys(WsGeom g, const uint16_t *__res
 
 // ONE workgroup: the used keys in ascending order, split into classes where the label changes; class j (ascending) gets
 // time stamp base + (T-1-j): the larger the key, the earlier the pop.  Clears the bitmap for the next level.
+// Every lane summarises its chunk of bitmap words as (first label, last label, label changes inside); summaries
+// combine associatively, so the class index at the start of a chunk is an exclusive scan (wave shuffles + 16 wave totals).
+struct WsSeg {
+    int32_t first, last; // NOLAB = empty
+    uint32_t flags;
+};
+__device__ __forceinline__ WsSeg ws_seg_join(const WsSeg &a, const WsSeg &b) {
+    if (a.first == NOLAB) return b;
+    if (b.first == NOLAB) return a;
+    WsSeg r;
+    r.first = a.first;
+    r.last = b.last;
+    r.flags = a.flags + b.flags + (a.last != b.first ? 1u : 0u);
+    return r;
+}
 __global__ __launch_bounds__(1024) void k_ws_rank(WsState *st, uint32_t *used, uint32_t *__restrict__ remap, int32_t *lab,
                                                   uint32_t cap) {
-    __shared__ int32_t s_first[1024], s_last[1024];
-    __shared__ uint32_t s_flags[1024], s_off[1024];
+    __shared__ WsSeg s_wave[16];
     __shared__ uint32_t s_total;
     const uint32_t base = st->base;
     const uint32_t nw = (base + 31) >> 5;
     const uint32_t chunk = (nw + 1023) / 1024;
     const uint32_t t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
     const uint32_t w0 = min(nw, t * chunk), w1 = min(nw, w0 + chunk);
-    int32_t first = NOLAB, last = NOLAB;
-    uint32_t flags = 0;
+    WsSeg mine = {NOLAB, NOLAB, 0};
     for (uint32_t w = w0; w < w1; w++) {
         uint32_t bits = used[w];
         while (bits) {
             const uint32_t k = w * 32 + (__ffs(bits) - 1);
             bits &= bits - 1;
             const int32_t l = lab[k];
-            if (first == NOLAB) first = l;
-            else if (l != last) flags++;
-            last = l;
+            if (mine.first == NOLAB) mine.first = l;
+            else if (l != mine.last) mine.flags++;
+            mine.last = l;
         }
     }
-    s_first[t] = first;
-    s_last[t] = last;
-    s_flags[t] = flags;
+    WsSeg inc = mine; // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        WsSeg up;
+        up.first = __shfl_up(inc.first, o, 64);
+        up.last = __shfl_up(inc.last, o, 64);
+        up.flags = __shfl_up(inc.flags, o, 64);
+        if (lane >= o) inc = ws_seg_join(up, inc);
+    }
+    if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
     if (t == 0) {
-        uint32_t run = 0;
-        int32_t prev = NOLAB;
-        for (int i = 0; i < 1024; i++) {
-            if (s_first[i] == NOLAB) continue;
-            if (prev != NOLAB && s_first[i] != prev) run++;
-            s_off[i] = run;
-            run += s_flags[i];
-            prev = s_last[i];
+        WsSeg run = {NOLAB, NOLAB, 0};
+        for (int i = 0; i < 16; i++) {
+            const WsSeg w = s_wave[i];
+            s_wave[i] = run; // exclusive prefix of wave i
+            run = ws_seg_join(run, w);
         }
-        s_total = prev == NOLAB ? 0u : run + 1u;
+        s_total = run.first == NOLAB ? 0u : run.flags + 1u;
     }
     __syncthreads();
     const uint32_t T = s_total;
@@ -469,9 +566,14 @@ __global__ __launch_bounds__(1024) void k_ws_rank(WsState *st, uint32_t *used, u
         if (t == 0) st->overflow = 1;
         return;
     }
-    uint32_t cls = s_off[t];
-    bool have = false;
-    last = NOLAB;
+    WsSeg ex; // everything before this lane's chunk
+    ex.first = __shfl_up(inc.first, 1, 64);
+    ex.last = __shfl_up(inc.last, 1, 64);
+    ex.flags = __shfl_up(inc.flags, 1, 64);
+    if (lane == 0) ex = WsSeg{NOLAB, NOLAB, 0};
+    ex = ws_seg_join(s_wave[wv], ex);
+    uint32_t cls = ex.flags;
+    int32_t last = ex.last;
     for (uint32_t w = w0; w < w1; w++) {
         uint32_t bits = used[w];
         if (bits) used[w] = 0;
@@ -479,8 +581,7 @@ __global__ __launch_bounds__(1024) void k_ws_rank(WsState *st, uint32_t *used, u
             const uint32_t k = w * 32 + (__ffs(bits) - 1);
             bits &= bits - 1;
             const int32_t l = lab[k];
-            if (have && l != last) cls++;
-            have = true;
+            if (last != NOLAB && l != last) cls++;
             last = l;
             const uint32_t tn = base + (T - 1 - cls);
             remap[k] = tn;
@@ -542,7 +643,7 @@ struct WsBufs {
     uint16_t *C;
     uint32_t *comp, *tau, *elist, *key, *hist, *cursor, *bcount, *bsum, *list, *used, *remap;
     int32_t *lab;
-    uint8_t *dirty;
+    uint8_t *dirty, *pending;
     WsState *st;
     uint32_t *total;
     size_t bytes;
@@ -563,6 +664,7 @@ static void ws_layout(const WsGeom &g, uint32_t cap, char *base, WsBufs *b) {
     b->bsum = (uint32_t *)take((size_t)(std::max<int64_t>(cdiv(nblk, 4096), 16) + 2) * 4);
     b->list = (uint32_t *)take((size_t)g.ntiles * 4);
     b->dirty = (uint8_t *)take((size_t)g.ntiles);
+    b->pending = (uint8_t *)take((size_t)g.ntiles);
     b->used = (uint32_t *)take(((size_t)cap / 32 + 2) * 4);
     b->remap = (uint32_t *)take((size_t)cap * 4);
     b->lab = (int32_t *)take((size_t)cap * 4);
@@ -609,6 +711,26 @@ static int conn_of(uint32_t m) {
     default: { constexpr int CC = 0; __VA_ARGS__; } break;  \
     }
 
+struct WsTimer { // stage boundaries on the stream, read back once at the end (only when the caller asks for stats)
+    hipEvent_t ev[8];
+    int n = 0;
+    bool on = false;
+    void mark(hipStream_t st) {
+        if (!on || n >= 8) return;
+        if (hipEventCreate(&ev[n]) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(ev[n++], st);
+    }
+    void read(int64_t *out_us) {
+        for (int i = 0; i + 1 < n; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            out_us[i] = (int64_t)(ms * 1000.0f);
+        }
+        for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
+        n = 0;
+    }
+};
+
 template <typename MT>
 static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uint8_t *out8, uint16_t *cost_out, int64_t *stats,
                   hipStream_t st) {
@@ -643,7 +765,7 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         if (out) IVX_HIP(hipMemsetAsync(out, 0, (size_t)g.n * sizeof(MT), st));
         if (out8) IVX_HIP(hipMemsetAsync(out8, 0, (size_t)g.n, st));
         if (cost_out) IVX_HIP(hipMemsetAsync(cost_out, 0xFF, (size_t)g.n * 2, st));
-        if (stats) memset(stats, 0, 8 * sizeof(int64_t));
+        if (stats) memset(stats, 0, 16 * sizeof(int64_t));
         return IVX_OK;
     }
     if ((uint64_t)M + (1u << 22) > cap) { // many marker voxels: larger time-stamp tables (layout changes only behind `used`)
@@ -662,26 +784,47 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     }
     IVX_HIP(hipMemsetAsync(b.used, 0, ((size_t)cap / 32 + 2) * 4, st));
 
+    WsTimer tm;
+    tm.on = stats != nullptr;
+    tm.mark(st);
     // ---- 1. costs ------------------------------------------------------------------------------------------
-    int64_t rounds = 0, visits = 0;
+    int64_t rounds = 0, visits = 0, gates = 0;
+    IVX_HIP(hipMemsetAsync(b.pending, 0, (size_t)g.ntiles, st));
+    hipLaunchKernelGGL(k_ws_wake, dim3(1), dim3(256), 0, st, (int64_t)0, b.dirty, b.pending, b.st); // minrej = NONE
+    IVX_LAUNCH_CHECK();
+    const char *gate_env = getenv("IVX_WS_GATE");
+    const bool gate = gate_env && gate_env[0] == '1'; // measured slower on the noise phantom (more rounds AND more visits): opt-in
+    const bool trace = getenv("IVX_WS_TRACE") != nullptr;
+    uint32_t theta = gate ? 0u : CINF;
     for (;;) {
         IVX_HIP(hipMemsetAsync(&b.st->nlist, 0, 4, st));
         hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, b.dirty, b.list, b.st);
         IVX_LAUNCH_CHECK();
-        uint32_t seq = 0, nl = 0;
-        int rc = mailbox_publish(&b.st->nlist, 1, st, &seq);
+        uint32_t seq = 0, msg[3] = {0, 0, 0};
+        int rc = mailbox_publish(&b.st->nlist, 3, st, &seq);
         if (rc != IVX_OK) return rc;
-        rc = mailbox_wait(seq, st, &nl, 1);
+        rc = mailbox_wait(seq, st, msg, 3);
         if (rc != IVX_OK) return rc;
-        if (nl == 0) break;
+        const uint32_t nl = msg[0];
+        if (trace) fprintf(stderr, "ws round %lld theta %u tiles %u minrej %u assigned %u\n", (long long)rounds, theta, nl, msg[1], msg[2]);
+        if (nl == 0) {
+            if (theta >= CINF || msg[1] == NONE) break; // nothing was refused: this is the fix-point
+            // converged below the gate: lift it to the first level that has work, or all the way once the bulk is in
+            theta = (uint64_t)msg[2] * 2 > (uint64_t)g.n ? CINF : msg[1];
+            gates++;
+            hipLaunchKernelGGL(k_ws_wake, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, b.dirty, b.pending, b.st);
+            IVX_LAUNCH_CHECK();
+            continue;
+        }
         rounds++;
         visits += nl;
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_relax<CC>, dim3(nl), dim3(256), 0, st, g, I, b.C, b.list, b.dirty));
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_relax<CC>, dim3(nl), dim3(256), 0, st, g, I, b.C, b.list, b.dirty, b.pending, b.st, theta));
         IVX_LAUNCH_CHECK();
         IVX_REQUIRE(rounds < 1000000, IVX_EHIP, "watershed_ift: relaxation does not terminate");
     }
     if (cost_out) IVX_HIP(hipMemcpyAsync(cost_out, b.C, (size_t)g.n * 2, hipMemcpyDeviceToDevice, st));
 
+    tm.mark(st);
     // ---- 2. entries and zones ------------------------------------------------------------------------------
     WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_entries<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.comp));
     IVX_LAUNCH_CHECK();
@@ -692,8 +835,9 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     hipLaunchKernelGGL(k_ws_flatten, dim3(gl), dim3(256), 0, st, g.n, b.comp);
     IVX_LAUNCH_CHECK();
 
+    tm.mark(st);
     // ---- 3. entries by level -------------------------------------------------------------------------------
-    hipLaunchKernelGGL((k_ws_bucket<MT, false>), dim3(gl), dim3(256), 0, st, g.n, b.C, mk, b.comp, b.hist, b.elist);
+    hipLaunchKernelGGL((k_ws_bucket<MT, false>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g.n, b.C, mk, b.comp, b.hist, b.elist);
     IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ws_set_hist0, dim3(1), dim3(1), 0, st, b.hist, M);
     std::vector<uint32_t> hist(65536);
@@ -705,12 +849,13 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     }
     hipLaunchKernelGGL((k_ws_marker_list<MT>), dim3((unsigned)nblk), dim3(256), 0, st, g, mk, b.bcount, b.elist, b.key, b.lab);
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_ws_bucket<MT, true>), dim3(gl), dim3(256), 0, st, g.n, b.C, mk, b.comp, b.cursor, b.elist);
+    hipLaunchKernelGGL((k_ws_bucket<MT, true>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g.n, b.C, mk, b.comp, b.cursor, b.elist);
     IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ws_fill32, dim3(2048), dim3(256), 0, st, b.tau, g.n, NONE);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipStreamSynchronize(st)); // hist is on the host now
 
+    tm.mark(st);
     // ---- 4. the level chain --------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_ws_fill_used, dim3((unsigned)cdiv((M + 31) / 32, 256)), dim3(256), 0, st, b.used, M);
     IVX_LAUNCH_CHECK();
@@ -736,15 +881,19 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         start += cnt;
     }
 
+    tm.mark(st);
     // ---- 5. labels -----------------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_ws_labels<MT>, dim3(gl), dim3(256), 0, st, g.n, b.comp, b.tau, b.lab, out, out8);
     IVX_LAUNCH_CHECK();
+    tm.mark(st);
     IVX_HIP(hipMemcpyAsync(&hs, b.st, sizeof(hs), hipMemcpyDeviceToHost, st));
     IVX_HIP(hipStreamSynchronize(st));
     IVX_REQUIRE(!hs.overflow, IVX_ENOMEM, "watershed_ift: more than %u time-stamp classes", cap);
     if (stats) {
         stats[0] = rounds; stats[1] = visits; stats[2] = nlevels; stats[3] = hs.base; stats[4] = M; stats[5] = start;
-        stats[6] = g.ntiles; stats[7] = 0;
+        stats[6] = g.ntiles; stats[7] = gates;
+        for (int i = 8; i < 16; i++) stats[i] = 0;
+        tm.read(stats + 8); // [8] costs, [9] zones, [10] bucketing, [11] level chain, [12] labels (microseconds)
     }
     return IVX_OK;
 }
@@ -753,7 +902,7 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
 
 extern "C" int ivx_dev_watershed_ift(const uint16_t *cost, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
                                      const uint8_t strct[27], void *out_labels, uint8_t *out_u8, uint16_t *cost_out,
-                                     int64_t stats[8], void *stream) {
+                                     int64_t stats[16], void *stream) {
     WsGeom g;
     const int rc = make_geom(dz, dy, dx, strct, &g);
     if (rc != IVX_OK) return rc;
@@ -769,7 +918,7 @@ __global__ void k_ws_widen(const uint8_t *__restrict__ in, uint16_t *__restrict_
 }
 
 extern "C" int ivx_watershed_ift(int idtype, const void *input, const int64_t shape[3], int mdtype, const void *markers,
-                                 const uint8_t strct[27], void *output, uint16_t *cost_out, int64_t stats[8]) {
+                                 const uint8_t strct[27], void *output, uint16_t *cost_out, int64_t stats[16]) {
     HostCallGuard guard;
     IVX_REQUIRE(idtype == IVX_U8 || idtype == IVX_U16, IVX_EINVAL, "watershed_ift: input must be uint8 or uint16 (scipy raises TypeError)");
     IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "watershed_ift: markers must be int16 or int8");

@@ -82,7 +82,7 @@ def watershed_ift(image: np.ndarray, markers: np.ndarray, structure=None, want_c
     shp = img.shape if img.ndim == 3 else (1,) + img.shape
     out = np.empty(mk.shape, mk.dtype)
     cost = np.empty(img.shape, np.uint16) if want_cost else None
-    stats = (ctypes.c_int64 * 8)()
+    stats = (ctypes.c_int64 * 16)()
     L.check(L.lib().ivx_watershed_ift(L.U8 if img.dtype == np.uint8 else L.U16, L.ptr(img), L.i64(shp),
                                       L.I16 if mk.dtype == np.int16 else L.I8, L.ptr(mk), L.ptr(s3), L.ptr(out),
                                       L.ptr(cost) if want_cost else None, stats), "watershed_ift")
@@ -90,7 +90,9 @@ def watershed_ift(image: np.ndarray, markers: np.ndarray, structure=None, want_c
     if want_cost:
         res += (cost,)
     if want_stats:
-        res += (dict(zip(("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles"), stats)),)
+        names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "gate_steps", "us_costs", "us_zones",
+                 "us_bucket", "us_levels", "us_labels")
+        res += ({k: int(v) for k, v in zip(names, stats) if k != "_"},)
     return res[0] if len(res) == 1 else res
 
 
