@@ -387,6 +387,11 @@ int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *cand, uint64
 int ivx_dev_flood_or_planes(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
                             const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch, int *changed,
                             void *stream);
+/* the same with NO read-back: the count is left in the caller's DEVICE word, where ivx_comm_exchange_vote's all-reduce
+ * reads it in the next round */
+int ivx_dev_flood_or_planes_dev(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
+                                const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch,
+                                uint32_t *changed_dev, void *stream);
 /* out[v] = fill where reached (uint8 out), or data[v] = fill (in-place form, dtype of data) */
 int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reached, int dtype, void *target,
                         double fill, void *stream);
@@ -526,6 +531,33 @@ int ivx_apply_view_matrix_transform(int dtype, const void *vol, const int64_t sh
                                     const double spacing[3], const double m[16], int64_t n, int orientation,
                                     int minterpol, double cval, void *out, const int64_t oshape[3],
                                     const int64_t ostrides[3]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Z-slab communicator: RCCL over xGMI behind the C ABI (one process per GPU).
+ *   the reference's decomposition: Z pieces + one overlap slice, invesalius/data/surface.py:1362-1380;
+ *   it has no multi-GPU code, so these entry points replace nothing upstream -- they are what the sharded
+ *   driver (invesalius3_amd/parallel.py, bench.py --gpus N) binds instead of torch.distributed.
+ * librccl.so is dlopen'ed by the first call.  All buffers are DEVICE pointers; every call only enqueues on `stream`.
+ *   ivx_comm_unique_id   rank 0 makes the 128-byte id; it reaches the other ranks out of band (a file / env)
+ *   ivx_comm_init        collective over all ranks, on the calling process's current device
+ *   ivx_comm_exchange    to_down -> rank-1, to_up -> rank+1 and the mirror receives, one group (halo slices, planes)
+ *   ivx_comm_exchange_vote   the same plus an in-place int32 sum all-reduce of `vote` in the same group
+ *   ivx_comm_allreduce   in place; op 0 sum / 1 max / 2 min; IVX_I32 / I64 / F32 / F64 / U8 / I8 (no 16-bit integers)
+ *   ivx_comm_allgather   recv = world * nbytes, rank order;   ivx_comm_bcast / send / recv: raw bytes
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_comm_unique_id(uint8_t id[128]);
+int ivx_comm_init(const uint8_t id[128], int rank, int world, void **comm);
+int ivx_comm_destroy(void *comm);
+int ivx_comm_rank(const void *comm, int *rank, int *world);
+int ivx_comm_exchange(void *comm, const void *to_down, void *from_down, const void *to_up, void *from_up, size_t nbytes,
+                      void *stream);
+int ivx_comm_exchange_vote(void *comm, const void *to_down, void *from_down, const void *to_up, void *from_up,
+                           size_t nbytes, int32_t *vote, int nvote, void *stream);
+int ivx_comm_allreduce(void *comm, void *buf, size_t count, int dtype, int op, void *stream);
+int ivx_comm_allgather(void *comm, const void *send, void *recv, size_t nbytes, void *stream);
+int ivx_comm_bcast(void *comm, void *buf, size_t nbytes, int root, void *stream);
+int ivx_comm_send(void *comm, const void *buf, size_t nbytes, int peer, void *stream);
+int ivx_comm_recv(void *comm, void *buf, size_t nbytes, int peer, void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, *objs, "-o", LIB])
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, *objs, "-ldl", "-o", LIB])
     return LIB
 
 

@@ -1618,6 +1618,35 @@ extern "C" int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *c
     return IVX_OK;
 }
 
+// The same, without any read-back: the number of words that gained bits is left in the caller's DEVICE word (overwritten),
+// where the next exchange's all-reduce picks it up (ivx_comm_exchange_vote): a sharded region-growing round is
+// enqueue-only up to its single host read.
+extern "C" int ivx_dev_flood_or_planes_dev(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
+                                           const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch_,
+                                           uint32_t *changed_dev, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    const FScratch s = make_fscratch(t);
+    const int64_t nw = t.dy * t.wx;
+    IVX_REQUIRE(changed_dev, IVX_EINVAL, "flood: null counter");
+    hipStream_t st = ivx::S(stream);
+    IVX_HIP(hipMemsetAsync(changed_dev, 0, 4, st));
+    if (!nw || (!plane_a && !plane_b)) return IVX_OK;
+    uint8_t *dirty = (uint8_t *)((char *)scratch_ + s.off_dirty0);
+    const int64_t zs[2] = {z_a, z_b};
+    const uint64_t *pl[2] = {plane_a, plane_b};
+    for (int q = 0; q < 2; q++) {
+        if (!pl[q]) continue;
+        IVX_REQUIRE(zs[q] >= 0 && zs[q] < t.dz, IVX_ERANGE, "flood: plane %lld outside slab", (long long)zs[q]);
+        hipLaunchKernelGGL(k_flood_or_plane<true>, dim3((unsigned)ivx::cdiv(nw, 256)), dim3(256), 0, st,
+                           (unsigned long long *)reached + zs[q] * nw, (const unsigned long long *)pl[q],
+                           (const unsigned long long *)cand + zs[q] * nw, nw, (unsigned int *)changed_dev, t, zs[q], dirty);
+        IVX_LAUNCH_CHECK();
+    }
+    return IVX_OK;
+}
+
 // Both halo planes of a slab in one call (either may be NULL): reached[z] |= plane & cand[z] for each, the tiles of the
 // words that gained bits are marked dirty on the device, and ONE read-back returns the number of such words.
 extern "C" int ivx_dev_flood_or_planes(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,

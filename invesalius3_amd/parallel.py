@@ -1,5 +1,5 @@
-"""Z-slab sharding of the voxel path across GPUs: one process per GPU, RCCL (torch.distributed "nccl") between
-Z-neighbours only.
+"""Z-slab sharding of the voxel path across GPUs: one process per GPU, RCCL between Z-neighbours through the C ABI
+(`invesalius3_amd.comm.RcclComm` -> ivx_comm_*, csrc/ivx_comm.hip); no PyTorch.
 
 The decomposition is the reference's own (SurfaceManager.AddNewActor, invesalius/data/surface.py:1362-1380: Z pieces
 plus ONE overlap slice, concatenated):
@@ -7,13 +7,17 @@ plus ONE overlap slice, concatenated):
 * threshold            no communication (each rank thresholds its slab and its halo slices).
 * marching cubes       rank g contours the cell layers between its slices and needs ONE slice of rank g+1 (its top
                        halo); pad_bottom only on rank 0, pad_top only on the last rank; soup = concatenation.
-* region growing       local fix-point -> send the two interior boundary REACHED bit planes to the Z-neighbours ->
-                       OR the received planes into the halo slices -> all-reduce(sum) of "words that gained bits"
-                       -> repeat until 0.  Monotone, so it converges to exactly the single-GPU component.
+* region growing       local fix-point -> ncclSend/Recv of the two interior boundary REACHED bit planes to the
+                       Z-neighbours + a 4-byte all-reduce of "words that gained bits", one group on the kernels' stream
+                       -> OR the received planes into the halo slices -> one host read -> repeat until nobody gained.
+                       Monotone, so it converges to exactly the single-GPU component.
+* projections          rays inside a slice are rank-local rows (all-gather); rays along Z: MaxIP / MinIP / MeanIP
+                       all-reduce one image, LMIP / MIDA hand the per-ray state from slab to slab device-to-device.
 
-The orchestration (`slab_region_grow`, `slab_layout`, `slab_mc_args`) is backend-agnostic: the GPU backend is
-`SlabVolume` below; tests/test_parallel_gloo.py drives the same functions with a numpy backend over gloo
-(world_size 2) and checks them against the single-volume oracle.
+The orchestration (`slab_region_grow`, `slab_layout`, `slab_mc_args`, `slab_project_combine`) is written against the
+communicator's pointer-level protocol (comm.py): the GPU backend is `SlabVolume` below over `RcclComm`;
+tests/test_parallel_gloo.py drives the same functions with a numpy backend over gloo (world_size 2 and 3, host
+pointers) and tests/test_gpu_slab.py with several ranks on ONE GPU through an in-process loop-back.
 """
 from __future__ import annotations
 
@@ -68,213 +72,38 @@ def local_seeds(lay: SlabLayout, seeds_xyz_global):
     return out
 
 
-class DevPlane:
-    """A block of device memory handed to / received from a communicator (anything with data_ptr() and nbytes)."""
+def slab_region_grow(backend, comm, lay: SlabLayout) -> int:
+    """Iterate local fix-point + halo exchange to the global fix-point; returns the number of exchange rounds.
 
-    def __init__(self, ptr: int, nbytes: int, keep=None):
-        self.ptr, self.nbytes, self._keep = int(ptr), int(nbytes), keep
-
-    def data_ptr(self) -> int:
-        return self.ptr
-
-
-class TorchComm:
-    """Neighbour exchange + scalar all-reduce over torch.distributed (RCCL on GPUs, gloo in the CPU tests).
-
-    On GPUs, initialise torch's device (``torch.cuda.set_device`` / ``init_process_group``) BEFORE the first call into
-    libivx: torch ships its own ROCm runtime and cannot find the GPU once the system runtime libivx links against has
-    come up first in the process."""
-
-    def __init__(self, dist, rank: int, world: int, device="cpu"):
-        import torch
-
-        self.dist, self.rank, self.world, self.device, self.torch = dist, rank, world, device, torch
-
-    def _as_tensor(self, x):
-        """DevPlane (raw HBM owned by libivx) -> a CUDA uint8 tensor RCCL can send; tensors pass through."""
-        if x is None or not isinstance(x, DevPlane):
-            return x
-        from . import _lib as L
-
-        t = self.torch.empty(x.nbytes, dtype=self.torch.uint8, device="cuda")
-        L.check(L.lib().ivx_memcpy_d2d(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(x.ptr), ctypes.c_size_t(x.nbytes), None))
-        L.synchronize()
-        return t
-
-    def exchange_host(self, to_down: np.ndarray, to_up: np.ndarray):
-        """numpy planes (the one-time halo of the static input image)."""
-        torch = self.torch
-        mk = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)) if self.device != "cpu" else \
-            (lambda a: torch.from_numpy(np.ascontiguousarray(a)))
-        fd, fu = self.exchange(mk(to_down), mk(to_up))
-        return (None if fd is None else fd.cpu().numpy()), (None if fu is None else fu.cpu().numpy())
-
-    def exchange(self, to_down, to_up):
-        """Send `to_down` to rank-1 and `to_up` to rank+1; returns (from_down, from_up) (None at the ends)."""
-        torch, dist = self.torch, self.dist
-        to_down, to_up = self._as_tensor(to_down), self._as_tensor(to_up)
-        ops, from_down, from_up = [], None, None
-        if self.rank > 0:
-            from_down = torch.empty_like(to_down)
-            ops += [dist.P2POp(dist.isend, to_down, self.rank - 1), dist.P2POp(dist.irecv, from_down, self.rank - 1)]
-        if self.rank < self.world - 1:
-            from_up = torch.empty_like(to_up)
-            ops += [dist.P2POp(dist.isend, to_up, self.rank + 1), dist.P2POp(dist.irecv, from_up, self.rank + 1)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if self.device != "cpu":
-                torch.cuda.current_stream().synchronize()
-        return from_down, from_up
-
-    def exchange_and_vote(self, to_down, to_up, changed: int):
-        """The neighbour exchange and the vote in one collective: every rank contributes [changed | plane to the rank
-        below | plane to the rank above] to an all-gather; returns (from_down, from_up, sum of everybody's `changed`).
-        The planes are a few tens of KB, so gathering all of them costs nothing next to a second collective's latency."""
-        torch, dist = self.torch, self.dist
-        to_down, to_up = self._as_tensor(to_down), self._as_tensor(to_up)
-        if self.world == 1:
-            return None, None, int(changed)
-        ref = to_down if to_down is not None else to_up
-        if ref.dtype != torch.uint8:
-            raise TypeError("exchange_and_vote: planes must be uint8 tensors")
-        nb = int(ref.numel())
-        rec = 16 + 2 * nb  # 16-byte header keeps the planes 16-byte aligned
-        st = self.__dict__.setdefault("_gather", {})
-        if st.get("nb") != nb:
-            st["nb"] = nb
-            st["send"] = torch.zeros(rec, dtype=torch.uint8, device=ref.device)
-            st["recv"] = torch.empty(rec * self.world, dtype=torch.uint8, device=ref.device)
-        send, recv = st["send"], st["recv"]
-        send[:8].view(torch.int64).fill_(int(changed))  # a fill kernel, not a pageable host-to-device copy
-        if to_down is not None:
-            send[16:16 + nb] = to_down.reshape(-1)
-        if to_up is not None:
-            send[16 + nb:16 + 2 * nb] = to_up.reshape(-1)
-        dist.all_gather_into_tensor(recv, send)
-        recs = recv.view(self.world, rec)
-        total = int(recs[:, :8].contiguous().view(torch.int64).sum().item())  # also waits for the gather to land
-        from_down = recs[self.rank - 1, 16 + nb:16 + 2 * nb].reshape(ref.shape) if self.rank > 0 else None  # its "up" plane
-        from_up = recs[self.rank + 1, 16:16 + nb].reshape(ref.shape) if self.rank < self.world - 1 else None  # its "down" plane
-        return from_down, from_up, total
-
-    def allreduce_sum(self, value: int) -> int:
-        if self.world == 1:
-            return int(value)
-        if self.device == "cpu":
-            t = self.torch.tensor([int(value)], dtype=self.torch.int64)
-        else:  # one resident word, filled by a kernel: no pageable host-to-device copy per vote
-            if getattr(self, "_vote", None) is None:
-                self._vote = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
-            t = self._vote
-            t.fill_(int(value))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return int(t.item())
-
-    def plane_buffer(self, nbytes: int, slot: int):
-        """A resident uint8 CUDA tensor the volume exports a boundary plane into directly (slot 0 = down, 1 = up): RCCL
-        sends it as it is, no staging copy per exchange."""
-        bufs = self.__dict__.setdefault("_planes", {})
-        t = bufs.get(slot)
-        if t is None or t.numel() != nbytes:
-            t = bufs[slot] = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
-        return t
-
-    def allreduce_array(self, a: np.ndarray, op: str) -> np.ndarray:
-        """Element-wise max / min / sum of one small host array per rank (a projection image)."""
-        a = np.ascontiguousarray(a)
-        wide = a.astype(np.int32) if a.dtype in (np.int16, np.uint16, np.uint8) else a  # neither gloo nor RCCL reduce 16-bit ints
-        t = self.torch.from_numpy(wide)
-        if self.device != "cpu":
-            t = t.to(self.device)
-        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN,
-                                    "sum": self.dist.ReduceOp.SUM}[op])
-        return t.cpu().numpy().astype(a.dtype)
-
-    def _bytes_tensor(self, a: np.ndarray):
-        t = self.torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
-        return t.to(self.device) if self.device != "cpu" else t
-
-    def send_array(self, a: np.ndarray, to: int):
-        """Blocking point-to-point send of a host array (a ray-state hand-over between Z-neighbours)."""
-        self.dist.send(self._bytes_tensor(a), dst=to)
-
-    def recv_array(self, shape, dtype, frm: int) -> np.ndarray:
-        out = np.empty(shape, dtype)
-        t = self._bytes_tensor(out)
-        self.dist.recv(t, src=frm)
-        return t.cpu().numpy().view(dtype).reshape(shape)
-
-    def bcast_array(self, a: np.ndarray | None, shape, dtype, root: int) -> np.ndarray:
-        buf = np.ascontiguousarray(a, dtype=dtype) if self.rank == root else np.empty(shape, dtype)
-        t = self._bytes_tensor(buf)
-        self.dist.broadcast(t, src=root)
-        return t.cpu().numpy().view(dtype).reshape(shape)
-
-    def allgather_rows(self, a: np.ndarray, rows_per_rank) -> np.ndarray:
-        """Concatenate every rank's rows (axis 0) in rank order; ranks may own different numbers of rows."""
-        torch = self.torch
-        a = np.ascontiguousarray(a)
-        most = max(rows_per_rank)
-        pad = np.zeros((most,) + a.shape[1:], a.dtype)
-        pad[: a.shape[0]] = a
-        t = torch.from_numpy(pad.view(np.uint8).reshape(-1))  # bytes: every backend moves uint8
-        if self.device != "cpu":
-            t = t.to(self.device)
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(parts, t)
-        return np.concatenate([p.cpu().numpy().view(a.dtype).reshape(pad.shape)[:n] for p, n in zip(parts, rows_per_rank)],
-                              axis=0)
-
-
-def slab_region_grow(backend, comm: TorchComm, lay: SlabLayout) -> int:
-    """Iterate local fix-point + halo exchange to the global fix-point.  `backend` provides
-    flood_run(), export_plane(z) -> tensor, or_plane(z, tensor) -> int (words/voxels that gained bits) and optionally
-    or_planes(from_down, from_up) -> int.  Returns the number of exchange rounds.
-
-    With a communicator that offers `exchange_and_vote` the "did anybody gain anything" vote of round k travels with the
-    planes of round k+1 -- ONE collective per round instead of a neighbour exchange plus an all-reduce: the loop ends
-    when a round reports that nobody gained anything in the round before (nobody flooded since, so the planes just
-    exchanged are the ones everybody already had)."""
+    One collective and ONE host read per round.  `backend` provides
+      flood_run()            local fix-point from whatever is reached / was OR-ed in;
+      round_ptrs()        -> (to_down, from_down, to_up, from_up, nbytes, vote, stream): the two interior boundary planes
+                             of the reached set (sent where they lie), two receive planes, and an int32 word;
+      stage_vote()           vote <- "words that gained bits in my last OR" (1 before the first round: the seeds);
+      or_planes()            OR the received planes into the halo slices, count the words that gained bits;
+      read_votes()        -> (everybody's staged votes summed, my new count): the round's only host read.
+    `comm.exchange_vote` moves the planes between Z-neighbours and all-reduces the vote word in the same group, so the
+    "did anybody gain anything" vote of round k travels with the planes of round k+1: the loop ends when a round
+    reports that nobody gained anything in the round before (nobody flooded since, so the planes just exchanged are
+    the ones everybody already had).  Monotone, so it converges to exactly the single-volume component."""
     rounds = 0
     gained = True  # the first pass floods from the seeds; later ones only where a neighbour's plane brought new bits
-    merged = hasattr(comm, "exchange_and_vote")
-    prev_changed = 1  # "something happened before round 1": the seeds
-    down = up = None
     while True:
         if gained:
             backend.flood_run()
-        if gained or rounds == 0:  # otherwise the planes exported last round are still current
-            if hasattr(backend, "export_planes"):  # both planes, one stream wait
-                down, up = backend.export_planes()
-            else:
-                down = backend.export_plane(lay.first_interior) if lay.hb else None
-                up = backend.export_plane(lay.last_interior) if lay.ht else None
-        if merged:
-            from_down, from_up, total_prev = comm.exchange_and_vote(down, up, prev_changed)
-            rounds += 1
-            if total_prev == 0:
-                return rounds
-        else:
-            from_down, from_up = comm.exchange(down, up)
-        if hasattr(backend, "or_planes"):  # both planes, one read-back
-            changed = backend.or_planes(from_down, from_up)
-        else:
-            changed = 0
-            if from_down is not None:
-                changed += backend.or_plane(0, from_down)
-            if from_up is not None:
-                changed += backend.or_plane(lay.local_dz - 1, from_up)
-        gained = changed > 0
-        if merged:
-            prev_changed = changed
-            continue
+        backend.stage_vote()
+        to_down, from_down, to_up, from_up, nbytes, vote, stream = backend.round_ptrs()
+        comm.exchange_vote(to_down if lay.hb else None, from_down if lay.hb else None, to_up if lay.ht else None,
+                           from_up if lay.ht else None, nbytes, vote, 1, stream)
+        backend.or_planes()
         rounds += 1
-        if comm.allreduce_sum(changed) == 0:
+        total_prev, changed = backend.read_votes()
+        if total_prev == 0:
             return rounds
+        gained = changed > 0
 
 
-def slab_project_combine(partial: np.ndarray, comm: TorchComm, axis: int, op: str, rows_per_rank, global_dz: int,
+def slab_project_combine(partial: np.ndarray, comm, axis: int, op: str, rows_per_rank, global_dz: int,
                          gather: bool = True) -> np.ndarray:
     """MaxIP / MinIP / MeanIP of a Z-sharded volume (`slice_.py:885-889,969-973,1056-1060`).
     `partial` is this rank's reduction over its OWN slices (halo slices excluded):
@@ -295,30 +124,55 @@ def slab_project_combine(partial: np.ndarray, comm: TorchComm, axis: int, op: st
 def _make_slab_volume():
     from . import _lib as L
     from .device import DeviceBuffer, DeviceVolume, c64
+    from .comm import HostArrayOps
+
+    class _SoloComm(HostArrayOps):
+        """world of one: nothing to exchange"""
+        rank, world = 0, 1
+
+        def exchange(self, *a):
+            pass
+
+        def exchange_vote(self, *a):
+            pass
+
+        def sync(self):
+            pass
 
     class SlabVolume(DeviceVolume):
         """This rank's Z-slab (+ halo slices) resident in HBM.  Same call surface as DeviceVolume; region growing and
         marching cubes are the sharded versions."""
 
-        def __init__(self, image_slab: np.ndarray, rank: int, world: int, dist=None, spacing=(1.0, 1.0, 1.0), comm=None,
-                     device=None):
-            self.lay = slab_layout(rank, world, image_slab.shape[0])
-            # `comm` may be injected (tests/test_gpu_slab.py drives several ranks on ONE GPU through an in-process
-            # loop-back that has the same exchange / allreduce_sum interface as TorchComm)
-            self.comm = comm if comm is not None else TorchComm(dist, rank, world, device="cuda")
-            # one-time halo exchange of the IMAGE (static input): my first slice goes down, my last slice goes up
-            from_down, from_up = self.comm.exchange_host(image_slab[0], image_slab[-1])
-            parts = []
-            if self.lay.hb:
-                parts.append(np.asarray(from_down).reshape(image_slab.shape[1:])[None])
-            parts.append(image_slab)
-            if self.lay.ht:
-                parts.append(np.asarray(from_up).reshape(image_slab.shape[1:])[None])
-            local = np.concatenate(parts) if len(parts) > 1 else image_slab
-            super().__init__(np.ascontiguousarray(local), spacing=spacing, device=device)
+        def __init__(self, image_slab: np.ndarray, rank: int, world: int, comm=None, spacing=(1.0, 1.0, 1.0), device=None):
+            if image_slab.dtype != np.int16 or image_slab.ndim != 3:
+                raise TypeError("image slab must be a 3-D int16 array")
+            self.lay = lay = slab_layout(rank, world, image_slab.shape[0])
+            if comm is None:
+                if world != 1:
+                    raise ValueError("SlabVolume: a communicator is required for world > 1 (invesalius3_amd.comm.init_from_env)")
+                comm = _SoloComm()
+            self.comm = comm
+            super().__init__(None, shape=(lay.local_dz,) + tuple(image_slab.shape[1:]), spacing=spacing, device=device)
+            # my slices go to their place in HBM; the halo slices of the IMAGE (static input) come from the Z-neighbours
+            # device to device: my first slice goes down, my last slice goes up (the reference's o_piece = 1)
+            sb = self.dy * self.dx * 2
+            img = np.ascontiguousarray(image_slab)
+            L.check(L.lib().ivx_memcpy_h2d(self.image.raw_at(lay.hb * sb), L.ptr(img), ctypes.c_size_t(img.nbytes)))
+            self.comm.exchange(self.image.raw_at(lay.first_interior * sb), self.image.raw_at(0),
+                               self.image.raw_at(lay.last_interior * sb), self.image.raw_at((lay.local_dz - 1) * sb), sb,
+                               self.stream)
+            self.sync()
             self.plane_words = self.dy * self.plan.wx
-            self._send = [DeviceBuffer(self.plane_words * 8) for _ in range(2)]
+            self._recv = [DeviceBuffer(self.plane_words * 8) for _ in range(2)]
+            self._votes = DeviceBuffer(64)  # int32 [0] vote travelling with the planes, [1] words my last OR gained
             self._cand = self.cand
+
+        def close(self):
+            for b in getattr(self, "_recv", []) + [getattr(self, "_votes", None)]:
+                if b is not None:
+                    b.close()
+            self._recv, self._votes = [], None
+            super().close()
 
         # -- backend protocol of slab_region_grow ---------------------------------------------------------------
         def flood_run(self):
@@ -327,58 +181,30 @@ def _make_slab_volume():
                                               self.flood_scratch.ptr, ctypes.byref(r), self.stream), "flood_run")
             self._rounds += r.value
 
-        def export_plane(self, z: int):
-            slot = 0 if z == self.lay.first_interior else 1
+        def round_ptrs(self):
             nb = self.plane_words * 8
-            if hasattr(self.comm, "plane_buffer") and self.comm.device != "cpu":
-                # straight into the tensor RCCL sends (TorchComm): one device copy, one stream wait
-                t = self.comm.plane_buffer(nb, slot)
-                L.check(L.lib().ivx_memcpy_d2d(ctypes.c_void_p(t.data_ptr()), self.reached.at(z * nb), ctypes.c_size_t(nb),
-                                               self.stream))
-                self.sync()  # complete before the communicator (RCCL runs on torch's stream) reads it
-                return t
-            b = self._send[slot]
-            L.check(L.lib().ivx_memcpy_d2d(b.ptr, self.reached.at(z * nb), ctypes.c_size_t(nb), self.stream))
+            return (self.reached.at(self.lay.first_interior * nb), self._recv[0].ptr, self.reached.at(self.lay.last_interior * nb),
+                    self._recv[1].ptr, nb, self._votes.ptr, self.stream)
+
+        def _seed_votes(self):
+            """before round 1: "something happened" = the seeds"""
+            L.check(L.lib().ivx_memset(self._votes.ptr, 0, ctypes.c_size_t(8), self.stream))
+            L.check(L.lib().ivx_memset(self._votes.at(4), 1, ctypes.c_size_t(1), self.stream))  # votes[1] = 1
+
+        def stage_vote(self):
+            L.check(L.lib().ivx_memcpy_d2d(self._votes.ptr, self._votes.at(4), ctypes.c_size_t(4), self.stream))
+
+        def or_planes(self):
+            pd = self._recv[0].ptr if self.lay.hb else None
+            pu = self._recv[1].ptr if self.lay.ht else None
+            L.check(L.lib().ivx_dev_flood_or_planes_dev(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr, c64(0), pd,
+                                                        c64(self.lay.local_dz - 1), pu, self.flood_scratch.ptr,
+                                                        self._votes.at(4), self.stream), "flood_or_planes")
+
+        def read_votes(self):
             self.sync()
-            return DevPlane(b.ptr.value, nb, keep=b)
-
-        def export_planes(self):
-            """(plane for the rank below, plane for the rank above), None at the ends; ONE stream wait for both"""
-            nb = self.plane_words * 8
-            direct = hasattr(self.comm, "plane_buffer") and self.comm.device != "cpu"
-            out = []
-            for slot, (have, z) in enumerate(((self.lay.hb, self.lay.first_interior), (self.lay.ht, self.lay.last_interior))):
-                if not have:
-                    out.append(None)
-                    continue
-                if direct:
-                    t = self.comm.plane_buffer(nb, slot)
-                    dst = ctypes.c_void_p(t.data_ptr())
-                    out.append(t)
-                else:
-                    b = self._send[slot]
-                    dst = b.ptr
-                    out.append(DevPlane(b.ptr.value, nb, keep=b))
-                L.check(L.lib().ivx_memcpy_d2d(dst, self.reached.at(z * nb), ctypes.c_size_t(nb), self.stream))
-            if out[0] is not None or out[1] is not None:
-                self.sync()  # complete before the communicator (RCCL runs on torch's stream) reads them
-            return out[0], out[1]
-
-        def or_planes(self, from_down, from_up) -> int:
-            chg = ctypes.c_int(0)
-            pd = ctypes.c_void_p(from_down.data_ptr()) if from_down is not None else None
-            pu = ctypes.c_void_p(from_up.data_ptr()) if from_up is not None else None
-            L.check(L.lib().ivx_dev_flood_or_planes(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr, c64(0), pd,
-                                                    c64(self.lay.local_dz - 1), pu, self.flood_scratch.ptr,
-                                                    ctypes.byref(chg), self.stream), "flood_or_planes")
-            return chg.value
-
-        def or_plane(self, z: int, tensor) -> int:
-            chg = ctypes.c_int(0)
-            L.check(L.lib().ivx_dev_flood_or_plane(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr, c64(z),
-                                                   ctypes.c_void_p(tensor.data_ptr()), self.flood_scratch.ptr,
-                                                   ctypes.byref(chg), self.stream), "flood_or_plane")
-            return chg.value
+            v = self._votes.download((2,), np.int32)
+            return int(v[0]), int(v[1])
 
         # -- sharded operations ----------------------------------------------------------------------------------
         def region_grow(self, seeds_xyz_global, t0, t1, strct, fill: int = 1, select_value=254) -> int:
@@ -402,6 +228,7 @@ def _make_slab_volume():
                                                L.ptr(seeds), c64(len(seeds)), self._cand.ptr, self.reached.ptr,
                                                self.flood_scratch.ptr, st), "region_grow")
             self._rounds = 0
+            self._seed_votes()
             slab_region_grow(self, self.comm, self.lay)
             self._gate_armed = False  # an armed gate has been opened by the first local flood
             self._apply_reached(fill, select_value, shared)
@@ -483,14 +310,14 @@ def _make_slab_volume():
             state = DeviceBuffer(npix * 5 * 8 + 16)
             out = DeviceBuffer(npix * 2 + 16)
             first, last = lay.rank == 0, lay.rank == lay.world - 1
-            if not first:
-                state.upload(self.comm.recv_array((npix * 5,), np.float64, lay.rank - 1))
+            if not first:  # the per-ray state arrives from the lower neighbour device to device, on this stream
+                self.comm.recv(state.ptr, npix * 5 * 8, lay.rank - 1, self.stream)
             L.check(lib.ivx_dev_rays_z_slab(code, L.I16, src, c64(nint), c64(self.dy), c64(self.dx), ctypes.c_double(p0),
                                             ctypes.c_double(p1), mm.ptr, None if first else state.ptr, None if last else state.ptr,
                                             L.I16, out.ptr, status.ptr, self.stream), "rays_z_slab")
-            self.sync()
             if not last:
-                self.comm.send_array(state.download((npix * 5,), np.float64), lay.rank + 1)
+                self.comm.send(state.ptr, npix * 5 * 8, lay.rank + 1, self.stream)
+            self.sync()
             img = out.download((self.dy, self.dx), np.int16) if last else None
             bad = int(status.download((1,), np.int32)[0]) if last else 0
             for b in (state, out, mm, status):

@@ -11,24 +11,43 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 class NumpyBackend:
-    """bool-array stand-in for the bit-plane kernels: flood_run = binary propagation inside `cand`."""
+    """bool-array stand-in for the bit-plane kernels (flood_run = binary propagation inside `cand`) speaking the backend
+    protocol of parallel.slab_region_grow with HOST pointers: planes are uint8 arrays, the votes one int32 pair."""
 
-    def __init__(self, cand, reached, strct):
-        self.cand, self.reached, self.strct = cand, reached, strct
+    def __init__(self, cand, reached, strct, lay):
+        self.cand, self.reached, self.strct, self.lay = cand, reached, strct, lay
+        shp = cand.shape[1:]
+        self.send = [np.zeros(shp, np.uint8), np.zeros(shp, np.uint8)]
+        self.recv = [np.zeros(shp, np.uint8), np.zeros(shp, np.uint8)]
+        self.votes = np.array([0, 1], np.int32)  # [1] = 1: "something happened before round 1" (the seeds)
+        self.reads = 0
 
     def flood_run(self):
         from scipy import ndimage
         if self.reached.any():
             self.reached = ndimage.binary_propagation(self.reached, structure=self.strct, mask=self.cand)
 
-    def export_plane(self, z):
-        import torch
-        return torch.from_numpy(self.reached[z].astype(np.uint8).copy())
+    def stage_vote(self):
+        self.votes[0] = self.votes[1]
 
-    def or_plane(self, z, tensor):
-        add = tensor.numpy().astype(bool) & self.cand[z] & ~self.reached[z]
-        self.reached[z] |= add
-        return int(add.sum())
+    def round_ptrs(self):
+        self.send[0][:] = self.reached[self.lay.first_interior]
+        self.send[1][:] = self.reached[self.lay.last_interior]
+        return (self.send[0].ctypes.data, self.recv[0].ctypes.data, self.send[1].ctypes.data, self.recv[1].ctypes.data,
+                self.send[0].nbytes, self.votes.ctypes.data, None)
+
+    def or_planes(self):
+        changed = 0
+        for have, z, buf in ((self.lay.hb, 0, self.recv[0]), (self.lay.ht, self.lay.local_dz - 1, self.recv[1])):
+            if have:
+                add = buf.astype(bool) & self.cand[z] & ~self.reached[z]
+                self.reached[z] |= add
+                changed += int(add.sum())
+        self.votes[1] = changed
+
+    def read_votes(self):
+        self.reads += 1
+        return int(self.votes[0]), int(self.votes[1])
 
 
 def main():
@@ -55,8 +74,9 @@ def main():
     for sx, sy, sz in par.local_seeds(lay, seeds):
         if cand[sz, sy, sx]:
             reached[sz, sy, sx] = True
-    be = NumpyBackend(cand, reached, strct)
-    comm = par.TorchComm(dist, rank, world, device="cpu")
+    from _ptr_comm import GlooPtrComm
+    be = NumpyBackend(cand, reached, strct, lay)
+    comm = GlooPtrComm(dist, rank, world)
     rounds = par.slab_region_grow(be, comm, lay)
     interior = be.reached[lay.first_interior: lay.last_interior + 1]
     np.save(os.path.join(outdir, "reached_%d.npy" % rank), interior)
@@ -82,11 +102,14 @@ def main():
             img = par.slab_project_combine(partial, comm, ax, op, [nz] * world, nz * world)
             np.save(os.path.join(outdir, "proj_%d_%d_%s.npy" % (rank, ax, op)), img)
     # the hand-over primitives of the Z-ray pipeline: a token walks up the ranks, the last one's value is broadcast
-    tok = np.arange(7, dtype=np.float64) if rank == 0 else comm.recv_array((7,), np.float64, rank - 1)
+    tok = np.arange(7, dtype=np.float64)
+    if rank > 0:
+        comm.recv(tok.ctypes.data, tok.nbytes, rank - 1, None)
     tok = tok + rank
     if rank < world - 1:
-        comm.send_array(tok, rank + 1)
+        comm.send(tok.ctypes.data, tok.nbytes, rank + 1, None)
     final = comm.bcast_array(tok if rank == world - 1 else None, (7,), np.float64, world - 1)
+    assert be.reads == rounds  # ONE host read per exchange round
     np.save(os.path.join(outdir, "token_%d.npy" % rank), final)
     dist.barrier()
     dist.destroy_process_group()

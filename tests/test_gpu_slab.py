@@ -1,8 +1,8 @@
-"""GPU: the multi-GPU slab backend (invesalius3_amd.parallel.SlabVolume) with 2 and 3 ranks driven on ONE device through
-an in-process loop-back communicator (same interface as TorchComm; RCCL itself needs >= 2 GPUs).  Exercises the real HIP
-path of every sharded step -- image halo, reached-plane export / OR, convergence loop, per-rank marching-cubes piece --
-against the single-volume oracle.  No torch here: planes are raw device buffers (DevPlane); TorchComm wraps them in
-CUDA tensors only when real RCCL traffic is needed."""
+"""GPU: the multi-GPU slab backend (invesalius3_amd.parallel.SlabVolume) with 2, 3 and 8 ranks driven on ONE device through
+an in-process loop-back communicator (tests/_ptr_comm.py: the pointer-level protocol of comm.RcclComm; RCCL itself refuses
+two ranks on one GPU).  Exercises the real HIP path of every sharded step -- device-to-device image halo, boundary planes
+sent from where they lie, OR + vote, convergence loop with one host read per round, per-rank marching-cubes piece, the
+Z-ray state hand-over -- against the single-volume oracle; plus the RCCL binding itself at world size 1."""
 import threading
 
 import numpy as np
@@ -14,85 +14,7 @@ from conftest import synth_volume
 pytestmark = pytest.mark.gpu
 
 
-class LoopbackWorld:
-    def __init__(self, world):
-        self.world = world
-        self.barrier = threading.Barrier(world)
-        self.box = {}
-        self.acc = [0] * world
-        self.p2p = {}
-        self.cv = threading.Condition()
-
-    def comm(self, rank):
-        return LoopbackComm(self, rank)
-
-
-class LoopbackComm:
-    def __init__(self, w, rank):
-        self.w, self.rank, self.world = w, rank, w.world
-
-    def exchange_host(self, to_down, to_up):
-        return self.exchange(np.array(to_down), np.array(to_up))
-
-    def exchange(self, to_down, to_up):
-        # same process, same device: the peer reads the sender's plane in place (the sender does not touch it again
-        # before the second barrier)
-        w = self.w
-        if self.rank > 0:
-            w.box[(self.rank, "down")] = to_down
-        if self.rank < self.world - 1:
-            w.box[(self.rank, "up")] = to_up
-        w.barrier.wait()
-        from_down = w.box[(self.rank - 1, "up")] if self.rank > 0 else None
-        from_up = w.box[(self.rank + 1, "down")] if self.rank < self.world - 1 else None
-        w.barrier.wait()
-        return from_down, from_up
-
-    def allreduce_sum(self, value):
-        w = self.w
-        w.acc[self.rank] = int(value)
-        w.barrier.wait()
-        total = sum(w.acc)
-        w.barrier.wait()
-        return total
-
-    def allreduce_array(self, a, op):
-        w = self.w
-        w.box[(self.rank, "arr")] = np.array(a)
-        w.barrier.wait()
-        parts = [w.box[(r, "arr")] for r in range(self.world)]
-        out = {"max": np.maximum.reduce, "min": np.minimum.reduce, "sum": np.add.reduce}[op](parts)
-        w.barrier.wait()
-        return out
-
-    def send_array(self, a, to):
-        w = self.w
-        with w.cv:
-            w.p2p[(self.rank, to)] = np.array(a)
-            w.cv.notify_all()
-
-    def recv_array(self, shape, dtype, frm):
-        w = self.w
-        with w.cv:
-            w.cv.wait_for(lambda: (frm, self.rank) in w.p2p, timeout=120)
-            return w.p2p.pop((frm, self.rank)).reshape(shape)
-
-    def bcast_array(self, a, shape, dtype, root):
-        w = self.w
-        if self.rank == root:
-            w.box[("bcast", root)] = np.array(a, dtype=dtype)
-        w.barrier.wait()
-        out = w.box[("bcast", root)].copy()
-        w.barrier.wait()
-        return out
-
-    def allgather_rows(self, a, rows_per_rank):
-        w = self.w
-        w.box[(self.rank, "rows")] = np.array(a)
-        w.barrier.wait()
-        out = np.concatenate([w.box[(r, "rows")] for r in range(self.world)], axis=0)
-        w.barrier.wait()
-        return out
+from _ptr_comm import LoopbackWorld  # noqa: E402  (N ranks as threads on ONE GPU, device-pointer protocol)
 
 
 @pytest.mark.parametrize("world,conn", [(2, 3), (3, 1)])
@@ -110,7 +32,7 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
 
     def run(rank):
         try:
-            vol = SlabVolume(full[rank * nz:(rank + 1) * nz], rank, world, spacing=(0.5, 0.5, 2.0), comm=lw.comm(rank))
+            vol = SlabVolume(full[rank * nz:(rank + 1) * nz], rank, world, comm=lw.comm(rank), spacing=(0.5, 0.5, 2.0))
             vol.threshold(t0, t1)
             vol.region_grow(seeds, t0, t1, strct, fill=1, select_value=254)
             tris = vol.marching_cubes(from_binary=True, download=True)
@@ -173,85 +95,36 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
             assert img.dtype == want.dtype and np.array_equal(img, want), (r, ax, op)
 
 
-_TORCH_PLANES = r"""
-import sys, threading
-import torch
-torch.cuda.init()                      # torch's HIP runtime first, as in bench.py: it cannot come up after libivx's
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import numpy as np
-from scipy.ndimage import generate_binary_structure
-from conftest import synth_volume
-from test_gpu_slab import LoopbackWorld, LoopbackComm
-from invesalius3_amd.parallel import SlabVolume
-from oracle import oracle
-oracle.build()
+def test_rccl_communicator_world_of_one(ivxlib):
+    """The RCCL binding behind the C ABI (csrc/ivx_comm.hip, dlopen of librccl.so): unique id, ncclCommInitRank on this
+    GPU, and every collective of the protocol at world size 1; a SlabVolume over it equals the plain DeviceVolume."""
+    from invesalius3_amd.comm import RcclComm
+    from invesalius3_amd.device import DeviceBuffer, DeviceVolume
+    from invesalius3_amd.parallel import SlabVolume
 
-
-class LoopbackTorchComm(LoopbackComm):
-    device = "cuda"
-
-    def plane_buffer(self, nbytes, slot):
-        bufs = self.__dict__.setdefault("_planes", {})
-        if slot not in bufs or bufs[slot].numel() != nbytes:
-            bufs[slot] = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        return bufs[slot]
-
-    def exchange(self, to_down, to_up):
-        if isinstance(to_down, np.ndarray) or isinstance(to_up, np.ndarray):  # the one-time image halo
-            return super().exchange(to_down, to_up)
-        for t in (to_down, to_up):
-            assert t is None or (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8)
-        # hand the peer a COPY, as a real exchange would (the sender's buffer is rewritten next round)
-        cd, cu = (None if to_down is None else to_down.clone()), (None if to_up is None else to_up.clone())
-        torch.cuda.current_stream().synchronize()  # as TorchComm.exchange does: the copies run on torch's stream
-        return super().exchange(cd, cu)
-
-
-world, nz = 3, 20
-full = synth_volume((world * nz, 48, 128), seed=79)
-t0, t1 = -850, 3071
-strct = generate_binary_structure(3, 3)
-z, y, x = np.unravel_index(int(np.argmax(full)), full.shape)
-seeds = [(int(x), int(y), int(z))]
-lw = LoopbackWorld(world)
-res, errs = {}, []
-
-
-def run(rank):
-    try:
-        vol = SlabVolume(full[rank * nz:(rank + 1) * nz], rank, world, comm=LoopbackTorchComm(lw, rank))
-        vol.threshold(t0, t1)
-        vol.region_grow(seeds, t0, t1, strct, fill=1, select_value=254)
-        lay = vol.lay
-        res[rank] = vol.download_out_mask()[lay.first_interior:lay.last_interior + 1]
-        vol.close()
-    except Exception as e:
-        import traceback
-        traceback.print_exc()
-        errs.append((rank, repr(e)))
-        lw.barrier.abort()
-
-
-th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-[t.start() for t in th]
-[t.join(timeout=300) for t in th]
-assert not errs, errs
-ref = np.zeros(full.shape, np.uint8)
-oracle.floodfill_threshold(full, seeds, t0, t1, 1, strct, ref)
-assert np.array_equal(np.concatenate([res[r] for r in range(world)]), ref)
-assert ref[:nz].any() and ref[-nz:].any()  # the region really crosses both slab faces
-print("torch-planes-ok")
-"""
-
-
-def test_slab_flood_through_cuda_tensor_planes(ivxlib):
-    """3 ranks on one GPU, planes exported straight into CUDA tensors (TorchComm.plane_buffer's role) and OR-ed in from
-    CUDA tensors: the plumbing RCCL traffic goes through.  In a fresh process, torch initialised first."""
-    pytest.importorskip("torch")
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-c", _TORCH_PLANES % (os.path.dirname(here), here)], capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "torch-planes-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    cid = RcclComm.unique_id()
+    assert len(cid) == 128 and any(cid)
+    comm = RcclComm(0, 1, cid)
+    a = np.arange(12, dtype=np.int16).reshape(3, 4)
+    assert np.array_equal(comm.allreduce_array(a, "max"), a)
+    assert comm.allreduce_sum(5) == 5
+    assert np.array_equal(comm.allgather_rows(a, [3]), a)
+    assert np.array_equal(comm.bcast_array(a, a.shape, a.dtype, 0), a)
+    buf = DeviceBuffer(4096)
+    buf.upload(np.arange(1024, dtype=np.int32))
+    comm.allreduce(buf.ptr, 1024, ivxlib.I32, 0, None)           # no-ops at world 1, but through librccl's entry checks
+    comm.exchange_vote(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 64, buf.ptr, 1, None)
+    comm.sync()
+    assert np.array_equal(buf.download((1024,), np.int32), np.arange(1024, dtype=np.int32))
+    img = synth_volume((20, 32, 64), seed=3)
+    strct = generate_binary_structure(3, 3)
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    sv = SlabVolume(img, 0, 1, comm=comm)
+    dv = DeviceVolume(img)
+    for v in (sv, dv):
+        v.threshold(-850, 3071)
+        v.region_grow([(int(x), int(y), int(z))], -850, 3071, strct, fill=1, select_value=254)
+    assert np.array_equal(sv.download_mask(), dv.download_mask()) and sv.reached_count() == dv.reached_count() > 100
+    sv.close()
+    dv.close()
+    comm.close()

@@ -134,57 +134,59 @@ def test_headless_argument_parsing():
         headless.main(["case.inv3", "--threshold", "1", "2", "--mask", "1"])  # either a new threshold or a saved mask
 
 
-def test_slab_region_grow_protocols_count_their_collectives():
-    """slab_region_grow against scripted stand-ins: with exchange_and_vote a flood that gains bits in k rounds costs k + 1
-    collectives (the vote of round k travels with round k + 1), a rank floods and re-exports only after a round in which
-    its halo gained something; without it (older communicators) every round is an exchange plus an all-reduce."""
+def test_slab_region_grow_counts_its_collectives_and_host_reads():
+    """slab_region_grow against scripted stand-ins: a flood that gains bits in k rounds costs k + 1 collectives (the vote
+    of round k travels with round k + 1) and k + 1 host reads; a rank floods only after a round in which its halo gained
+    something; end ranks pass no pointers for the neighbour they do not have."""
     from invesalius3_amd import parallel as par
 
     class Backend:
         def __init__(self, gains):
-            self.gains, self.floods, self.exports, self.ors = list(gains), 0, 0, 0
+            self.gains, self.floods, self.ors, self.reads, self.staged = list(gains), 0, 0, 0, 0
+            self.vote, self.changed = 0, 1  # the seeds count as "something happened"
 
         def flood_run(self):
             self.floods += 1
 
-        def export_plane(self, z):
-            self.exports += 1
-            return "plane%d" % z
+        def stage_vote(self):
+            self.staged += 1
+            self.vote = self.changed
 
-        def or_planes(self, from_down, from_up):
+        def round_ptrs(self):
+            return ("down", "rdown", "up", "rup", 64, self, "stream")
+
+        def or_planes(self):
             self.ors += 1
-            return self.gains.pop(0) if self.gains else 0
+            self.changed = self.gains.pop(0) if self.gains else 0
 
-    class Merged:
-        """two ranks' worth of votes: `other` is what the peer reports for the same rounds"""
+        def read_votes(self):
+            self.reads += 1
+            return self.vote, self.changed
+
+    class Comm:
+        """two ranks' worth of votes: `other` is what the peer contributes to the same rounds' all-reduce"""
         def __init__(self, other):
-            self.other, self.calls = list(other), 0
+            self.other, self.calls, self.args = list(other), 0, []
 
-        def exchange_and_vote(self, down, up, changed):
+        def exchange_vote(self, to_down, from_down, to_up, from_up, nbytes, vote, nvote, stream):
             self.calls += 1
-            return "fd", "fu", changed + (self.other.pop(0) if self.other else 0)
+            self.args.append((to_down, from_down, to_up, from_up, nbytes, nvote, stream))
+            vote.vote += self.other.pop(0) if self.other else 0
 
     lay = par.slab_layout(1, 3, 8)  # a middle rank: both neighbours exist
     # this rank gains in rounds 1 and 2, the peer only in round 1: rounds 1, 2 productive, round 3 gains nothing, round 4
-    # learns that -> 4 collectives, 3 floods (initial + after the two productive rounds), 3 x 2 exports
-    be, comm = Backend([5, 2, 0]), Merged([1, 3, 0, 0])  # peer's "previous changed": seeds, then its gains
+    # learns that -> 4 collectives, 4 host reads, 3 floods (initial + after the two productive rounds)
+    be, comm = Backend([5, 2, 0]), Comm([1, 3, 0, 0])  # peer's staged votes: seeds, then its gains
     rounds = par.slab_region_grow(be, comm, lay)
-    assert (rounds, comm.calls, be.floods, be.ors, be.exports) == (4, 4, 3, 3, 6)
+    assert (rounds, comm.calls, be.floods, be.ors, be.reads, be.staged) == (4, 4, 3, 4, 4, 4)
+    assert comm.args[0] == ("down", "rdown", "up", "rup", 64, 1, "stream")
     # nothing ever gained: one round to exchange, a second one to learn that nobody gained -> 2 collectives, 1 flood
-    be, comm = Backend([0]), Merged([1, 0])
-    assert par.slab_region_grow(be, comm, lay) == 2 and (comm.calls, be.floods, be.exports) == (2, 1, 2)
-
-    class Plain:
-        def __init__(self, other):
-            self.other, self.exchanges, self.votes = list(other), 0, 0
-
-        def exchange(self, down, up):
-            self.exchanges += 1
-            return "fd", "fu"
-
-        def allreduce_sum(self, v):
-            self.votes += 1
-            return v + (self.other.pop(0) if self.other else 0)
-
-    be, comm = Backend([5, 2, 0]), Plain([3, 0, 0])
-    assert par.slab_region_grow(be, comm, lay) == 3 and (comm.exchanges, comm.votes, be.floods) == (3, 3, 3)
+    be, comm = Backend([0]), Comm([1, 0])
+    assert par.slab_region_grow(be, comm, lay) == 2 and (comm.calls, be.floods, be.reads) == (2, 1, 2)
+    # end ranks: no pointers towards the missing neighbour
+    be, comm = Backend([0]), Comm([1, 0])
+    par.slab_region_grow(be, comm, par.slab_layout(0, 3, 8))
+    assert comm.args[0][:4] == (None, None, "up", "rup")
+    be, comm = Backend([0]), Comm([1, 0])
+    par.slab_region_grow(be, comm, par.slab_layout(2, 3, 8))
+    assert comm.args[0][:4] == ("down", "rdown", None, None)
