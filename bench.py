@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json configs[1]: 512x512x512 synthetic int16 volume,
-threshold + 26-neighbour region growing + marching cubes, on N x MI355X (one process per GPU).
+"""bench.py -- BASELINE.json configs[1] (default): 512x512x512 synthetic int16 volume,
+threshold + 26-neighbour region growing + marching cubes, on N x MI355X (one process per GPU, RCCL through libivx's
+ivx_comm_* -- no PyTorch).  `--config watershed` = configs[2] (1024^3 IFT watershed), `--config mip` = configs[4]
+(3-axis MaxIP sweep of 512^3 into a 2048^2 viewport); each prints its own line with `roofline` and `cpu_baseline`.
 
 A "step" is one pass of the hot path over the resident volume:
     1. out_mask = zeros                       (np.zeros of styles.py:3190)
@@ -8,12 +10,15 @@ A "step" is one pass of the hot path over the resident volume:
     3. floodfill_threshold(image, seed, lo, hi, 1, 26-conn, out_mask); mask[out_mask==1] = 254   (styles.py:3200-3214)
     4. marching cubes of the mask at iso 127 (from_binary), whole volume   (surface_process.py:100-186)
 The volume is uploaded once before the timed region (inputs resident in HBM).  N > 1: weak scaling, every rank
-owns one 512^3 Z-slab of a (512*N) x 512 x 512 volume; slab boundaries exchange one mask plane per region-growing
-round and one mask slice for marching cubes over RCCL (torch.distributed, backend "nccl").
+owns one 512^3 Z-slab of a (512*N) x 512 x 512 volume; slab boundaries exchange one reached-bit plane per
+region-growing round (ncclSend/Recv + a 4-byte all-reduce in one group) and the image's halo slice once.
+Launch: under torchrun (RANK / WORLD_SIZE / LOCAL_RANK in the environment) or plainly `python bench.py --gpus N`,
+which then starts the N ranks itself; fewer than N visible GPUs is an error, never a silent N=1.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family of the step, measured live with HIP
 events on the stream the kernels run on; `cpu_baseline` is the CPU oracle (a C/numpy restatement of the reference:
-"port") timed on a bounded sample of the same volume on this box's host cores.
+"port") timed on the SAME volume on this box's host cores; its outputs double as the full-size parity gate
+(`parity`: region voxels, triangle count and a CRC of the whole mask must equal the oracle's).
 """
 from __future__ import annotations
 
@@ -73,12 +78,40 @@ def synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
     return out
 
 
-def cpu_baseline(img, seed_xyz, sample_slices):
-    """CPU oracle on the first `sample_slices` slices, with the parallelism the REFERENCE has on each stage: numpy
-    threshold (one thread, slice loop), serial C flood fill (the Rust one is serial too), and marching cubes over the
-    reference's 20+1-slice pieces on a pool of min(pieces, host cores) workers (surface.py:1362-1380 uses
-    multiprocessing.Pool the same way; ctypes releases the GIL, so threads do here).  `value` uses the pooled
-    marching-cubes time; the one-thread time is in `sample`."""
+
+
+def src_sha16():
+    """fingerprint of the kernel sources + this file: a committed PMC summary is only quoted when it was measured on them"""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "bench.py")]
+    for d in (os.path.join(ROOT, "invesalius3_amd", "csrc"), os.path.join(ROOT, "include")):
+        files += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".h")))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(config, stage):
+    """HBM bytes per step of `stage` from the rocprofv3 --pmc passes of tools/profile_round.sh, if (and only if) the
+    committed summary was measured on exactly these sources; None otherwise (rocprofv3 cannot run inside the bench)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            j = json.load(f)
+        if j.get("src_sha16") != src_sha16() or j.get("config", "grow_mc") != config:
+            return None
+        return j["traffic_bytes_per_step"].get(stage)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def cpu_grow_mc(img, seed_xyz):
+    """CPU oracle on the WHOLE bench volume, with the parallelism the REFERENCE has on each stage: numpy threshold (one
+    thread, slice loop), serial C flood fill (the Rust one is serial too), and marching cubes over the reference's
+    20+1-slice pieces on a pool of min(pieces, host cores) workers (surface.py:1362-1380 uses multiprocessing.Pool the
+    same way; ctypes releases the GIL, so threads do here).  Returns the baseline record and the oracle's outputs."""
+    import zlib
     from concurrent.futures import ThreadPoolExecutor
 
     from scipy.ndimage import generate_binary_structure
@@ -86,88 +119,151 @@ def cpu_baseline(img, seed_xyz, sample_slices):
     from oracle import oracle as orc
 
     orc.build()
-    sub = np.ascontiguousarray(img[:sample_slices])
-    dz = sub.shape[0]
-    z, y, x = np.unravel_index(int(np.argmax(sub)), sub.shape)
+    dz = img.shape[0]
     t0 = time.perf_counter()
-    mask = np.zeros(tuple(s + 1 for s in sub.shape), np.uint8)
-    orc.set_mask_threshold_volume(mask, sub, BONE)
+    mask = np.zeros(tuple(s + 1 for s in img.shape), np.uint8)
+    orc.set_mask_threshold_volume(mask, img, BONE)
     t1 = time.perf_counter()
-    out_mask = np.zeros(sub.shape, np.uint8)
-    orc.floodfill_threshold(sub, [(int(x), int(y), int(z))], BONE[0], BONE[1], 1, generate_binary_structure(3, 3), out_mask)
+    out_mask = np.zeros(img.shape, np.uint8)
+    orc.floodfill_threshold(img, [seed_xyz], BONE[0], BONE[1], 1, generate_binary_structure(3, 3), out_mask)
     mask[1:, 1:, 1:][out_mask.astype(bool)] = 254
     t2 = time.perf_counter()
     n_pieces = int(round(dz / 20 + 0.5, 0))
     rois = [slice(i * 20, i * 20 + 21) for i in range(n_pieces) if i * 20 < dz]
     piece = lambda roi: len(orc.create_surface_piece(None, mask, roi, (1.0, 1.0, 1.0), 0, 0, True))
-    ntri = sum(piece(r) for r in rois)
-    t3 = time.perf_counter()
     cores = max(1, min(len(rois), os.cpu_count() or 1))
     with ThreadPoolExecutor(cores) as pool:
-        ntri_pool = sum(pool.map(piece, rois))
-    t4 = time.perf_counter()
-    assert ntri_pool == ntri
-    nvox = sub.size
-    total = (t2 - t0) + (t4 - t3)
-    return {
+        ntri = sum(pool.map(piece, rois))
+    t3 = time.perf_counter()
+    nvox = img.size
+    total = t3 - t0
+    rec = {
         "value": round(nvox / total / 1e6, 3), "unit": "Mvoxel/s", "cores": cores, "kind": "port",
-        "sample": "first %d of 512 slices (%d voxels): numpy threshold %.2fs + serial C floodfill %.2fs + C marching cubes "
-                  "%.2fs on %d threads over %d pieces (%.2fs on one thread; %d triangles, %.2f Mtri/s pooled); all on one "
-                  "thread: %.3f Mvoxel/s"
-                  % (dz, nvox, t1 - t0, t2 - t1, t4 - t3, cores, len(rois), t3 - t2, ntri, ntri / max(t4 - t3, 1e-9) / 1e6,
-                     nvox / (t3 - t0) / 1e6),
+        "sample": "the whole bench volume, %d slices (%d voxels): numpy threshold %.2fs + serial C floodfill %.2fs + C marching "
+                  "cubes %.2fs on %d threads over %d pieces of 20+1 slices (%d triangles, %.2f Mtri/s)"
+                  % (dz, nvox, t1 - t0, t2 - t1, t3 - t2, cores, len(rois), ntri, ntri / max(t3 - t2, 1e-9) / 1e6),
     }
+    interior = np.ascontiguousarray(mask[1:, 1:, 1:])
+    return rec, {"region_voxels": int(out_mask.sum()), "triangles": int(ntri), "mask_crc32": zlib.crc32(interior)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=512, help="edge of the per-GPU volume (BASELINE: 512)")
-    ap.add_argument("--cpu-slices", type=int, default=192, help="slices of the CPU-baseline sample (0 = skip)")
-    args = ap.parse_args()
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (fresh processes, one GPU each), relay rank 0's line."""
+    import subprocess
+    import tempfile
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    force_slab = os.environ.get("IVX_FORCE_SLAB") == "1"  # exercise the sharded path (torch + RCCL) at world 1
-    if world > 1 or force_slab:
-        import torch
-        import torch.distributed as dist  # RCCL
+    from invesalius3_amd import _lib as L
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    L.require_device()
+    have = L.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible -- one GPU per rank is required" % (args.gpus, have))
+    idfile = os.path.join(tempfile.mkdtemp(prefix="ivx_bench_"), "comm.id")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), IVX_COMM_FILE=idfile,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
+class Ranks:
+    """what the timing contract needs from the job: barrier, max over ranks, sums -- over RCCL, or trivially at N = 1"""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        self.comm = None
+        if self.world > 1:
+            from invesalius3_amd.comm import init_from_env
+            self.comm = init_from_env()
+
+    def barrier(self):
+        from invesalius3_amd import _lib as L
+        L.synchronize()
+        if self.comm is not None:
+            self.comm.barrier()
+
+    def max(self, v: float) -> float:
+        return float(self.comm.allreduce_array(np.array([v], np.float64), "max")[0]) if self.comm is not None else v
+
+    def sum(self, v: int) -> int:
+        return int(self.comm.allreduce_array(np.array([int(v)], np.int64), "sum")[0]) if self.comm is not None else int(v)
+
+
+def copy_bandwidth(vol, nvox):
+    """achievable streaming bandwidth on this box, measured the same way (HIP events, same stream): device-to-device copy
+    of the int16 volume, read + written bytes over the time of the copy"""
+    import ctypes
+
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceBuffer
+    tmp = DeviceBuffer(nvox * 2)
+    for _ in range(2):
+        L.check(L.lib().ivx_memcpy_d2d(tmp.ptr, vol.image.raw, ctypes.c_size_t(nvox * 2), vol.stream))
+    for _ in range(5):
+        with vol.timer.span("copy"):
+            L.check(L.lib().ivx_memcpy_d2d(tmp.ptr, vol.image.raw, ctypes.c_size_t(nvox * 2), vol.stream))
+    vol.sync()
+    copy_ms = float(np.median(vol.timer.collect()["copy"]))
+    tmp.close()
+    return 4.0 * nvox / (copy_ms * 1e-3) / 1e9
+
+
+def roofline(kernel, nbytes, ms, traffic, copy_gbs, extra=None):
+    achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+         "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+         "frac_of_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+         "algorithmic_bytes": nbytes, "ms": round(ms, 4)}
+    if extra:
+        r.update(extra)
+    return r
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# configs[1]: threshold + 26-neighbour region growing + marching cubes
+# ----------------------------------------------------------------------------------------------------------------
+def run_grow_mc(args, job):
+    import zlib
 
     from scipy.ndimage import generate_binary_structure
 
     from invesalius3_amd import _lib as L
     from invesalius3_amd.device import DeviceVolume
 
-    L.require_device()
-    L.set_device(local_rank if dist is not None else 0)
-    n = args.size
+    rank, world = job.rank, job.world
+    n = args.size or 512
     shape = (n, n, n)
     img = synth_v512(shape, z_offset=rank * n, z_total=world * n)
     z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
     seed = (int(x), int(y), int(z) + rank * n)  # global (x, y, z): every rank seeds the brightest voxel of its slab
     strct = generate_binary_structure(3, 3)
-
-    if dist is not None:
+    force_slab = os.environ.get("IVX_FORCE_SLAB") == "1"  # exercise the sharded path at world 1
+    t_up = time.perf_counter()
+    if world > 1 or force_slab:
         from invesalius3_amd.parallel import SlabVolume
 
-        vol = SlabVolume(img, rank, world, dist, device=local_rank)
+        vol = SlabVolume(img, rank, world, comm=job.comm, device=job.local_rank)
     else:
         vol = DeviceVolume(img)
+    vol.sync()
+    upload_ms = (time.perf_counter() - t_up) * 1e3
     nvox = img.size
 
     # Marching cubes' count, scan and triangle list depend on WHICH voxels are >= 127 only, and `mask[reached] = 254`
     # does not change that: with IVX_PREFETCH=1 the timed steps queue them on a second, low-priority stream right after
     # the threshold pass, held back until the region growing's busy rounds are over; the emit waits for the mask's final
-    # bytes (DeviceVolume.surface_prefetch; measured 0.498 -> 0.466 ms per step, profiles/r01_bench_v11_overlap*).
-    # The default is strictly one stage after the other: the per-stage roofline figures then describe kernels that
-    # had the GPU to themselves, and every GPU count runs the same schedule.
+    # bytes (DeviceVolume.surface_prefetch).  The default is strictly one stage after the other: the per-stage roofline
+    # figures then describe kernels that had the GPU to themselves, and every GPU count runs the same schedule.
     overlap = os.environ.get("IVX_PREFETCH", "") == "1"
 
     def step(prefetch=False):
@@ -184,12 +280,7 @@ def main():
 
     def barrier():
         vol.sync()
-        L.synchronize()
-        if dist is not None:
-            import torch
-
-            torch.cuda.synchronize()
-            dist.barrier()
+        job.barrier()
 
     # A recorded HIP event is a barrier packet in the stream (~4 us of idle GPU each; ten per step with every stage
     # bracketed).  The timed steps bracket only the dominant stage -- the roofline figure is measured live in the timed
@@ -215,93 +306,313 @@ def main():
     spans = vol.timer.collect()
     spans["region_grow"] = spans_timed.get("region_grow", spans.get("region_grow", []))
     reached = vol.reached_count()
-    # achievable streaming bandwidth on this box, measured the same way (HIP events, same stream): device-to-device
-    # copy of the int16 volume, read + written bytes over the time of the copy
-    copy_gbs = None
-    if rank == 0:
-        import ctypes
+    copy_gbs = copy_bandwidth(vol, nvox) if rank == 0 else None
+    # one step the way a caller without a resident volume pays for it: host -> HBM, the step, mask + triangles -> host
+    e2e_ms = None
+    if world == 1 and not force_slab:
+        t = time.perf_counter()
+        vol.image.upload(img)
+        step()
+        mask_host = vol.download_mask()
+        tris_host = vol.marching_cubes(from_binary=True, download=True)
+        e2e_ms = (time.perf_counter() - t) * 1e3
+        mask_crc, ntri_dl = zlib.crc32(mask_host), len(tris_host)
+        del tris_host
+    dt = job.max(dt)
+    ntri_all, reached_all = job.sum(ntri), job.sum(reached)
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    stage_ms = {k: float(np.mean(v)) for k, v in spans.items()}
+    mc_ms = stage_ms.get("mc_count", 0.0) + stage_ms.get("mc_emit", 0.0)
+    stage_bytes = {"threshold": 3.0 * nvox, "region_grow": 3.0 * nvox, "marching_cubes": 1.0 * nvox + 36.0 * ntri}
+    stage_time = {"threshold": stage_ms.get("threshold", 0.0), "region_grow": stage_ms.get("region_grow", 0.0),
+                  "marching_cubes": mc_ms}
+    dom = max(stage_time, key=lambda k: stage_time[k])
+    traffic = pmc_traffic("grow_mc", dom) if n == 512 and world == 1 else None
+    res = {
+        "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
+        "value": round(world * nvox / (dt / args.steps) / 1e6, 2),
+        "unit": "Mvoxel/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i16", "data": "synthetic",
+        "config": {"workload": "configs[1]: %dx%dx%d int16 per GPU, threshold(226..3071) + 26-neighbour region-grow + marching-cubes(mask@127)" % shape,
+                   "global_voxels": world * nvox, "parallelism": "z-slab x%d" % world,
+                   "collectives": "RCCL via libivx ivx_comm_* (no PyTorch)" if world > 1 else "none",
+                   "overlap": "marching-cubes count+scan+list on a second stream under region growing" if overlap else "none"},
+        "mtriangles_per_s": round(ntri / (mc_ms * 1e-3) / 1e6, 2) if mc_ms > 0 else None,
+        "triangles": ntri_all, "region_voxels": reached_all, "region_grow_rounds": rounds,
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "stage_ms_source": "region_grow: HIP events inside the timed steps; other stages: HIP events in up to 5 extra steps "
+                           "after the timed region, one stage after the other (every recorded event idles the stream for ~4 us)",
+        "stage_mvoxel_per_s": {k: round(nvox / (v * 1e-3) / 1e6, 1) for k, v in stage_time.items() if v > 0},
+        "end_to_end_ms": round(e2e_ms, 2) if e2e_ms else None,
+        "end_to_end_note": "host int16 volume -> HBM (pageable), one step, dense uint8 mask and float32 triangle soup back to "
+                           "the host; first upload at start-up took %.1f ms" % upload_ms,
+        "roofline": roofline(dom, stage_bytes[dom], stage_time[dom], traffic, copy_gbs,
+                             {"per_stage_frac": {k: round(stage_bytes[k] / (stage_time[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                 for k in stage_time if stage_time[k] > 0}}),
+        "device": L.device_name(),
+    }
+    if args.cpu and world == 1 and not force_slab:
+        rec, orc_out = cpu_grow_mc(img, seed)
+        res["cpu_baseline"] = rec
+        got = {"region_voxels": reached, "triangles": ntri, "mask_crc32": mask_crc}
+        ok = got == orc_out and ntri_dl == ntri
+        res["parity"] = {"ok": bool(ok), "checked": "region voxels, triangle count, CRC-32 of the whole uint8 mask vs the CPU oracle "
+                         "on the same volume (oracle pinned upstream for threshold / flood fill; marching-cubes table unpinned vs VTK)",
+                         "gpu": got, "oracle": orc_out}
+        if not ok:
+            print(json.dumps(res), flush=True)
+            raise SystemExit("bench.py: GPU result differs from the CPU oracle: %s vs %s" % (got, orc_out))
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
 
-        from invesalius3_amd.device import DeviceBuffer
-        tmp = DeviceBuffer(nvox * 2)
-        for _ in range(2):
-            L.check(L.lib().ivx_memcpy_d2d(tmp.ptr, vol.image.raw, ctypes.c_size_t(nvox * 2), vol.stream))
-        for _ in range(5):
-            with vol.timer.span("copy"):
-                L.check(L.lib().ivx_memcpy_d2d(tmp.ptr, vol.image.raw, ctypes.c_size_t(nvox * 2), vol.stream))
+
+# ----------------------------------------------------------------------------------------------------------------
+# configs[2]: IFT watershed at 1024^3 (replicas only: SURVEY.md 8e)
+# ----------------------------------------------------------------------------------------------------------------
+def ws_markers(img):
+    """label 1 = 5^3 cube at the brightest voxel, label 2 = 5^3 cubes at the 8 corners; int8 like
+    watershed_process.py:57"""
+    mk = np.zeros(img.shape, np.int8)
+    d, h, w = img.shape
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    z, y, x = min(max(z, 2), d - 3), min(max(y, 2), h - 3), min(max(x, 2), w - 3)
+    for cz in (0, d - 5):
+        for cy in (0, h - 5):
+            for cx in (0, w - 5):
+                mk[cz:cz + 5, cy:cy + 5, cx:cx + 5] = 2
+    mk[z - 2:z + 3, y - 2:y + 3, x - 2:x + 3] = 1
+    return mk
+
+
+def run_watershed(args, job):
+    import ctypes
+
+    from scipy import ndimage
+    from scipy.ndimage import generate_binary_structure
+
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd import watershed_process as wp
+    from invesalius3_amd.device import DeviceBuffer, Timer, c64
+
+    L.require_device()
+    L.set_device(job.local_rank)
+    n = args.size or 1024
+    shape = (n, n, n)
+    nvox = n ** 3
+    img = synth_v512(shape, seed=SEED + job.rank)
+    mk = ws_markers(img)
+    strct = generate_binary_structure(3, 1)  # con_3d = 6 is the reference's default (styles.py:1632)
+    s3 = np.ascontiguousarray(strct, dtype=np.uint8)
+    lib = L.lib()
+    st = ctypes.c_void_p()
+    L.check(lib.ivx_stream_create(ctypes.byref(st)))
+    timer = Timer(st)
+    d_img, d_mk = DeviceBuffer(nvox * 2), DeviceBuffer(nvox)
+    d_cost, d_lab, d_mask = DeviceBuffer(nvox * 2), DeviceBuffer(nvox), DeviceBuffer(nvox)
+    d_mm = DeviceBuffer(64)
+    d_img.upload(img)
+    d_mk.upload(mk)
+    d_mask.zero(st)
+    stats = (ctypes.c_int64 * 16)()
+
+    def step():
+        # watershed_process.py:55-59 + styles.py:2147-2152: (image - image.min()).astype(uint16) -> watershed_ift -> merge
+        L.check(lib.ivx_dev_minmax_f32(L.I16, d_img.ptr, c64(nvox), d_mm.ptr, st))
+        L.check(lib.ivx_stream_synchronize(st))
+        imin = int(d_mm.download((2,), np.float32)[0])
+        with timer.span("cost_image"):
+            L.check(lib.ivx_dev_shift_min_u16(d_img.ptr, c64(nvox), imin, d_cost.ptr, st))
+        with timer.span("flood"):
+            L.check(lib.ivx_dev_watershed_ift(d_cost.ptr, L.I8, d_mk.ptr, c64(n), c64(n), c64(n), L.ptr(s3), None, d_lab.ptr,
+                                              None, stats, st), "watershed_ift")
+        with timer.span("merge"):
+            L.check(lib.ivx_dev_watershed_merge(d_mask.ptr, d_lab.ptr, c64(nvox), 1, st))
+
+    def barrier():
+        L.check(lib.ivx_stream_synchronize(st))
+        job.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = job.max(time.perf_counter() - t0)
+    spans = {k: float(np.mean(v)) for k, v in timer.collect().items()}
+    lab = d_lab.download(shape, np.uint8)
+    obj = job.sum(int((lab == 1).sum()))
+    if job.rank != 0:
+        return
+    names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "gate_steps", "us_costs",
+             "us_zones", "us_bucket", "us_levels", "us_labels")
+    flood_ms = spans.get("flood", 0.0)
+    res = {
+        "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
+        "value": round(job.world * nvox / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",
+        "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "configs[2]: %dx%dx%d int16, watershed segmentation, IFT branch of do_watershed (min-shift cost image, "
+                               "6-neighbour marker flood, merge), markers: 5^3 cube at the maximum (1) + 8 corner cubes (2)" % shape,
+                   "parallelism": "replicas only (global priority order: SURVEY.md 8e)" if job.world > 1 else "single GPU"},
+        "stage_ms": {k: round(v, 3) for k, v in spans.items()},
+        "flood": {k: int(v) for k, v in zip(names, stats)},
+        "object_voxels": obj,
+        "roofline": roofline("watershed flood (k_ws_*)", 7.0 * nvox, flood_ms, None, None,
+                             {"note": "7 B/voxel = cost 2 + markers 2 read, labels 2 + mask 1 written (SURVEY.md 8d); the flood is a "
+                                      "multi-pass algorithm (relaxation rounds + zones + level chain), so the fraction is small by design"}),
+        "device": L.device_name(),
+    }
+    if args.cpu:
+        # the reference's own flood, live: scipy.ndimage.watershed_ift on a bounded sample of the same volume (its first
+        # slices with the same marker rule), one core like the reference's worker process
+        sl = min(n, max(16, int(1.0e8 // (n * n))))
+        sub = np.ascontiguousarray(img[:sl])
+        smk = ws_markers(sub)
+        cost = (sub - sub.min()).astype(np.uint16)
+        t = time.perf_counter()
+        sci = ndimage.watershed_ift(cost, smk, strct)
+        ts = time.perf_counter() - t
+        got = wp.watershed_ift(cost, smk, strct)
+        from oracle import oracle as orc
+        orc.build()
+        clean = orc.watershed_ift_clean(cost, smk, strct)
+        _, ev = orc.watershed_ift_events(cost, smk, strct)
+        res["cpu_baseline"] = {"value": round(sub.size / ts / 1e6, 3), "unit": "Mvoxel/s", "cores": 1, "kind": "reference",
+                               "sample": "live scipy.ndimage.watershed_ift (the call of watershed_process.py:57) on the first %d "
+                                         "slices (%d voxels), %.2f s" % (sl, sub.size, ts)}
+        res["parity"] = {"ok": bool(np.array_equal(got, clean)),
+                         "mismatch_vs_defect_free_oracle": int((got != clean).sum()),
+                         "mismatch_vs_live_scipy": int((got != sci).sum()), "sample_voxels": int(sub.size),
+                         "scipy_defect_events": {"requeued_unlinked": ev[0], "popped_late": ev[1], "popped_twice": ev[2], "never_popped": ev[3]},
+                         "note": "the GPU flood equals the defect-free statement of NI_WatershedIFT bit for bit; live scipy differs from "
+                                 "that statement only downstream of its linked-list defect (ni_measure.c: `if (p->next || p->prev)`)"}
+        if not res["parity"]["ok"]:
+            print(json.dumps(res), flush=True)
+            raise SystemExit("bench.py: watershed differs from the defect-free oracle")
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# configs[4]: MIP raycasting, 512^3 volume to a 2048^2 viewport, 3-axis sweep
+# ----------------------------------------------------------------------------------------------------------------
+def run_mip(args, job):
+    import ctypes
+
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceBuffer, DeviceVolume, c64
+
+    n = args.size or 512
+    shape = (n, n, n)
+    nvox = n ** 3
+    img = synth_v512(shape, seed=SEED + job.rank)
+    L.require_device()
+    vol = DeviceVolume(img, device=job.local_rank)
+    lib = L.lib()
+    f = 2048 // n if n <= 2048 and 2048 % n == 0 else 1
+    proj = DeviceBuffer(n * n * 2 + 64)
+    view = [DeviceBuffer(n * f * n * f * 2) for _ in range(3)]
+
+    def step():
+        for axis in range(3):
+            with vol.timer.span("maxip_axis%d" % axis):
+                L.check(lib.ivx_dev_mip_reduce(L.I16, vol.image.raw, c64(n), c64(n), c64(n), axis, L.MIP_MAX, proj.ptr, vol.stream))
+            with vol.timer.span("viewport_axis%d" % axis):
+                L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[axis].ptr, vol.stream))
+
+    def barrier():
         vol.sync()
-        copy_ms = float(np.median(vol.timer.collect()["copy"]))
-        copy_gbs = 4.0 * nvox / (copy_ms * 1e-3) / 1e9
-        tmp.close()
+        job.barrier()
 
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([float(ntri), float(reached)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        ntri, reached = int(c[0].item()), int(c[1].item())
-
-    if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        stage_ms = {k: float(np.mean(v)) for k, v in spans.items()}
-        mc_ms = stage_ms.get("mc_count", 0.0) + stage_ms.get("mc_emit", 0.0)
-        ntri_local = ntri // world
-        # algorithmic bytes per launch family (SURVEY.md 8d / DESIGN.md)
-        stage_bytes = {
-            "threshold": 3.0 * nvox,
-            "region_grow": 3.0 * nvox,
-            "marching_cubes": 1.0 * nvox + 36.0 * ntri_local,
-        }
-        stage_time = {"threshold": stage_ms.get("threshold", 0.0), "region_grow": stage_ms.get("region_grow", 0.0),
-                      "marching_cubes": mc_ms}
-        dom = max(stage_time, key=lambda k: stage_time[k])
-        achieved = stage_bytes[dom] / (stage_time[dom] * 1e-3) / 1e9 if stage_time[dom] > 0 else 0.0
-        # HBM traffic of the dominant stage from the committed PMC passes (rocprofv3 cannot run inside the bench):
-        # profiles/pmc_traffic.json = 2 x FETCH_SIZE + WRITE_SIZE per step, produced by tools/summarize_pmc.py
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["traffic_bytes_per_step"].get(dom) if n == 512 and world == 1 else None
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        res = {
-            "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
-            "value": round(world * nvox / (dt / args.steps) / 1e6, 2),
-            "unit": "Mvoxel/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i16", "data": "synthetic",
-            "config": {"workload": "configs[1]: %dx%dx%d int16 per GPU, threshold(226..3071) + 26-neighbour region-grow + marching-cubes(mask@127)" % shape,
-                       "global_voxels": world * nvox, "parallelism": "z-slab x%d" % world,
-                       "overlap": "marching-cubes count+scan+list on a second stream under region growing" if overlap else "none"},
-            "mtriangles_per_s": round(ntri / (mc_ms * 1e-3) / 1e6, 2) if mc_ms > 0 else None,
-            "triangles": ntri, "region_voxels": reached, "region_grow_rounds": rounds,
-            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_ms_source": "region_grow: HIP events inside the timed steps (with marching cubes' count + list running "
-                               "beside it when config.overlap says so); other stages: HIP events in up to 5 extra steps "
-                               "after the timed region, one stage after the other (every recorded event idles the stream "
-                               "for ~4 us)",
-            "stage_mvoxel_per_s": {k: round(nvox / (v * 1e-3) / 1e6, 1) for k, v in stage_time.items() if v > 0},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
-                         "frac_of_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
-                         "algorithmic_bytes": stage_bytes[dom], "ms": round(stage_time[dom], 4),
-                         "per_stage_frac": {k: round(stage_bytes[k] / (stage_time[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                            for k in stage_time if stage_time[k] > 0}},
-            "device": L.device_name(),
-        }
-        if args.cpu_slices > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(img, seed, min(args.cpu_slices, n))
-        else:
-            res["cpu_baseline"] = None
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    vol.timer.collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = job.max(time.perf_counter() - t0)
+    spans = {k: float(np.mean(v)) for k, v in vol.timer.collect().items()}
+    copy_gbs = copy_bandwidth(vol, nvox) if job.rank == 0 else None
+    got = [view[a].download((n * f, n * f), np.int16) for a in range(3)]
+    ok = all(np.array_equal(got[a], np.repeat(np.repeat(img.max(axis=a), f, axis=0), f, axis=1)) for a in range(3))
+    if job.rank != 0:
+        return
+    proj_ms = sum(v for k, v in spans.items() if k.startswith("maxip"))
+    sweep_bytes = 3 * (2.0 * nvox + 2.0 * n * n) + 3 * (2.0 * n * n + 2.0 * (n * f) ** 2)
+    worst = max((k for k in spans if k.startswith("maxip")), key=lambda k: spans[k])
+    res = {
+        "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
+        "value": round(job.world * 3 * nvox / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",
+        "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16", "data": "synthetic",
+        "config": {"workload": "configs[4]: MaxIP of a %d^3 int16 volume along each of the 3 axes, each written to a %dx%d int16 viewport "
+                               "(%dx%d rays per voxel column, volume.py:678); int16 arithmetic: fp16 cannot hold int16 data (SURVEY H3)"
+                               % (n, n * f, n * f, f, f),
+                   "parallelism": "replicas x%d" % job.world},
+        "stage_ms": {k: round(v, 4) for k, v in spans.items()},
+        "parity": {"ok": bool(ok), "checked": "all three viewports == numpy max(axis) repeated %dx%d, bit for bit" % (f, f)},
+        "roofline": roofline("3-axis MaxIP sweep + viewports", sweep_bytes, sum(spans.values()), None, copy_gbs,
+                             {"slowest_axis": worst, "slowest_axis_frac": round(2.0 * nvox / (spans[worst] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "projection_ms": round(proj_ms, 4)}),
+        "device": L.device_name(),
+    }
+    if args.cpu:
+        t = time.perf_counter()
+        ref = [np.repeat(np.repeat(np.array(img).max(axis=a), f, axis=0), f, axis=1) for a in range(3)]
+        ts = time.perf_counter() - t
+        res["cpu_baseline"] = {"value": round(3 * nvox / ts / 1e6, 2), "unit": "Mvoxel/s", "cores": 1, "kind": "reference",
+                               "sample": "numpy .max(axis) of the whole volume for the 3 axes (slice_.py:885-889,969-973,1056-1060) + "
+                                         "np.repeat to the viewport, %.2f s; VTK's ray caster is not installed" % ts}
+        del ref
+    else:
+        res["cpu_baseline"] = None
+    if not ok:
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        raise SystemExit("bench.py: viewport differs from numpy")
+    print(json.dumps(res), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=("grow_mc", "watershed", "mip"), default="grow_mc",
+                    help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2]; mip = configs[4]")
+    ap.add_argument("--size", type=int, default=None, help="edge of the per-GPU volume (defaults: 512 / 1024 / 512)")
+    ap.add_argument("--no-cpu", dest="cpu", action="store_false", help="skip the CPU baseline + full-size parity check")
+    ap.add_argument("--cpu-slices", type=int, default=None, help="(kept for old command lines; 0 = --no-cpu)")
+    args = ap.parse_args()
+    if args.cpu_slices == 0:
+        args.cpu = False
+    dflt = {"grow_mc": (20, 3), "watershed": (3, 1), "mip": (20, 3)}[args.config]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    from invesalius3_amd import _lib as L
+    L.require_device()
+    job = Ranks()
+    {"grow_mc": run_grow_mc, "watershed": run_watershed, "mip": run_mip}[args.config](args, job)
+    if job.comm is not None:
+        job.comm.barrier()
+        job.comm.close()
 
 
 if __name__ == "__main__":

@@ -120,6 +120,9 @@ int ivx_dev_mip_reduce(int dtype, const void *vol, int64_t dz, int64_t dy, int64
                        void *out, void *stream);
 int ivx_mip_reduce(int dtype, const void *vol, const int64_t shape[3], const int64_t strides[3], int axis,
                    int op, void *out, const int64_t out_strides[2]);
+/* viewport magnification of a projection: dst (h*f, w*f) = every pixel of src (h, w) repeated f x f times -- what the
+ * reference's ray caster renders for axis-aligned rays at SetImageSampleDistance(1/f) (invesalius/data/volume.py:678) */
+int ivx_dev_replicate_i16(const int16_t *src, int64_t h, int64_t w, int factor, int16_t *dst, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MIDA, LMIP, fast contour MIP

@@ -208,3 +208,38 @@ extern "C" int ivx_mip_reduce(int dtype, const void *vol, const int64_t shape[3]
     IVX_HIP(hipDeviceSynchronize());
     return download_strided2(out, osh, out_strides, d_out, osz, WS_OUT);
 }
+
+// ---- viewport: nearest-sample magnification of a projection ------------------------------------------------------
+// BASELINE configs[4] asks for a 2048 x 2048 viewport over a 512^3 volume: the reference's ray caster samples 4 x 4
+// rays per voxel column (SetImageSampleDistance(0.25), invesalius/data/volume.py:678); for axis-aligned rays every one of
+// them sees the same samples, so the viewport image IS the projection with each pixel repeated f x f times.
+namespace {
+__global__ __launch_bounds__(256) void k_replicate_i16(const int16_t *__restrict__ src, int64_t h, int64_t w, int f,
+                                                       int16_t *__restrict__ dst) {
+    const int64_t W = w * f, H = h * f;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; // 8 output pixels = one 16-byte store
+    if (i >= W * H) return;
+    const int64_t y = i / W, x = i - y * W;
+    const int16_t *row = src + (y / f) * w;
+    short v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = x + q < W ? row[(x + q) / f] : (short)0;
+    if (x + 8 <= W && (W & 7) == 0) {
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(v);
+    } else {
+        for (int q = 0; q < 8 && i + q < W * H; q++) { // ragged width: pixel by pixel, rows may straddle the chunk
+            const int64_t j = i + q, yy = j / W, xx = j - yy * W;
+            dst[j] = src[(yy / f) * w + xx / f];
+        }
+    }
+}
+} // namespace
+
+extern "C" int ivx_dev_replicate_i16(const int16_t *src, int64_t h, int64_t w, int factor, int16_t *dst, void *stream) {
+    IVX_REQUIRE(src && dst && h > 0 && w > 0 && factor >= 1, IVX_EINVAL, "replicate: bad arguments");
+    const int64_t n = h * factor * w * factor;
+    hipLaunchKernelGGL(k_replicate_i16, dim3((unsigned)ivx::cdiv(ivx::cdiv(n, 8), 256)), dim3(256), 0, ivx::S(stream), src, h, w,
+                       factor, dst);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
