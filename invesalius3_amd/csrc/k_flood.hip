@@ -204,6 +204,17 @@ __global__ __launch_bounds__(256) void k_flood_candidates(const T *__restrict__ 
 }
 
 // ---- seeds ----------------------------------------------------------------------------------------
+// Bits that enter `reached` from OUTSIDE a tile visit (seeds, a neighbour slab's plane OR-ed into a halo slice) are news
+// nobody has reported: a visit only tells its neighbours about the faces IT changed.  Wake the word's own tile and every
+// tile that can see the word.
+__device__ __forceinline__ void mark_tile_nbhd(const Tiles &t, uint8_t *__restrict__ dirty, int64_t tz, int64_t ty, int64_t tx) {
+    for (int64_t az = tz - 1; az <= tz + 1; az++)
+        for (int64_t ay = ty - 1; ay <= ty + 1; ay++)
+            for (int64_t ax = tx - 1; ax <= tx + 1; ax++)
+                if (az >= 0 && az < t.ntz && ay >= 0 && ay < t.nty && ax >= 0 && ax < t.wx)
+                    dirty[(az * t.nty + ay) * t.wx + ax] = 1;
+}
+
 template <typename T>
 __global__ void k_flood_seed(const T *__restrict__ data, Tiles t, double t0, double t1, const int64_t *__restrict__ seeds,
                              int64_t nseeds, unsigned long long *__restrict__ cand,
@@ -217,7 +228,7 @@ __global__ void k_flood_seed(const T *__restrict__ data, Tiles t, double t0, dou
     const unsigned long long bit = 1ull << (x & 63);
     atomicOr(&cand[w], bit); // a seed expands even when its barrier byte already equals `fill`
     atomicOr(&reached[w], bit);
-    dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + (x >> 6)] = 1;
+    mark_tile_nbhd(t, dirty, z / TZ, y / TY, x >> 6);
 }
 
 struct SeedPack {
@@ -237,7 +248,7 @@ __global__ void k_flood_seed_args(const T *__restrict__ data, Tiles t, double t0
     const unsigned long long bit = 1ull << (x & 63);
     atomicOr(&cand[w], bit);
     atomicOr(&reached[w], bit);
-    dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + (x >> 6)] = 1;
+    mark_tile_nbhd(t, dirty, z / TZ, y / TY, x >> 6);
 }
 
 // ---- one round over the dirty tiles ---------------------------------------------------------------
@@ -815,8 +826,14 @@ __global__ __launch_bounds__(256) void k_flood_coarse_apply(Tiles t, const unsig
     const unsigned long long whole = rowW[blockIdx.x];
     if (threadIdx.x < 64) s_chg[threadIdx.x] = 0u;
     if ((int)threadIdx.x < wx && dirty[tile0 + threadIdx.x]) {
-        if (whole >> threadIdx.x & 1ull) dirty[tile0 + threadIdx.x] = 0; // final: a wholly reached tile has nothing to gain
-        else coarse_enlist(dirty, tile0 + threadIdx.x, list, count);
+        if (whole >> threadIdx.x & 1ull) {
+            dirty[tile0 + threadIdx.x] = 0; // final: a wholly reached tile has nothing to gain
+            // ... but it was marked because bits arrived in it from OUTSIDE the flood (a seed, a neighbour slab's plane
+            // OR-ed into a halo slice): even when those bits already fill the tile, nobody has told its neighbours yet
+            s_chg[threadIdx.x] = 1u;
+        } else {
+            coarse_enlist(dirty, tile0 + threadIdx.x, list, count);
+        }
     }
     if (!whole) return; // uniform
     __syncthreads();
@@ -907,7 +924,7 @@ __global__ void k_flood_seed_forced(Tiles t, const int64_t *__restrict__ seeds, 
     const unsigned long long bit = 1ull << (x & 63);
     if (cand) atomicOr(&cand[w], bit);
     atomicOr(&reached[w], bit);
-    dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + (x >> 6)] = 1;
+    mark_tile_nbhd(t, dirty, z / TZ, y / TY, x >> 6);
 }
 
 // ---- apply: out[v] = fill where reached ---------------------------------------------------------------
@@ -1571,7 +1588,7 @@ __global__ __launch_bounds__(256) void k_flood_or_plane(unsigned long long *__re
         atomicAdd(changed, 1u);
         if (MARK) {
             const int64_t y = i / t.wx, txi = i - y * t.wx;
-            dirty[((z / TZ) * t.nty + (y / TY)) * t.wx + txi] = 1;
+            mark_tile_nbhd(t, dirty, z / TZ, y / TY, txi);
         }
     }
 }
@@ -1614,7 +1631,7 @@ extern "C" int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *c
     IVX_HIP(hipMemcpyAsync(&h, d_chg, 4, hipMemcpyDeviceToHost, st));
     IVX_HIP(hipStreamSynchronize(st));
     *changed = (int)h;
-    if (h) return ivx_dev_flood_mark_slab(p, scratch_, z, z + 1, stream);
+    if (h) return ivx_dev_flood_mark_slab(p, scratch_, z - TZ, z + 1 + TZ, stream); // the layers that can see slice z
     return IVX_OK;
 }
 

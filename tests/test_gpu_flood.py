@@ -459,3 +459,26 @@ def test_more_than_64_resident_volumes_can_flood(ivxlib, oracle):
     finally:
         for v in vols:
             v.close()
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_seed_on_a_tile_face_reaches_the_next_tile(ivxlib, oracle, axis):
+    """A seed whose only in-range neighbours lie in the ADJACENT flood tile (tiles are 64 x 16 x 16 voxels): the seed's
+    own tile visit gains nothing, so the neighbours have to be woken by the seeding itself (regression: found by the
+    8-slab configs[3] test, where a plane OR-ed into a halo slice hit the same blind spot)."""
+    from invesalius3_amd import invesalius_rs as rs
+    shape = (40, 40, 160)
+    img = np.zeros(shape, np.int16)
+    lo = [5, 5, 5]
+    lo[axis] = {0: 15, 1: 15, 2: 63}[axis]          # last voxel of the first tile along `axis`
+    hi = list(lo)
+    hi[axis] += 20
+    sl = tuple(slice(a, b + 1) for a, b in zip(lo, hi))
+    img[sl] = 1000                                   # a 1-voxel-wide line leaving the seed's tile
+    seed = (lo[2], lo[1], lo[0])
+    for conn in (1, 3):
+        s = generate_binary_structure(3, conn)
+        g, r = np.zeros(shape, np.uint8), np.zeros(shape, np.uint8)
+        rs.floodfill_threshold(img, [seed], 500, 2000, 1, s, g)
+        oracle.floodfill_threshold(img, [seed], 500, 2000, 1, s, r)
+        assert r.sum() == 21 and np.array_equal(g, r)
