@@ -375,6 +375,9 @@ int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *r
  * than `below_tiles` tiles -- its throughput-bound head is over -- or when it returns, if no round did.
  * ivx_dev_gate_wait parks `stream` behind a one-wave kernel polling the word; it gives up after `timeout_us`. */
 int ivx_dev_flood_arm_gate(const void *scratch, uint32_t *word, uint32_t value, uint32_t below_tiles);
+/* drop an arm no flood has consumed (gate opened by hand / buffers about to be freed): the arm is keyed by the scratch
+ * address, which a later allocation may reuse */
+int ivx_dev_flood_disarm_gate(const void *scratch);
 int ivx_dev_gate_wait(const uint32_t *word, uint32_t value, uint32_t timeout_us, void *stream);
 int ivx_dev_gate_open(uint32_t *word, uint32_t value, void *stream); /* open it by hand (no flood came) */
 /* mark every tile of the plan whose z-range touches [z0,z1) dirty (multi-GPU halo re-seeding) */

@@ -1479,6 +1479,13 @@ extern "C" int ivx_dev_flood_arm_gate(const void *scratch, uint32_t *word, uint3
     g_gates[scratch] = GateArm{word, value, below_tiles};
     return IVX_OK;
 }
+// forget an arm that no flood consumed (the gate was opened by hand, or the buffers are about to be freed): the entry is
+// keyed by the scratch ADDRESS, and a later allocation may get the same one
+extern "C" int ivx_dev_flood_disarm_gate(const void *scratch) {
+    std::lock_guard<std::mutex> lk(g_gates_mu);
+    g_gates.erase(scratch);
+    return IVX_OK;
+}
 extern "C" int ivx_dev_gate_open(uint32_t *word, uint32_t value, void *stream) {
     IVX_REQUIRE(word, IVX_EINVAL, "gate_open: NULL argument");
     hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, ivx::S(stream), word, value);

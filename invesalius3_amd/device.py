@@ -244,6 +244,9 @@ class DeviceVolume:
             return  # already closed (or never fully built)
         self._out_pending = None
         self._prefetch = None
+        if getattr(self, "flood_scratch", None) is not None and self.flood_scratch.ptr is not None:
+            L.lib().ivx_dev_flood_disarm_gate(self.flood_scratch.ptr)  # an unconsumed arm must not outlive the buffers
+        self._gate_armed = False
         if self._stream2 is not None:
             L.lib().ivx_stream_destroy(self._stream2)  # synchronises it first
             self._stream2 = None
@@ -486,6 +489,7 @@ class DeviceVolume:
         if self._prefetch is not None:
             if self._gate_armed:
                 L.check(L.lib().ivx_dev_gate_open(self._gate.ptr, ctypes.c_uint32(self._gate_epoch), self.stream))
+                L.check(L.lib().ivx_dev_flood_disarm_gate(self.flood_scratch.ptr))
                 self._gate_armed = False
             L.check(L.lib().ivx_stream_synchronize(self._stream2))
             self._prefetch = None
@@ -547,6 +551,7 @@ class DeviceVolume:
                 s2, cap = self._stream2, pf[2]
                 if self._gate_armed:  # no flood came in between: open the gate by hand instead of waiting it out
                     L.check(lib.ivx_dev_gate_open(self._gate.ptr, ctypes.c_uint32(self._gate_epoch), self.stream))
+                    L.check(lib.ivx_dev_flood_disarm_gate(self.flood_scratch.ptr))
                     self._gate_armed = False
                 L.check(lib.ivx_event_record(self._sync_events[1], self.stream))
                 L.check(lib.ivx_stream_wait_event(s2, self._sync_events[1]))

@@ -45,6 +45,12 @@ def run(args) -> dict:
             lo, hi = rec.threshold_range
             out["mask"] = {"index": args.mask, "name": rec.name, "threshold_range": [lo, hi]}
         if args.seed:
+            if args.threshold is None and rec.edited:
+                # the region is grown in the IMAGE inside the mask's threshold range; an edited mask (brush, cut, earlier
+                # region growing) is no longer that threshold, and growing would silently throw the edits away
+                raise SystemExit("--seed with --mask %d: that mask was edited by hand; region growing floods the image inside "
+                                 "the mask's threshold range and would discard the edits -- use --threshold LO HI instead"
+                                 % args.mask)
             seeds = [tuple(args.seed[i:i + 3]) for i in range(0, len(args.seed), 3)]
             strct = np.ones((3, 3, 3), np.uint8) if args.connectivity == 26 else _strct(args.connectivity)
             vol.zero_out_mask()
@@ -123,7 +129,7 @@ def main(argv=None) -> int:
     g = ap.add_mutually_exclusive_group()
     g.add_argument("--threshold", nargs=2, type=int, metavar=("LO", "HI"), help="threshold the image into a new mask")
     g.add_argument("--mask", type=int, default=0, help="use the project's mask with this index (default 0)")
-    ap.add_argument("--seed", nargs="+", type=int, default=None, metavar="X Y Z", help="keep the region grown from these voxels")
+    ap.add_argument("--seed", nargs="+", type=int, default=None, metavar="X Y Z", help="keep the region grown (in the image, inside the threshold range) from these voxels; refused for a hand-edited --mask")
     ap.add_argument("--connectivity", type=int, choices=(6, 18, 26), default=26)
     ap.add_argument("--largest", action="store_true", help="keep the largest connected surface")
     ap.add_argument("--smooth", action="store_true", help="context-aware smoothing")

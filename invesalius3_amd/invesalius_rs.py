@@ -32,19 +32,27 @@ def _strct(strct) -> np.ndarray:
 
 def floodfill_threshold(data, seeds, t0, t1, fill, strct, out):
     """generic_floodfill_threshold (invesalius_rs/src/floodfill.rs:96-166) through the wrapper semantics of
-    invesalius_rs/__init__.py:21-40: seeds are (x, y, z); for integer images t0/t1/fill are truncated with
-    int(); `out` (uint8, same shape) receives `fill` on the connected in-range region; voxels of `out` that
-    already hold `fill` are barriers."""
+    invesalius_rs/__init__.py:21-40: seeds are (x, y, z); for int16 images t0/t1/fill are truncated with int(); for
+    uint8 images they must be integers in 0..255 (TypeError / OverflowError like the binding's u8 extraction); `out`
+    (uint8, same shape) receives `fill` on the connected in-range region; voxels of `out` that already hold `fill` are
+    barriers."""
     if data.ndim != 3 or out.ndim != 3 or tuple(data.shape) != tuple(out.shape):
         raise TypeError("data and out must be 3-D arrays of the same shape")
     if out.dtype != np.uint8:
         raise TypeError("out must be uint8")
     code = L.dtype_code(data, (L.U8, L.I16, L.F64))
     strct_u8 = _strct(strct)
-    if data.dtype.kind in "iu":
-        t0, t1, fill = int(t0), int(t1), int(fill)
+    if data.dtype == np.int16:          # the wrapper's int() truncation (invesalius_rs/__init__.py:32-35) ...
+        t0, t1, fill = _fits(int(t0), data.dtype, "t0"), _fits(int(t1), data.dtype, "t1"), _fits(int(fill), np.dtype(np.uint8), "fill")
+    elif data.dtype == np.uint8:        # ... does not cover uint8: t0 / t1 / fill reach `extract::<u8>()` as they are
+        for name, v in (("t0", t0), ("t1", t1), ("fill", fill)):
+            if not isinstance(v, (int, np.integer)) or isinstance(v, (bool, np.bool_)):
+                raise TypeError("%s must be an integer for uint8 data (the reference's u8 extraction rejects %r)" % (name, v))
+        t0, t1, fill = (_fits(v, data.dtype, n) for n, v in (("t0", t0), ("t1", t1), ("fill", fill)))
     else:
         t0, t1, fill = float(t0), float(t1), float(fill)
+        if not 0 <= fill <= 255 or fill != int(fill):
+            raise OverflowError("fill=%r does not fit the uint8 out array" % (fill,))
     s = _seeds(seeds)
     L.check(L.lib().ivx_floodfill_threshold(
         code, L.ptr(data), L.i64(data.shape), L.i64(data.strides), L.ptr(s), ctypes.c_int64(len(s)),

@@ -73,14 +73,16 @@ class Project:
     measurements: dict = field(default_factory=dict)
     image_versions: list = field(default_factory=list)
     dirpath: str = ""
+    _owned_tmp: str = ""  # the directory open_inv3 made with mkdtemp (removed by close()); never a caller's workdir
 
     def close(self):
         """drop the memmaps and the extraction directory"""
         self.matrix = None
         self.masks.clear()
         self.image_versions.clear()
-        if self.dirpath and os.path.isdir(self.dirpath) and os.path.basename(os.path.dirname(self.dirpath)).startswith("ivx3_"):
-            shutil.rmtree(os.path.dirname(self.dirpath), ignore_errors=True)
+        if self._owned_tmp and os.path.isdir(self._owned_tmp):
+            shutil.rmtree(self._owned_tmp, ignore_errors=True)
+        self._owned_tmp = ""
         self.dirpath = ""
 
 
@@ -199,15 +201,24 @@ def open_mask_plist(filename: str) -> MaskRecord:
 
 def open_inv3(filename, workdir: str | None = None) -> Project:
     """Project.OpenPlistProject (project.py:346-376): extract, then load the folder the archive holds."""
-    base = workdir or tempfile.mkdtemp(prefix="ivx3_")
-    files = extract(filename, base)
-    if not files:
-        raise ValueError("%s holds no files" % filename)
-    return load_from_folder(os.path.abspath(os.path.dirname(files[0])))
+    owned = "" if workdir else tempfile.mkdtemp(prefix="ivx3_")
+    base = workdir or owned
+    try:
+        files = extract(filename, base)
+        if not files:
+            raise ValueError("%s holds no files" % filename)
+        p = load_from_folder(os.path.abspath(os.path.dirname(files[0])))
+    except BaseException:
+        if owned:
+            shutil.rmtree(owned, ignore_errors=True)  # nothing is returned that could clean it up later
+        raise
+    p._owned_tmp = owned
+    return p
 
 
 def save_inv3(filename, project: Project, gz: bool | None = None):
-    """Project.SavePlistProject (project.py:219-345) for image + masks (+ surface / measurement dictionaries as given)."""
+    """Project.SavePlistProject (project.py:219-345): image, filtered image versions, masks, surfaces (plist + polydata
+    file) and measurements.  A project opened with open_inv3 and written back keeps all of them."""
     gz = project.compress if gz is None else gz
     tmp = tempfile.mkdtemp(prefix="ivx3_save_")
     try:
@@ -230,9 +241,17 @@ def save_inv3(filename, project: Project, gz: bool | None = None):
             "spacing": list(project.spacing),
             "image_fiducials": [],
             "matrix": {"filename": "matrix.dat", "shape": list(image.shape), "dtype": str(image.dtype)},
-            "image_versions": [],
             "annotations": {},
         }
+        # filtered image versions (project.py:267-295): matrix_vN.dat + label
+        versions = []
+        for i, (label, mat) in enumerate(project.image_versions):
+            vname = "matrix_v%d.dat" % i
+            vpath = os.path.join(tmp, vname)
+            np.ascontiguousarray(mat).tofile(vpath)
+            filelist[vpath] = vname
+            versions.append({"label": label, "filename": vname})
+        main["image_versions"] = versions
         if project.affine is not None:
             main["affine"] = project.affine
         masks = {}
@@ -252,7 +271,26 @@ def save_inv3(filename, project: Project, gz: bool | None = None):
             filelist[ppath] = stem + ".plist"
             masks[str(index)] = stem + ".plist"
         main["masks"] = masks
-        main["surfaces"] = {}
+        # surfaces (surface.py:121-156 SavePlist): the dictionary as loaded / given + its polydata file, found next to
+        # the project it was loaded from (or at an absolute path the caller put there)
+        surfaces = {}
+        for index, sdict in project.surfaces.items():
+            stem = "surface_%d" % int(index)
+            sd = dict(sdict)
+            payload = sd.get("polydata")
+            if payload:
+                src = payload if os.path.isabs(payload) else os.path.join(project.dirpath or "", payload)
+                if not os.path.exists(src):
+                    raise FileNotFoundError("surface %s: polydata file %r not found (looked in %r)" % (index, payload, project.dirpath))
+                ext = os.path.splitext(payload)[1] or ".vtp"
+                filelist[src] = stem + ext
+                sd["polydata"] = stem + ext
+            ppath = os.path.join(tmp, stem + ".plist")
+            with open(ppath, "wb") as f:
+                plistlib.dump(sd, f)
+            filelist[ppath] = stem + ".plist"
+            surfaces[str(index)] = stem + ".plist"
+        main["surfaces"] = surfaces
         mp = os.path.join(tmp, "measurements.plist")
         with open(mp, "wb") as f:
             plistlib.dump(project.measurements or {}, f)

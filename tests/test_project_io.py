@@ -130,3 +130,59 @@ def test_truncated_matrix_is_rejected(tmp_path):
         f.truncate(10)
     with pytest.raises(ValueError, match="matrix.dat"):
         prj.load_from_folder(d)
+
+
+def test_surfaces_and_image_versions_survive_open_then_save(tmp_path):
+    """SavePlistProject keeps surfaces (plist + .vtp payload) and filtered image versions (project.py:267-307); a
+    project opened with open_inv3 and written back must not lose them (headless --save does exactly this)."""
+    rng = np.random.default_rng(3)
+    p = _project(rng)
+    vtp = tmp_path / "mesh_payload.vtp"
+    vtp.write_bytes(b"<VTKFile>not really</VTKFile>")
+    p.surfaces[0] = {"colour": [1.0, 0.5, 0.25], "index": 0, "name": "Bone surface", "polydata": str(vtp),
+                     "transparency": 0.0, "visible": True, "volume": 12.5, "area": 40.25, "category": "Default"}
+    p.image_versions.append(("Gaussian sigma 1", (p.matrix // 2).astype(np.int16)))
+    first = tmp_path / "a.inv3"
+    prj.save_inv3(first, p)
+    q = prj.open_inv3(first)
+    second = tmp_path / "b.inv3"
+    prj.save_inv3(second, q)          # the round trip that used to drop everything but image + masks
+    owned = q._owned_tmp
+    q.close()
+    assert owned and not os.path.exists(owned)
+    r = prj.open_inv3(second)
+    try:
+        assert list(r.surfaces) == [0] and r.surfaces[0]["name"] == "Bone surface" and r.surfaces[0]["volume"] == 12.5
+        assert r.surfaces[0]["polydata"] == "surface_0.vtp"
+        assert open(os.path.join(r.dirpath, "surface_0.vtp"), "rb").read() == vtp.read_bytes()
+        assert len(r.image_versions) == 1 and r.image_versions[0][0] == "Gaussian sigma 1"
+        assert np.array_equal(r.image_versions[0][1], p.matrix // 2)
+    finally:
+        r.close()
+    p.surfaces[1] = {"name": "lost payload", "polydata": str(tmp_path / "missing.vtp")}
+    with pytest.raises(FileNotFoundError):
+        prj.save_inv3(tmp_path / "c.inv3", p)
+
+
+def test_close_never_removes_a_callers_workdir_and_failed_open_cleans_up(tmp_path):
+    rng = np.random.default_rng(4)
+    p = _project(rng)
+    path = tmp_path / "case.inv3"
+    prj.save_inv3(path, p)
+    work = tmp_path / "ivx3_mine"          # looks like one of ours by name; it is not
+    work.mkdir()
+    (work / "keep.txt").write_text("caller's file")
+    q = prj.open_inv3(path, workdir=str(work))
+    q.close()
+    assert (work / "keep.txt").exists()
+    bad = tmp_path / "bad.inv3"
+    with tarfile.open(bad, "w") as tar:   # an archive without main.plist: load fails after mkdtemp + extract
+        info = tarfile.TarInfo("x/readme.txt")
+        data = b"hello"
+        info.size = len(data)
+        tar.addfile(info, io.BytesIO(data))
+    import tempfile
+    before = set(os.listdir(tempfile.gettempdir()))
+    with pytest.raises(FileNotFoundError):
+        prj.open_inv3(bad)
+    assert not [d for d in set(os.listdir(tempfile.gettempdir())) - before if d.startswith("ivx3_")]
