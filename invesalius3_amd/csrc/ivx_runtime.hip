@@ -9,6 +9,8 @@
 #include <map>
 #include <vector>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "ivx_internal.h"
 
@@ -72,16 +74,22 @@ int ws_get_s(int slot, hipStream_t stream, size_t nbytes, void **dptr) {
 }
 
 static std::recursive_mutex g_host_mu;
+static int g_host_depth = 0;       // nesting of host-level entry points (they call each other)
+static uint64_t g_host_epoch = 1;  // one per OUTERMOST host call: what upload_strided staged stays valid inside it
 static void ivx_bt_handler(int sig);
 HostCallGuard::HostCallGuard() {
     g_host_mu.lock();
+    if (g_host_depth++ == 0) g_host_epoch++;
     static const bool bt = getenv("IVX_BACKTRACE") != nullptr;
     if (bt) { // re-arm on every host call: test runners install their own handlers after the library is loaded
         signal(SIGABRT, ivx_bt_handler);
         signal(SIGSEGV, ivx_bt_handler);
     }
 }
-HostCallGuard::~HostCallGuard() { g_host_mu.unlock(); }
+HostCallGuard::~HostCallGuard() {
+    g_host_depth--;
+    g_host_mu.unlock();
+}
 
 int hs_get(int slot, size_t nbytes, void **hptr) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -103,6 +111,85 @@ static inline bool dense3(const int64_t shape[3], const int64_t st[3], size_t is
     return st[2] == (int64_t)isz && st[1] == shape[2] * (int64_t)isz && st[0] == shape[1] * shape[2] * (int64_t)isz;
 }
 
+// ---- strided host views at PCIe speed ------------------------------------------------------------------------
+// The views the GUI passes -- `mask.matrix[1:, 1:, 1:]` of the (d+1, h+1, w+1) memmap, axis-sliced slabs -- are
+// sub-boxes of a C-contiguous parent: contiguous rows, constant pitches.  Such a view lies inside ONE contiguous byte
+// span of the parent that is barely larger than the view itself, so it travels as one dense copy each way and the
+// re-pitching is a device kernel (TB/s) instead of a host memcpy per row (the round-1 path: 65 ms for a 512^3 mask).
+// On the way back the span is first fetched (unless this very call uploaded it), the kernel scatters the result into
+// the view's bytes, and the whole span returns: the parent's pad / flag cells between the rows come back unchanged.
+struct SpanSlot {
+    void *d = nullptr;
+    size_t cap = 0;
+    const void *host = nullptr;
+    size_t nbytes = 0;
+    uint64_t epoch = 0;
+};
+static SpanSlot g_span[WS_COUNT];
+
+static bool span_of(const int64_t shape[3], const int64_t st[3], size_t isz, size_t *span) {
+    const int64_t row = shape[2] * (int64_t)isz;
+    if (st[2] != (int64_t)isz || st[1] < row || st[0] < st[1] * shape[1]) return false;
+    const size_t n = (size_t)shape[0] * shape[1] * row;
+    const size_t sp = (size_t)(shape[0] - 1) * st[0] + (size_t)(shape[1] - 1) * st[1] + row;
+    if (sp > n + n / 4 + 65536) return false; // a thin slice of a big parent: not worth moving the parent
+    *span = sp;
+    return true;
+}
+
+// dense (rows packed) <-> pitched, 16 bytes of the dense side per lane; TO_PITCHED: dense -> pitched
+template <bool TO_PITCHED>
+__global__ __launch_bounds__(256) void k_repitch(uint8_t *__restrict__ pitched, int64_t p0, int64_t p1, uint8_t *__restrict__ dense,
+                                                 int64_t nz, int64_t ny, int64_t row) {
+    const int64_t chunks = (row + 15) / 16;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nz * ny * chunks) return;
+    const int64_t c = i % chunks, r = i / chunks, y = r % ny, z = r / ny;
+    const int64_t off = c * 16, len = row - off < 16 ? row - off : 16;
+    uint8_t *pp = pitched + z * p0 + y * p1 + off;
+    uint8_t *dp = dense + (z * ny + y) * row + off;
+    uint8_t v[16];
+    if (TO_PITCHED) {
+        if (len == 16 && ((uintptr_t)dp & 15) == 0) *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(dp);
+        else
+            for (int q = 0; q < len; q++) v[q] = dp[q];
+        if (len == 16 && ((uintptr_t)pp & 15) == 0) *reinterpret_cast<uint4 *>(pp) = *reinterpret_cast<const uint4 *>(v);
+        else
+            for (int q = 0; q < len; q++) pp[q] = v[q];
+    } else {
+        if (len == 16 && ((uintptr_t)pp & 15) == 0) *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(pp);
+        else
+            for (int q = 0; q < len; q++) v[q] = pp[q];
+        if (len == 16 && ((uintptr_t)dp & 15) == 0) *reinterpret_cast<uint4 *>(dp) = *reinterpret_cast<const uint4 *>(v);
+        else
+            for (int q = 0; q < len; q++) dp[q] = v[q];
+    }
+}
+
+static int span_buffer(int hslot, size_t span, SpanSlot **out) {
+    SpanSlot &sp = g_span[hslot];
+    if (sp.cap < span) {
+        if (sp.d) IVX_HIP(hipFree(sp.d));
+        sp.d = nullptr;
+        sp.cap = 0;
+        const size_t want = span + (span >> 3) + 4096;
+        IVX_HIP(hipMalloc(&sp.d, want));
+        sp.cap = want;
+        sp.epoch = 0;
+    }
+    *out = &sp;
+    return IVX_OK;
+}
+
+// rows gathered / scattered by a few host threads (views that are not sub-boxes of a contiguous parent)
+template <typename F> static void rows_parallel(int64_t nrows, F f) {
+    const int nt = nrows > 4096 ? 4 : 1;
+    if (nt == 1) { f(0, nrows); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(f, nrows * t / nt, nrows * (t + 1) / nt);
+    for (auto &t : th) t.join();
+}
+
 int upload_strided(void *dst_dev, const void *src, const int64_t shape[3], const int64_t st[3], size_t isz,
                    int hslot) {
     const size_t n = (size_t)shape[0] * shape[1] * shape[2] * isz;
@@ -111,20 +198,38 @@ int upload_strided(void *dst_dev, const void *src, const int64_t shape[3], const
         IVX_HIP(hipMemcpy(dst_dev, src, n, hipMemcpyHostToDevice));
         return IVX_OK;
     }
+    size_t span = 0;
+    if (hslot >= 0 && hslot < WS_COUNT && span_of(shape, st, isz, &span)) {
+        SpanSlot *sp;
+        int rc = span_buffer(hslot, span, &sp);
+        if (rc) return rc;
+        IVX_HIP(hipMemcpy(sp->d, src, span, hipMemcpyHostToDevice));
+        sp->host = src;
+        sp->nbytes = span;
+        sp->epoch = g_host_depth > 0 ? g_host_epoch : 0;
+        const int64_t row = shape[2] * (int64_t)isz, chunks = (row + 15) / 16;
+        hipLaunchKernelGGL(k_repitch<false>, dim3((unsigned)cdiv(shape[0] * shape[1] * chunks, 256)), dim3(256), 0, 0,
+                           (uint8_t *)sp->d, st[0], st[1], (uint8_t *)dst_dev, shape[0], shape[1], row);
+        IVX_LAUNCH_CHECK();
+        return IVX_OK;
+    }
     void *h;
     int rc = hs_get(hslot, n, &h);
     if (rc) return rc;
     char *d = (char *)h;
     const char *s = (const char *)src;
     const size_t row = (size_t)shape[2] * isz;
-    for (int64_t z = 0; z < shape[0]; z++)
-        for (int64_t y = 0; y < shape[1]; y++) {
+    const int64_t ny = shape[1], nx = shape[2];
+    rows_parallel(shape[0] * shape[1], [=](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; r++) {
+            const int64_t z = r / ny, y = r - z * ny;
             const char *sp = s + z * st[0] + y * st[1];
-            char *dp = d + ((size_t)z * shape[1] + y) * row;
+            char *dp = d + (size_t)r * row;
             if (st[2] == (int64_t)isz) memcpy(dp, sp, row);
             else
-                for (int64_t x = 0; x < shape[2]; x++) memcpy(dp + x * isz, sp + x * st[2], isz);
+                for (int64_t x = 0; x < nx; x++) memcpy(dp + x * isz, sp + x * st[2], isz);
         }
+    });
     IVX_HIP(hipMemcpy(dst_dev, h, n, hipMemcpyHostToDevice));
     return IVX_OK;
 }
@@ -137,6 +242,21 @@ int download_strided(void *dst, const int64_t shape[3], const int64_t st[3], con
         IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
         return IVX_OK;
     }
+    size_t span = 0;
+    if (hslot >= 0 && hslot < WS_COUNT && span_of(shape, st, isz, &span)) {
+        SpanSlot *sp;
+        int rc = span_buffer(hslot, span, &sp);
+        if (rc) return rc;
+        const bool fresh = sp->host == dst && sp->nbytes == span && sp->epoch != 0 && sp->epoch == g_host_epoch && g_host_depth > 0;
+        if (!fresh) IVX_HIP(hipMemcpy(sp->d, dst, span, hipMemcpyHostToDevice)); // the bytes between the view's rows
+        const int64_t row = shape[2] * (int64_t)isz, chunks = (row + 15) / 16;
+        hipLaunchKernelGGL(k_repitch<true>, dim3((unsigned)cdiv(shape[0] * shape[1] * chunks, 256)), dim3(256), 0, 0,
+                           (uint8_t *)sp->d, st[0], st[1], (uint8_t *)const_cast<void *>(src_dev), shape[0], shape[1], row);
+        IVX_LAUNCH_CHECK();
+        IVX_HIP(hipMemcpy(dst, sp->d, span, hipMemcpyDeviceToHost));
+        sp->epoch = 0; // the host copy is the truth again
+        return IVX_OK;
+    }
     void *h;
     int rc = hs_get(hslot, n, &h);
     if (rc) return rc;
@@ -144,14 +264,17 @@ int download_strided(void *dst, const int64_t shape[3], const int64_t st[3], con
     const char *s = (const char *)h;
     char *d = (char *)dst;
     const size_t row = (size_t)shape[2] * isz;
-    for (int64_t z = 0; z < shape[0]; z++)
-        for (int64_t y = 0; y < shape[1]; y++) {
+    const int64_t ny = shape[1], nx = shape[2];
+    rows_parallel(shape[0] * shape[1], [=](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; r++) {
+            const int64_t z = r / ny, y = r - z * ny;
             char *dp = d + z * st[0] + y * st[1];
-            const char *sp = s + ((size_t)z * shape[1] + y) * row;
+            const char *sp = s + (size_t)r * row;
             if (st[2] == (int64_t)isz) memcpy(dp, sp, row);
             else
-                for (int64_t x = 0; x < shape[2]; x++) memcpy(dp + x * st[2], sp + x * isz, isz);
+                for (int64_t x = 0; x < nx; x++) memcpy(dp + x * st[2], sp + x * isz, isz);
         }
+    });
     return IVX_OK;
 }
 
@@ -408,6 +531,8 @@ int ivx_release_workspace(void) {
         g_ws[i] = Slot();
         if (g_hs[i].p) (void)hipHostFree(g_hs[i].p);
         g_hs[i] = Slot();
+        if (ivx::g_span[i].d) (void)hipFree(ivx::g_span[i].d);
+        ivx::g_span[i] = ivx::SpanSlot();
     }
     for (auto &kv : g_ws_stream)
         if (kv.second.p) (void)hipFree(kv.second.p);

@@ -130,8 +130,18 @@ def test_dtypes_2d_strct_and_errors(ivxlib, oracle):
         floodfill.floodfill_threshold(u, [(70, 0, 0)], 0, 255, 1, s2d, out)
     with pytest.raises(TypeError):
         floodfill.floodfill_threshold(u.astype(np.float32), [(0, 0, 0)], 0, 255, 1, s2d, out)
-    # seed out of range: nothing happens
-    floodfill.floodfill_threshold(u, [(0, 0, 0)], 256, 300, 1, s2d, out)
+    # uint8 data: thresholds / fill reach the binding's `extract::<u8>()` untouched (invesalius_rs/__init__.py:32-38 only
+    # converts for the wider integer dtypes): out of range -> OverflowError, floats -> TypeError
+    with pytest.raises(OverflowError):
+        floodfill.floodfill_threshold(u, [(0, 0, 0)], 256, 300, 1, s2d, out)
+    with pytest.raises(OverflowError):
+        floodfill.floodfill_threshold(u, [(0, 0, 0)], 0, 255, 257, s2d, out)
+    with pytest.raises(TypeError):
+        floodfill.floodfill_threshold(u, [(0, 0, 0)], 0.5, 255, 1, s2d, out)
+    # seed value outside the range: nothing happens
+    lo = int(u[0, 0, 0]) + 1
+    if lo <= 255:
+        floodfill.floodfill_threshold(u, [(0, 0, 0)], lo, 255, 1, s2d, out)
     assert out.sum() == 0
 
 

@@ -15,13 +15,16 @@ from bench import BONE, synth_v512  # noqa: E402
 from invesalius3_amd import invesalius_rs as rs, slice_, surface_process as sp  # noqa: E402
 
 
-def timeit(fn, reps=3):
-    fn()
+def timeit(fn, reps=3, before=None):
+    """min wall time of fn() over `reps` calls (after one warm-up); `before()` runs untimed ahead of every call"""
     t = []
-    for _ in range(reps):
+    for i in range(reps + 1):
+        if before is not None:
+            before()
         t0 = time.perf_counter()
         fn()
-        t.append(time.perf_counter() - t0)
+        if i:
+            t.append(time.perf_counter() - t0)
     return min(t)
 
 
@@ -32,24 +35,27 @@ def main():
     mask = np.zeros((n + 1,) * 3, np.uint8)
     res = {}
 
-    def thr():
+    def thr_reset():
         mask[1:, 0, 0] = 0
-        slice_.do_threshold_to_all_slices(mask, img, BONE)
-    res["do_threshold_to_all_slices (strided mask, preserve rule)"] = timeit(thr)
+
+    res["do_threshold_to_all_slices (strided mask, preserve rule)"] = timeit(
+        lambda: slice_.do_threshold_to_all_slices(mask, img, BONE), before=thr_reset)
     z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
     out = np.zeros(img.shape, np.uint8)
     s26 = generate_binary_structure(3, 3)
 
-    def grow():
+    def out_reset():
         out[:] = 0
-        rs.floodfill_threshold(img, [(int(x), int(y), int(z))], BONE[0], BONE[1], 1, s26, out)
-    res["floodfill_threshold (26-conn, dense out)"] = timeit(grow)
+
+    res["floodfill_threshold (26-conn, dense out)"] = timeit(
+        lambda: rs.floodfill_threshold(img, [(int(x), int(y), int(z))], BONE[0], BONE[1], 1, s26, out), before=out_reset)
     view = mask[1:, 1:, 1:]
 
-    def grow_view():
-        rs.floodfill_threshold_inplace(view, [(int(x), int(y), int(z))], 253, 255, 254, s26)
+    def view_reset():
         view[view == 254] = 255
-    res["floodfill_threshold_inplace (mask view [1:,1:,1:])"] = timeit(grow_view, reps=2)
+
+    res["floodfill_threshold_inplace (mask view [1:,1:,1:])"] = timeit(
+        lambda: rs.floodfill_threshold_inplace(view, [(int(x), int(y), int(z))], 253, 255, 254, s26), reps=2, before=view_reset)
     tri = [None]
 
     def mc():
