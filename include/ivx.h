@@ -539,6 +539,18 @@ int ivx_apply_view_matrix_transform(int dtype, const void *vol, const int64_t sh
                                     const int64_t ostrides[3]);
 
 /* ------------------------------------------------------------------------------------------------
+ * quality-preset resample of the surface pipeline
+ *   replaces imagedata_utils.resize_image_array (invesalius/data/imagedata_utils.py:121-130) =
+ *            scipy.ndimage.zoom(image, factor, image.dtype, order=2), applied to image and mask by
+ *            SurfaceManager.AddNewActor for the Low / Medium presets (invesalius/data/surface.py:1350-1353)
+ * int16 or uint8 volumes, dense C order; oshape[a] = round(ishape[a] * factor) is the caller's (scipy's rule).
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_zoom_scratch_bytes(const int64_t ishape[3], const int64_t oshape[3], size_t *nbytes);
+int ivx_dev_zoom_order2(int dtype, const void *in, const int64_t ishape[3], void *out, const int64_t oshape[3],
+                        void *scratch, void *stream);
+int ivx_zoom_order2(int dtype, const void *in, const int64_t ishape[3], void *out, const int64_t oshape[3]);
+
+/* ------------------------------------------------------------------------------------------------
  * Z-slab communicator: RCCL over xGMI behind the C ABI (one process per GPU).
  *   the reference's decomposition: Z pieces + one overlap slice, invesalius/data/surface.py:1362-1380;
  *   it has no multi-GPU code, so these entry points replace nothing upstream -- they are what the sharded

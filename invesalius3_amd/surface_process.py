@@ -3,12 +3,18 @@
 The reference pads the piece (``pad_image`` surface_process.py:52-68), wraps it as vtkImageData with the extent
 conventions of ``converters.to_vtk`` (converters.py:34-101), flips Y about the origin and contours it with
 ``vtkContourFilter`` (surface_process.py:156-186), then writes a ``.vtp``.  Here padding and flip are folded into
-the kernel's addressing and the result is the triangle soup itself (float32 ``(T, 3, 3)``); ``write_stl_binary``
-is the vtkSTLWriter-compatible sink (surface.py:1827-1829).
+the kernel's addressing.  ``create_surface_piece`` keeps the reference's 20-argument signature (memmap file names in,
+``.vtp`` file name out -- what ``SurfaceManager.AddNewActor`` passes, surface.py:1381-1410); ``surface_piece`` is the
+same geometry on arrays and returns the float32 ``(T, 3, 3)`` soup; ``write_stl_binary`` is the vtkSTLWriter-compatible
+sink (surface.py:1827-1829).
 """
 from __future__ import annotations
 
+import base64
 import ctypes
+import os
+import re
+import tempfile
 
 import numpy as np
 
@@ -123,14 +129,18 @@ def keep_largest(verts, faces):
     return ov[: nv.value].copy(), of[: nt.value].copy(), nr.value
 
 
-def create_surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
-                         fill_border_holes=True) -> np.ndarray:
-    """One piece of surface_process.py:71-201 (arguments reduced to the ones that reach the geometry).
+def surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
+                  fill_border_holes=True) -> np.ndarray:
+    """The geometry of one piece of surface_process.py:71-201 on arrays already in memory (the arguments that reach it).
 
     ``mask_matrix`` is the ``(dz+1,dy+1,dx+1)`` mask; ``roi`` a ``slice`` over the IMAGE z axis
     (surface.py:1378-1380).  from_binary contours ``mask[roi+1, 1:, 1:]`` at 127; otherwise the raw image at
     ``min_value`` and ``max_value``."""
     shape0 = image.shape[0] if image is not None else mask_matrix.shape[0] - 1
+    return _surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary, fill_border_holes, shape0)
+
+
+def _surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary, fill_border_holes, shape0):
     pad_bottom = roi.start == 0
     pad_top = roi.stop >= shape0
     if from_binary:
@@ -144,6 +154,144 @@ def create_surface_piece(image, mask_matrix, roi, spacing, min_value, max_value,
     return marching_cubes(a, spacing, isos, roi.start, False, False, False, padv, 0)
 
 
+# ---- VTK XML PolyData (.vtp), the piece format of the reference (vtkXMLPolyDataWriter, surface_process.py:193-196) ----
+def write_vtp(path, verts, faces):
+    """Indexed triangles as an uncompressed inline-binary ``.vtp``: per DataArray, base64 of a UInt32 byte count followed by
+    the raw little-endian data -- the layout vtkXMLPolyDataReader (surface_process.py:237-243) parses.  VTK is not
+    installed in this environment, so the file is checked against the format's documentation and our own reader only."""
+    v = np.ascontiguousarray(verts, dtype="<f4").reshape(-1, 3)
+    f = np.ascontiguousarray(faces, dtype="<i4").reshape(-1, 3)
+
+    def arr(a, name, ncomp=None):
+        raw = a.tobytes()
+        text = base64.b64encode(np.uint32(len(raw)).tobytes() + raw).decode()
+        t = {"<f4": "Float32", "<i4": "Int32"}[a.dtype.str]
+        comp = ' NumberOfComponents="%d"' % ncomp if ncomp else ""
+        return '<DataArray type="%s" Name="%s"%s format="binary">%s</DataArray>' % (t, name, comp, text)
+
+    offsets = (np.arange(1, len(f) + 1, dtype="<i4") * 3)
+    xml = ('<?xml version="1.0"?>\n<VTKFile type="PolyData" version="0.1" byte_order="LittleEndian" header_type="UInt32">\n'
+           '<PolyData>\n<Piece NumberOfPoints="%d" NumberOfVerts="0" NumberOfLines="0" NumberOfStrips="0" NumberOfPolys="%d">\n'
+           '<Points>%s</Points>\n<Polys>%s%s</Polys>\n</Piece>\n</PolyData>\n</VTKFile>\n'
+           % (len(v), len(f), arr(v, "Points", 3), arr(f.reshape(-1), "connectivity"), arr(offsets, "offsets")))
+    with open(path, "w") as fh:
+        fh.write(xml)
+
+
+def read_vtp(path):
+    """Reader for the files `write_vtp` makes -> ``(verts (V,3) float32, faces (T,3) int32)`` (triangles only)."""
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r'<DataArray type="(\w+)" Name="(\w+)"[^>]*format="binary">([^<]*)</DataArray>', txt):
+        raw = base64.b64decode(m.group(3))
+        n = int(np.frombuffer(raw[:4], "<u4")[0])
+        out[m.group(2)] = np.frombuffer(raw[4:4 + n], {"Float32": "<f4", "Int32": "<i4"}[m.group(1)]).copy()
+    verts = out.get("Points", np.zeros(0, np.float32)).reshape(-1, 3)
+    conn = out.get("connectivity", np.zeros(0, np.int32))
+    off = out.get("offsets", np.zeros(0, np.int32))
+    if len(off) and not np.array_equal(off, np.arange(1, len(off) + 1, dtype=np.int32) * 3):
+        raise ValueError("%s: only triangle pieces are supported" % path)
+    return verts, conn.reshape(-1, 3)
+
+
+def create_surface_piece(filename, shape, dtype, mask_filename, mask_shape, mask_dtype, roi, spacing, mode, min_value,
+                         max_value, decimate_reduction, smooth_relaxation_factor, smooth_iterations, language, flip_image,
+                         from_binary, algorithm, imagedata_resolution, fill_border_holes):
+    """``invesalius.data.surface_process.create_surface_piece`` (:71-201) with its own signature: opens the image and
+    mask memmaps by file name, contours the piece ``roi`` on the GPU and writes the surface to a ``.vtp`` whose name it
+    returns (``tempfile.mkstemp(suffix="_%d_%d.vtp" % (roi.start, roi.stop))``, :192).
+
+    Like the reference's body, `mode`, the decimate / smooth numbers, `language`, `flip_image` and
+    `imagedata_resolution` are accepted and unused here (the flip is unconditional, :156-161; the resampling of the
+    Low / Medium presets happens in the caller, surface.py:1350-1353 -> `resize_image_array` below).  ``from_binary``
+    contours ``mask[roi + 1, 1:, 1:]`` at 127; otherwise the raw image at `min_value` and `max_value` -- after the
+    ``"InVesalius 3.b2"`` value rewrite (:128-146) when that algorithm is named: voxels the mask marks 1 drop below the
+    image minimum, voxels marked 254 become the mid threshold; the vtkImageGaussianSmooth that follows there has radius
+    factor 0.3 at VTK's default standard deviation 2 -> kernel radius int(0.6) = 0, i.e. the identity (parity unpinned:
+    VTK is not installed; the branch is unreachable from AddNewActor, which passes from_binary=True for it)."""
+    roi = roi if isinstance(roi, slice) else slice(*roi)
+    mask = np.memmap(mask_filename, mode="r", dtype=mask_dtype, shape=tuple(mask_shape))
+    shape = tuple(shape)
+    pad_bottom = roi.start == 0
+    pad_top = roi.stop >= shape[0]
+    if from_binary:
+        image = None
+    else:
+        image = np.memmap(filename, mode="r", dtype=dtype, shape=shape)
+        if image.dtype != np.int16:
+            raise TypeError("the image memmap must be int16")
+    if not from_binary and algorithm == "InVesalius 3.b2":
+        a_image = np.array(image[roi])
+        a_mask = np.array(mask[roi.start + 1: roi.stop + 1, 1:, 1:])
+        # (with fill_border_holes the reference indexes its PADDED piece with the unpadded mask and raises IndexError: dead
+        #  code there; here the rewrite is applied to the piece itself and the padding stays virtual)
+        a_image[a_mask == 1] = np.array(int(a_image.min()) - 1).astype(a_image.dtype)
+        a_image[a_mask == 254] = (min_value + max_value) / 2.0
+        padv = float(np.iinfo(a_image.dtype).min)
+        tris = (marching_cubes(a_image, spacing, [float(min_value), float(max_value)], roi.start, True, pad_bottom, pad_top, padv,
+                               int(pad_bottom)) if fill_border_holes else
+                marching_cubes(a_image, spacing, [float(min_value), float(max_value)], roi.start, False, False, False, padv, 0))
+    else:
+        dz = shape[0]
+        tris = _surface_piece(image, mask, roi, spacing, min_value, max_value, from_binary, fill_border_holes, dz)
+    verts = tris.reshape(-1, 3)
+    faces = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    fd, out_name = tempfile.mkstemp(suffix="_%d_%d.vtp" % (roi.start, roi.stop))
+    os.close(fd)
+    write_vtp(out_name, verts, faces)
+    return out_name
+
+
+def join_surface_pieces(filenames, keep_largest_region=False):
+    """The stages of join_process_surface (surface_process.py:204-472) that are built here, on piece FILES: read the
+    ``.vtp`` pieces in z order (:229-250 sorts by the roi in the name), append them, merge coincident points
+    (vtkCleanPolyData: exact float32 coincidence, as between two pieces' copies of their shared plane), optionally keep
+    the largest region (:376-391), and report area / volume (:452-458).  Returns ``(verts, faces, measures)``."""
+    def zkey(name):
+        m = re.search(r"_(\d+)_(\d+)\.vtp$", name)
+        return int(m.group(1)) if m else 0
+
+    soups = []
+    for name in sorted(filenames, key=zkey):
+        v, f = read_vtp(name)
+        if len(f):
+            soups.append(v[f])
+    if not soups:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), {"volume": 0.0, "area": 0.0}
+    soup = np.concatenate(soups).reshape(-1, 3)
+    key = np.ascontiguousarray(soup).view([("", np.uint32)] * 3).ravel()
+    _, first, inverse = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")          # vertices numbered by first appearance
+    rank = np.empty(len(order), np.int64)
+    rank[order] = np.arange(len(order))
+    verts = soup[first[order]]
+    faces = rank[inverse].reshape(-1, 3).astype(np.int32)
+    if keep_largest_region and len(faces):
+        verts, faces, _ = keep_largest(verts, faces)
+    volume, area = mass_properties(verts, faces)
+    return verts, faces, {"volume": volume, "area": area}
+
+
+def resize_image_array(image, resolution_percentage, as_mmap=False):
+    """``imagedata_utils.resize_image_array`` (:121-130): ``scipy.ndimage.zoom(image, factor, image.dtype, order=2)``, the
+    down-sampling AddNewActor applies to image AND mask for the Low / Medium quality presets (surface.py:1350-1353), on
+    the GPU (csrc/k_zoom.hip: quadratic B-spline prefilter + interpolation in float64, scipy's operation order)."""
+    a = np.asarray(image)
+    if a.ndim != 3 or a.dtype not in (np.int16, np.uint8):
+        raise TypeError("resize_image_array: 3-D int16 or uint8 volume expected")
+    a = np.ascontiguousarray(a)
+    oshape = tuple(int(round(s * float(resolution_percentage))) for s in a.shape)
+    out = np.empty(oshape, a.dtype)
+    L.check(L.lib().ivx_zoom_order2(L.DT[a.dtype], L.ptr(a), L.i64(a.shape), L.ptr(out), L.i64(oshape)), "zoom")
+    if as_mmap:
+        fd, fname = tempfile.mkstemp(suffix="_resized")
+        os.close(fd)
+        mm = np.memmap(fname, shape=out.shape, dtype=out.dtype, mode="w+")
+        mm[:] = out
+        return mm
+    return out
+
+
 def create_surface(image, mask_matrix, spacing, min_value, max_value, from_binary, fill_border_holes=True,
                    piece_size=20, o_piece=1):
     """SurfaceManager.AddNewActor's piece loop (surface.py:1362-1380): 20-slice pieces + 1 overlap slice,
@@ -155,8 +303,8 @@ def create_surface(image, mask_matrix, spacing, min_value, max_value, from_binar
         roi = slice(i * piece_size, i * piece_size + piece_size + o_piece)
         if roi.start >= dz:
             break
-        parts.append(create_surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
-                                          fill_border_holes))
+        parts.append(surface_piece(image, mask_matrix, roi, spacing, min_value, max_value, from_binary,
+                                   fill_border_holes))
     return np.concatenate(parts) if parts else np.empty((0, 3, 3), np.float32)
 
 

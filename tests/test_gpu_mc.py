@@ -30,7 +30,7 @@ def test_two_iso_default_mode(ivxlib, oracle):
     img = synth_volume((24, 40, 48), seed=21)
     mask = np.zeros((25, 41, 49), np.uint8)
     for roi in (slice(0, 21), slice(20, 41)):
-        g = sp.create_surface_piece(img, mask, roi, (0.4785156, 0.4785156, 2.0), 226, 3071, False)
+        g = sp.surface_piece(img, mask, roi, (0.4785156, 0.4785156, 2.0), 226, 3071, False)
         r = oracle.create_surface_piece(img, mask, roi, (0.4785156, 0.4785156, 2.0), 226, 3071, False)
         _cmp(g, r)
         assert len(g) > 0
@@ -78,7 +78,7 @@ def test_full_size_properties_512(ivxlib):
     ball = ((z - 250.5) ** 2 + (y - 260.25) ** 2 + (x - 240.75) ** 2) <= 180.0 ** 2
     mask = np.zeros((n + 1,) * 3, np.uint8)
     mask[1:, 1:, 1:] = np.where(ball, 255, 0)
-    whole = sp.create_surface_piece(None, mask, slice(0, n), (1, 1, 1), 0, 0, True)
+    whole = sp.surface_piece(None, mask, slice(0, n), (1, 1, 1), 0, 0, True)
     t = whole.astype(np.float64)
     vol = np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() / 6.0
     assert abs(vol / (4 / 3 * np.pi * 180.0 ** 3) - 1) < 5e-3

@@ -59,7 +59,7 @@ def main():
     tri = [None]
 
     def mc():
-        tri[0] = sp.create_surface_piece(None, mask, slice(0, n), (1.0, 1.0, 1.0), 0, 0, True)
+        tri[0] = sp.surface_piece(None, mask, slice(0, n), (1.0, 1.0, 1.0), 0, 0, True)
     res["create_surface_piece (whole volume, from_binary)"] = timeit(mc)
     o2 = np.zeros((n, n), np.int16)
     res["mida axis 0"] = timeit(lambda: rs.mida(img, 0, 300, 600, o2))
