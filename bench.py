@@ -452,7 +452,7 @@ def run_watershed(args, job):
     obj = job.sum(int((lab == 1).sum()))
     if job.rank != 0:
         return
-    names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "gate_steps", "us_costs",
+    names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "tile_sweeps", "us_costs",
              "us_zones", "us_bucket", "us_levels", "us_labels")
     flood_ms = spans.get("flood", 0.0)
     res = {

@@ -502,7 +502,7 @@ int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mas
  * cost = largest arc, LIFO inside a cost bucket, neighbours by linear index (row wrap-around like scipy): the
  * defect-free statement of NI_WatershedIFT, see k_wsift.hip.  cost_out (optional): the minimax cost map.
  * stats (optional, host): [0] relaxation rounds, [1] tile visits, [2] non-empty cost levels, [3] time stamps used,
- * [4] marker voxels, [5] entry voxels, [6] tiles, [8..12] microseconds of: costs, zones, bucketing, level chain, labels.
+ * [4] marker voxels, [5] entry voxels, [6] tiles, [7] LDS sweeps over all tile visits, [8..12] microseconds of: costs, zones, bucketing, level chain, labels.
  * The host form uploads / downloads dense C-order arrays.
  * ---------------------------------------------------------------------------------------------- */
 int ivx_dev_watershed_ift(const uint16_t *cost, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,

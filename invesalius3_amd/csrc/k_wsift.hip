@@ -63,7 +63,7 @@ struct WsState {
     uint32_t nlist;    // dirty tiles of the next round            } read by the host
     uint32_t minrej;   // smallest cost refused by the gate so far } after every round
     uint32_t assigned; // voxels that have a finite cost           } (one mailbox message)
-    uint32_t pad1;
+    uint32_t sweeps;   // LDS sweeps over all tile visits (statistics)
 };
 
 template <int CONN> __device__ __forceinline__ bool has_off(uint32_t smask, int k) {
@@ -95,15 +95,27 @@ __device__ __forceinline__ void tile_origin(const WsGeom &g, int64_t tile, int &
     z0 = (int)(r / g.nty) * TZ;
 }
 
-// stage the tile and its halo: cell = cost << 16 | intensity; cells outside [0, n) can never lower anything
+// stage the tile and its halo: cell = cost << 16 | intensity; cells outside [0, n) can never lower anything.
+// All of a lane's loads (14 cells x 2 arrays) are issued before the first one is consumed: a visit in the flood's long
+// tail changes a handful of voxels, so the staging latency IS the visit.
 __device__ __forceinline__ void load_tile(const WsGeom &g, int z0, int y0, int x0, const uint16_t *__restrict__ I,
                                           const uint16_t *C, uint32_t *s) {
-    for (int c = threadIdx.x; c < NCELL; c += 256) {
+    constexpr int PER = (NCELL + 255) / 256;
+    uint32_t cv[PER], iv[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int c = threadIdx.x + q * 256;
         const int lx = c % BX, ly = (c / BX) % BY, lz = c / (BX * BY);
         const int64_t L = (int64_t)(z0 + lz - 1) * g.hw + (int64_t)(y0 + ly - 1) * g.w + (x0 + lx - 1);
-        uint32_t v = CINF << 16;
-        if (L >= 0 && L < g.n) v = ((uint32_t)C[L] << 16) | I[L];
-        s[c] = v;
+        const bool ok = c < NCELL && L >= 0 && L < g.n;
+        const int64_t La = ok ? L : 0;
+        cv[q] = ok ? (uint32_t)C[La] : CINF;
+        iv[q] = ok ? (uint32_t)I[La] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int c = threadIdx.x + q * 256;
+        if (c < NCELL) s[c] = (cv[q] << 16) | iv[q];
     }
 }
 
@@ -289,6 +301,7 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
             atomicMin(&st->minrej, s_rej);
         }
         if (s_new) atomicAdd(&st->assigned, s_new);
+        atomicAdd(&st->sweeps, (uint32_t)it);
     }
 }
 
@@ -788,7 +801,7 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     tm.on = stats != nullptr;
     tm.mark(st);
     // ---- 1. costs ------------------------------------------------------------------------------------------
-    int64_t rounds = 0, visits = 0, gates = 0;
+    int64_t rounds = 0, visits = 0;
     IVX_HIP(hipMemsetAsync(b.pending, 0, (size_t)g.ntiles, st));
     hipLaunchKernelGGL(k_ws_wake, dim3(1), dim3(256), 0, st, (int64_t)0, b.dirty, b.pending, b.st); // minrej = NONE
     IVX_LAUNCH_CHECK();
@@ -811,7 +824,6 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
             if (theta >= CINF || msg[1] == NONE) break; // nothing was refused: this is the fix-point
             // converged below the gate: lift it to the first level that has work, or all the way once the bulk is in
             theta = (uint64_t)msg[2] * 2 > (uint64_t)g.n ? CINF : msg[1];
-            gates++;
             hipLaunchKernelGGL(k_ws_wake, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, b.dirty, b.pending, b.st);
             IVX_LAUNCH_CHECK();
             continue;
@@ -891,7 +903,7 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     IVX_REQUIRE(!hs.overflow, IVX_ENOMEM, "watershed_ift: more than %u time-stamp classes", cap);
     if (stats) {
         stats[0] = rounds; stats[1] = visits; stats[2] = nlevels; stats[3] = hs.base; stats[4] = M; stats[5] = start;
-        stats[6] = g.ntiles; stats[7] = gates;
+        stats[6] = g.ntiles; stats[7] = hs.sweeps;
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] zones, [10] bucketing, [11] level chain, [12] labels (microseconds)
     }

@@ -90,7 +90,7 @@ def watershed_ift(image: np.ndarray, markers: np.ndarray, structure=None, want_c
     if want_cost:
         res += (cost,)
     if want_stats:
-        names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "gate_steps", "us_costs", "us_zones",
+        names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "tile_sweeps", "us_costs", "us_zones",
                  "us_bucket", "us_levels", "us_labels")
         res += ({k: int(v) for k, v in zip(names, stats) if k != "_"},)
     return res[0] if len(res) == 1 else res
