@@ -1,18 +1,24 @@
+# One family of evidence files per call: GPU suite summary, the three bench configs, rocprofv3 kernel stats and the two PMC
+# passes of the default bench (same command line), joined by tools/summarize_pmc.py.  Usage (on the GPU box, via gpurun):
+#   bash tools/profile_round.sh r02_v2 [--tests]
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof_v12
+TAG=${1:-r02}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
 cd $R
-timeout -k 5 400 python -m pytest tests -m gpu -q < /dev/null 2>&1 | tail -4 > gpurun_out/prof_v12/gpu_tests.txt
-timeout -k 5 200 python bench.py < /dev/null > gpurun_out/prof_v12/bench.json 2> gpurun_out/prof_v12/bench.err
-timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v12 -o kt -- python bench.py --steps 5 --warmup 1 --cpu-slices 0 < /dev/null > gpurun_out/prof_v12/kt.log 2>&1
-timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_v12 -o fetch -- python bench.py --steps 3 --warmup 1 --cpu-slices 0 < /dev/null > /dev/null 2>&1
-timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_v12 -o write -- python bench.py --steps 3 --warmup 1 --cpu-slices 0 < /dev/null > /dev/null 2>&1
-find gpurun_out/prof_v12 -name "*.csv" | head -20
-D=$(dirname $(find gpurun_out/prof_v12 -name "kt_kernel_stats.csv" | head -1))
-echo "D=$D"
-for f in fetch_counter_collection.csv write_counter_collection.csv; do s=$(find gpurun_out/prof_v12 -name $f | head -1); [ -n "$s" ] && [ "$(dirname $s)" != "$D" ] && cp $s $D/; done
-python tools/summarize_pmc.py $D gpurun_out/prof_v12/kernels_pmc.md gpurun_out/prof_v12/pmc_traffic.json auto < /dev/null | head -30
-timeout -k 5 100 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v12 -o mesh -- python tools/bench_mesh.py 512 < /dev/null > gpurun_out/prof_v12/mesh.log 2>&1
-tail -1 gpurun_out/prof_v12/mesh.log | cut -c1-900
-cat gpurun_out/prof_v12/gpu_tests.txt
-cat gpurun_out/prof_v12/bench.json
+if [ "$2" = "--tests" ]; then
+  timeout -k 5 1500 python -m pytest tests -m gpu -q < /dev/null > $O/gpu_tests_full.txt 2>&1
+  grep -E "passed|failed|error" $O/gpu_tests_full.txt | tail -3 > $O/gpu_tests.txt
+fi
+timeout -k 5 300 python bench.py < /dev/null > $O/bench.json 2> $O/bench.err
+timeout -k 5 300 python bench.py --config mip < /dev/null > $O/bench_mip.json 2> $O/bench_mip.err
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu < /dev/null > $O/kt.log 2>&1
+timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
+timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o write -- python bench.py --steps 3 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
+D=$(dirname $(find $O -name "kt_kernel_stats.csv" | head -1))
+for f in fetch_counter_collection.csv write_counter_collection.csv; do s=$(find $O -name $f | head -1); [ -n "$s" ] && [ "$(dirname $s)" != "$D" ] && cp $s $D/; done
+python tools/summarize_pmc.py $D $O/kernels_pmc.md $O/pmc_traffic.json auto < /dev/null | head -40
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o wskt -- python bench.py --config watershed --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > $O/wskt.log 2>&1
+cat $O/gpu_tests.txt 2>/dev/null
+cat $O/bench.json

@@ -63,7 +63,11 @@ def main():
                 continue
             per_launch = (2 * sum(fe[k]) / len(fe[k]) + sum(wr[k]) / len(wr[k])) * 1024
             traffic[st] = traffic.get(st, 0.0) + per_launch * calls / nsteps
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import src_sha16
         json.dump({"unit": "bytes per bench step (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B), kernels of the stage only",
+                   "config": "grow_mc", "src_sha16": src_sha16(),
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
                    "traffic_bytes_per_step": {k: round(v) for k, v in traffic.items()}}, open(sys.argv[3], "w"), indent=1)
 
