@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json configs[1] (default): 512x512x512 synthetic int16 volume,
 threshold + 26-neighbour region growing + marching cubes, on N x MI355X (one process per GPU, RCCL through libivx's
-ivx_comm_* -- no PyTorch).  `--config watershed` = configs[2] (1024^3 IFT watershed), `--config mip` = configs[4]
+ivx_comm_* -- no PyTorch).  `--config watershed` = configs[2] (1024^3 IFT watershed), `--config sharded2048` = configs[3]
+(2048^3 split over the ranks, threshold + marching cubes + stitch), `--config mip` = configs[4]
 (3-axis MaxIP sweep of 512^3 into a 2048^2 viewport); each prints its own line with `roofline` and `cpu_baseline`.
 
 A "step" is one pass of the hot path over the resident volume:
@@ -584,20 +585,155 @@ def run_mip(args, job):
     print(json.dumps(res), flush=True)
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# configs[3]: 2048^3 Z-sharded over the ranks (STRONG scaling), threshold + marching cubes + cross-slab stitch
+# ----------------------------------------------------------------------------------------------------------------
+def run_sharded2048(args, job):
+    import ctypes
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceVolume, c64
+    from invesalius3_amd.parallel import SlabVolume
+
+    rank, world = job.rank, job.world
+    n = args.size or 2048
+    if n % world:
+        raise SystemExit("bench.py --config sharded2048: %d slices do not split over %d ranks" % (n, world))
+    nz = n // world
+    rng = np.random.default_rng(SEED)
+    blobs = np.stack([rng.uniform(0.15, 0.85, 6), rng.uniform(0.15, 0.85, 6), rng.uniform(0.15, 0.85, 6),
+                      rng.uniform(0.12, 0.28, 6)], axis=1).astype(np.float32)  # (cz, cy, cx, sigma) x 6, as synth_v512 draws them
+    lib = L.lib()
+
+    def fill(ptr, stream, z0=rank * nz, dz=nz):
+        L.check(lib.ivx_dev_synth_volume(ptr, c64(dz), c64(n), c64(n), c64(z0), c64(n), ctypes.c_uint32(SEED), L.ptr(blobs), stream),
+                "synth_volume")
+
+    L.set_device(job.local_rank)
+    vol = SlabVolume(None, rank, world, comm=job.comm, device=job.local_rank, shape=(nz, n, n), fill=fill)
+    nvox_local = nz * n * n
+
+    def step():
+        with vol.timer.span("threshold"):
+            vol.threshold(BONE[0], BONE[1], preserve=False)
+        return vol.marching_cubes(from_binary=True)
+
+    def barrier():
+        vol.sync()
+        job.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    vol.timer.collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ntri = step()
+    barrier()
+    dt = job.max(time.perf_counter() - t0)
+    spans = {k: float(np.mean(v)) for k, v in vol.timer.collect().items()}
+    # cross-slab stitch (vtkCleanPolyData's job in the reference's join): the vertices two neighbours both carry on their
+    # shared plane, matched by exact float32 coordinates; once, outside the timed steps
+    t_st = time.perf_counter()
+    verts, faces = vol.marching_cubes_indexed(from_binary=True, download=True)
+    nverts = len(verts)
+    merged = 0
+    if world > 1:
+        top = verts[verts[:, 2] == np.float32((rank + 1) * nz)] if rank < world - 1 else verts[:0]
+        bot = verts[verts[:, 2] == np.float32(rank * nz)] if rank > 0 else verts[:0]
+        counts = job.comm.allreduce_array(np.eye(world, dtype=np.int64)[rank] * len(bot), "sum")
+        bots = job.comm.allgather_rows(np.ascontiguousarray(bot), [int(c) for c in counts])
+        if rank < world - 1:
+            lo = int(np.sum(counts[:rank + 1]))
+            nb = bots[lo: lo + int(counts[rank + 1])]
+            key = lambda v: np.ascontiguousarray(v, dtype=np.float32).view([("", np.uint32)] * 3).ravel()
+            merged = int(np.isin(key(top), key(nb)).sum())
+    stitch_ms = (time.perf_counter() - t_st) * 1e3
+    ntri_all, nverts_all, merged_all = job.sum(ntri), job.sum(nverts), job.sum(merged)
+    copy_gbs = copy_bandwidth(vol, nvox_local) if rank == 0 else None
+    if rank != 0:
+        return
+    mc_ms = spans.get("mc_count", 0.0) + spans.get("mc_emit", 0.0)
+    stage_time = {"threshold": spans.get("threshold", 0.0), "marching_cubes": mc_ms}
+    stage_bytes = {"threshold": 3.0 * nvox_local, "marching_cubes": 1.0 * nvox_local + 36.0 * ntri}
+    dom = max(stage_time, key=lambda k: stage_time[k])
+    res = {
+        "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
+        "value": round(n ** 3 / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i16", "data": "synthetic",
+        "config": {"workload": "configs[3]: %d^3 int16 (synthesised in HBM, %d slices per GPU), threshold(226..3071) + marching-cubes(mask@127) "
+                               "+ cross-slab stitch" % (n, nz), "parallelism": "z-slab x%d" % world,
+                   "collectives": "RCCL via libivx ivx_comm_* (one image-halo slice per neighbour, once)" if world > 1 else "none"},
+        "triangles": ntri_all, "mtriangles_per_s": round(ntri / (mc_ms * 1e-3) / 1e6, 2) if mc_ms > 0 else None,
+        "stage_ms": {k: round(v, 4) for k, v in spans.items()},
+        "stitch": {"ms_once_outside_the_timed_steps": round(stitch_ms, 1), "indexed_vertices": nverts_all,
+                   "merged_on_shared_planes": merged_all, "note": "indexed marching cubes + download + exact-match of the shared planes' vertices"},
+        "roofline": roofline(dom, stage_bytes[dom], stage_time[dom], None, copy_gbs,
+                             {"per_stage_frac": {k: round(stage_bytes[k] / (stage_time[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                 for k in stage_time if stage_time[k] > 0}}),
+        "device": L.device_name(),
+    }
+    if args.cpu:
+        # bounded sample: the first slices of rank 0's slab, through the oracle with the reference's own parallelism (numpy threshold on
+        # one thread, marching cubes pooled over 20+1-slice pieces) and, for parity, through a fresh resident volume on the GPU
+        from oracle import oracle as orc
+        orc.build()
+        # a multiple of the reference's 20-slice piece: with dz % 20 == 1 its piece loop (surface.py:1366-1380) contours the top cell
+        # layer twice, and the sample could not be compared with one whole-volume pass
+        sl = min(nz, max(20, int(1.0e8 // (n * n)) // 20 * 20))
+        from invesalius3_amd.device import DeviceBuffer
+        buf = DeviceBuffer(sl * n * n * 2)
+        fill(buf.ptr, None, 0, sl)
+        L.synchronize()
+        sub = buf.download((sl, n, n), np.int16)
+        buf.close()
+        t = time.perf_counter()
+        mask = np.zeros((sl + 1, n + 1, n + 1), np.uint8)
+        orc.set_mask_threshold_volume(mask, sub, BONE)
+        t1 = time.perf_counter()
+        rois = [slice(i * 20, i * 20 + 21) for i in range(int(round(sl / 20 + 0.5, 0))) if i * 20 < sl]
+        cores = max(1, min(len(rois), os.cpu_count() or 1))
+        with ThreadPoolExecutor(cores) as pool:
+            parts = list(pool.map(lambda r: orc.create_surface_piece(None, mask, r, (1.0, 1.0, 1.0), 0, 0, True), rois))
+        t2 = time.perf_counter()
+        want = np.concatenate(parts)
+        small = DeviceVolume(sub)
+        small.threshold(BONE[0], BONE[1])
+        got = small.marching_cubes(from_binary=True, download=True)
+        gmask = small.download_mask()
+        small.close()
+        ok = got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)) and \
+            zlib.crc32(gmask) == zlib.crc32(np.ascontiguousarray(mask[1:, 1:, 1:]))
+        res["cpu_baseline"] = {"value": round(sub.size / (t2 - t) / 1e6, 3), "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+                               "sample": "first %d slices of the volume (%d voxels): numpy threshold %.2fs + C marching cubes %.2fs on %d "
+                                         "threads over %d pieces (%d triangles)" % (sl, sub.size, t1 - t, t2 - t1, cores, len(rois), len(want))}
+        res["parity"] = {"ok": bool(ok), "checked": "mask CRC and float32 triangle soup of the sample, bit for bit, GPU vs CPU oracle"}
+        if not ok:
+            print(json.dumps(res), flush=True)
+            raise SystemExit("bench.py: sharded2048 sample differs from the CPU oracle")
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("grow_mc", "watershed", "mip"), default="grow_mc",
-                    help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2]; mip = configs[4]")
-    ap.add_argument("--size", type=int, default=None, help="edge of the per-GPU volume (defaults: 512 / 1024 / 512)")
+    ap.add_argument("--config", choices=("grow_mc", "watershed", "mip", "sharded2048"), default="grow_mc",
+                    help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2]; sharded2048 = "
+                         "configs[3] (strong scaling: the whole volume split over --gpus); mip = configs[4]")
+    ap.add_argument("--size", type=int, default=None, help="edge of the volume (defaults: 512 / 1024 / 512 per GPU; 2048 in total for sharded2048)")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false", help="skip the CPU baseline + full-size parity check")
     ap.add_argument("--cpu-slices", type=int, default=None, help="(kept for old command lines; 0 = --no-cpu)")
     args = ap.parse_args()
     if args.cpu_slices == 0:
         args.cpu = False
-    dflt = {"grow_mc": (20, 3), "watershed": (3, 1), "mip": (20, 3)}[args.config]
+    dflt = {"grow_mc": (20, 3), "watershed": (3, 1), "mip": (20, 3), "sharded2048": (5, 2)}[args.config]
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
 
@@ -609,7 +745,7 @@ def main():
     from invesalius3_amd import _lib as L
     L.require_device()
     job = Ranks()
-    {"grow_mc": run_grow_mc, "watershed": run_watershed, "mip": run_mip}[args.config](args, job)
+    {"grow_mc": run_grow_mc, "watershed": run_watershed, "mip": run_mip, "sharded2048": run_sharded2048}[args.config](args, job)
     if job.comm is not None:
         job.comm.barrier()
         job.comm.close()

@@ -551,6 +551,15 @@ int ivx_dev_zoom_order2(int dtype, const void *in, const int64_t ishape[3], void
 int ivx_zoom_order2(int dtype, const void *in, const int64_t ishape[3], void *out, const int64_t oshape[3]);
 
 /* ------------------------------------------------------------------------------------------------
+ * bench / test input made in HBM (no reference counterpart): a CT-like int16 phantom -- six Gaussian blobs + sinusoid +
+ * hashed N(0,25) noise, clipped to [-1024, 3071] -- for the slices [z0, z0 + dz) of a z_total-slice volume; deterministic
+ * in (seed, global voxel index), so slabs made by different ranks tile the whole volume.  centres_zyx_sigma: 6 x (cz, cy,
+ * cx, sigma) in normalised coordinates.  Used by bench.py --config sharded2048 (BASELINE configs[3]).
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_synth_volume(int16_t *out, int64_t dz, int64_t dy, int64_t dx, int64_t z0, int64_t z_total, uint32_t seed,
+                         const float centres_zyx_sigma[24], void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Z-slab communicator: RCCL over xGMI behind the C ABI (one process per GPU).
  *   the reference's decomposition: Z pieces + one overlap slice, invesalius/data/surface.py:1362-1380;
  *   it has no multi-GPU code, so these entry points replace nothing upstream -- they are what the sharded

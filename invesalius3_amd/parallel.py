@@ -143,21 +143,34 @@ def _make_slab_volume():
         """This rank's Z-slab (+ halo slices) resident in HBM.  Same call surface as DeviceVolume; region growing and
         marching cubes are the sharded versions."""
 
-        def __init__(self, image_slab: np.ndarray, rank: int, world: int, comm=None, spacing=(1.0, 1.0, 1.0), device=None):
-            if image_slab.dtype != np.int16 or image_slab.ndim != 3:
-                raise TypeError("image slab must be a 3-D int16 array")
-            self.lay = lay = slab_layout(rank, world, image_slab.shape[0])
+        def __init__(self, image_slab, rank: int, world: int, comm=None, spacing=(1.0, 1.0, 1.0), device=None, shape=None,
+                     fill=None):
+            """`image_slab`: this rank's (nz, dy, dx) int16 slices on the host -- or None with `shape` = that shape and
+            `fill(device_pointer, stream)` a callable that makes the slices in HBM where they are used (bench.py's
+            configs[3]: every rank synthesises its own 2 GB slab)."""
+            if image_slab is None:
+                if shape is None or fill is None:
+                    raise ValueError("SlabVolume: pass an image slab, or shape= and fill=")
+                slab_shape = tuple(int(v) for v in shape)
+            else:
+                if image_slab.dtype != np.int16 or image_slab.ndim != 3:
+                    raise TypeError("image slab must be a 3-D int16 array")
+                slab_shape = tuple(image_slab.shape)
+            self.lay = lay = slab_layout(rank, world, slab_shape[0])
             if comm is None:
                 if world != 1:
                     raise ValueError("SlabVolume: a communicator is required for world > 1 (invesalius3_amd.comm.init_from_env)")
                 comm = _SoloComm()
             self.comm = comm
-            super().__init__(None, shape=(lay.local_dz,) + tuple(image_slab.shape[1:]), spacing=spacing, device=device)
+            super().__init__(None, shape=(lay.local_dz,) + slab_shape[1:], spacing=spacing, device=device)
             # my slices go to their place in HBM; the halo slices of the IMAGE (static input) come from the Z-neighbours
             # device to device: my first slice goes down, my last slice goes up (the reference's o_piece = 1)
             sb = self.dy * self.dx * 2
-            img = np.ascontiguousarray(image_slab)
-            L.check(L.lib().ivx_memcpy_h2d(self.image.raw_at(lay.hb * sb), L.ptr(img), ctypes.c_size_t(img.nbytes)))
+            if image_slab is None:
+                fill(self.image.raw_at(lay.hb * sb), self.stream)
+            else:
+                img = np.ascontiguousarray(image_slab)
+                L.check(L.lib().ivx_memcpy_h2d(self.image.raw_at(lay.hb * sb), L.ptr(img), ctypes.c_size_t(img.nbytes)))
             self.comm.exchange(self.image.raw_at(lay.first_interior * sb), self.image.raw_at(0),
                                self.image.raw_at(lay.last_interior * sb), self.image.raw_at((lay.local_dz - 1) * sb), sb,
                                self.stream)
