@@ -59,3 +59,67 @@ def test_2d_variant(oracle):
     mk[15, 22] = 2
     s = generate_binary_structure(2, 2)
     assert np.array_equal(oracle.watershed_ift(img, mk, s), ndimage.watershed_ift(img, mk, s))
+
+
+def _random_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        nd = int(rng.choice([2, 3]))
+        shape = tuple(int(v) for v in (rng.integers(1, 9, 3) if nd == 3 else rng.integers(1, 14, 2)))
+        conn = int(rng.integers(1, nd + 1))
+        hi = int(rng.choice([2, 4, 10, 60, 3000]))
+        img = rng.integers(0, hi, shape).astype(np.uint16)
+        if rng.random() < 0.5:
+            img[rng.random(shape) < 0.4] = 0
+        if rng.random() < 0.3:
+            img = ndimage.uniform_filter(img.astype(float), 3).astype(np.uint16)
+        mk = np.zeros(shape, np.int16)
+        nm = int(rng.integers(1, 8))
+        mk.ravel()[rng.integers(0, img.size, nm)] = rng.choice(np.array([1, 2, 3], np.int16), nm)
+        if rng.random() < 0.3 and img.size > 8:
+            mk[tuple(slice(0, max(1, s // 2)) for s in shape)] = 2
+        yield img, mk, generate_binary_structure(nd, conn)
+
+
+def test_defect_free_statement_equals_scipy_unless_the_unlink_defect_fires(oracle):
+    """orc_watershed_ift_clean (ivx_oracle_wsz.c) is what the GPU flood is held to.  It equals live scipy on every input
+    where scipy's linked-list defect (ni_measure.c: `if (p->next || p->prev)` misses the only element of a bucket) stays
+    harmless -- no element popped late, none lost -- and the instrumented faithful restatement (== scipy always) tells."""
+    n_equal = n_defect = n_defect_differs = 0
+    for seed in (1, 2, 3):
+        for img, mk, s in _random_cases(seed, 250):
+            sci = ndimage.watershed_ift(img, mk, s)
+            faithful, ev = oracle.watershed_ift_events(img, mk, s)
+            assert np.array_equal(faithful, sci)
+            clean = oracle.watershed_ift_clean(img, mk, s)
+            if ev[1] == 0 and ev[3] == 0:
+                assert np.array_equal(clean, sci), (img.shape, ev)
+                n_equal += 1
+            else:
+                n_defect += 1
+                n_defect_differs += int(not np.array_equal(clean, sci))
+    assert n_equal > 600 and n_defect > 0
+    print("clean == scipy on %d cases; %d cases with late / lost pops, %d of them differ" % (n_equal, n_defect, n_defect_differs))
+
+
+def test_zone_formulation_equals_the_defect_free_flood(oracle):
+    """The order-free statement csrc/k_wsift.hip implements (minimax cost, entries, zones, time-stamp classes), executed by
+    the pure-Python prototype tools/proto_ws_zones.py, equals the serial defect-free flood -- labels on every voxel."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from proto_ws_zones import ift_zones
+    worst = 0
+    for img, mk, s in _random_cases(21, 150):
+        got, info = ift_zones(img, mk, s)
+        assert np.array_equal(got, oracle.watershed_ift_clean(img, mk, s)), img.shape
+        worst = max(worst, info["taus"])
+    assert worst < 400  # merged label classes keep the time-stamp table tiny
+
+
+def test_cost_map_is_the_minimax_arc_cost(oracle):
+    a = np.array([[0, 6, 5, 8, 20, 19]], np.uint16)
+    m = np.array([[1, 0, 0, 0, 0, 0]], np.int16)
+    line = np.array([[0, 0, 0], [1, 1, 1], [0, 0, 0]], np.uint8)
+    lab, cost = oracle.watershed_ift_clean(a, m, line, want_cost=True)
+    assert list(cost.ravel()) == [0, 6, 6, 6, 12, 12] and (lab == 1).all()
