@@ -7,9 +7,10 @@
  *     (ndimage/src/ni_measure.c, NI_WatershedIFT: bucket queue over max-arc path cost, positive
  *     labels pushed at the FRONT of a bucket, negative at the back, relabel on strictly smaller
  *     cost) and is PINNED against the live scipy in tests/test_oracle_watershed.py.
- *   - skimage.segmentation.watershed (scikit-image 0.24.0, NOT installed, not vendored) ->
- *     orc_watershed_sk restates the published algorithm (_watershed_cy.pyx: binary heap keyed by
- *     (value, age), neighbours labelled at push time) -- PARITY UNPINNED.
+ *   - skimage.segmentation.watershed (scikit-image 0.24.0, NOT installed, not vendored): a binary heap
+ *     keyed by (value, age) with neighbours labelled at push time (_watershed_cy.pyx).  NOT restated here:
+ *     its neighbour ordering and tie rules cannot be recovered without the source, and there is nothing
+ *     in this image to pin a restatement to.
  */
 #include <stdint.h>
 #include <stdlib.h>
