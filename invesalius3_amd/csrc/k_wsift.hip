@@ -17,7 +17,7 @@
 //          rank of the marker voxel (markers are queued in raster order, the last one is popped first).
 //
 // Pipeline (all on one stream, no CPU arithmetic):
-//   1. k_ws_relax      chaotic min-max relaxation of C over 32x8x8 tiles staged in LDS with their 1-voxel halo, only
+//   1. k_ws_relax      chaotic min-max relaxation of C over 16x16x8 tiles staged in LDS with their 1-voxel halo, only
 //                      dirty tiles per round (compact list), rounds until nothing changes;
 //   2. k_ws_entries    entry flags; k_ws_runs / k_ws_union / k_ws_flatten: zones by union-find (x-runs first);
 //   3. k_ws_hist / k_ws_scatter: entries bucketed by level (markers first, in raster order);
@@ -43,7 +43,9 @@
 namespace {
 using namespace ivx;
 
-constexpr int TX = 32, TY = 8, TZ = 8, BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NCELL = BX * BY * BZ;
+// tile: TX * TY == 256 lanes, one z-column of TZ voxels per lane (32x8x8: 39.5 ms, 16x16x8: 36.4, 16x16x16: 35.5 at 512^3)
+static_assert(16 * 16 == 256, "one lane per (x, y) column");
+constexpr int TX = 16, TY = 16, TZ = 8, BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NCELL = BX * BY * BZ;
 constexpr uint32_t ENTRY = 0xFFFFFFFFu, NONE = 0xFFFFFFFFu, CINF = 0xFFFFu;
 constexpr int RELAX_ITCAP = 64;
 constexpr int32_t NOLAB = 0;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
     int z0, y0, x0;
     tile_origin(g, tile, z0, y0, x0);
     load_tile(g, z0, y0, x0, I, C, s);
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
     s_act[ly][lx] = 0;
     if (threadIdx.x == 0) { s_new = 0; s_rej = NONE; }
     __syncthreads();
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void k_ws_entries(WsGeom g, const uint16_t *__
     tile_origin(g, blockIdx.x, z0, y0, x0);
     load_tile(g, z0, y0, x0, I, C, s);
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
     if (!(x0 + lx < g.w && y0 + ly < g.h)) return;
     const int nz = min(TZ, (int)(g.d - z0));
     for (int zz = 0; zz < nz; zz++) {
