@@ -12,7 +12,7 @@ A "step" is one pass of the hot path over the resident volume:
     4. marching cubes of the mask at iso 127 (from_binary), whole volume   (surface_process.py:100-186)
 The volume is uploaded once before the timed region (inputs resident in HBM).  N > 1: weak scaling, every rank
 owns one 512^3 Z-slab of a (512*N) x 512 x 512 volume; slab boundaries exchange one reached-bit plane per
-region-growing round (ncclSend/Recv + a 4-byte all-reduce in one group) and the image's halo slice once.
+region-growing round (ncclSend/Recv + a 4-byte all-reduce, one enqueue-only call) and the image's halo slice once.
 Launch: under torchrun (RANK / WORLD_SIZE / LOCAL_RANK in the environment) or plainly `python bench.py --gpus N`,
 which then starts the N ranks itself; fewer than N visible GPUs is an error, never a silent N=1.
 

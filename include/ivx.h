@@ -568,7 +568,7 @@ int ivx_dev_synth_volume(int16_t *out, int64_t dz, int64_t dy, int64_t dx, int64
  *   ivx_comm_unique_id   rank 0 makes the 128-byte id; it reaches the other ranks out of band (a file / env)
  *   ivx_comm_init        collective over all ranks, on the calling process's current device
  *   ivx_comm_exchange    to_down -> rank-1, to_up -> rank+1 and the mirror receives, one group (halo slices, planes)
- *   ivx_comm_exchange_vote   the same plus an in-place int32 sum all-reduce of `vote` in the same group
+ *   ivx_comm_exchange_vote   the same followed by an in-place int32 sum all-reduce of `vote` on the same stream
  *   ivx_comm_allreduce   in place; op 0 sum / 1 max / 2 min; IVX_I32 / I64 / F32 / F64 / U8 / I8 (no 16-bit integers)
  *   ivx_comm_allgather   recv = world * nbytes, rank order;   ivx_comm_bcast / send / recv: raw bytes
  * ---------------------------------------------------------------------------------------------- */

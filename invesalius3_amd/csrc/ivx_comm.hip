@@ -153,8 +153,8 @@ extern "C" int ivx_comm_exchange(void *comm, const void *to_down, void *from_dow
     return IVX_OK;
 }
 
-// the same exchange plus an in-place all-reduce (sum) of `nvote` int32 words, all in ONE group: the region-growing
-// round's planes and its "did anybody gain anything" vote cost one collective's latency
+// the same exchange followed, on the same stream, by an in-place all-reduce (sum) of `nvote` int32 words: the
+// region-growing round's planes and its "did anybody gain anything" vote are enqueued by ONE call, nothing waits in between
 extern "C" int ivx_comm_exchange_vote(void *comm, const void *to_down, void *from_down, const void *to_up, void *from_up,
                                       size_t nbytes, int32_t *vote, int nvote, void *stream) {
     IVX_REQUIRE(comm, IVX_EINVAL, "ivx_comm: null communicator");
@@ -172,8 +172,10 @@ extern "C" int ivx_comm_exchange_vote(void *comm, const void *to_down, void *fro
             if (from_up) IVX_NCCL(g_rccl.Recv(from_up, nbytes, ncclUint8, c->rank + 1, c->nc, st));
         }
     }
-    if (vote && nvote > 0) IVX_NCCL(g_rccl.AllReduce(vote, vote, (size_t)nvote, ncclInt32, ncclSum, c->nc, st));
     IVX_NCCL(g_rccl.GroupEnd());
+    // the vote follows on the same stream, outside the point-to-point group: fusing a collective into a send / recv group is
+    // not something every RCCL release accepts, and this path cannot be exercised on a one-GPU box
+    if (vote && nvote > 0) IVX_NCCL(g_rccl.AllReduce(vote, vote, (size_t)nvote, ncclInt32, ncclSum, c->nc, st));
     return IVX_OK;
 }
 

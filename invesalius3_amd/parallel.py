@@ -8,7 +8,7 @@ plus ONE overlap slice, concatenated):
 * marching cubes       rank g contours the cell layers between its slices and needs ONE slice of rank g+1 (its top
                        halo); pad_bottom only on rank 0, pad_top only on the last rank; soup = concatenation.
 * region growing       local fix-point -> ncclSend/Recv of the two interior boundary REACHED bit planes to the
-                       Z-neighbours + a 4-byte all-reduce of "words that gained bits", one group on the kernels' stream
+                       Z-neighbours + a 4-byte all-reduce of "words that gained bits", one enqueue-only call on the kernels' stream
                        -> OR the received planes into the halo slices -> one host read -> repeat until nobody gained.
                        Monotone, so it converges to exactly the single-GPU component.
 * projections          rays inside a slice are rank-local rows (all-gather); rays along Z: MaxIP / MinIP / MeanIP
@@ -82,7 +82,7 @@ def slab_region_grow(backend, comm, lay: SlabLayout) -> int:
       stage_vote()           vote <- "words that gained bits in my last OR" (1 before the first round: the seeds);
       or_planes()            OR the received planes into the halo slices, count the words that gained bits;
       read_votes()        -> (everybody's staged votes summed, my new count): the round's only host read.
-    `comm.exchange_vote` moves the planes between Z-neighbours and all-reduces the vote word in the same group, so the
+    `comm.exchange_vote` moves the planes between Z-neighbours and all-reduces the vote word right behind them, so the
     "did anybody gain anything" vote of round k travels with the planes of round k+1: the loop ends when a round
     reports that nobody gained anything in the round before (nobody flooded since, so the planes just exchanged are
     the ones everybody already had).  Monotone, so it converges to exactly the single-volume component."""
