@@ -318,9 +318,12 @@ __global__ __launch_bounds__(256) void k_ws_wake(int64_t ntiles, uint8_t *__rest
 }
 
 // entry flags: comp = ENTRY for entries (markers included), own index for the others
+// also, per voxel, which neighbours can be its parents (lower cost, arc == its cost) and which can be zone members it
+// touches (equal cost, arc <= cost): the per-level kernels then follow set bits instead of probing every neighbour
 template <int CONN, typename MT>
 __global__ __launch_bounds__(256) void k_ws_entries(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                    const MT *__restrict__ mk, uint32_t *__restrict__ comp) {
+                                                    const MT *__restrict__ mk, uint32_t *__restrict__ comp,
+                                                    uint32_t *__restrict__ pmask, uint32_t *__restrict__ zmask) {
     __shared__ uint32_t s[NCELL];
     int z0, y0, x0;
     tile_origin(g, blockIdx.x, z0, y0, x0);
@@ -334,38 +337,36 @@ __global__ __launch_bounds__(256) void k_ws_entries(WsGeom g, const uint16_t *__
         const uint32_t cell = s[ci];
         const uint32_t c = cell >> 16, iv = cell & 0xFFFFu;
         const int64_t p = (int64_t)(z0 + zz) * g.hw + (int64_t)(y0 + ly) * g.w + (x0 + lx);
-        bool e = mk[p] != 0;
-        if (!e) {
+        const bool marker = mk[p] != 0;
+        uint32_t pm = 0, zm = 0;
 #pragma unroll
-            for (int k = 0; k < 27; k++) {
-                if (!has_off<CONN>(g.smask, k)) continue;
-                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-                const uint32_t qv = s[ci + (dz * BY + dy) * BX + dx];
-                e |= (qv >> 16) < c && absdiff(qv & 0xFFFFu, iv) == c;
-            }
+        for (int k = 0; k < 27; k++) {
+            if (!has_off<CONN>(g.smask, k)) continue;
+            const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+            const uint32_t qv = s[ci + (dz * BY + dy) * BX + dx];
+            const uint32_t qc = qv >> 16, w = absdiff(qv & 0xFFFFu, iv);
+            // (a staged cell outside the volume carries cost CINF and intensity 0: it can be neither)
+            const int64_t q = p + dz * g.hw + dy * g.w + dx;
+            const bool in = q >= 0 && q < g.n;
+            pm |= (in && qc < c && w == c) ? 1u << k : 0u;
+            zm |= (in && qc == c && w <= c) ? 1u << k : 0u;
         }
+        const bool e = marker || pm != 0;
         comp[p] = e ? ENTRY : (uint32_t)p;
+        pmask[p] = marker ? 0u : pm;
+        zmask[p] = zm;
     }
-}
-
-__device__ __forceinline__ bool ws_linked(const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                          const uint32_t *comp, int64_t p, uint32_t cp, uint32_t ip, int64_t q) {
-    return comp[q] != ENTRY && C[q] == cp && absdiff(I[q], ip) <= cp;
 }
 
 // x-runs inside a wave's 64 voxels: parent = start of the run (saves most of the unions on plateaus)
-__global__ __launch_bounds__(256) void k_ws_runs(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                 uint32_t *comp, int has_x) {
+__global__ __launch_bounds__(256) void k_ws_runs(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp, int has_x) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    bool mine = p < g.n && comp[p] != ENTRY;
+    const bool mine = p < g.n && comp[p] != ENTRY;
     bool link = false;
-    if (mine && has_x && lane > 0) {
-        // comp[p-1] is either ENTRY or (p-1) at this point or an earlier value of this kernel: only ENTRY-ness is read
-        link = ws_linked(I, C, comp, p, C[p], I[p], p - 1);
-    }
+    // comp[p-1] is ENTRY, (p-1), or a value this kernel just wrote there: only its ENTRY-ness is read
+    if (mine && has_x && lane > 0) link = ((zmask[p] >> 12) & 1u) && comp[p - 1] != ENTRY;
     const unsigned long long starts = __ballot(mine && !link);
-    // every lane of the wave has read comp[p-1] before anyone writes (the ballot is a wave-wide join)
     if (mine && link) {
         const unsigned long long below = starts & ((2ull << lane) - 1ull);
         const int s0 = 63 - __clzll(below);
@@ -395,21 +396,18 @@ __device__ __forceinline__ void ws_unite(uint32_t *comp, uint32_t a, uint32_t b)
 }
 
 template <int CONN>
-__global__ __launch_bounds__(256) void k_ws_union(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                  uint32_t *comp) {
+__global__ __launch_bounds__(256) void k_ws_union(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= g.n) return;
     if (__hip_atomic_load(&comp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) return;
-    const uint32_t cp = C[p], ip = I[p];
-#pragma unroll
-    for (int k = 14; k < 27; k++) { // forward offsets only
-        if (!has_off<CONN>(g.smask, k)) continue;
+    uint32_t zm = zmask[p] >> 14; // forward neighbours only (k = 14 .. 26)
+    if ((threadIdx.x & 63) != 63) zm &= ~1u; // +x inside a wave: done by k_ws_runs
+    while (zm) {
+        const int k = 14 + __ffs(zm) - 1;
+        zm &= zm - 1;
         const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-        if (k == 14 && (threadIdx.x & 63) != 63) continue; // +x inside a wave: done by k_ws_runs
         const int64_t q = p + dz * g.hw + dy * g.w + dx;
-        if (q >= g.n || q < 0) continue;
         if (__hip_atomic_load(&comp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) continue;
-        if (C[q] != cp || absdiff(I[q], ip) > cp) continue;
         ws_unite(comp, (uint32_t)p, (uint32_t)q);
     }
 }
@@ -478,25 +476,23 @@ __device__ __forceinline__ uint32_t ws_tau_of(const uint32_t *__restrict__ comp,
     return __hip_atomic_load(&tau[cv == ENTRY ? (uint32_t)v : cv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// key of every entry of level c: the earliest time stamp among its admissible parents; mark the key as used
+// key of every entry of level c: the earliest time stamp among its admissible parents (the set bits of pmask); mark the
+// key as used
 template <int CONN>
-__global__ __launch_bounds__(256) void k_ws_keys(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                 const uint32_t *__restrict__ comp, const uint32_t *tau,
-                                                 const uint32_t *__restrict__ elist, uint32_t *__restrict__ key, uint32_t *used,
-                                                 uint32_t start, uint32_t count, uint32_t c) {
+__global__ __launch_bounds__(256) void k_ws_keys(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ comp,
+                                                 const uint32_t *tau, const uint32_t *__restrict__ elist, uint32_t *__restrict__ key,
+                                                 uint32_t *used, uint32_t start, uint32_t count) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < count;
     uint32_t K = NONE;
     if (act) {
         const int64_t p = elist[start + i];
-        const uint32_t ip = I[p];
-#pragma unroll
-        for (int k = 0; k < 27; k++) {
-            if (!has_off<CONN>(g.smask, k)) continue;
+        uint32_t pm = pmask[p];
+        while (pm) {
+            const int k = __ffs(pm) - 1;
+            pm &= pm - 1;
             const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-            const int64_t v = p + dz * g.hw + dy * g.w + dx;
-            if (v < 0 || v >= g.n) continue;
-            if (C[v] < c && absdiff(I[v], ip) == c) K = min(K, ws_tau_of(comp, tau, v));
+            K = min(K, ws_tau_of(comp, tau, p + dz * g.hw + dy * g.w + dx));
         }
         key[start + i] = K;
     }
@@ -607,12 +603,12 @@ __global__ __launch_bounds__(1024) void k_ws_rank(WsState *st, uint32_t *used, u
     if (t == 0) st->base = base + T;
 }
 
-// entries of level c take their time stamp and hand it to the zones they touch (the earliest stamp wins the zone)
+// entries of level c take their time stamp and hand it to the zones they touch (the set bits of zmask that are not
+// entries themselves): the earliest stamp wins the zone
 template <int CONN>
-__global__ __launch_bounds__(256) void k_ws_claim(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                  const uint32_t *__restrict__ comp, uint32_t *tau,
-                                                  const uint32_t *__restrict__ elist, const uint32_t *__restrict__ key,
-                                                  const uint32_t *__restrict__ remap, uint32_t start, uint32_t count, uint32_t c) {
+__global__ __launch_bounds__(256) void k_ws_claim(WsGeom g, const uint32_t *__restrict__ zmask, const uint32_t *__restrict__ comp,
+                                                  uint32_t *tau, const uint32_t *__restrict__ elist, const uint32_t *__restrict__ key,
+                                                  const uint32_t *__restrict__ remap, uint32_t start, uint32_t count) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     const int64_t p = elist[start + i];
@@ -620,15 +616,13 @@ __global__ __launch_bounds__(256) void k_ws_claim(WsGeom g, const uint16_t *__re
     if (K == NONE) return;
     const uint32_t t = remap[K];
     tau[p] = t;
-    const uint32_t ip = I[p];
-#pragma unroll
-    for (int k = 0; k < 27; k++) {
-        if (!has_off<CONN>(g.smask, k)) continue;
+    uint32_t zm = zmask[p];
+    while (zm) {
+        const int k = __ffs(zm) - 1;
+        zm &= zm - 1;
         const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-        const int64_t q = p + dz * g.hw + dy * g.w + dx;
-        if (q < 0 || q >= g.n) continue;
-        const uint32_t r = comp[q];
-        if (r == ENTRY || C[q] != c || absdiff(I[q], ip) > c) continue;
+        const uint32_t r = comp[p + dz * g.hw + dy * g.w + dx];
+        if (r == ENTRY) continue;
         if (__hip_atomic_load(&tau[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > t) atomicMin(&tau[r], t);
     }
 }
@@ -656,7 +650,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsBufs {
     uint16_t *C;
-    uint32_t *comp, *tau, *elist, *key, *hist, *cursor, *bcount, *bsum, *list, *used, *remap;
+    uint32_t *comp, *tau, *elist, *key, *pmask, *zmask, *hist, *cursor, *bcount, *bsum, *list, *used, *remap;
     int32_t *lab;
     uint8_t *dirty, *pending;
     WsState *st;
@@ -673,6 +667,8 @@ static void ws_layout(const WsGeom &g, uint32_t cap, char *base, WsBufs *b) {
     b->tau = (uint32_t *)take((size_t)g.n * 4);
     b->elist = (uint32_t *)take((size_t)g.n * 4);
     b->key = (uint32_t *)take((size_t)g.n * 4);
+    b->pmask = (uint32_t *)take((size_t)g.n * 4);
+    b->zmask = (uint32_t *)take((size_t)g.n * 4);
     b->hist = (uint32_t *)take(65536 * 4);
     b->cursor = (uint32_t *)take(65536 * 4);
     b->bcount = (uint32_t *)take((size_t)(nblk + 1) * 4);
@@ -840,11 +836,11 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
 
     tm.mark(st);
     // ---- 2. entries and zones ------------------------------------------------------------------------------
-    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_entries<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.comp));
+    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_entries<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.comp, b.pmask, b.zmask));
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ws_runs, dim3(gl), dim3(256), 0, st, g, I, b.C, b.comp, (int)((g.smask >> 12) & 1u));
+    hipLaunchKernelGGL(k_ws_runs, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp, (int)((g.smask >> 12) & 1u));
     IVX_LAUNCH_CHECK();
-    WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_union<CC>, dim3(gl), dim3(256), 0, st, g, I, b.C, b.comp));
+    WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_union<CC>, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp));
     IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ws_flatten, dim3(gl), dim3(256), 0, st, g.n, b.comp);
     IVX_LAUNCH_CHECK();
@@ -883,14 +879,14 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         nlevels++;
         const unsigned gb = (unsigned)cdiv(cnt, 256);
         if (c > 0) {
-            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_keys<CC>, dim3(gb), dim3(256), 0, st, g, I, b.C, b.comp, b.tau, b.elist, b.key,
-                                                      b.used, start, cnt, c));
+            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_keys<CC>, dim3(gb), dim3(256), 0, st, g, b.pmask, b.comp, b.tau, b.elist, b.key,
+                                                      b.used, start, cnt));
             IVX_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(k_ws_rank, dim3(1), dim3(1024), 0, st, b.st, b.used, b.remap, b.lab, cap);
         IVX_LAUNCH_CHECK();
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_claim<CC>, dim3(gb), dim3(256), 0, st, g, I, b.C, b.comp, b.tau, b.elist, b.key,
-                                                  b.remap, start, cnt, c));
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_claim<CC>, dim3(gb), dim3(256), 0, st, g, b.zmask, b.comp, b.tau, b.elist, b.key,
+                                                  b.remap, start, cnt));
         IVX_LAUNCH_CHECK();
         start += cnt;
     }
