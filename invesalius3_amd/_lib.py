@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libivx.so")
+LIB_PATH = os.environ.get("IVX_LIB_PATH") or os.path.join(_HERE, "libivx.so")  # IVX_LIB_PATH: A/B builds of the same ABI
 
 IVX_OK, IVX_EINVAL, IVX_ERANGE, IVX_ENOMEM, IVX_EDOM, IVX_EHIP = 0, -1, -2, -3, -4, -5
 U8, I16, F64, U16, F32, I32, I64, I8 = 0, 1, 2, 3, 4, 5, 6, 7

@@ -44,8 +44,11 @@ namespace {
 using namespace ivx;
 
 // tile: TX * TY == 256 lanes, one z-column of TZ voxels per lane (32x8x8: 39.5 ms, 16x16x8: 36.4, 16x16x16: 35.5 at 512^3)
-static_assert(16 * 16 == 256, "one lane per (x, y) column");
-constexpr int TX = 16, TY = 16, TZ = 8, BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NCELL = BX * BY * BZ;
+#ifndef IVX_WS_TX
+#define IVX_WS_TX 16
+#define IVX_WS_TY 16
+#endif
+constexpr int TX = IVX_WS_TX, TY = IVX_WS_TY, TZ = 8, BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NCELL = BX * BY * BZ;
 constexpr uint32_t ENTRY = 0xFFFFFFFFu, NONE = 0xFFFFFFFFu, CINF = 0xFFFFu;
 constexpr int RELAX_ITCAP = 64;
 constexpr int32_t NOLAB = 0;
@@ -66,7 +69,6 @@ struct WsState {
     uint32_t minrej;   // smallest cost refused by the gate so far } after every round
     uint32_t assigned; // voxels that have a finite cost           } (one mailbox message)
     uint32_t sweeps;   // LDS sweeps over all tile visits (statistics)
-    unsigned long long evals; // voxel evaluations over all sweeps (statistics)
 };
 
 template <int CONN> __device__ __forceinline__ bool has_off(uint32_t smask, int k) {
@@ -105,14 +107,14 @@ __device__ __forceinline__ void tile_origin(const WsGeom &g, int64_t tile, int &
 // that straddles the ends of the volume, go cell by cell.  Staging was 40 % of a visit's time before this.
 __device__ __forceinline__ void load_tile(const WsGeom &g, int z0, int y0, int x0, const uint16_t *__restrict__ I,
                                           const uint16_t *C, uint32_t *s) {
-    static_assert(TX == 16, "rows of 16 interior cells");
+    static_assert(TX % 8 == 0, "rows of whole 8-cell chunks");
     if ((g.w & 7) == 0) {
-        constexpr int NROW = BZ * BY, NITEM = NROW * 2; // (row, half of 8 cells)
+        constexpr int NROW = BZ * BY, CH = TX / 8, NITEM = NROW * CH; // (row, chunk of 8 cells)
 #pragma unroll
         for (int q = 0; q < (NITEM + 255) / 256; q++) {
             const int it = threadIdx.x + q * 256;
             if (it < NITEM) {
-                const int row = it >> 1, half = it & 1, ly = row % BY, lz = row / BY;
+                const int row = it / CH, half = it % CH, ly = row % BY, lz = row / BY;
                 const int64_t L = (int64_t)(z0 + lz - 1) * g.hw + (int64_t)(y0 + ly - 1) * g.w + x0 + half * 8;
                 uint32_t *dst = s + row * BX + 1 + half * 8;
                 if (L >= 0 && L + 8 <= g.n) {
@@ -134,9 +136,9 @@ __device__ __forceinline__ void load_tile(const WsGeom &g, int z0, int y0, int x
             }
         }
 #pragma unroll
-        for (int q = 0; q < (NITEM + 255) / 256; q++) { // the two x-halo cells of every row
+        for (int q = 0; q < (NROW * 2 + 255) / 256; q++) { // the two x-halo cells of every row
             const int it = threadIdx.x + q * 256;
-            if (it < NITEM) {
+            if (it < NROW * 2) {
                 const int row = it >> 1, side = it & 1, ly = row % BY, lz = row / BY;
                 const int64_t L = (int64_t)(z0 + lz - 1) * g.hw + (int64_t)(y0 + ly - 1) * g.w + x0 + (side ? TX : -1);
                 s[row * BX + (side ? BX - 1 : 0)] = (L >= 0 && L < g.n) ? ((uint32_t)C[L] << 16) | I[L] : CINF << 16;
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void k_ws_build_list(int64_t ntiles, uint8_t *
 // evaluations of a 512^3 flood, at a tenth of the lanes).
 // theta gates the flood: a cost above it is not accepted yet (the tile is parked in `pending`), so that below the level
 // where the bulk of the volume connects only final costs spread -- no wave of provisional costs to correct later.
-template <int CONN>
+template <int CONN, bool LDS_CHG>
 __device__ __forceinline__ bool ws_eval(uint32_t *s, uint32_t (*s_act)[TX], uint32_t (*s_chg)[TX], int lx, int ly, int zz, int nz,
                                         uint32_t smask, uint32_t theta, uint32_t &fresh, uint32_t &rej) {
     const int ci = ((zz + 1) * BY + (ly + 1)) * BX + (lx + 1);
@@ -274,7 +276,7 @@ __device__ __forceinline__ bool ws_eval(uint32_t *s, uint32_t (*s_act)[TX], uint
         return false;
     }
     s[ci] = (best << 16) | iv;
-    atomicOr(&s_chg[ly][lx], 1u << zz);
+    if (LDS_CHG) atomicOr(&s_chg[ly][lx], 1u << zz); // pooled sweeps: any lane may change any voxel
     fresh += c == CINF;
     // the neighbours inside the tile have to look again
 #pragma unroll
@@ -298,28 +300,29 @@ __device__ __forceinline__ bool ws_eval(uint32_t *s, uint32_t (*s_act)[TX], uint
 template <int CONN>
 __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__restrict__ I, uint16_t *C,
                                                   const uint32_t *__restrict__ list, uint8_t *dirty, uint8_t *pending,
-                                                  WsState *st, uint32_t theta) {
+                                                  WsState *st, uint32_t theta_flags) {
     __shared__ uint32_t s[NCELL];
     __shared__ uint32_t s_act[TY][TX], s_chg[TY][TX];
-    __shared__ uint16_t s_queue[TX * TY * TZ];
+    __shared__ uint16_t s_queue[CONN == 6 ? 2 : TX * TY * TZ]; // (the 6-neighbour form never pools)
     __shared__ uint32_t s_qn[2];
-    __shared__ uint32_t s_new, s_rej, s_ev, s_ev2;
+    __shared__ uint32_t s_new, s_rej, s_ev2;
     const int64_t tile = list[blockIdx.x];
+    const uint32_t theta = theta_flags & 0xFFFFu; // bit 31 of the argument: collect the sweep statistic
     int z0, y0, x0;
     tile_origin(g, tile, z0, y0, x0);
     load_tile(g, z0, y0, x0, I, C, s);
     const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
     s_act[ly][lx] = 0;
     s_chg[ly][lx] = 0;
-    if (threadIdx.x == 0) { s_new = 0; s_rej = NONE; s_ev = 0; s_ev2 = 0; s_qn[0] = 0; s_qn[1] = 0; }
+    if (threadIdx.x == 0) { s_new = 0; s_rej = NONE; s_ev2 = 0; s_qn[0] = 0; s_qn[1] = 0; }
     __syncthreads();
     const bool col = x0 + lx < g.w && y0 + ly < g.h;
     const int nz = min(TZ, (int)(g.d - z0));
-    uint32_t fresh = 0, rej = NONE, nev = 0;
+    uint32_t fresh = 0, rej = NONE, chg = 0; // chg: changes this lane made to ITS column (a register is enough there)
     // sweep 0: every voxel, column by column
     if (col) {
-        nev += nz;
-        for (int zz = 0; zz < nz; zz++) ws_eval<CONN>(s, s_act, s_chg, lx, ly, zz, nz, g.smask, theta, fresh, rej);
+        for (int zz = 0; zz < nz; zz++)
+            if (ws_eval<CONN, false>(s, s_act, s_chg, lx, ly, zz, nz, g.smask, theta, fresh, rej)) chg |= 1u << zz;
     }
     __syncthreads();
     int it = 1;
@@ -330,11 +333,13 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
         while (more && it < RELAX_ITCAP) {
             bool any = false;
             uint32_t a = col ? atomicExch(&s_act[ly][lx], 0u) : 0u;
-            nev += __popc(a);
             while (a) {
                 const int zz = (it & 1) ? 31 - __clz(a) : __ffs(a) - 1; // alternate the sweep direction
                 a &= ~(1u << zz);
-                any |= ws_eval<CONN>(s, s_act, s_chg, lx, ly, zz, nz, g.smask, theta, fresh, rej);
+                if (ws_eval<CONN, false>(s, s_act, s_chg, lx, ly, zz, nz, g.smask, theta, fresh, rej)) {
+                    any = true;
+                    chg |= 1u << zz;
+                }
             }
             more = __syncthreads_or(any);
             it++;
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
                 while (m) {
                     const int zz = __ffs(m) - 1;
                     m &= m - 1;
-                    s_queue[off++] = (uint16_t)((zz << 8) | (ly << 4) | lx);
+                    s_queue[off++] = (uint16_t)((zz * TY + ly) * TX + lx);
                 }
             }
             __syncthreads();
@@ -358,19 +363,17 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
             if (T == 0) { more = false; break; } // uniform: nothing left to look at
             for (uint32_t i = threadIdx.x; i < T; i += 256) {
                 const uint32_t code = s_queue[i];
-                ws_eval<CONN>(s, s_act, s_chg, (int)(code & 15u), (int)((code >> 4) & 15u), (int)(code >> 8), nz, g.smask, theta, fresh, rej);
-                nev++;
+                ws_eval<CONN, true>(s, s_act, s_chg, (int)(code % TX), (int)((code / TX) % TY), (int)(code / (TX * TY)), nz, g.smask, theta, fresh, rej);
             }
             __syncthreads();
             it++;
         }
     }
-    static_assert(TX == 16 && TY == 16 && TZ <= 16, "queue code packs lx:4 | ly:4 | zz");
+    static_assert(TX * TY == 256 && TX * TY * TZ <= 65536, "one lane per column; queue codes are 16 bits");
     if (more && threadIdx.x == 0) dirty[tile] = 1; // iteration cap: come back
     if (rej != NONE) atomicMin(&s_rej, rej);
     if (fresh) atomicAdd(&s_new, fresh);
-    if (nev) atomicAdd(&s_ev, nev);
-    const uint32_t chg = col ? s_chg[ly][lx] : 0u;
+    if (col) chg |= s_chg[ly][lx];
     // Which tiles read a changed voxel?  Inside the volume proper it is the lattice neighbour in the direction the voxel
     // leaves the box by: collect those directions in one 27-bit mask per workgroup and mark each tile once.  Only voxels
     // whose neighbour wraps around a row / slice end (scipy's linear-index neighbourhood) look their reader up one by one.
@@ -411,9 +414,9 @@ __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__re
             pending[tile] = 1;
             atomicMin(&st->minrej, s_rej);
         }
-        if (s_new) atomicAdd(&st->assigned, s_new);
-        atomicAdd(&st->sweeps, (uint32_t)it);
-        atomicAdd(&st->evals, (unsigned long long)s_ev);
+        // hot single-address atomics from a million visits cost milliseconds: only when somebody reads them
+        if (s_new && theta < CINF) atomicAdd(&st->assigned, s_new); // the gate's "bulk is in" test
+        if (theta_flags & 0x80000000u) atomicAdd(&st->sweeps, (uint32_t)it); // statistics (IVX_WS_TRACE)
     }
 }
 
@@ -938,7 +941,7 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         }
         rounds++;
         visits += nl;
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_relax<CC>, dim3(nl), dim3(256), 0, st, g, I, b.C, b.list, b.dirty, b.pending, b.st, theta));
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_relax<CC>, dim3(nl), dim3(256), 0, st, g, I, b.C, b.list, b.dirty, b.pending, b.st, theta | (trace ? 0x80000000u : 0u)));
         IVX_LAUNCH_CHECK();
         IVX_REQUIRE(rounds < 1000000, IVX_EHIP, "watershed_ift: relaxation does not terminate");
     }
@@ -1014,7 +1017,6 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         stats[6] = g.ntiles; stats[7] = hs.sweeps;
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] zones, [10] bucketing, [11] level chain, [12] labels (microseconds)
-        stats[15] = (int64_t)hs.evals;
     }
     return IVX_OK;
 }

@@ -28,7 +28,7 @@ def markers_for(img):
 def main():
     L.require_device()
     sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [256]
-    conns = [1, 3]
+    conns = [int(a[5:]) for a in sys.argv[1:] if a.startswith("conn=")] or [1, 3]
     for n in sizes:
         img = synth_v512((n, n, n))
         cost = (img - img.min()).astype(np.uint16)
