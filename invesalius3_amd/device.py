@@ -637,6 +637,44 @@ class DeviceVolume:
             return self._verts.download((nv.value, 3), np.float32), self._faces.download((nt.value, 3), np.int32)
         return nv.value, nt.value
 
+    # -- watershed (watershed_process.py:19-60 + the merge of styles.py:2147-2152) on the resident volume -------------------
+    def watershed(self, markers: np.ndarray, strct, use_ww_wl: bool = False, wl=0, ww=0, overwrite: bool = False):
+        """The IFT branch of do_watershed followed by the caller's merge rule, all in HBM: cost image (LUT or
+        ``image - image.min()``) -> marker flood (`ivx_dev_watershed_ift`) -> ``mask`` gets 253 where the flood says 1 and
+        2 where it says 2 (only over cells that hold 0 / 2 / 253, or over everything after zeroing with `overwrite`).
+        `markers`: int8 / int16 (0, 1, 2) array of the volume's shape, uploaded for the call.  Returns the flood's stats."""
+        mk = np.ascontiguousarray(markers)
+        if mk.shape != self.shape or mk.dtype.type not in (np.int8, np.int16):
+            raise TypeError("markers must be an int8 / int16 array of the volume's shape")
+        s3 = np.zeros((3, 3, 3), np.uint8)
+        s3[:] = np.asarray(strct).astype(bool)
+        lib, n = L.lib(), self.n
+        d_mk, d_cost, d_lab = DeviceBuffer(mk.nbytes), DeviceBuffer(n * 2), DeviceBuffer(n)
+        d_mk.upload(mk)
+        try:
+            if use_ww_wl:
+                L.check(lib.ivx_dev_lut_u16(self.image.raw, c64(n), ctypes.c_double(float(ww)), ctypes.c_double(float(wl)), 0,
+                                            d_cost.ptr, self.stream), "lut")
+            else:
+                mm = DeviceBuffer(64)
+                L.check(lib.ivx_dev_minmax_f32(L.I16, self.image.raw, c64(n), mm.ptr, self.stream))
+                self.sync()
+                imin = int(mm.download((2,), np.float32)[0])
+                mm.close()
+                L.check(lib.ivx_dev_shift_min_u16(self.image.raw, c64(n), imin, d_cost.ptr, self.stream), "min shift")
+            stats = (ctypes.c_int64 * 16)()
+            with self.timer.span("watershed_flood"):
+                L.check(lib.ivx_dev_watershed_ift(d_cost.ptr, L.I16 if mk.dtype == np.int16 else L.I8, d_mk.ptr, c64(self.dz),
+                                                  c64(self.dy), c64(self.dx), L.ptr(s3), None, d_lab.ptr, None, stats, self.stream),
+                        "watershed_ift")
+            L.check(lib.ivx_dev_watershed_merge(self.mask.ptr, d_lab.ptr, c64(n), int(bool(overwrite)), self.stream), "merge")
+            self.sync()
+        finally:
+            for b in (d_mk, d_cost, d_lab):
+                b.close()
+        names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles")
+        return {k: int(v) for k, v in zip(names, stats)}
+
     # -- projections ---------------------------------------------------------------------------------
     def project(self, axis: int, op: int, out: DeviceBuffer):
         L.check(L.lib().ivx_dev_mip_reduce(L.I16, self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(axis),

@@ -215,3 +215,31 @@ def test_calc_image_density_matches_numpy(ivxlib):
     assert (lo, hi) == (int(vals.min()), int(vals.max()))
     assert mean == pytest.approx(float(vals.mean()), rel=1e-13) and std == pytest.approx(float(vals.std()), rel=1e-10)
     assert sl.calc_image_density(img, np.zeros_like(m)) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("use_ww_wl,overwrite", [(False, True), (True, False)])
+def test_device_volume_watershed_matches_reference_recipe(ivxlib, oracle, use_ww_wl, overwrite):
+    """resident watershed == cost image of watershed_process.py:41-57 -> flood (defect-free oracle; == live scipy when its
+    unlink defect stays harmless) -> merge rule of styles.py:2147-2152"""
+    from invesalius3_amd.device import DeviceVolume
+    img = synth_volume((24, 48, 64), seed=66)
+    mk = np.zeros(img.shape, np.int16 if use_ww_wl else np.int8)
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    mk[z, y, x] = 1
+    mk[0, 0, 0] = mk[-1, -1, -1] = 2
+    s = generate_binary_structure(3, 1)
+    vol = DeviceVolume(img)
+    vol.threshold(226, 3071)
+    before = vol.download_mask()
+    vol.watershed(mk, s, use_ww_wl=use_ww_wl, wl=300, ww=400, overwrite=overwrite)
+    if use_ww_wl:
+        cost = np.piecewise(img, [img <= (300 - 0.5 - (400 - 1) / 2.0), img > (300 - 0.5 + (400 - 1) / 2.0)],
+                            [0, 400, lambda v: ((v - (300 - 0.5)) / (400 - 1) + 0.5) * 400]).astype(np.uint16)
+    else:
+        cost = (img - img.min()).astype(np.uint16)
+    lab = oracle.watershed_ift_clean(cost, mk, s).astype(np.uint8)
+    want = before.copy()
+    oracle.watershed_merge(want, lab, overwrite)
+    assert np.array_equal(vol.download_mask(), want) and (want == 253).any()
+    assert overwrite or (want == 2).any()  # overwrite keeps the object only (styles.py:2147-2149)
+    vol.close()
