@@ -174,6 +174,32 @@ def launch_ranks(args):
         raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
+class CStdoutToStderr:
+    """RCCL announces itself (version / host / library path) on the C-level stdout, block-buffered, so it would land
+    after rank 0's JSON line when the process exits.  While this is active file descriptor 1 IS stderr; leaving it
+    flushes the C buffers first.  `stay()` makes the switch permanent (used right before the ranks exit)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+    @staticmethod
+    def stay():
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(2, 1)
+
+
 class Ranks:
     """what the timing contract needs from the job: barrier, max over ranks, sums -- over RCCL, or trivially at N = 1"""
 
@@ -184,7 +210,8 @@ class Ranks:
         self.comm = None
         if self.world > 1:
             from invesalius3_amd.comm import init_from_env
-            self.comm = init_from_env()
+            with CStdoutToStderr():
+                self.comm = init_from_env()
 
     def barrier(self):
         from invesalius3_amd import _lib as L
@@ -747,6 +774,7 @@ def main():
     job = Ranks()
     {"grow_mc": run_grow_mc, "watershed": run_watershed, "mip": run_mip, "sharded2048": run_sharded2048}[args.config](args, job)
     if job.comm is not None:
+        CStdoutToStderr.stay()  # the JSON line is out; whatever RCCL still has to say goes to stderr
         job.comm.barrier()
         job.comm.close()
 
