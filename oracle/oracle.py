@@ -648,3 +648,28 @@ def watershed_ift_clean(image, markers, strct, want_cost=False):
                                          1 if markers.dtype == np.int16 else 4, _p(markers), _p(s3), _p(out),
                                          _p(cost) if want_cost else None))
     return (out, cost) if want_cost else out
+
+
+def watershed_sk(image, markers, strct, tie_mode=0, want_stats=False):
+    """skimage.segmentation.watershed(image, markers, strct) as the reference calls it (watershed_process.py:39,52),
+    restated in ivx_oracle_wssk.c.  tie_mode 0 = scikit-image's binary heap move for move (pinned to the compiled
+    0.18.3 kernel, tests/golden/watershed_sk.npz); 1 = equal-valued marker voxels leave the queue in raster order.
+    Returns int32 labels (scikit-image's output dtype)."""
+    image = np.ascontiguousarray(image)
+    markers = np.ascontiguousarray(markers)
+    idt = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 3, np.dtype(np.int16): 1}[image.dtype]
+    mdt = {np.dtype(np.int16): 1, np.dtype(np.int8): 4, np.dtype(np.int32): 2}[markers.dtype]
+    s3 = np.zeros((3, 3, 3), np.uint8)
+    if image.ndim == 3:
+        s3[:] = np.asarray(strct, dtype=np.uint8)
+        shp = image.shape
+    else:
+        s3[1] = np.asarray(strct, dtype=np.uint8)
+        shp = (1,) + image.shape
+    out = np.zeros(image.shape, np.int32)
+    st = np.zeros(4, np.int64)
+    _check(lib().orc_watershed_sk(idt, _p(image), _i64(shp), mdt, _p(markers), _p(s3), ctypes.c_int(int(tie_mode)),
+                                  _p(out), _p(st)))
+    if want_stats:
+        return out, {"pushes": int(st[0]), "pops": int(st[1]), "heap_peak": int(st[2]), "tied_marker_pops": int(st[3])}
+    return out

@@ -26,6 +26,51 @@ def test_oracles_reproduce_the_golden_watershed_vectors(oracle):
     assert (lab0 == 1).sum() == 27 and (lab0 == 2).sum() == 98  # the reference fixture's counts
 
 
+def _sk():
+    z = np.load(os.path.join(GOLD, "watershed_sk.npz"))
+    for nm in z["names"]:
+        yield str(nm), z["img_" + nm], z["mk_" + nm], z["st_" + nm], z["hi_" + nm], z["lo_" + nm], bool(z["same_order_" + nm])
+
+
+def test_skimage_watershed_oracle_is_pinned_to_the_compiled_kernel(oracle):
+    """tests/golden/watershed_sk.npz comes from scikit-image 0.18.3's compiled flood run in the build container
+    (make_golden_sk.py): the restated heap flood equals it voxel for voxel, with the neighbour list in the documented
+    (stable) order always, and through skimage.segmentation.watershed itself wherever 0.18.3's unstable argsort yields
+    that same order (with the container's numpy 1.26.4: every 6-neighbour 3-D and 4-neighbour 2-D call)."""
+    n = via_api = tied = 0
+    for nm, img, mk, st, hi, lo, same in _sk():
+        lab, stats = oracle.watershed_sk(img, mk, st, 0, True)
+        assert lab.dtype == np.int32 and np.array_equal(lab, lo), nm
+        assert stats["pushes"] == stats["pops"] == img.size, nm          # every voxel is queued exactly once
+        if same:
+            assert np.array_equal(lab, hi), nm
+            via_api += 1
+        if st.sum() in (7, 5):                                           # 6-neighbour 3-D, 4-neighbour 2-D
+            assert same, nm
+        tied += stats["tied_marker_pops"] > 0
+        n += 1
+    assert n >= 100 and via_api >= 36 and tied >= 50
+    ref = {nm: hi for nm, _i, _m, _s, hi, _l, _o in _sk()}["ref5"]   # tests/test_segmentation_tools.py:170-213
+    assert np.any(ref > 0) and (ref == 1).sum() == 109 and (ref == 2).sum() == 16
+
+
+def test_skimage_watershed_depends_on_the_heap_layout(oracle):
+    """Why this branch has no order-free statement: equal-valued marker voxels (all of age 0) leave scikit-image's binary
+    heap in an order that depends on the heap's array layout.  Breaking those ties by raster index instead -- a total
+    order, under which ANY priority queue gives one result -- changes the labels on many golden cases, and never
+    when no two queued markers tied."""
+    differ = same_when_untied = 0
+    for nm, img, mk, st, _hi, lo, _same in _sk():
+        lab0, stats = oracle.watershed_sk(img, mk, st, 0, True)
+        lab1 = oracle.watershed_sk(img, mk, st, 1)
+        if stats["tied_marker_pops"] == 0:
+            assert np.array_equal(lab0, lab1), nm
+            same_when_untied += 1
+        elif not np.array_equal(lab0, lab1):
+            differ += 1
+    assert differ >= 20 and same_when_untied >= 20
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_the_golden_vectors(ivxlib):
     from invesalius3_amd import surface_process as sp, watershed_process as wp
