@@ -513,6 +513,29 @@ int ivx_watershed_ift(int idtype /* IVX_U8 | IVX_U16 */, const void *input, cons
                       const void *markers, const uint8_t strct[27], void *output, uint16_t *cost_out, int64_t stats[16]);
 
 /* ------------------------------------------------------------------------------------------------
+ * the marker flood of do_watershed's scikit-image branch (algorithm == "Watershed", the GUI's default)
+ *   replaces skimage.segmentation.watershed(tmp_image, markers, bstruct) as called at
+ *            invesalius/data/watershed_process.py:36-39,49-52 (3-D) and invesalius/data/styles.py:1958,1975 (one slice,
+ *            shape (1, h, w) with the 3x3 structure in strct[9..17]); no mask, no compactness, no watershed lines.
+ * image: uint16 (the gradient of the LUT / min-shifted image; 65535 is refused), markers int16 or int8 (any non-zero
+ * label, negative ones included), strct: 3x3x3 uint8, symmetric.  Labels come back in the markers' dtype, as int32
+ * (scikit-image's output dtype) and / or as uint8 (what `mask[:] = tmp_mask` stores).  The serial rule -- pop the
+ * smallest (image value, age), age = push counter, label at push time -- is evaluated without the heap: k_wssk.hip.
+ * Marker voxels of equal image value are taken in raster order (scikit-image's heap takes them in an order that
+ * depends on its array layout); stats[6] counts the tied neighbours in that order that carry different labels:
+ * 0 = identical to scikit-image by construction.  cost_out (optional): the minimax map of image values.
+ * stats (optional, host): [0] relaxation rounds, [1] tile visits, [2] non-empty levels, [3] generations, [4] marker
+ * voxels, [5] generation-0 voxels, [6] tied markers of different labels, [7] frontier launches, [8..11] microseconds
+ * of: costs, generation 0, level chain, labels, [13] generation steps, [14] sorted keys.
+ * ---------------------------------------------------------------------------------------------- */
+int ivx_dev_watershed_sk(const uint16_t *image, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
+                         const uint8_t strct[27], void *out_labels /* markers' dtype, may be NULL */,
+                         int32_t *out_i32 /* may be NULL */, uint8_t *out_u8 /* may be NULL */,
+                         uint16_t *cost_out /* may be NULL */, int64_t stats[16], void *stream);
+int ivx_watershed_sk(int idtype /* IVX_U8 | IVX_U16 */, const void *input, const int64_t shape[3], int mdtype,
+                     const void *markers, const uint8_t strct[27], int32_t *output, uint16_t *cost_out, int64_t stats[16]);
+
+/* ------------------------------------------------------------------------------------------------
  * confidence-connected region growing support (do_rg_confidence, invesalius/data/styles.py:3220-3251):
  * exact integer count / sum / sum-of-squares of image[sel != 0]; dst[v] = 1 where src[v] == value.
  * ---------------------------------------------------------------------------------------------- */

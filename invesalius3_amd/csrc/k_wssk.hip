@@ -1,0 +1,466 @@
+// k_wssk.hip -- the marker flood of do_watershed's scikit-image branch ("Watershed", the GUI's default) on the GPU.
+//
+// Replaces skimage.segmentation.watershed(image, markers, bstruct) as called by
+// invesalius/data/watershed_process.py:39,52 (3-D) and invesalius/data/styles.py:1958,1975 (one slice): no mask, no
+// compactness, no watershed lines.  scikit-image's routine (_watershed_cy.pyx, watershed_raveled) is a serial binary-heap
+// flood keyed (image value, age) with age = a global push counter, labels handed out at PUSH time.  What it computes can
+// be said without the heap (oracle/ivx_oracle_wssk.c is the serial statement, tools/proto_ws_runs.py the prototype of
+// this one):
+//
+//   cost   C(p) = min over paths from a marker of the largest image value ON the path (markers: C = I).  The heap pops
+//          in non-decreasing C: level c = {C == c}.
+//   GEN 0  of level c: the markers of value c (they carry age 0: before everything else, in raster order -- see TIES)
+//          and the voxels of value c with a neighbour of lower C (queued before the level starts, ordered by the pop
+//          time of the first such neighbour to pop).
+//   STEPS  every other voxel of the level is reached from generation 0: a step INTO a voxel of value c costs one
+//          generation (FIFO among equal values = breadth first), a step INTO a voxel of value < c costs nothing (the
+//          heap drains a basin the moment it is reached, before the next voxel of value c pops).
+//   TIME   T(p) = (G, R): G = generation counted across all levels, R = rank of p's generation-0 ancestor in its level's
+//          sorted generation 0.  A voxel's label is the label of the neighbour with the smallest T.  The order INSIDE one
+//          R never matters -- all those voxels carry one label, and a voxel contested by two labels is contested by two
+//          different R -- which is also why scikit-image's neighbour order (an unstable argsort in 0.18) drops out.
+//   TIES   marker voxels of equal image value all carry age 0 and leave scikit-image's heap in an order that depends on
+//          the heap's array layout (every earlier push and pop).  That order is irrelevant whenever the tied markers
+//          carry one label; otherwise it is not a function of the input a parallel machine can evaluate.  This kernel
+//          takes tied markers in raster order and counts, in stats[6], the adjacent tied markers of different labels:
+//          0 = identical to scikit-image by construction.
+//
+// Pipeline (one stream, no CPU arithmetic):
+//   1. k_ws_relax<SK>  the cost map by chaotic relaxation over dirty 16x16x8 tiles (shared with the IFT flood);
+//   2. k_sk_classify   generation-0 flags; k_ws_bucket: generation 0 bucketed by level;
+//   3. per non-empty level, ascending: k_sk_keys (marker: raster index; other: smallest T among lower-C neighbours)
+//      -> radix sort -> k_sk_assign (T, run labels, first frontier) -> k_sk_round until the level is exhausted: one
+//      launch per frontier; zero-cost steps are closed before the generation advances (0-1 breadth-first search);
+//   4. k_sk_labels     label = label of the run in T's low word.
+#include <algorithm>
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
+#include "ivx_internal.h"
+#include "scan_u32.h"
+#include "ws_tiles.h"
+
+namespace {
+
+constexpr unsigned long long TINF = ~0ull;
+constexpr unsigned long long GEN1 = 1ull << 32;
+
+struct SkState {
+    uint32_t n_closure; // voxels whose T fell in this round through a zero-cost step  } read by the host after
+    uint32_t n_next;    // voxels of the next generation so far                        } every round (mailbox)
+    uint32_t mixed;     // adjacent tied markers with different labels (see TIES)
+    uint32_t neg;
+};
+
+template <typename MT> struct SkGen0Pred {
+    const uint8_t *kind;
+    __device__ bool operator()(int64_t p) const { return kind[p] != 0; }
+};
+
+// generation-0 flags: markers, and voxels that sit AT their cost (I == C) next to a voxel of lower cost
+template <int CONN, typename MT>
+__global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
+                                                     const MT *__restrict__ mk, uint8_t *__restrict__ kind) {
+    __shared__ uint32_t s[NCELL];
+    int z0, y0, x0;
+    tile_origin(g, blockIdx.x, z0, y0, x0);
+    load_tile<true>(g, z0, y0, x0, I, C, s);
+    __syncthreads();
+    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
+    if (!(x0 + lx < g.w && y0 + ly < g.h)) return;
+    const int nz = min(TZ, (int)(g.d - z0));
+    for (int zz = 0; zz < nz; zz++) {
+        const int ci = ((zz + 1) * BY + (ly + 1)) * BX + (lx + 1);
+        const uint32_t cell = s[ci];
+        const uint32_t c = cell >> 16, iv = cell & 0xFFFFu;
+        const int64_t p = (int64_t)(z0 + zz) * g.hw + (int64_t)(y0 + ly) * g.w + (x0 + lx);
+        bool lower = false;
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            if (!has_off<CONN>(g.smask, k)) continue;
+            const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+            lower |= (s[ci + (dz * BY + dy) * BX + dx] >> 16) < c; // cells outside the volume carry CINF
+        }
+        kind[p] = (mk[p] != 0 || (c != CINF && iv == c && lower)) ? 1 : 0;
+    }
+}
+
+__device__ __forceinline__ unsigned long long ld64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// keys of a level's generation 0: marker -> raster index (< 2^32 <= every T); other -> smallest T among lower-C neighbours
+template <int CONN, typename MT>
+__global__ __launch_bounds__(256) void k_sk_keys(WsGeom g, const uint16_t *__restrict__ C, const MT *__restrict__ mk,
+                                                 const unsigned long long *tau, const uint32_t *__restrict__ elist,
+                                                 unsigned long long *__restrict__ key, uint32_t *__restrict__ val, uint32_t cnt, uint32_t c) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    const uint32_t p = elist[i];
+    unsigned long long K = p;
+    if (mk[p] == 0) {
+        K = TINF;
+        const int64_t z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            if (!has_off<CONN>(g.smask, k)) continue;
+            const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+            const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+            if ((uint64_t)X >= (uint64_t)g.w || (uint64_t)Y >= (uint64_t)g.h || (uint64_t)Z >= (uint64_t)g.d) continue;
+            const int64_t q = (int64_t)p + dz * g.hw + dy * g.w + dx;
+            if ((uint32_t)C[q] < c) K = min(K, ld64(&tau[q]));
+        }
+    }
+    key[i] = K;
+    val[i] = p;
+}
+
+// sorted generation 0 -> time stamps (G = gbase, R = roff + position), the runs' labels, the first frontier
+template <typename MT>
+__global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
+                                                   const MT *__restrict__ mk, unsigned long long *tau, int32_t *runlabel,
+                                                   uint32_t *__restrict__ front, uint32_t cnt, uint32_t roff, uint32_t gbase, SkState *st) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    const uint32_t p = val[i];
+    const unsigned long long K = key[i];
+    const int m = (int)mk[p];
+    // a run's label: its marker's, or the label of the run its parent belongs to (an earlier level: final)
+    const int32_t l = m ? (int32_t)m : runlabel[(uint32_t)(K & 0xFFFFFFFFull)];
+    runlabel[roff + i] = l;
+    tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + i);
+    front[i] = p;
+    if (m && i > 0 && (int)mk[val[i - 1]] != m) atomicAdd(&st->mixed, 1u); // markers sort first: val[i-1] is one too
+}
+
+__device__ __forceinline__ void wave_push(bool want, uint32_t v, uint32_t *__restrict__ list, uint32_t *counter) {
+    const unsigned long long b = __ballot(want);
+    if (!b) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)b) - 1;
+    uint32_t off = 0;
+    if (lane == leader) off = atomicAdd(counter, (uint32_t)__popcll(b));
+    off = __shfl(off, leader, 64);
+    if (want) list[off + __popcll(b & ((1ull << lane) - 1ull))] = v;
+}
+
+// one frontier: every listed voxel offers its time stamp to its neighbours of the same level -- unchanged to those of a
+// lower image value (drained at once), one generation later to those AT the level's value.  A drained voxel whose
+// stamp fell goes to `closure` (it has to pass the better stamp on within this generation); a voxel stamped for the
+// first time with the next generation goes to `next`.
+template <int CONN>
+__global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
+                                                  unsigned long long *tau, uint32_t *mark, uint32_t epoch, uint32_t c,
+                                                  const uint32_t *__restrict__ in, uint32_t n_in, uint32_t *__restrict__ closure,
+                                                  uint32_t *__restrict__ next, SkState *st) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < n_in;
+    const uint32_t q = act ? in[i] : 0u;
+    const unsigned long long t = act ? ld64(&tau[q]) : TINF;
+    const int64_t z = q / g.hw, r = q - z * g.hw, y = r / g.w, x = r - y * g.w;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        if (!has_off<CONN>(g.smask, k)) continue; // (wave-uniform: the pushes below stay convergent)
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+        bool push_c = false, push_n = false;
+        uint32_t p = 0;
+        if (act && (uint64_t)X < (uint64_t)g.w && (uint64_t)Y < (uint64_t)g.h && (uint64_t)Z < (uint64_t)g.d) {
+            p = (uint32_t)((int64_t)q + dz * g.hw + dy * g.w + dx);
+            if ((uint32_t)C[p] == c) {
+                if ((uint32_t)I[p] < c) {
+                    if (t < ld64(&tau[p]) && t < atomicMin(&tau[p], t)) push_c = atomicExch(&mark[p], epoch) != epoch;
+                } else {
+                    const unsigned long long nt = t + GEN1;
+                    if (nt < ld64(&tau[p])) push_n = atomicMin(&tau[p], nt) == TINF;
+                }
+            }
+        }
+        wave_push(push_c, p, closure, &st->n_closure);
+        wave_push(push_n, p, next, &st->n_next);
+    }
+}
+
+template <typename MT>
+__global__ __launch_bounds__(256) void k_sk_labels(int64_t n, const unsigned long long *__restrict__ tau, const int32_t *__restrict__ runlabel,
+                                                   MT *__restrict__ out, int32_t *__restrict__ out32, uint8_t *__restrict__ out8) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const unsigned long long t = tau[p];
+    const int32_t l = t == TINF ? 0 : runlabel[(uint32_t)(t & 0xFFFFFFFFull)];
+    if (out) out[p] = (MT)l;
+    if (out32) out32[p] = l;
+    if (out8) out8[p] = (uint8_t)l;
+}
+
+__global__ void k_sk_fill64(unsigned long long *p, int64_t n, unsigned long long v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+struct SkBufs {
+    uint16_t *C;
+    uint8_t *kind, *dirty, *pending;
+    unsigned long long *tau, *key_a, *key_b;
+    uint32_t *mark, *elist, *lists[4], *val_a, *val_b, *hist, *cursor, *bcount, *bsum, *tlist, *total;
+    int32_t *runlabel;
+    WsState *wst;
+    SkState *st;
+    void *cub;
+    size_t bytes;
+};
+
+// fixed part, sized by the volume (slot WS_WSIFT)
+static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
+    size_t o = 0;
+    auto take = [&](size_t n) { char *p = base ? base + o : nullptr; o += al(n); return p; };
+    const int64_t nblk = cdiv(g.n, 2048);
+    b->C = (uint16_t *)take((size_t)g.n * 2);
+    b->kind = (uint8_t *)take((size_t)g.n);
+    b->tau = (unsigned long long *)take((size_t)g.n * 8);
+    b->mark = (uint32_t *)take((size_t)g.n * 4);
+    b->elist = (uint32_t *)take((size_t)g.n * 4);
+    for (int i = 0; i < 4; i++) b->lists[i] = (uint32_t *)take((size_t)g.n * 4);
+    b->hist = (uint32_t *)take(65536 * 4);
+    b->cursor = (uint32_t *)take(65536 * 4);
+    b->bcount = (uint32_t *)take((size_t)(nblk + 1) * 4);
+    b->bsum = (uint32_t *)take((size_t)(std::max<int64_t>(cdiv(nblk, 4096), 16) + 2) * 4);
+    b->tlist = (uint32_t *)take((size_t)g.ntiles * 4);
+    b->dirty = (uint8_t *)take((size_t)g.ntiles);
+    b->pending = (uint8_t *)take((size_t)g.ntiles);
+    b->wst = (WsState *)take(sizeof(WsState));
+    b->st = (SkState *)take(sizeof(SkState));
+    b->total = (uint32_t *)take(256);
+    b->bytes = o;
+}
+
+// the part sized once generation 0 has been counted (slot WS_WSSK)
+static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, size_t cub_bytes, char *base, SkBufs *b) {
+    size_t o = 0;
+    auto take = [&](size_t n) { char *p = base ? base + o : nullptr; o += al(n); return p; };
+    b->runlabel = (int32_t *)take((size_t)(ngen0 + 1) * 4);
+    b->key_a = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
+    b->key_b = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
+    b->val_a = (uint32_t *)take((size_t)maxcnt * 4 + 8);
+    b->val_b = (uint32_t *)take((size_t)maxcnt * 4 + 8);
+    b->cub = take(cub_bytes + 256);
+    return o;
+}
+
+template <typename MT>
+static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int32_t *out32, uint8_t *out8, uint16_t *cost_out,
+                  int64_t *stats, hipStream_t st) {
+    const int conn = conn_of(g.smask);
+    const int64_t nblk = cdiv(g.n, 2048);
+    const int gl = (int)cdiv(g.n, 256);
+    SkBufs b;
+    sk_layout(g, nullptr, &b);
+    void *mem = nullptr;
+    IVX_REQUIRE(ws_get_s(WS_WSIFT, st, b.bytes, &mem) == IVX_OK, IVX_ENOMEM, "watershed: %zu bytes of scratch", b.bytes);
+    sk_layout(g, (char *)mem, &b);
+
+    WsTimer tm;
+    tm.on = stats != nullptr;
+    tm.mark(st);
+    // ---- 1. costs ------------------------------------------------------------------------------------------
+    IVX_HIP(hipMemsetAsync(b.wst, 0, sizeof(WsState), st));
+    IVX_HIP(hipMemsetAsync(b.st, 0, sizeof(SkState), st));
+    IVX_HIP(hipMemsetAsync(b.dirty, 0, (size_t)g.ntiles, st));
+    hipLaunchKernelGGL((k_ws_init<MT, true>), dim3((unsigned)nblk), dim3(256), 0, st, g, mk, I, b.C, b.dirty, b.bcount, b.wst);
+    IVX_LAUNCH_CHECK();
+    {
+        const int rc = scan_u32_exclusive(b.bcount, nblk, b.bsum, b.total, st);
+        if (rc != IVX_OK) return rc;
+    }
+    uint32_t M = 0;
+    WsState hw;
+    IVX_HIP(hipMemcpyAsync(&M, b.total, 4, hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipMemcpyAsync(&hw, b.wst, sizeof(hw), hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipStreamSynchronize(st));
+    IVX_REQUIRE(!hw.overflow, IVX_EINVAL, "watershed: image value 65535 is reserved (the reference's gradient images stay far below)");
+    if (M == 0) { // no marker: nothing is ever queued, every label stays 0
+        if (out) IVX_HIP(hipMemsetAsync(out, 0, (size_t)g.n * sizeof(MT), st));
+        if (out32) IVX_HIP(hipMemsetAsync(out32, 0, (size_t)g.n * 4, st));
+        if (out8) IVX_HIP(hipMemsetAsync(out8, 0, (size_t)g.n, st));
+        if (cost_out) IVX_HIP(hipMemsetAsync(cost_out, 0xFF, (size_t)g.n * 2, st));
+        if (stats) memset(stats, 0, 16 * sizeof(int64_t));
+        return IVX_OK;
+    }
+    int64_t rounds = 0, visits = 0;
+    {
+        const int rc = ws_cost_rounds<true>(g, conn, I, b.C, b.tlist, b.dirty, b.pending, b.wst, st, &rounds, &visits);
+        if (rc != IVX_OK) return rc;
+    }
+    if (cost_out) IVX_HIP(hipMemcpyAsync(cost_out, b.C, (size_t)g.n * 2, hipMemcpyDeviceToDevice, st));
+
+    tm.mark(st);
+    // ---- 2. generation 0, bucketed by level ------------------------------------------------------------------
+    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind));
+    IVX_LAUNCH_CHECK();
+    IVX_HIP(hipMemsetAsync(b.hist, 0, 65536 * 4, st));
+    const unsigned gbk = (unsigned)cdiv(g.n, 256 * BK_CH);
+    hipLaunchKernelGGL((k_ws_bucket<SkGen0Pred<MT>, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkGen0Pred<MT>{b.kind}, b.hist, b.elist);
+    IVX_LAUNCH_CHECK();
+    std::vector<uint32_t> hist(65536);
+    IVX_HIP(hipMemcpyAsync(hist.data(), b.hist, 65536 * 4, hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, 65536 * 4, hipMemcpyDeviceToDevice, st));
+    {
+        const int rc = scan_u32_exclusive(b.cursor, 65536, b.bsum, b.total, st);
+        if (rc != IVX_OK) return rc;
+    }
+    hipLaunchKernelGGL((k_ws_bucket<SkGen0Pred<MT>, true>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkGen0Pred<MT>{b.kind}, b.cursor, b.elist);
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sk_fill64, dim3(2048), dim3(256), 0, st, b.tau, g.n, TINF);
+    IVX_LAUNCH_CHECK();
+    IVX_HIP(hipMemsetAsync(b.mark, 0, (size_t)g.n * 4, st));
+    IVX_HIP(hipStreamSynchronize(st)); // hist is on the host now
+    uint64_t ngen0 = 0;
+    uint32_t maxcnt = 0;
+    for (uint32_t c = 0; c < 65535; c++) { // (65535 = never reached: no generation 0 there)
+        ngen0 += hist[c];
+        maxcnt = std::max(maxcnt, hist[c]);
+    }
+    IVX_REQUIRE(ngen0 < 0xFFFFFFF0ull, IVX_EINVAL, "watershed: more than 2^32 queue entries");
+    size_t cub_bytes = 0;
+    IVX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                               (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)maxcnt, 0, 64, st));
+    {
+        void *mem2 = nullptr;
+        const size_t need = sk_layout2(ngen0, maxcnt, cub_bytes, nullptr, &b);
+        IVX_REQUIRE(ws_get_s(WS_WSSK, st, need, &mem2) == IVX_OK, IVX_ENOMEM, "watershed: %zu bytes of scratch", need);
+        sk_layout2(ngen0, maxcnt, cub_bytes, (char *)mem2, &b);
+    }
+
+    tm.mark(st);
+    // ---- 3. the level chain ----------------------------------------------------------------------------------
+    int64_t nlevels = 0, nrounds = 0, ngens = 0, nsorted = 0;
+    uint32_t start = 0, roff = 0, gbase = 1, epoch = 0;
+    for (uint32_t c = 0; c < 65535; c++) {
+        const uint32_t cnt = hist[c];
+        if (!cnt) continue;
+        nlevels++;
+        const unsigned gb = (unsigned)cdiv(cnt, 256);
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, b.tau, b.elist + start, b.key_a,
+                                                  b.val_a, cnt, c));
+        IVX_LAUNCH_CHECK();
+        const unsigned long long *ks = b.key_a;
+        const uint32_t *vs = b.val_a;
+        if (cnt > 1) {
+            int end_bit = 33; // keys are below (gbase << 32): the bits that can differ
+            while (end_bit < 64 && (gbase >> (end_bit - 32))) end_bit++;
+            size_t tb = cub_bytes + 256;
+            IVX_HIP(hipcub::DeviceRadixSort::SortPairs(b.cub, tb, b.key_a, b.key_b, b.val_a, b.val_b, (int)cnt, 0, end_bit, st));
+            ks = b.key_b;
+            vs = b.val_b;
+            nsorted += cnt;
+        }
+        uint32_t *cur = b.lists[0], *nxt = b.lists[1], *cl_a = b.lists[2], *cl_b = b.lists[3];
+        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, cur, cnt, roff, gbase, b.st);
+        IVX_LAUNCH_CHECK();
+        // generations: `cur` = the voxels stamped with the current generation (first round) or the drained voxels whose
+        // stamp just fell (closure rounds); `nxt` collects the next generation across those rounds
+        uint32_t n_in = cnt, n_next_seen = 0;
+        uint32_t *in = cur;
+        for (;;) {
+            IVX_HIP(hipMemsetAsync(&b.st->n_closure, 0, 4, st));
+            epoch++;
+            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3((unsigned)cdiv(n_in, 256)), dim3(256), 0, st, g, I, b.C, b.tau, b.mark,
+                                                      epoch, c, in, n_in, cl_a, nxt, b.st));
+            IVX_LAUNCH_CHECK();
+            nrounds++;
+            uint32_t seq = 0, msg[2] = {0, 0};
+            int rc = mailbox_publish(&b.st->n_closure, 2, st, &seq);
+            if (rc != IVX_OK) return rc;
+            rc = mailbox_wait(seq, st, msg, 2);
+            if (rc != IVX_OK) return rc;
+            n_next_seen = msg[1];
+            if (msg[0]) { // zero-cost steps still spreading inside this generation
+                in = cl_a;
+                n_in = msg[0];
+                std::swap(cl_a, cl_b);
+                continue;
+            }
+            if (!n_next_seen) break; // level exhausted
+            // next generation
+            ngens++;
+            gbase++;
+            std::swap(cur, nxt);
+            in = cur;
+            n_in = n_next_seen;
+            IVX_HIP(hipMemsetAsync(&b.st->n_next, 0, 4, st));
+        }
+        gbase++;
+        IVX_REQUIRE(gbase < 0x7FFFFFF0u, IVX_EINVAL, "watershed: more than 2^31 generations");
+        roff += cnt;
+        start += cnt;
+    }
+
+    tm.mark(st);
+    // ---- 4. labels -------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_sk_labels<MT>, dim3(gl), dim3(256), 0, st, g.n, b.tau, b.runlabel, out, out32, out8);
+    IVX_LAUNCH_CHECK();
+    tm.mark(st);
+    SkState hs;
+    IVX_HIP(hipMemcpyAsync(&hs, b.st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipStreamSynchronize(st));
+    if (stats) {
+        stats[0] = rounds; stats[1] = visits; stats[2] = nlevels; stats[3] = gbase; stats[4] = M; stats[5] = (int64_t)ngen0;
+        stats[6] = hs.mixed; stats[7] = nrounds;
+        for (int i = 8; i < 16; i++) stats[i] = 0;
+        tm.read(stats + 8); // [8] costs, [9] generation 0, [10] level chain, [11] labels (microseconds)
+        stats[13] = ngens; stats[14] = nsorted;
+    }
+    return IVX_OK;
+}
+
+} // namespace
+
+extern "C" int ivx_dev_watershed_sk(const uint16_t *image, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
+                                    const uint8_t strct[27], void *out_labels, int32_t *out_i32, uint8_t *out_u8, uint16_t *cost_out,
+                                    int64_t stats[16], void *stream) {
+    WsGeom g;
+    const int rc = make_geom(dz, dy, dx, strct, &g);
+    if (rc != IVX_OK) return rc;
+    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "watershed: markers must be int16 or int8");
+    IVX_REQUIRE(image && markers && (out_labels || out_i32 || out_u8), IVX_EINVAL, "watershed: null buffer");
+    if (mdtype == IVX_I16)
+        return sk_run<int16_t>(g, image, (const int16_t *)markers, (int16_t *)out_labels, out_i32, out_u8, cost_out, stats, S(stream));
+    return sk_run<int8_t>(g, image, (const int8_t *)markers, (int8_t *)out_labels, out_i32, out_u8, cost_out, stats, S(stream));
+}
+
+__global__ void k_sk_widen(const uint8_t *__restrict__ in, uint16_t *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// host arrays in, int32 labels out (scikit-image's output dtype)
+extern "C" int ivx_watershed_sk(int idtype, const void *input, const int64_t shape[3], int mdtype, const void *markers,
+                                const uint8_t strct[27], int32_t *output, uint16_t *cost_out, int64_t stats[16]) {
+    HostCallGuard guard;
+    IVX_REQUIRE(idtype == IVX_U8 || idtype == IVX_U16, IVX_EINVAL, "watershed: image must be uint8 or uint16");
+    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "watershed: markers must be int16 or int8");
+    const int64_t n = shape[0] * shape[1] * shape[2];
+    if (n == 0) return IVX_OK;
+    const size_t msz = mdtype == IVX_I16 ? 2 : 1;
+    void *dI = nullptr, *dM = nullptr, *dO = nullptr, *dC = nullptr, *dT = nullptr;
+    int rc;
+    if ((rc = ws_get(WS_IN, (size_t)n * 2, &dI)) != IVX_OK) return rc;
+    if ((rc = ws_get(WS_AUX0, (size_t)n * msz, &dM)) != IVX_OK) return rc;
+    if ((rc = ws_get(WS_OUT, (size_t)n * 4, &dO)) != IVX_OK) return rc;
+    if (cost_out && (rc = ws_get(WS_AUX1, (size_t)n * 2, &dC)) != IVX_OK) return rc;
+    if (idtype == IVX_U8) {
+        if ((rc = ws_get(WS_AUX2, (size_t)n, &dT)) != IVX_OK) return rc;
+        IVX_HIP(hipMemcpy(dT, input, (size_t)n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_sk_widen, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, 0, (const uint8_t *)dT, (uint16_t *)dI, n);
+        IVX_LAUNCH_CHECK();
+    } else {
+        IVX_HIP(hipMemcpy(dI, input, (size_t)n * 2, hipMemcpyHostToDevice));
+    }
+    IVX_HIP(hipMemcpy(dM, markers, (size_t)n * msz, hipMemcpyHostToDevice));
+    rc = ivx_dev_watershed_sk((const uint16_t *)dI, mdtype, dM, shape[0], shape[1], shape[2], strct, nullptr, (int32_t *)dO, nullptr,
+                              (uint16_t *)dC, stats, nullptr);
+    if (rc != IVX_OK) return rc;
+    IVX_HIP(hipMemcpy(output, dO, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (cost_out) IVX_HIP(hipMemcpy(cost_out, dC, (size_t)n * 2, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}

@@ -1,0 +1,571 @@
+// ws_tiles.h -- what the two marker floods share (k_wsift.hip: scipy's IFT flood, k_wssk.hip: scikit-image's heap flood):
+// volume geometry, the 16x16x8 tile staged in LDS with its halo, the chaotic min-max relaxation of the path cost over
+// dirty tiles, the per-level bucketing of voxels, small helpers.  Everything is templated on SK:
+//   SK = false  scipy.ndimage.watershed_ift: arc cost |I(p) - I(q)|, markers cost 0, neighbours by LINEAR index
+//               (row / slice wrap-around neighbours are real neighbours there);
+//   SK = true   skimage.segmentation.watershed: a path costs the largest image value ON it, markers cost their own
+//               value, neighbours are lattice neighbours inside the volume.
+// Included by exactly those two translation units; all symbols have internal linkage.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "ivx_internal.h"
+#include "scan_u32.h"
+
+namespace {
+using namespace ivx;
+
+// tile: TX * TY == 256 lanes, one z-column of TZ voxels per lane (32x8x8: 39.5 ms, 16x16x8: 36.4, 16x16x16: 35.5 at 512^3)
+#ifndef IVX_WS_TX
+#define IVX_WS_TX 16
+#define IVX_WS_TY 16
+#endif
+constexpr int TX = IVX_WS_TX, TY = IVX_WS_TY, TZ = 8, BX = TX + 2, BY = TY + 2, BZ = TZ + 2, NCELL = BX * BY * BZ;
+constexpr uint32_t ENTRY = 0xFFFFFFFFu, NONE = 0xFFFFFFFFu, CINF = 0xFFFFu;
+constexpr int RELAX_ITCAP = 64;
+constexpr int32_t NOLAB = 0;
+
+struct WsGeom {
+    int64_t d, h, w, hw, n;
+    int ntx, nty, ntz;
+    int64_t ntiles;
+    uint32_t smask; // bit k = (dz+1)*9 + (dy+1)*3 + (dx+1) of the 3x3x3 structure, centre cleared
+};
+
+struct WsState {
+    uint32_t base;     // next free time stamp
+    uint32_t overflow; // time stamps ran out of the table
+    uint32_t neg;      // a negative marker was seen
+    uint32_t pad0;
+    uint32_t nlist;    // dirty tiles of the next round            } read by the host
+    uint32_t minrej;   // smallest cost refused by the gate so far } after every round
+    uint32_t assigned; // voxels that have a finite cost           } (one mailbox message)
+    uint32_t sweeps;   // LDS sweeps over all tile visits (statistics)
+};
+
+template <int CONN> __device__ __forceinline__ bool has_off(uint32_t smask, int k) {
+    if (CONN == 26) return k != 13;
+    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+    const int m = (dz != 0) + (dy != 0) + (dx != 0);
+    if (CONN == 6) return m == 1;
+    if (CONN == 18) return m == 1 || m == 2;
+    return (smask >> k) & 1u;
+}
+
+__device__ __forceinline__ uint32_t absdiff(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+
+// lattice coordinates (x in [-1, W], y, z anything) -> owning tile, or -1 outside the volume
+__device__ __forceinline__ int64_t owner_tile(const WsGeom &g, int64_t z, int64_t y, int64_t x) {
+    while (x < 0) { x += g.w; y -= 1; }
+    while (x >= g.w) { x -= g.w; y += 1; }
+    while (y < 0) { y += g.h; z -= 1; }
+    while (y >= g.h) { y -= g.h; z += 1; }
+    if (z < 0 || z >= g.d) return -1;
+    return ((z / TZ) * g.nty + y / TY) * g.ntx + x / TX;
+}
+
+__device__ __forceinline__ void tile_origin(const WsGeom &g, int64_t tile, int &z0, int &y0, int &x0) {
+    const int tx = (int)(tile % g.ntx);
+    const int64_t r = tile / g.ntx;
+    x0 = tx * TX;
+    y0 = (int)(r % g.nty) * TY;
+    z0 = (int)(r / g.nty) * TZ;
+}
+
+// stage the tile and its halo: cell = cost << 16 | intensity; cells outside [0, n) can never lower anything.
+// Rows are 16 voxels + 2 halo cells.  When W is a multiple of 8 the 16 interior cells of every lattice row start on a
+// 16-byte boundary (the wrap-around rows too: everything is addressed by linear index), so a lane fetches 8 cells of
+// both arrays with two 16-byte loads (720 per tile instead of 6800 two-byte loads); the 360 halo cells, and any row
+// that straddles the ends of the volume, go cell by cell.  Staging was 40 % of a visit's time before this.
+template <bool SK> __device__ __forceinline__ bool cell_ok(const WsGeom &g, int64_t z, int64_t y, int64_t x, int64_t L) {
+    if (SK) return (uint64_t)x < (uint64_t)g.w && (uint64_t)y < (uint64_t)g.h && (uint64_t)z < (uint64_t)g.d; // lattice neighbours only
+    return L >= 0 && L < g.n;                                                                                   // scipy: by linear index
+}
+
+template <bool SK>
+__device__ __forceinline__ void load_tile(const WsGeom &g, int z0, int y0, int x0, const uint16_t *__restrict__ I,
+                                          const uint16_t *C, uint32_t *s) {
+    static_assert(TX % 8 == 0, "rows of whole 8-cell chunks");
+    if ((g.w & 7) == 0) {
+        constexpr int NROW = BZ * BY, CH = TX / 8, NITEM = NROW * CH; // (row, chunk of 8 cells)
+#pragma unroll
+        for (int q = 0; q < (NITEM + 255) / 256; q++) {
+            const int it = threadIdx.x + q * 256;
+            if (it < NITEM) {
+                const int row = it / CH, half = it % CH, ly = row % BY, lz = row / BY;
+                const int64_t zz = z0 + lz - 1, yy = y0 + ly - 1, xx = x0 + half * 8;
+                const int64_t L = zz * g.hw + yy * g.w + xx;
+                uint32_t *dst = s + row * BX + 1 + half * 8;
+                if (SK ? (cell_ok<true>(g, zz, yy, xx, L) && xx + 8 <= g.w) : (L >= 0 && L + 8 <= g.n)) {
+                    const uint4 cv = *reinterpret_cast<const uint4 *>(C + L);
+                    const uint4 iv = *reinterpret_cast<const uint4 *>(I + L);
+                    const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, iw[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        dst[2 * e] = (cw[e] << 16) | (iw[e] & 0xFFFFu);
+                        dst[2 * e + 1] = (cw[e] & 0xFFFF0000u) | (iw[e] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int64_t Le = L + e;
+                        dst[e] = cell_ok<SK>(g, zz, yy, xx + e, Le) ? ((uint32_t)C[Le] << 16) | I[Le] : CINF << 16;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (NROW * 2 + 255) / 256; q++) { // the two x-halo cells of every row
+            const int it = threadIdx.x + q * 256;
+            if (it < NROW * 2) {
+                const int row = it >> 1, side = it & 1, ly = row % BY, lz = row / BY;
+                const int64_t zz = z0 + lz - 1, yy = y0 + ly - 1, xx = x0 + (side ? TX : -1);
+                const int64_t L = zz * g.hw + yy * g.w + xx;
+                s[row * BX + (side ? BX - 1 : 0)] = cell_ok<SK>(g, zz, yy, xx, L) ? ((uint32_t)C[L] << 16) | I[L] : CINF << 16;
+            }
+        }
+        return;
+    }
+    constexpr int PER = (NCELL + 255) / 256;
+    uint32_t cv[PER], iv[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int c = threadIdx.x + q * 256;
+        const int lx = c % BX, ly = (c / BX) % BY, lz = c / (BX * BY);
+        const int64_t L = (int64_t)(z0 + lz - 1) * g.hw + (int64_t)(y0 + ly - 1) * g.w + (x0 + lx - 1);
+        const bool ok = c < NCELL && cell_ok<SK>(g, z0 + lz - 1, y0 + ly - 1, x0 + lx - 1, L);
+        const int64_t La = ok ? L : 0;
+        cv[q] = ok ? (uint32_t)C[La] : CINF;
+        iv[q] = ok ? (uint32_t)I[La] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int c = threadIdx.x + q * 256;
+        if (c < NCELL) s[c] = (cv[q] << 16) | iv[q];
+    }
+}
+
+template <typename MT, bool SK>
+__global__ __launch_bounds__(256) void k_ws_init(WsGeom g, const MT *__restrict__ mk, const uint16_t *__restrict__ I,
+                                                 uint16_t *__restrict__ C, uint8_t *__restrict__ dirty,
+                                                 uint32_t *__restrict__ bcount, WsState *st) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * 2048;
+    uint32_t mine = 0;
+    bool neg = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int64_t p = b0 + j * 256 + threadIdx.x;
+        if (p >= g.n) continue;
+        const int m = (int)mk[p];
+        C[p] = m ? (SK ? I[p] : (uint16_t)0) : (uint16_t)CINF; // a marker's cost is final from the start
+        if (SK && I[p] == (uint16_t)CINF) st->overflow = 1;       // 65535 is the "never reached" cost
+        if (m) {
+            mine++;
+            neg |= m < 0;
+            const int64_t z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
+            dirty[((z / TZ) * g.nty + y / TY) * g.ntx + x / TX] = 1;
+        }
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    if (neg) st->neg = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) bcount[blockIdx.x] = s_cnt;
+}
+
+// markers in raster order -> elist[0 .. M), keys = their raster rank, labels of the ranks
+template <typename MT>
+__global__ __launch_bounds__(256) void k_ws_marker_list(WsGeom g, const MT *__restrict__ mk, const uint32_t *__restrict__ boff,
+                                                        uint32_t *__restrict__ elist, uint32_t *__restrict__ key,
+                                                        int32_t *__restrict__ lab) {
+    __shared__ uint32_t s_c[8][4];
+    const int64_t b0 = (int64_t)blockIdx.x * 2048;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int m[8];
+    uint32_t pre[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int64_t p = b0 + j * 256 + threadIdx.x;
+        m[j] = p < g.n ? (int)mk[p] : 0;
+        const unsigned long long b = __ballot(m[j] != 0);
+        pre[j] = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_c[j][wv] = __popcll(b);
+    }
+    __syncthreads();
+    const uint32_t base = boff[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (!m[j]) continue;
+        uint32_t off = base + pre[j];
+        for (int q = 0; q < j * 4 + wv; q++) off += s_c[q >> 2][q & 3];
+        elist[off] = (uint32_t)(b0 + j * 256 + threadIdx.x);
+        key[off] = off;
+        lab[off] = m[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ws_fill_used(uint32_t *used, uint32_t m) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t nw = (m + 31) >> 5;
+    if (w >= nw) return;
+    used[w] = (w == nw - 1 && (m & 31)) ? ((1u << (m & 31)) - 1u) : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_ws_build_list(int64_t ntiles, uint8_t *__restrict__ dirty, uint32_t *__restrict__ list,
+                                                       WsState *st) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool d = t < ntiles && dirty[t];
+    const unsigned long long b = __ballot(d);
+    if (!b) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t off = 0;
+    if (lane == 0) off = atomicAdd(&st->nlist, (uint32_t)__popcll(b));
+    off = __shfl(off, 0, 64);
+    if (d) {
+        list[off + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)t;
+        dirty[t] = 0;
+    }
+}
+
+// one visit of a dirty tile: relax to the local fix-point, write the changed costs back, wake the tiles that read them.
+// The first sweep evaluates every voxel (lane = z-column); after that only voxels a neighbour of which changed are
+// looked at again -- a flag word per z-column in LDS -- and those few are pooled into a work queue in LDS and dealt out
+// one per lane (sparse sweeps walked column by column kept one or two lanes of a wave busy: 1.6e9 of the 3.7e9 voxel
+// evaluations of a 512^3 flood, at a tenth of the lanes).
+// theta gates the flood: a cost above it is not accepted yet (the tile is parked in `pending`), so that below the level
+// where the bulk of the volume connects only final costs spread -- no wave of provisional costs to correct later.
+template <int CONN, bool LDS_CHG, bool SK>
+__device__ __forceinline__ bool ws_eval(uint32_t *s, uint32_t (*s_act)[TX], uint32_t (*s_chg)[TX], int lx, int ly, int zz, int nz,
+                                        uint32_t smask, uint32_t theta, uint32_t &fresh, uint32_t &rej) {
+    const int ci = ((zz + 1) * BY + (ly + 1)) * BX + (lx + 1);
+    const uint32_t cell = s[ci];
+    const uint32_t c = cell >> 16, iv = cell & 0xFFFFu;
+    if (c == (SK ? iv : 0u)) return false; // at its floor already (markers always are)
+    uint32_t best = c;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        if (!has_off<CONN>(smask, k)) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const uint32_t qv = s[ci + (dz * BY + dy) * BX + dx];
+        const uint32_t m = max(qv >> 16, SK ? iv : absdiff(qv & 0xFFFFu, iv));
+        best = min(best, m);
+    }
+    if (best >= c) return false;
+    if (best > theta) {
+        rej = min(rej, best);
+        return false;
+    }
+    s[ci] = (best << 16) | iv;
+    if (LDS_CHG) atomicOr(&s_chg[ly][lx], 1u << zz); // pooled sweeps: any lane may change any voxel
+    fresh += c == CINF;
+    // the neighbours inside the tile have to look again
+#pragma unroll
+    for (int cy = -1; cy <= 1; cy++) {
+#pragma unroll
+        for (int cx = -1; cx <= 1; cx++) {
+            uint32_t m3 = 0;
+#pragma unroll
+            for (int dz = -1; dz <= 1; dz++)
+                if (has_off<CONN>(smask, (dz + 1) * 9 + (cy + 1) * 3 + (cx + 1))) m3 |= 1u << (dz + 1);
+            if (!m3) continue;
+            const int tx = lx + cx, ty = ly + cy;
+            if ((unsigned)tx >= (unsigned)TX || (unsigned)ty >= (unsigned)TY) continue;
+            const uint32_t bits = ((m3 << zz) >> 1) & ((1u << nz) - 1u);
+            if (bits) atomicOr(&s_act[ty][tx], bits);
+        }
+    }
+    return true;
+}
+
+template <int CONN, bool SK>
+__global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__restrict__ I, uint16_t *C,
+                                                  const uint32_t *__restrict__ list, uint8_t *dirty, uint8_t *pending,
+                                                  WsState *st, uint32_t theta_flags) {
+    __shared__ uint32_t s[NCELL];
+    __shared__ uint32_t s_act[TY][TX], s_chg[TY][TX];
+    __shared__ uint16_t s_queue[CONN == 6 ? 2 : TX * TY * TZ]; // (the 6-neighbour form never pools)
+    __shared__ uint32_t s_qn[2];
+    __shared__ uint32_t s_new, s_rej, s_ev2;
+    const int64_t tile = list[blockIdx.x];
+    const uint32_t theta = theta_flags & 0xFFFFu; // bit 31 of the argument: collect the sweep statistic
+    int z0, y0, x0;
+    tile_origin(g, tile, z0, y0, x0);
+    load_tile<SK>(g, z0, y0, x0, I, C, s);
+    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
+    s_act[ly][lx] = 0;
+    s_chg[ly][lx] = 0;
+    if (threadIdx.x == 0) { s_new = 0; s_rej = NONE; s_ev2 = 0; s_qn[0] = 0; s_qn[1] = 0; }
+    __syncthreads();
+    const bool col = x0 + lx < g.w && y0 + ly < g.h;
+    const int nz = min(TZ, (int)(g.d - z0));
+    uint32_t fresh = 0, rej = NONE, chg = 0; // chg: changes this lane made to ITS column (a register is enough there)
+    // sweep 0: every voxel, column by column
+    if (col) {
+        for (int zz = 0; zz < nz; zz++)
+            if (ws_eval<CONN, false, SK>(s, s_act, s_chg, lx, ly, zz, nz, g.smask, theta, fresh, rej)) chg |= 1u << zz;
+    }
+    __syncthreads();
+    int it = 1;
+    bool more = true;
+    if (CONN == 6) {
+        // six cheap neighbours per voxel: walking the flagged voxels of its own column costs a lane less than the two
+        // barriers of the pooled form (measured 36.6 vs 42.3 ms at 512^3)
+        while (more && it < RELAX_ITCAP) {
+            bool any = false;
+            uint32_t a = col ? atomicExch(&s_act[ly][lx], 0u) : 0u;
+            while (a) {
+                const int zz = (it & 1) ? 31 - __clz(a) : __ffs(a) - 1; // alternate the sweep direction
+                a &= ~(1u << zz);
+                if (ws_eval<CONN, false, SK>(s, s_act, s_chg, lx, ly, zz, nz, g.smask, theta, fresh, rej)) {
+                    any = true;
+                    chg |= 1u << zz;
+                }
+            }
+            more = __syncthreads_or(any);
+            it++;
+        }
+    } else {
+        while (it < RELAX_ITCAP) {
+            // pool the flagged voxels (18 / 26 neighbours per evaluation: lanes are worth keeping busy)
+            const uint32_t a = col ? atomicExch(&s_act[ly][lx], 0u) : 0u;
+            if (threadIdx.x == 0) s_qn[(it + 1) & 1] = 0; // the next sweep's counter: nobody touches it during this sweep
+            if (a) {
+                uint32_t off = atomicAdd(&s_qn[it & 1], (uint32_t)__popc(a));
+                uint32_t m = a;
+                while (m) {
+                    const int zz = __ffs(m) - 1;
+                    m &= m - 1;
+                    s_queue[off++] = (uint16_t)((zz * TY + ly) * TX + lx);
+                }
+            }
+            __syncthreads();
+            const uint32_t T = s_qn[it & 1];
+            if (T == 0) { more = false; break; } // uniform: nothing left to look at
+            for (uint32_t i = threadIdx.x; i < T; i += 256) {
+                const uint32_t code = s_queue[i];
+                ws_eval<CONN, true, SK>(s, s_act, s_chg, (int)(code % TX), (int)((code / TX) % TY), (int)(code / (TX * TY)), nz, g.smask, theta, fresh, rej);
+            }
+            __syncthreads();
+            it++;
+        }
+    }
+    static_assert(TX * TY == 256 && TX * TY * TZ <= 65536, "one lane per column; queue codes are 16 bits");
+    if (more && threadIdx.x == 0) dirty[tile] = 1; // iteration cap: come back
+    if (rej != NONE) atomicMin(&s_rej, rej);
+    if (fresh) atomicAdd(&s_new, fresh);
+    if (col) chg |= s_chg[ly][lx];
+    // Which tiles read a changed voxel?  Inside the volume proper it is the lattice neighbour in the direction the voxel
+    // leaves the box by: collect those directions in one 27-bit mask per workgroup and mark each tile once.  Only voxels
+    // whose neighbour wraps around a row / slice end (scipy's linear-index neighbourhood) look their reader up one by one.
+    uint32_t dirs = 0;
+    for (int zz = 0; zz < nz && chg; zz++) {
+        if (!((chg >> zz) & 1u)) continue;
+        const int z = z0 + zz, y = y0 + ly, x = x0 + lx;
+        C[(int64_t)z * g.hw + (int64_t)y * g.w + x] = (uint16_t)(s[((zz + 1) * BY + (ly + 1)) * BX + (lx + 1)] >> 16);
+        const bool edge = lx == 0 || lx == TX - 1 || ly == 0 || ly == TY - 1 || zz == 0 || zz == TZ - 1 || x == (int)g.w - 1 ||
+                          y == (int)g.h - 1 || z == (int)g.d - 1;
+        if (!edge) continue; // every neighbour is inside this tile
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            if (!has_off<CONN>(g.smask, k)) continue;
+            const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+            const int Z = z + dz, Y = y + dy, X = x + dx;
+            if ((unsigned)X < (unsigned)g.w && (unsigned)Y < (unsigned)g.h) {
+                if ((unsigned)Z >= (unsigned)g.d) continue; // outside the volume
+                const int ex = X < x0 ? 0 : (X >= x0 + TX ? 2 : 1), ey = Y < y0 ? 0 : (Y >= y0 + TY ? 2 : 1),
+                          ez = Z < z0 ? 0 : (Z >= z0 + TZ ? 2 : 1);
+                dirs |= 1u << (ez * 9 + ey * 3 + ex); // bit 13 = this tile itself: ignored below
+            } else if (!SK) { // wraps to the neighbouring row / slice (scipy's linear-index neighbourhood only)
+                const int64_t t = owner_tile(g, Z, Y, X);
+                if (t >= 0) dirty[t] = 1;
+            }
+        }
+    }
+    if (dirs & ~(1u << 13)) atomicOr(&s_ev2, dirs);
+    __syncthreads();
+    if (threadIdx.x < 27 && threadIdx.x != 13 && ((s_ev2 >> threadIdx.x) & 1u)) {
+        const int k = threadIdx.x;
+        const int tz = z0 / TZ + k / 9 - 1, ty = y0 / TY + (k / 3) % 3 - 1, tx = x0 / TX + k % 3 - 1;
+        if (tz >= 0 && tz < g.ntz && ty >= 0 && ty < g.nty && tx >= 0 && tx < g.ntx) dirty[((int64_t)tz * g.nty + ty) * g.ntx + tx] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_rej != NONE) {
+            pending[tile] = 1;
+            atomicMin(&st->minrej, s_rej);
+        }
+        // hot single-address atomics from a million visits cost milliseconds: only when somebody reads them
+        if (s_new && theta < CINF) atomicAdd(&st->assigned, s_new); // the gate's "bulk is in" test
+        if (theta_flags & 0x80000000u) atomicAdd(&st->sweeps, (uint32_t)it); // statistics (IVX_WS_TRACE)
+    }
+}
+
+// the gate moved up: every parked tile is dirty again
+__global__ __launch_bounds__(256) void k_ws_wake(int64_t ntiles, uint8_t *__restrict__ dirty, uint8_t *__restrict__ pending, WsState *st) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) st->minrej = NONE;
+    if (t < ntiles && pending[t]) {
+        pending[t] = 0;
+        dirty[t] = 1;
+    }
+}
+// entries (markers excluded) per level: histogram, then scatter into the level's segment of elist.  A workgroup owns
+// 16384 consecutive voxels and counts in LDS (levels below BK_LB; the rare higher ones go straight to global memory), so
+// the hot global counters see one atomic per workgroup and level instead of one per wave and level.
+constexpr int BK_LB = 4096, BK_CH = 64;
+// PRED: device functor, pred(p) = "voxel p goes into its level's list"
+template <typename PRED, bool SCATTER>
+__global__ __launch_bounds__(256) void k_ws_bucket(int64_t n, const uint16_t *__restrict__ C, PRED pred,
+                                                   uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist) {
+    __shared__ uint32_t sh[BK_LB];
+    for (int i = threadIdx.x; i < BK_LB; i += 256) sh[i] = 0;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
+    const int lane = threadIdx.x & 63;
+    for (int pass = 0; pass < (SCATTER ? 2 : 1); pass++) {
+        for (int j = 0; j < BK_CH; j++) {
+            const int64_t p = b0 + (int64_t)j * 256 + threadIdx.x;
+            const bool e = p < n && pred(p);
+            const uint32_t c = e ? C[p] : 0;
+            unsigned long long act = __ballot(e);
+            while (act) {
+                const int leader = __ffsll((long long)act) - 1;
+                const uint32_t lc = __shfl(c, leader, 64);
+                const unsigned long long same = __ballot(e && c == lc);
+                const uint32_t cnt = (uint32_t)__popcll(same);
+                uint32_t off = 0;
+                if (lane == leader) {
+                    if (lc < BK_LB) off = atomicAdd(&sh[lc], cnt);
+                    else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[lc], cnt);
+                }
+                if (SCATTER && pass == 1) {
+                    off = __shfl(off, leader, 64);
+                    if (e && c == lc) elist[off + __popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)p;
+                }
+                act &= ~same;
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            // flush the counts (histogram) / turn them into this workgroup's base offsets (scatter)
+            for (int i = threadIdx.x; i < BK_LB; i += 256) {
+                const uint32_t v = sh[i];
+                if (v) {
+                    const uint32_t base = atomicAdd(&hist_or_cursor[i], v);
+                    if (SCATTER) sh[i] = base;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ void k_ws_fill32(uint32_t *p, int64_t n, uint32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int make_geom(int64_t dz, int64_t dy, int64_t dx, const uint8_t *strct, WsGeom *g) {
+    IVX_REQUIRE(dz > 0 && dy > 0 && dx > 0, IVX_EINVAL, "watershed: empty volume");
+    IVX_REQUIRE((double)dz * (double)dy * (double)dx < 4294967000.0, IVX_EINVAL, "watershed: more than 2^32 voxels");
+    g->d = dz; g->h = dy; g->w = dx; g->hw = dy * dx; g->n = dz * dy * dx;
+    g->ntx = (int)cdiv(dx, TX); g->nty = (int)cdiv(dy, TY); g->ntz = (int)cdiv(dz, TZ);
+    g->ntiles = (int64_t)g->ntx * g->nty * g->ntz;
+    uint32_t m = 0;
+    for (int k = 0; k < 27; k++)
+        if (strct[k] && k != 13) m |= 1u << k;
+    for (int k = 0; k < 27; k++) // the zone formulation needs an undirected neighbourhood
+        IVX_REQUIRE(((m >> k) & 1u) == ((m >> (26 - k)) & 1u), IVX_EINVAL, "watershed: structuring element must be symmetric");
+    g->smask = m;
+    return IVX_OK;
+}
+
+static int conn_of(uint32_t m) {
+    uint32_t m6 = 0, m18 = 0;
+    for (int k = 0; k < 27; k++) {
+        if (k == 13) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const int q = (dz != 0) + (dy != 0) + (dx != 0);
+        if (q == 1) m6 |= 1u << k;
+        if (q <= 2) m18 |= 1u << k;
+    }
+    if (m == m6) return 6;
+    if (m == m18) return 18;
+    if (m == (0x7FFFFFFu & ~(1u << 13))) return 26;
+    return 0;
+}
+
+#define WS_CONN_SWITCH(conn, ...)  \
+    switch (conn) {                 \
+    case 6: { constexpr int CC = 6; __VA_ARGS__; } break;   \
+    case 18: { constexpr int CC = 18; __VA_ARGS__; } break; \
+    case 26: { constexpr int CC = 26; __VA_ARGS__; } break; \
+    default: { constexpr int CC = 0; __VA_ARGS__; } break;  \
+    }
+
+// The cost map: rounds of dirty-tile visits until nothing changes (one host read per round through the mailbox).
+template <bool SK>
+static int ws_cost_rounds(const WsGeom &g, int conn, const uint16_t *I, uint16_t *C, uint32_t *list, uint8_t *dirty, uint8_t *pending,
+                          WsState *wst, hipStream_t st, int64_t *rounds_out, int64_t *visits_out) {
+    int64_t rounds = 0, visits = 0;
+    IVX_HIP(hipMemsetAsync(pending, 0, (size_t)g.ntiles, st));
+    hipLaunchKernelGGL(k_ws_wake, dim3(1), dim3(256), 0, st, (int64_t)0, dirty, pending, wst); // minrej = NONE
+    IVX_LAUNCH_CHECK();
+    const char *gate_env = getenv("IVX_WS_GATE");
+    const bool gate = gate_env && gate_env[0] == '1'; // measured slower on the noise phantom (more rounds AND more visits): opt-in
+    const bool trace = getenv("IVX_WS_TRACE") != nullptr;
+    uint32_t theta = gate ? 0u : CINF;
+    for (;;) {
+        IVX_HIP(hipMemsetAsync(&wst->nlist, 0, 4, st));
+        hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, dirty, list, wst);
+        IVX_LAUNCH_CHECK();
+        uint32_t seq = 0, msg[3] = {0, 0, 0};
+        int rc = mailbox_publish(&wst->nlist, 3, st, &seq);
+        if (rc != IVX_OK) return rc;
+        rc = mailbox_wait(seq, st, msg, 3);
+        if (rc != IVX_OK) return rc;
+        const uint32_t nl = msg[0];
+        if (trace) fprintf(stderr, "ws round %lld theta %u tiles %u minrej %u assigned %u\n", (long long)rounds, theta, nl, msg[1], msg[2]);
+        if (nl == 0) {
+            if (theta >= CINF || msg[1] == NONE) break; // nothing was refused: this is the fix-point
+            // converged below the gate: lift it to the first level that has work, or all the way once the bulk is in
+            theta = (uint64_t)msg[2] * 2 > (uint64_t)g.n ? CINF : msg[1];
+            hipLaunchKernelGGL(k_ws_wake, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, dirty, pending, wst);
+            IVX_LAUNCH_CHECK();
+            continue;
+        }
+        rounds++;
+        visits += nl;
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_relax<CC, SK>), dim3(nl), dim3(256), 0, st, g, I, C, list, dirty, pending, wst, theta | (trace ? 0x80000000u : 0u)));
+        IVX_LAUNCH_CHECK();
+        IVX_REQUIRE(rounds < 1000000, IVX_EHIP, "watershed: relaxation does not terminate");
+    }
+    *rounds_out = rounds;
+    *visits_out = visits;
+    return IVX_OK;
+}
+
+struct WsTimer { // stage boundaries on the stream, read back once at the end (only when the caller asks for stats)
+    hipEvent_t ev[8];
+    int n = 0;
+    bool on = false;
+    void mark(hipStream_t st) {
+        if (!on || n >= 8) return;
+        if (hipEventCreate(&ev[n]) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(ev[n++], st);
+    }
+    void read(int64_t *out_us) {
+        for (int i = 0; i + 1 < n; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            out_us[i] = (int64_t)(ms * 1000.0f);
+        }
+        for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
+        n = 0;
+    }
+};
+
+} // namespace

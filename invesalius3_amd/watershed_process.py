@@ -4,10 +4,10 @@
 [morphological gradient] -> marker flood (``skimage.segmentation.watershed`` or ``scipy.ndimage.watershed_ift``)
 -> uint8 labels, followed in the caller by the merge rule (styles.py:2147-2152).
 
-Everything runs in HIP kernels: the LUT / min-shift, the 3x3x3 (or larger, odd) morphological gradient, the marker
-flood of the IFT branch (``watershed_ift`` below: csrc/k_wsift.hip, the zone formulation of scipy's serial bucket
-flood) and the merge.  The scikit-image branch (``algorithm == "Watershed"``: a (value, age) heap flood, FIFO ties) has
-no GPU flood yet and raises; there is no CPU path in this package.
+Everything runs in HIP kernels: the LUT / min-shift, the 3x3x3 (or larger, odd) morphological gradient, both marker
+floods -- ``watershed_ift`` (csrc/k_wsift.hip, the zone formulation of scipy's serial bucket flood) and ``watershed``
+(csrc/k_wssk.hip, the run formulation of scikit-image's serial (value, age) heap flood) -- and the merge.  There is no
+CPU path in this package.
 """
 from __future__ import annotations
 
@@ -96,17 +96,56 @@ def watershed_ift(image: np.ndarray, markers: np.ndarray, structure=None, want_c
     return res[0] if len(res) == 1 else res
 
 
+def watershed(image: np.ndarray, markers: np.ndarray, connectivity=None, want_cost=False, want_stats=False):
+    """``skimage.segmentation.watershed(image, markers, connectivity)`` on the GPU, for the call the reference makes
+    (watershed_process.py:39,52; styles.py:1958,1975): `connectivity` is the 3x3(x3) structure array, no offset, mask,
+    compactness or watershed lines.  2-D or 3-D uint8 / uint16 image, int8 / int16 markers; int32 labels like
+    scikit-image.  ``stats["tied_markers_of_different_labels"] == 0`` means: identical to scikit-image by construction
+    (DESIGN.md section 6b)."""
+    image = np.asarray(image)
+    markers = np.asarray(markers)
+    if image.dtype.type not in (np.uint8, np.uint16):
+        raise TypeError("image must be uint8 or uint16 (the reference passes the uint16 gradient image)")
+    if markers.dtype.type not in (np.int8, np.int16):
+        raise TypeError("markers must be int8 or int16 (the reference casts them: watershed_process.py:39,52)")
+    if image.ndim not in (2, 3):
+        raise ValueError("image must be 2-D or 3-D")
+    if markers.shape != image.shape:  # scikit-image's message (_validate_inputs)
+        raise ValueError("`markers` (shape {}) must have same shape as `image` (shape {})".format(markers.shape, image.shape))
+    if connectivity is None:
+        from scipy.ndimage import generate_binary_structure
+        connectivity = generate_binary_structure(image.ndim, 1)
+    s3 = _strct27(connectivity, image.ndim)
+    img = np.ascontiguousarray(image)
+    mk = np.ascontiguousarray(markers)
+    shp = img.shape if img.ndim == 3 else (1,) + img.shape
+    out = np.zeros(mk.shape, np.int32)
+    cost = np.empty(img.shape, np.uint16) if want_cost else None
+    stats = (ctypes.c_int64 * 16)()
+    L.check(L.lib().ivx_watershed_sk(L.U8 if img.dtype == np.uint8 else L.U16, L.ptr(img), L.i64(shp),
+                                     L.I16 if mk.dtype == np.int16 else L.I8, L.ptr(mk), L.ptr(s3), L.ptr(out),
+                                     L.ptr(cost) if want_cost else None, stats), "watershed")
+    res = (out,)
+    if want_cost:
+        res += (cost,)
+    if want_stats:
+        names = ("rounds", "tile_visits", "levels", "generations", "markers", "generation0", "tied_markers_of_different_labels",
+                 "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "_", "generation_steps", "sorted_keys")
+        res += ({k: int(v) for k, v in zip(names, stats) if not k.startswith("_")},)
+    return res[0] if len(res) == 1 else res
+
+
 def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_ww_wl, wl, ww, q=None):
     """Same signature and side effects as watershed_process.do_watershed (:19-60): writes the uint8 label volume to
     the memmap `tfile` and signals ``q.put(1)``.  Cost image and flood run on the GPU."""
-    if algorithm == "Watershed":
-        raise NotImplementedError(
-            "do_watershed(algorithm='Watershed'): the scikit-image (value, age)-heap flood has no HIP implementation; "
-            "use the 'Watershed IFT' algorithm (watershed_process.py:41-46,54-57)")
     mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")
-    tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, 0)
-    mk = np.asarray(markers).astype("int16" if use_ww_wl else "int8")  # watershed_process.py:45,57
-    tmp_mask = watershed_ift(tmp_image, mk, bstruct)
+    if algorithm == "Watershed":  # watershed_process.py:33-39,47-52: gradient image, scikit-image's flood, int16 markers
+        tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, mg_size)
+        tmp_mask = watershed(tmp_image, np.asarray(markers).astype("int16"), bstruct)
+    else:
+        tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, 0)
+        mk = np.asarray(markers).astype("int16" if use_ww_wl else "int8")  # watershed_process.py:45,57
+        tmp_mask = watershed_ift(tmp_image, mk, bstruct)
     mask[:] = tmp_mask
     mask.flush()
     if q is not None:

@@ -110,8 +110,11 @@ def test_do_watershed_ift_pipeline_matches_reference_calls(ivxlib, tmp_path):
                        [0, 120, lambda v: ((v - (50 - 0.5)) / (120 - 1) + 0.5) * 120])
     exp = ndimage.watershed_ift(lut.astype("uint16"), markers.astype("int16"), bstruct)
     assert np.array_equal(got, exp.astype(np.uint8))
-    with pytest.raises(NotImplementedError):  # the scikit-image flood is not built and there is no CPU path
-        wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed", (3, 3, 3), False, 0, 0, q)
+    # the scikit-image branch (the GUI's default): gradient image + heap flood; counts from live scikit-image (tests/golden)
+    wp.do_watershed(image, markers, tfile, image.shape, bstruct, "Watershed", (3, 3, 3), False, 0, 0, q)
+    assert q.get() == 1
+    got = np.array(np.memmap(tfile, shape=image.shape, dtype="uint8", mode="r"))
+    assert (got == 1).sum() == 109 and (got == 2).sum() == 16
 
 
 def test_device_volume_pipeline_matches_oracle(ivxlib, oracle):

@@ -1,0 +1,140 @@
+"""The scikit-image branch of do_watershed on the GPU (csrc/k_wssk.hip) against the serial heap flood
+(oracle/ivx_oracle_wssk.c, pinned to scikit-image's compiled kernel by tests/golden/watershed_sk.npz)."""
+import os
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rand_case(rng, k):
+    nd = 3 if k % 5 else 2
+    shape = tuple(int(v) for v in rng.integers(1 if nd == 3 else 3, 20 if nd == 3 else 40, size=nd))
+    levels = int(rng.choice([1, 2, 3, 6, 30, 3000, 65535]))
+    img = rng.integers(0, levels, size=shape).astype(np.uint16 if k % 4 else np.uint8 if levels <= 256 else np.uint16)
+    if k % 3 == 0 and min(shape) >= 3 and img.dtype == np.uint16:
+        img = ndimage.morphological_gradient(img, (3,) * nd)
+    mk = np.zeros(shape, np.int16 if k % 2 else np.int8)
+    n_mark = int(rng.integers(1, max(2, img.size // 6)))
+    pos = rng.choice(img.size, size=min(n_mark, img.size), replace=False)
+    mk.ravel()[pos] = rng.integers(1, 4, size=len(pos))
+    st = ndimage.generate_binary_structure(nd, int(rng.integers(1, nd + 1)))
+    return img, mk, st
+
+
+def test_run_formulation_equals_the_serial_flood_on_random_volumes(ivxlib, oracle):
+    from invesalius3_amd import watershed_process as wp
+    rng = np.random.default_rng(11)
+    for k in range(300):
+        img, mk, st = _rand_case(rng, k)
+        want = oracle.watershed_sk(img, mk, st, 1)
+        got = wp.watershed(img, mk, st)
+        assert got.dtype == np.int32 and np.array_equal(got, want), (k, img.shape, int(st.sum()) - 1, int((got != want).sum()))
+
+
+def test_golden_vectors_of_the_compiled_scikit_image_kernel(ivxlib, oracle):
+    """Every golden case equals the serial flood with raster marker ties; wherever the GPU reports no tied markers of
+    different labels its result is scikit-image's own (the compiled 0.18.3 kernel with the documented neighbour order, and
+    -- the neighbour order being irrelevant then -- skimage.segmentation.watershed itself)."""
+    from invesalius3_amd import watershed_process as wp
+    z = np.load(os.path.join(GOLD, "watershed_sk.npz"))
+    provable = equal_anyway = 0
+    for nm in z["names"]:
+        img, mk, st = z["img_" + nm], z["mk_" + nm], z["st_" + nm]
+        got, stats = wp.watershed(img, mk, st, want_stats=True)
+        assert np.array_equal(got, oracle.watershed_sk(img, mk, st, 1)), nm
+        if stats["tied_markers_of_different_labels"] == 0:
+            assert np.array_equal(got, z["lo_" + nm]) and np.array_equal(got, z["hi_" + nm]), nm
+            provable += 1
+        elif np.array_equal(got, z["lo_" + nm]):
+            equal_anyway += 1
+    assert provable >= 20
+    print("golden: %d cases identical to scikit-image by construction, %d more identical in fact, of %d"
+          % (provable, equal_anyway, len(z["names"])))
+
+
+def test_do_watershed_default_algorithm_on_the_reference_fixture(ivxlib, tmp_path):
+    """tests/test_segmentation_tools.py:170-213 verbatim (algorithm="Watershed"), plus the counts live scikit-image gives."""
+    import queue
+
+    from invesalius3_amd import watershed_process as wp
+    image = np.zeros((5, 5, 5), dtype=np.int16)
+    image[1:4, 1:4, 1:4] = 100
+    markers = np.zeros((5, 5, 5), dtype=np.int16)
+    markers[2, 2, 2] = 1
+    markers[0, 0, 0] = 2
+    bstruct = ndimage.generate_binary_structure(3, 1)
+    q = queue.Queue()
+    tfile = str(tmp_path / "watershed_mask.tmp")
+    tmp_mask = np.memmap(tfile, shape=(5, 5, 5), dtype="uint8", mode="w+")
+    wp.do_watershed(image=image, markers=markers, tfile=tfile, shape=(5, 5, 5), bstruct=bstruct, algorithm="Watershed",
+                    mg_size=(3, 3, 3), use_ww_wl=False, wl=0, ww=0, q=q)
+    result = np.array(tmp_mask)
+    del tmp_mask
+    assert np.any(result > 0), "Watershed should produce segmentation"
+    assert q.get(timeout=2) == 1
+    ref = np.load(os.path.join(GOLD, "watershed_sk.npz"))["hi_ref5"]
+    assert np.array_equal(result, ref.astype(np.uint8)) and (result == 1).sum() == 109 and (result == 2).sum() == 16
+
+
+def _ct_like(shape, seed):
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    f = np.zeros(shape)
+    for _ in range(5):
+        c = rng.uniform(0, 1, 3) * np.array(shape)
+        s = rng.uniform(8, 24)
+        f += 1800 * np.exp(-(((z - c[0]) * 2) ** 2 + (y - c[1]) ** 2 + (x - c[2]) ** 2) / (2 * s * s))
+    f += rng.normal(0, 25, shape) - 1000
+    return np.clip(f, -1024, 3071).astype(np.int16), np.unravel_index(int(np.argmax(f)), shape)
+
+
+@pytest.mark.parametrize("conn,use_ww_wl", [(1, True), (3, True), (2, False)])
+def test_brush_markers_on_a_ct_like_volume(ivxlib, oracle, conn, use_ww_wl):
+    """The GUI's case: gradient of the windowed image (256 levels, huge zero plateau) or of the raw image (thousands of
+    levels), two brush blobs.  GPU == serial flood with raster ties == serial flood with scikit-image's heap ties."""
+    from invesalius3_amd import watershed_process as wp
+    img, am = _ct_like((40, 112, 128), 5)
+    grad = wp.cost_image(img, use_ww_wl, 300, 400, (3, 3, 3))
+    mk = np.zeros(img.shape, np.int16)
+    mk[max(am[0] - 2, 0):am[0] + 3, am[1] - 4:am[1] + 5, am[2] - 4:am[2] + 5] = 1
+    mk[:4, :8, :8] = 2
+    mk[-4:, -8:, -8:] = 2
+    st = ndimage.generate_binary_structure(3, conn)
+    got, stats = wp.watershed(grad, mk, st, want_stats=True)
+    want1 = oracle.watershed_sk(grad, mk, st, 1)
+    want0 = oracle.watershed_sk(grad, mk, st, 0)
+    assert np.array_equal(got, want1)
+    print("ct-like conn %d ww_wl %s: levels %d generations %d launches %d, tied markers of different labels %d, vs heap ties: %d voxels differ"
+          % (conn, use_ww_wl, stats["levels"], stats["generations"], stats["frontier_launches"],
+             stats["tied_markers_of_different_labels"], int((got != want0).sum())))
+    assert np.array_equal(got, want0)
+
+
+def test_edge_cases(ivxlib, oracle):
+    from invesalius3_amd import watershed_process as wp
+    s6 = ndimage.generate_binary_structure(3, 1)
+    img = np.random.default_rng(0).integers(0, 50, size=(6, 7, 8)).astype(np.uint16)
+    assert not wp.watershed(img, np.zeros(img.shape, np.int16), s6).any()            # no marker: nothing is queued
+    mk = np.zeros(img.shape, np.int16)
+    mk[3, 3, 3] = -2                                                                   # negative labels flood like any other
+    mk[0, 0, 0] = 5
+    assert np.array_equal(wp.watershed(img, mk, s6), oracle.watershed_sk(img, mk, s6, 1))
+    one = np.array([[[7]]], np.uint16)
+    assert wp.watershed(one, np.array([[[3]]], np.int8), s6)[0, 0, 0] == 3
+    only_x = np.zeros((3, 3, 3), bool)
+    only_x[1, 1, :] = True                                                             # rows never meet: unreached voxels stay 0
+    assert np.array_equal(wp.watershed(img, mk, only_x), oracle.watershed_sk(img, mk, only_x, 1))
+    full = np.ones(img.shape, np.int16)                                                # every voxel a marker
+    assert np.array_equal(wp.watershed(img, full, s6), full)
+    top = img.copy()
+    top[1, 1, 1] = 65535
+    with pytest.raises((ValueError, RuntimeError, TypeError)):
+        wp.watershed(top, mk, s6)
+    with pytest.raises(ValueError):
+        wp.watershed(img, mk[:-1], s6)
+    with pytest.raises(TypeError):
+        wp.watershed(img.astype(np.float32), mk, s6)
