@@ -534,6 +534,124 @@ def run_watershed(args, job):
 # ----------------------------------------------------------------------------------------------------------------
 # configs[4]: MIP raycasting, 512^3 volume to a 2048^2 viewport, 3-axis sweep
 # ----------------------------------------------------------------------------------------------------------------
+
+def run_watershed_sk(args, job):
+    """configs[2] with the GUI's DEFAULT algorithm ("Watershed"): min-shift -> 3x3x3 morphological gradient ->
+    skimage.segmentation.watershed's marker flood (csrc/k_wssk.hip) -> merge (watershed_process.py:47-52, styles.py:2147-2152)."""
+    import ctypes
+
+    from scipy.ndimage import generate_binary_structure
+
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd import watershed_process as wp
+    from invesalius3_amd.device import DeviceBuffer, Timer, c64
+
+    L.require_device()
+    L.set_device(job.local_rank)
+    n = args.size or 1024
+    shape = (n, n, n)
+    nvox = n ** 3
+    img = synth_v512(shape, seed=SEED + job.rank)
+    mk = ws_markers(img).astype(np.int16)  # watershed_process.py:52 casts to int16
+    strct = generate_binary_structure(3, 1)
+    s3 = np.ascontiguousarray(strct, dtype=np.uint8)
+    lib = L.lib()
+    st = ctypes.c_void_p()
+    L.check(lib.ivx_stream_create(ctypes.byref(st)))
+    timer = Timer(st)
+    d_img, d_mk = DeviceBuffer(nvox * 2), DeviceBuffer(nvox * 2)
+    d_cost, d_grad, d_lab, d_mask = DeviceBuffer(nvox * 2), DeviceBuffer(nvox * 2), DeviceBuffer(nvox), DeviceBuffer(nvox)
+    d_mm = DeviceBuffer(64)
+    d_img.upload(img)
+    d_mk.upload(mk)
+    d_mask.zero(st)
+    stats = (ctypes.c_int64 * 16)()
+    gsz = (ctypes.c_int * 3)(3, 3, 3)
+
+    def step():
+        L.check(lib.ivx_dev_minmax_f32(L.I16, d_img.ptr, c64(nvox), d_mm.ptr, st))
+        L.check(lib.ivx_stream_synchronize(st))
+        imin = int(d_mm.download((2,), np.float32)[0])
+        with timer.span("cost_image"):
+            L.check(lib.ivx_dev_shift_min_u16(d_img.ptr, c64(nvox), imin, d_cost.ptr, st))
+            L.check(lib.ivx_dev_morph_gradient_u16(d_cost.ptr, c64(n), c64(n), c64(n), gsz, d_grad.ptr, st), "gradient")
+        with timer.span("flood"):
+            L.check(lib.ivx_dev_watershed_sk(d_grad.ptr, L.I16, d_mk.ptr, c64(n), c64(n), c64(n), L.ptr(s3), None, None, d_lab.ptr,
+                                             None, stats, st), "watershed_sk")
+        with timer.span("merge"):
+            L.check(lib.ivx_dev_watershed_merge(d_mask.ptr, d_lab.ptr, c64(nvox), 1, st))
+
+    def barrier():
+        L.check(lib.ivx_stream_synchronize(st))
+        job.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = job.max(time.perf_counter() - t0)
+    spans = {k: float(np.mean(v)) for k, v in timer.collect().items()}
+    lab = d_lab.download(shape, np.uint8)
+    obj = job.sum(int((lab == 1).sum()))
+    if job.rank != 0:
+        return
+    names = ("rounds", "tile_visits", "levels", "generations", "markers", "generation0", "tied_markers_of_different_labels",
+             "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "_", "generation_steps", "sorted_keys")
+    flood_ms = spans.get("flood", 0.0)
+    res = {
+        "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
+        "value": round(job.world * nvox / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",
+        "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "configs[2]: %dx%dx%d int16, watershed segmentation, 'Watershed' branch of do_watershed (the GUI's "
+                               "default: min-shift, 3x3x3 morphological gradient, scikit-image's 6-neighbour marker flood, merge), "
+                               "markers: 5^3 cube at the maximum (1) + 8 corner cubes (2)" % shape,
+                   "parallelism": "replicas only (global priority order: SURVEY.md 8e)" if job.world > 1 else "single GPU"},
+        "stage_ms": {k: round(v, 3) for k, v in spans.items()},
+        "flood": {k: int(v) for k, v in zip(names, stats) if k != "_"},
+        "object_voxels": obj,
+        "roofline": roofline("watershed flood (k_ws_relax + k_sk_*)", 7.0 * nvox, flood_ms, None, None,
+                             {"note": "7 B/voxel = image 2 + markers 2 read, labels 2 + mask 1 written (SURVEY.md 8d; + 4 B/voxel for "
+                                      "the gradient pass, timed apart); the flood is a level-ordered breadth-first search whose serial "
+                                      "depth (generations) bounds it, not the bytes"}),
+        "device": L.device_name(),
+    }
+    if args.cpu:
+        # the serial heap flood (oracle/ivx_oracle_wssk.c, pinned move for move to scikit-image's compiled kernel) on a bounded
+        # sample of the same volume: its first slices with the same marker rule, one core like the reference's worker process
+        from oracle import oracle as orc
+        orc.build()
+        sl = min(n, max(8, int(1.6e7 // (n * n))))
+        sub = np.ascontiguousarray(img[:sl])
+        smk = ws_markers(sub).astype(np.int16)
+        grad = wp.cost_image(sub, False, 0, 0, (3, 3, 3))
+        t = time.perf_counter()
+        heap = orc.watershed_sk(grad, smk, strct, 0)
+        ts = time.perf_counter() - t
+        raster = orc.watershed_sk(grad, smk, strct, 1)
+        got, gst = wp.watershed(grad, smk, strct, want_stats=True)
+        res["cpu_baseline"] = {"value": round(sub.size / ts / 1e6, 3), "unit": "Mvoxel/s", "cores": 1, "kind": "port",
+                               "sample": "the (value, age) binary-heap flood of skimage.segmentation.watershed restated in C and pinned to "
+                                         "scikit-image 0.18.3's compiled kernel (tests/golden/watershed_sk.npz), on the first %d slices "
+                                         "(%d voxels), %.2f s" % (sl, sub.size, ts)}
+        res["parity"] = {"ok": bool(np.array_equal(got, raster)),
+                         "mismatch_vs_serial_flood_raster_marker_ties": int((got != raster).sum()),
+                         "mismatch_vs_serial_flood_heap_marker_ties": int((got != heap).sum()),
+                         "tied_markers_of_different_labels": gst["tied_markers_of_different_labels"], "sample_voxels": int(sub.size),
+                         "note": "the GPU flood equals the serial flood bit for bit when equal-valued marker voxels are taken in raster "
+                                 "order; scikit-image's heap takes them in an order that depends on its array layout, which matters "
+                                 "only where tied markers of different labels compete (second count)"}
+        if not res["parity"]["ok"]:
+            print(json.dumps(res), flush=True)
+            raise SystemExit("bench.py: watershed_sk differs from the serial flood")
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+
 def run_mip(args, job):
     import ctypes
 
@@ -751,8 +869,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("grow_mc", "watershed", "mip", "sharded2048"), default="grow_mc",
-                    help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2]; sharded2048 = "
+    ap.add_argument("--config", choices=("grow_mc", "watershed", "watershed_sk", "mip", "sharded2048"), default="grow_mc",
+                    help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2] (IFT branch), watershed_sk = configs[2] with the GUI's default scikit-image branch; sharded2048 = "
                          "configs[3] (strong scaling: the whole volume split over --gpus); mip = configs[4]")
     ap.add_argument("--size", type=int, default=None, help="edge of the volume (defaults: 512 / 1024 / 512 per GPU; 2048 in total for sharded2048)")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false", help="skip the CPU baseline + full-size parity check")
@@ -760,7 +878,7 @@ def main():
     args = ap.parse_args()
     if args.cpu_slices == 0:
         args.cpu = False
-    dflt = {"grow_mc": (20, 3), "watershed": (3, 1), "mip": (20, 3), "sharded2048": (5, 2)}[args.config]
+    dflt = {"grow_mc": (20, 3), "watershed": (3, 1), "watershed_sk": (2, 1), "mip": (20, 3), "sharded2048": (5, 2)}[args.config]
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
 
@@ -772,7 +890,7 @@ def main():
     from invesalius3_amd import _lib as L
     L.require_device()
     job = Ranks()
-    {"grow_mc": run_grow_mc, "watershed": run_watershed, "mip": run_mip, "sharded2048": run_sharded2048}[args.config](args, job)
+    {"grow_mc": run_grow_mc, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048}[args.config](args, job)
     if job.comm is not None:
         CStdoutToStderr.stay()  # the JSON line is out; whatever RCCL still has to say goes to stderr
         job.comm.barrier()

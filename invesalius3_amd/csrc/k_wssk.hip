@@ -45,12 +45,28 @@ namespace {
 
 constexpr unsigned long long TINF = ~0ull;
 constexpr unsigned long long GEN1 = 1ull << 32;
+constexpr int CHASE_DEPTH = 16, CHASE_STEPS = 48;
 
+// The frontier loop of a level runs without the host: every round is one launch of k_sk_round over a fixed grid; the
+// last workgroup to finish turns the counters into the next round's input (closure list, or the next generation, or
+// "level exhausted").  The host queues rounds in batches and reads {done, gen, rounds} once per batch.
 struct SkState {
-    uint32_t n_closure; // voxels whose T fell in this round through a zero-cost step  } read by the host after
-    uint32_t n_next;    // voxels of the next generation so far                        } every round (mailbox)
+    uint32_t done;      // level exhausted: further rounds return at once   }
+    uint32_t gen;       // G of the voxels on the current input list        } read by the host once per batch (mailbox)
+    uint32_t rounds;    // rounds that did work (statistics)                }
+    uint32_t n_in;      // entries of the coming round's input list         }
+    uint32_t in_sel, nxt_sel, cla_sel, clb_sel; // roles of the four lists: input, next generation, closure out, closure spare
+    uint32_t n_closure; // voxels whose T fell in this round through a zero-cost step
+    uint32_t n_next;    // voxels of the next generation so far
+    uint32_t epoch;     // round counter (de-duplicates the closure list)
+    uint32_t ticket;    // workgroups of the running round that have finished
     uint32_t mixed;     // adjacent tied markers with different labels (see TIES)
-    uint32_t neg;
+    uint32_t gens;      // generation steps (statistics)
+    uint32_t pad[2];
+};
+
+struct SkLists {
+    uint32_t *l[4];
 };
 
 template <typename MT> struct SkGen0Pred {
@@ -122,6 +138,12 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
                                                    const MT *__restrict__ mk, unsigned long long *tau, int32_t *runlabel,
                                                    uint32_t *__restrict__ front, uint32_t cnt, uint32_t roff, uint32_t gbase, SkState *st) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { // the level's frontier loop starts from list 0
+        st->done = 0; st->gen = gbase; st->n_in = cnt;
+        st->in_sel = 0; st->nxt_sel = 1; st->cla_sel = 2; st->clb_sel = 3;
+        st->n_closure = 0; st->n_next = 0; st->ticket = 0;
+        st->epoch += 1;
+    }
     if (i >= cnt) return;
     const uint32_t p = val[i];
     const unsigned long long K = key[i];
@@ -145,40 +167,135 @@ __device__ __forceinline__ void wave_push(bool want, uint32_t v, uint32_t *__res
     if (want) list[off + __popcll(b & ((1ull << lane) - 1ull))] = v;
 }
 
+// Appends to the two output lists are staged per wave in LDS and handed to the global list with ONE atomic per wave,
+// list and pass (a frontier of 10^5 voxels otherwise sends ~10^4 atomics to one counter word, one after the other).
+constexpr int WB_CAP = 768;
+struct SkStage {
+    volatile uint32_t buf[2][4][WB_CAP];
+    volatile uint32_t n[2][4];
+};
+
+__device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, int which, uint32_t *__restrict__ glist, uint32_t *gcnt) {
+    const unsigned long long b = __ballot(want);
+    if (!b) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int leader = __ffsll((long long)b) - 1;
+    const uint32_t n = (uint32_t)__popcll(b), rank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (lane == leader) {
+        base = sg.n[which][wv];
+        if (base + n <= WB_CAP) sg.n[which][wv] = base + n;
+        else base = 0x80000000u | atomicAdd(gcnt, n); // no room (rare): straight to the global list
+    }
+    base = __shfl(base, leader, 64);
+    if (!want) return;
+    if (base & 0x80000000u) glist[(base & 0x7FFFFFFFu) + rank] = v;
+    else sg.buf[which][wv][base + rank] = v;
+}
+
+// all lanes of the wave are here
+__device__ __forceinline__ void stage_flush(SkStage &sg, int which, uint32_t *__restrict__ glist, uint32_t *gcnt) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = sg.n[which][wv];
+    if (!n) return;
+    uint32_t off = 0;
+    if (lane == 0) off = atomicAdd(gcnt, n);
+    off = __shfl(off, 0, 64);
+    for (uint32_t j = lane; j < n; j += 64) glist[off + j] = sg.buf[which][wv][j];
+    if (lane == 0) sg.n[which][wv] = 0;
+}
+
 // one frontier: every listed voxel offers its time stamp to its neighbours of the same level -- unchanged to those of a
 // lower image value (drained at once), one generation later to those AT the level's value.  A drained voxel whose
-// stamp fell goes to `closure` (it has to pass the better stamp on within this generation); a voxel stamped for the
-// first time with the next generation goes to `next`.
+// stamp fell goes to the closure list (it has to pass the better stamp on within this generation); a voxel stamped for
+// the first time with the next generation goes to the next list.  Fixed grid, grid-stride over the list.
 template <int CONN>
 __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                  unsigned long long *tau, uint32_t *mark, uint32_t epoch, uint32_t c,
-                                                  const uint32_t *__restrict__ in, uint32_t n_in, uint32_t *__restrict__ closure,
-                                                  uint32_t *__restrict__ next, SkState *st) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool act = i < n_in;
-    const uint32_t q = act ? in[i] : 0u;
-    const unsigned long long t = act ? ld64(&tau[q]) : TINF;
-    const int64_t z = q / g.hw, r = q - z * g.hw, y = r / g.w, x = r - y * g.w;
+                                                  unsigned long long *tau, uint32_t *mark, uint32_t c, SkLists L, SkState *st) {
+    if (st->done) return; // (uniform: written only between rounds)
+    const uint32_t n_in = st->n_in, epoch = st->epoch;
+    const uint32_t *__restrict__ in = L.l[st->in_sel];
+    uint32_t *__restrict__ closure = L.l[st->cla_sel];
+    uint32_t *__restrict__ next = L.l[st->nxt_sel];
+    const uint32_t stride = gridDim.x * 256;
+    // A voxel whose stamp this lane just lowered through a zero-cost step is followed at once (a small stack per lane):
+    // drained basins are crossed in a few rounds instead of one round per voxel of their diameter.  Whatever does not fit
+    // the stack or the step budget goes to the closure list as before.
+    __shared__ uint32_t s_stack[CHASE_DEPTH][256];
+    __shared__ SkStage sg;
+    if (threadIdx.x < 8) sg.n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+    __syncthreads();
+    for (uint32_t i0 = blockIdx.x * 256; i0 < n_in; i0 += stride) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool have = i < n_in;
+        uint32_t cur = have ? in[i] : 0u;
+        int sp = 0, steps = 0;
+        while (have) { // (lanes leave this loop one by one: the ballots inside see the lanes still in it)
+            const unsigned long long t = ld64(&tau[cur]);
+            const int64_t z = cur / g.hw, r = cur - z * g.hw, y = r / g.w, x = r - y * g.w;
 #pragma unroll
-    for (int k = 0; k < 27; k++) {
-        if (!has_off<CONN>(g.smask, k)) continue; // (wave-uniform: the pushes below stay convergent)
-        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-        const int64_t Z = z + dz, Y = y + dy, X = x + dx;
-        bool push_c = false, push_n = false;
-        uint32_t p = 0;
-        if (act && (uint64_t)X < (uint64_t)g.w && (uint64_t)Y < (uint64_t)g.h && (uint64_t)Z < (uint64_t)g.d) {
-            p = (uint32_t)((int64_t)q + dz * g.hw + dy * g.w + dx);
-            if ((uint32_t)C[p] == c) {
-                if ((uint32_t)I[p] < c) {
-                    if (t < ld64(&tau[p]) && t < atomicMin(&tau[p], t)) push_c = atomicExch(&mark[p], epoch) != epoch;
-                } else {
-                    const unsigned long long nt = t + GEN1;
-                    if (nt < ld64(&tau[p])) push_n = atomicMin(&tau[p], nt) == TINF;
+            for (int k = 0; k < 27; k++) {
+                if (!has_off<CONN>(g.smask, k)) continue;
+                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+                bool push_c = false, push_n = false;
+                uint32_t p = 0;
+                if ((uint64_t)X < (uint64_t)g.w && (uint64_t)Y < (uint64_t)g.h && (uint64_t)Z < (uint64_t)g.d) {
+                    p = (uint32_t)((int64_t)cur + dz * g.hw + dy * g.w + dx);
+                    if ((uint32_t)C[p] == c) {
+                        if ((uint32_t)I[p] < c) {
+                            if (t < ld64(&tau[p]) && t < atomicMin(&tau[p], t)) {
+                                if (sp < CHASE_DEPTH && steps < CHASE_STEPS) s_stack[sp++][threadIdx.x] = p;
+                                else push_c = atomicExch(&mark[p], epoch) != epoch;
+                            }
+                        } else {
+                            const unsigned long long nt = t + GEN1;
+                            if (nt < ld64(&tau[p])) push_n = atomicMin(&tau[p], nt) == TINF;
+                        }
+                    }
                 }
+                stage_push(push_c, p, sg, 0, closure, &st->n_closure);
+                stage_push(push_n, p, sg, 1, next, &st->n_next);
             }
+            steps++;
+            have = sp > 0;
+            if (have) cur = s_stack[--sp][threadIdx.x];
         }
-        wave_push(push_c, p, closure, &st->n_closure);
-        wave_push(push_n, p, next, &st->n_next);
+        stage_flush(sg, 0, closure, &st->n_closure);
+        stage_flush(sg, 1, next, &st->n_next);
+    }
+    // the last workgroup out sets up the next round
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    const uint32_t ncl = __hip_atomic_load(&st->n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nnx = __hip_atomic_load(&st->n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st->ticket = 0;
+    st->rounds += 1;
+    st->epoch = epoch + 1;
+    if (ncl) { // zero-cost steps still spreading inside this generation
+        st->n_in = ncl;
+        st->n_closure = 0;
+        const uint32_t oldin = st->in_sel;
+        st->in_sel = st->cla_sel; // the four roles stay a permutation of the four lists
+        st->cla_sel = st->clb_sel;
+        st->clb_sel = oldin;
+    } else if (nnx) { // next generation
+        st->n_in = nnx;
+        st->n_next = 0;
+        st->gen += 1;
+        st->gens += 1;
+        const uint32_t oldin = st->in_sel;
+        st->in_sel = st->nxt_sel;
+        st->nxt_sel = oldin;
+    } else {
+        st->done = 1;
     }
 }
 
@@ -333,8 +450,10 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
 
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
-    int64_t nlevels = 0, nrounds = 0, ngens = 0, nsorted = 0;
-    uint32_t start = 0, roff = 0, gbase = 1, epoch = 0;
+    int64_t nlevels = 0, nsorted = 0;
+    uint32_t start = 0, roff = 0, gbase = 1;
+    SkLists lists;
+    for (int i = 0; i < 4; i++) lists.l[i] = b.lists[i];
     for (uint32_t c = 0; c < 65535; c++) {
         const uint32_t cnt = hist[c];
         if (!cnt) continue;
@@ -354,40 +473,26 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             vs = b.val_b;
             nsorted += cnt;
         }
-        uint32_t *cur = b.lists[0], *nxt = b.lists[1], *cl_a = b.lists[2], *cl_b = b.lists[3];
-        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, cur, cnt, roff, gbase, b.st);
+        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, b.st);
         IVX_LAUNCH_CHECK();
-        // generations: `cur` = the voxels stamped with the current generation (first round) or the drained voxels whose
-        // stamp just fell (closure rounds); `nxt` collects the next generation across those rounds
-        uint32_t n_in = cnt, n_next_seen = 0;
-        uint32_t *in = cur;
+        // rounds are queued in growing batches; one host read per batch (a round after the level's last returns at once)
+        uint32_t batch = 4, width = cnt;
         for (;;) {
-            IVX_HIP(hipMemsetAsync(&b.st->n_closure, 0, 4, st));
-            epoch++;
-            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3((unsigned)cdiv(n_in, 256)), dim3(256), 0, st, g, I, b.C, b.tau, b.mark,
-                                                      epoch, c, in, n_in, cl_a, nxt, b.st));
-            IVX_LAUNCH_CHECK();
-            nrounds++;
-            uint32_t seq = 0, msg[2] = {0, 0};
-            int rc = mailbox_publish(&b.st->n_closure, 2, st, &seq);
-            if (rc != IVX_OK) return rc;
-            rc = mailbox_wait(seq, st, msg, 2);
-            if (rc != IVX_OK) return rc;
-            n_next_seen = msg[1];
-            if (msg[0]) { // zero-cost steps still spreading inside this generation
-                in = cl_a;
-                n_in = msg[0];
-                std::swap(cl_a, cl_b);
-                continue;
+            // the frontier can grow a lot inside one batch: the grid is sized for a large one (idle workgroups leave at once)
+            const unsigned nb = (unsigned)std::min<int64_t>(std::max<int64_t>(4 * cdiv(width, 256), 1024), 4096);
+            for (uint32_t r = 0; r < batch; r++) {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3(nb), dim3(256), 0, st, g, I, b.C, b.tau, b.mark, c, lists, b.st));
+                IVX_LAUNCH_CHECK();
             }
-            if (!n_next_seen) break; // level exhausted
-            // next generation
-            ngens++;
-            gbase++;
-            std::swap(cur, nxt);
-            in = cur;
-            n_in = n_next_seen;
-            IVX_HIP(hipMemsetAsync(&b.st->n_next, 0, 4, st));
+            uint32_t seq = 0, msg[4] = {0, 0, 0, 0};
+            int rc = mailbox_publish(&b.st->done, 4, st, &seq);
+            if (rc != IVX_OK) return rc;
+            rc = mailbox_wait(seq, st, msg, 4);
+            if (rc != IVX_OK) return rc;
+            gbase = msg[1];
+            if (msg[0]) break;
+            width = std::max(msg[3], 1u);
+            batch = std::min(batch * 2, 64u);
         }
         gbase++;
         IVX_REQUIRE(gbase < 0x7FFFFFF0u, IVX_EINVAL, "watershed: more than 2^31 generations");
@@ -405,10 +510,10 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_HIP(hipStreamSynchronize(st));
     if (stats) {
         stats[0] = rounds; stats[1] = visits; stats[2] = nlevels; stats[3] = gbase; stats[4] = M; stats[5] = (int64_t)ngen0;
-        stats[6] = hs.mixed; stats[7] = nrounds;
+        stats[6] = hs.mixed; stats[7] = hs.rounds;
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] generation 0, [10] level chain, [11] labels (microseconds)
-        stats[13] = ngens; stats[14] = nsorted;
+        stats[13] = hs.gens; stats[14] = nsorted;
     }
     return IVX_OK;
 }

@@ -7,10 +7,9 @@
  *     (ndimage/src/ni_measure.c, NI_WatershedIFT: bucket queue over max-arc path cost, positive
  *     labels pushed at the FRONT of a bucket, negative at the back, relabel on strictly smaller
  *     cost) and is PINNED against the live scipy in tests/test_oracle_watershed.py.
- *   - skimage.segmentation.watershed (scikit-image 0.24.0, NOT installed, not vendored): a binary heap
- *     keyed by (value, age) with neighbours labelled at push time (_watershed_cy.pyx).  NOT restated here:
- *     its neighbour ordering and tie rules cannot be recovered without the source, and there is nothing
- *     in this image to pin a restatement to.
+ *   - skimage.segmentation.watershed (scikit-image 0.24.0 pinned by the reference; 0.18.3 sits under
+ *     /opt/conda in this image): restated in ivx_oracle_wssk.c and PINNED to that compiled kernel
+ *     (tests/golden/watershed_sk.npz, tests/golden/make_golden_sk.py).
  */
 #include <stdint.h>
 #include <stdlib.h>
