@@ -84,68 +84,6 @@ __global__ __launch_bounds__(256) void k_ws_entries(WsGeom g, const uint16_t *__
     }
 }
 
-// x-runs inside a wave's 64 voxels: parent = start of the run (saves most of the unions on plateaus)
-__global__ __launch_bounds__(256) void k_ws_runs(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp, int has_x) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool mine = p < g.n && comp[p] != ENTRY;
-    bool link = false;
-    // comp[p-1] is ENTRY, (p-1), or a value this kernel just wrote there: only its ENTRY-ness is read
-    if (mine && has_x && lane > 0) link = ((zmask[p] >> 12) & 1u) && comp[p - 1] != ENTRY;
-    const unsigned long long starts = __ballot(mine && !link);
-    if (mine && link) {
-        const unsigned long long below = starts & ((2ull << lane) - 1ull);
-        const int s0 = 63 - __clzll(below);
-        comp[p] = (uint32_t)(p - (lane - s0));
-    }
-}
-
-__device__ __forceinline__ uint32_t ws_find(const uint32_t *comp, uint32_t a) {
-    uint32_t r = __hip_atomic_load(&comp[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (r != a) {
-        a = r;
-        r = __hip_atomic_load(&comp[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return a;
-}
-
-__device__ __forceinline__ void ws_unite(uint32_t *comp, uint32_t a, uint32_t b) {
-    for (;;) {
-        a = ws_find(comp, a);
-        b = ws_find(comp, b);
-        if (a == b) return;
-        if (a > b) { const uint32_t t = a; a = b; b = t; }
-        const uint32_t old = atomicMin(&comp[b], a);
-        if (old == b) return;
-        b = old;
-    }
-}
-
-template <int CONN>
-__global__ __launch_bounds__(256) void k_ws_union(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= g.n) return;
-    if (__hip_atomic_load(&comp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) return;
-    uint32_t zm = zmask[p] >> 14; // forward neighbours only (k = 14 .. 26)
-    if ((threadIdx.x & 63) != 63) zm &= ~1u; // +x inside a wave: done by k_ws_runs
-    while (zm) {
-        const int k = 14 + __ffs(zm) - 1;
-        zm &= zm - 1;
-        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-        const int64_t q = p + dz * g.hw + dy * g.w + dx;
-        if (__hip_atomic_load(&comp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) continue;
-        ws_unite(comp, (uint32_t)p, (uint32_t)q);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_ws_flatten(int64_t n, uint32_t *comp) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t c = comp[p];
-    if (c == ENTRY || c == (uint32_t)p) return;
-    comp[p] = ws_find(comp, c);
-}
-
 __device__ __forceinline__ uint32_t ws_tau_of(const uint32_t *__restrict__ comp, const uint32_t *tau, int64_t v) {
     const uint32_t cv = comp[v];
     return __hip_atomic_load(&tau[cv == ENTRY ? (uint32_t)v : cv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

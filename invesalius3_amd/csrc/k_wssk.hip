@@ -27,10 +27,16 @@
 //
 // Pipeline (one stream, no CPU arithmetic):
 //   1. k_ws_relax<SK>  the cost map by chaotic relaxation over dirty 16x16x8 tiles (shared with the IFT flood);
-//   2. k_sk_classify   generation-0 flags; k_ws_bucket: generation 0 bucketed by level;
+//   2. k_sk_classify   generation-0 flags, drained voxels (I < C) and their same-level drained neighbours; union-find
+//                      (k_ws_runs / k_ws_union / k_ws_flatten) makes every drained basin one set whose time stamp lives at
+//                      its root; k_ws_bucket: generation 0 and the drained voxels, each bucketed by level;
 //   3. per non-empty level, ascending: k_sk_keys (marker: raster index; other: smallest T among lower-C neighbours)
-//      -> radix sort -> k_sk_assign (T, run labels, first frontier) -> k_sk_round until the level is exhausted: one
-//      launch per frontier; zero-cost steps are closed before the generation advances (0-1 breadth-first search);
+//      -> radix sort -> k_sk_assign (T, run labels, first frontier) -> k_sk_round until the level is exhausted.  A
+//      generation is at most two launches: A -- the frontier stamps its unstamped neighbours of value c with the next
+//      generation and offers its own stamp to the basins it touches (atomicMin at the root); B -- only if a basin was
+//      stamped: the level's drained voxels whose basin carries this generation's stamp hand it, one generation later, to
+//      their unstamped neighbours of value c.  The last workgroup of a launch sets up the next one; the host queues
+//      launches in batches and reads one mailbox line per batch.
 //   4. k_sk_labels     label = label of the run in T's low word.
 #include <algorithm>
 #include <vector>
@@ -45,39 +51,42 @@ namespace {
 
 constexpr unsigned long long TINF = ~0ull;
 constexpr unsigned long long GEN1 = 1ull << 32;
-constexpr int CHASE_DEPTH = 16, CHASE_STEPS = 48;
 
 // The frontier loop of a level runs without the host: every round is one launch of k_sk_round over a fixed grid; the
-// last workgroup to finish turns the counters into the next round's input (closure list, or the next generation, or
-// "level exhausted").  The host queues rounds in batches and reads {done, gen, rounds} once per batch.
+// last workgroup to finish turns the counters into the next round's input (phase B, or the next generation, or "level
+// exhausted").  The host queues rounds in batches and reads {done, gen, rounds, n_in} once per batch.
 struct SkState {
     uint32_t done;      // level exhausted: further rounds return at once   }
     uint32_t gen;       // G of the voxels on the current input list        } read by the host once per batch (mailbox)
     uint32_t rounds;    // rounds that did work (statistics)                }
-    uint32_t n_in;      // entries of the coming round's input list         }
-    uint32_t in_sel, nxt_sel, cla_sel, clb_sel; // roles of the four lists: input, next generation, closure out, closure spare
-    uint32_t n_closure; // voxels whose T fell in this round through a zero-cost step
+    uint32_t n_in;      // entries of the current frontier                  }
+    uint32_t phase;     // 0: the coming round is A (frontier), 1: B (basins stamped in this generation relay)
+    uint32_t in_sel;    // which of the two lists is the frontier (the other collects the next generation)
     uint32_t n_next;    // voxels of the next generation so far
-    uint32_t epoch;     // round counter (de-duplicates the closure list)
+    uint32_t n_stamped; // basins stamped for the first time by this generation's round A
     uint32_t ticket;    // workgroups of the running round that have finished
     uint32_t mixed;     // adjacent tied markers with different labels (see TIES)
     uint32_t gens;      // generation steps (statistics)
-    uint32_t pad[2];
+    uint32_t brounds;   // B rounds (statistics)
 };
 
 struct SkLists {
-    uint32_t *l[4];
+    uint32_t *l[2];
 };
 
-template <typename MT> struct SkGen0Pred {
+struct SkKindPred {
     const uint8_t *kind;
-    __device__ bool operator()(int64_t p) const { return kind[p] != 0; }
+    uint8_t which;
+    __device__ bool operator()(int64_t p) const { return kind[p] == which; }
 };
+constexpr uint8_t KIND_GEN0 = 1, KIND_DRAINED = 2;
 
-// generation-0 flags: markers, and voxels that sit AT their cost (I == C) next to a voxel of lower cost
+// per voxel: generation 0 (markers, and voxels that sit AT their cost, I == C, next to a voxel of lower cost), or drained
+// (I < C: part of a basin that is flooded the moment it is reached) with the mask of its drained neighbours of equal cost
 template <int CONN, typename MT>
 __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                     const MT *__restrict__ mk, uint8_t *__restrict__ kind) {
+                                                     const MT *__restrict__ mk, uint8_t *__restrict__ kind, uint32_t *__restrict__ comp,
+                                                     uint32_t *__restrict__ zmask) {
     __shared__ uint32_t s[NCELL];
     int z0, y0, x0;
     tile_origin(g, blockIdx.x, z0, y0, x0);
@@ -91,14 +100,20 @@ __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *_
         const uint32_t cell = s[ci];
         const uint32_t c = cell >> 16, iv = cell & 0xFFFFu;
         const int64_t p = (int64_t)(z0 + zz) * g.hw + (int64_t)(y0 + ly) * g.w + (x0 + lx);
+        const bool drained = c != CINF && iv < c; // (never a marker: those sit at their own value)
         bool lower = false;
+        uint32_t zm = 0;
 #pragma unroll
         for (int k = 0; k < 27; k++) {
             if (!has_off<CONN>(g.smask, k)) continue;
             const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-            lower |= (s[ci + (dz * BY + dy) * BX + dx] >> 16) < c; // cells outside the volume carry CINF
+            const uint32_t qv = s[ci + (dz * BY + dy) * BX + dx]; // cells outside the volume carry CINF
+            lower |= (qv >> 16) < c;
+            zm |= ((qv >> 16) == c && (qv & 0xFFFFu) < c) ? 1u << k : 0u;
         }
-        kind[p] = (mk[p] != 0 || (c != CINF && iv == c && lower)) ? 1 : 0;
+        kind[p] = (mk[p] != 0 || (c != CINF && iv == c && lower)) ? KIND_GEN0 : drained ? KIND_DRAINED : 0;
+        comp[p] = drained ? (uint32_t)p : ENTRY;
+        zmask[p] = drained ? zm : 0u;
     }
 }
 
@@ -109,6 +124,7 @@ __device__ __forceinline__ unsigned long long ld64(const unsigned long long *p) 
 // keys of a level's generation 0: marker -> raster index (< 2^32 <= every T); other -> smallest T among lower-C neighbours
 template <int CONN, typename MT>
 __global__ __launch_bounds__(256) void k_sk_keys(WsGeom g, const uint16_t *__restrict__ C, const MT *__restrict__ mk,
+                                                 const uint16_t *__restrict__ I, const uint32_t *__restrict__ comp,
                                                  const unsigned long long *tau, const uint32_t *__restrict__ elist,
                                                  unsigned long long *__restrict__ key, uint32_t *__restrict__ val, uint32_t cnt, uint32_t c) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -125,7 +141,8 @@ __global__ __launch_bounds__(256) void k_sk_keys(WsGeom g, const uint16_t *__res
             const int64_t Z = z + dz, Y = y + dy, X = x + dx;
             if ((uint64_t)X >= (uint64_t)g.w || (uint64_t)Y >= (uint64_t)g.h || (uint64_t)Z >= (uint64_t)g.d) continue;
             const int64_t q = (int64_t)p + dz * g.hw + dy * g.w + dx;
-            if ((uint32_t)C[q] < c) K = min(K, ld64(&tau[q]));
+            const uint32_t qc = C[q];
+            if (qc < c) K = min(K, ld64(&tau[(uint32_t)I[q] < qc ? comp[q] : (uint32_t)q])); // a drained voxel's stamp is its basin's
         }
     }
     key[i] = K;
@@ -138,11 +155,10 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
                                                    const MT *__restrict__ mk, unsigned long long *tau, int32_t *runlabel,
                                                    uint32_t *__restrict__ front, uint32_t cnt, uint32_t roff, uint32_t gbase, SkState *st) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) { // the level's frontier loop starts from list 0
+    if (i == 0) { // the level's frontier loop starts from list 0, phase A
         st->done = 0; st->gen = gbase; st->n_in = cnt;
-        st->in_sel = 0; st->nxt_sel = 1; st->cla_sel = 2; st->clb_sel = 3;
-        st->n_closure = 0; st->n_next = 0; st->ticket = 0;
-        st->epoch += 1;
+        st->phase = 0; st->in_sel = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
     }
     if (i >= cnt) return;
     const uint32_t p = val[i];
@@ -156,26 +172,15 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
     if (m && i > 0 && (int)mk[val[i - 1]] != m) atomicAdd(&st->mixed, 1u); // markers sort first: val[i-1] is one too
 }
 
-__device__ __forceinline__ void wave_push(bool want, uint32_t v, uint32_t *__restrict__ list, uint32_t *counter) {
-    const unsigned long long b = __ballot(want);
-    if (!b) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)b) - 1;
-    uint32_t off = 0;
-    if (lane == leader) off = atomicAdd(counter, (uint32_t)__popcll(b));
-    off = __shfl(off, leader, 64);
-    if (want) list[off + __popcll(b & ((1ull << lane) - 1ull))] = v;
-}
-
-// Appends to the two output lists are staged per wave in LDS and handed to the global list with ONE atomic per wave,
-// list and pass (a frontier of 10^5 voxels otherwise sends ~10^4 atomics to one counter word, one after the other).
-constexpr int WB_CAP = 768;
+// Appends to the next-generation list are staged per wave in LDS and handed to the global list with ONE atomic per wave
+// and pass (a frontier of 10^5 voxels otherwise sends ~10^4 atomics to one counter word, one after the other).
+constexpr int WB_CAP = 1024;
 struct SkStage {
-    volatile uint32_t buf[2][4][WB_CAP];
-    volatile uint32_t n[2][4];
+    volatile uint32_t buf[4][WB_CAP];
+    volatile uint32_t n[4];
 };
 
-__device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, int which, uint32_t *__restrict__ glist, uint32_t *gcnt) {
+__device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, uint32_t *__restrict__ glist, uint32_t *gcnt) {
     const unsigned long long b = __ballot(want);
     if (!b) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -183,88 +188,101 @@ __device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, i
     const uint32_t n = (uint32_t)__popcll(b), rank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
     uint32_t base = 0;
     if (lane == leader) {
-        base = sg.n[which][wv];
-        if (base + n <= WB_CAP) sg.n[which][wv] = base + n;
+        base = sg.n[wv];
+        if (base + n <= WB_CAP) sg.n[wv] = base + n;
         else base = 0x80000000u | atomicAdd(gcnt, n); // no room (rare): straight to the global list
     }
     base = __shfl(base, leader, 64);
     if (!want) return;
     if (base & 0x80000000u) glist[(base & 0x7FFFFFFFu) + rank] = v;
-    else sg.buf[which][wv][base + rank] = v;
+    else sg.buf[wv][base + rank] = v;
 }
 
 // all lanes of the wave are here
-__device__ __forceinline__ void stage_flush(SkStage &sg, int which, uint32_t *__restrict__ glist, uint32_t *gcnt) {
+__device__ __forceinline__ void stage_flush(SkStage &sg, uint32_t *__restrict__ glist, uint32_t *gcnt) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t n = sg.n[which][wv];
+    const uint32_t n = sg.n[wv];
     if (!n) return;
     uint32_t off = 0;
     if (lane == 0) off = atomicAdd(gcnt, n);
     off = __shfl(off, 0, 64);
-    for (uint32_t j = lane; j < n; j += 64) glist[off + j] = sg.buf[which][wv][j];
-    if (lane == 0) sg.n[which][wv] = 0;
+    for (uint32_t j = lane; j < n; j += 64) glist[off + j] = sg.buf[wv][j];
+    if (lane == 0) sg.n[wv] = 0;
 }
 
-// one frontier: every listed voxel offers its time stamp to its neighbours of the same level -- unchanged to those of a
-// lower image value (drained at once), one generation later to those AT the level's value.  A drained voxel whose
-// stamp fell goes to the closure list (it has to pass the better stamp on within this generation); a voxel stamped for
-// the first time with the next generation goes to the next list.  Fixed grid, grid-stride over the list.
+// stamp the unstamped neighbours of value c of voxel `v` with `nt` (one generation after v's own stamp)
+template <int CONN>
+__device__ __forceinline__ void sk_offer_plateau(const WsGeom &g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
+                                                 unsigned long long *tau, uint32_t c, bool act, uint32_t v, unsigned long long nt,
+                                                 SkStage &sg, uint32_t *__restrict__ next, SkState *st) {
+    const int64_t z = v / g.hw, r = v - z * g.hw, y = r / g.w, x = r - y * g.w;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        if (!has_off<CONN>(g.smask, k)) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+        bool push_n = false;
+        uint32_t p = 0;
+        if (act && (uint64_t)X < (uint64_t)g.w && (uint64_t)Y < (uint64_t)g.h && (uint64_t)Z < (uint64_t)g.d) {
+            p = (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx);
+            if ((uint32_t)C[p] == c && (uint32_t)I[p] == c && nt < ld64(&tau[p])) push_n = atomicMin(&tau[p], nt) == TINF;
+        }
+        stage_push(push_n, p, sg, next, &st->n_next);
+    }
+}
+
+// One round.  Phase A: every frontier voxel (stamp t, generation G) stamps its unstamped neighbours of value c with
+// t + one generation and offers t to the basins it touches (atomicMin at the basin's root; a basin is stamped by exactly
+// one generation, and all its candidates arrive in this one launch).  Phase B: every drained voxel of the level whose basin
+// carries a stamp of generation G relays it, one generation later, to its unstamped neighbours of value c.  Fixed grid,
+// grid-stride over the list; the last workgroup out sets up the next round.
 template <int CONN>
 __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                  unsigned long long *tau, uint32_t *mark, uint32_t c, SkLists L, SkState *st) {
+                                                  const uint32_t *__restrict__ comp, unsigned long long *tau, uint32_t c, SkLists L,
+                                                  const uint32_t *__restrict__ dlist, uint32_t ndl, SkState *st) {
     if (st->done) return; // (uniform: written only between rounds)
-    const uint32_t n_in = st->n_in, epoch = st->epoch;
-    const uint32_t *__restrict__ in = L.l[st->in_sel];
-    uint32_t *__restrict__ closure = L.l[st->cla_sel];
-    uint32_t *__restrict__ next = L.l[st->nxt_sel];
+    const uint32_t phase = st->phase, gen = st->gen;
+    const uint32_t n_in = phase ? ndl : st->n_in;
+    const uint32_t *__restrict__ in = phase ? dlist : L.l[st->in_sel];
+    uint32_t *__restrict__ next = L.l[st->in_sel ^ 1u];
     const uint32_t stride = gridDim.x * 256;
-    // A voxel whose stamp this lane just lowered through a zero-cost step is followed at once (a small stack per lane):
-    // drained basins are crossed in a few rounds instead of one round per voxel of their diameter.  Whatever does not fit
-    // the stack or the step budget goes to the closure list as before.
-    __shared__ uint32_t s_stack[CHASE_DEPTH][256];
     __shared__ SkStage sg;
-    if (threadIdx.x < 8) sg.n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+    if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i0 = blockIdx.x * 256; i0 < n_in; i0 += stride) {
+    uint32_t stamped = 0;
+    for (uint32_t i0 = blockIdx.x * 256; i0 < n_in; i0 += stride) { // (i0 is wave-uniform: the staged pushes stay convergent)
         const uint32_t i = i0 + threadIdx.x;
-        bool have = i < n_in;
-        uint32_t cur = have ? in[i] : 0u;
-        int sp = 0, steps = 0;
-        while (have) { // (lanes leave this loop one by one: the ballots inside see the lanes still in it)
-            const unsigned long long t = ld64(&tau[cur]);
-            const int64_t z = cur / g.hw, r = cur - z * g.hw, y = r / g.w, x = r - y * g.w;
+        bool act = i < n_in;
+        const uint32_t v = act ? in[i] : 0u;
+        if (phase == 0) {
+            const unsigned long long t = act ? ld64(&tau[v]) : TINF;
+            sk_offer_plateau<CONN>(g, I, C, tau, c, act, v, t + GEN1, sg, next, st);
+            if (ndl && act) { // the basins this voxel touches
+                const int64_t z = v / g.hw, r = v - z * g.hw, y = r / g.w, x = r - y * g.w;
+                uint32_t last = ENTRY;
 #pragma unroll
-            for (int k = 0; k < 27; k++) {
-                if (!has_off<CONN>(g.smask, k)) continue;
-                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-                const int64_t Z = z + dz, Y = y + dy, X = x + dx;
-                bool push_c = false, push_n = false;
-                uint32_t p = 0;
-                if ((uint64_t)X < (uint64_t)g.w && (uint64_t)Y < (uint64_t)g.h && (uint64_t)Z < (uint64_t)g.d) {
-                    p = (uint32_t)((int64_t)cur + dz * g.hw + dy * g.w + dx);
-                    if ((uint32_t)C[p] == c) {
-                        if ((uint32_t)I[p] < c) {
-                            if (t < ld64(&tau[p]) && t < atomicMin(&tau[p], t)) {
-                                if (sp < CHASE_DEPTH && steps < CHASE_STEPS) s_stack[sp++][threadIdx.x] = p;
-                                else push_c = atomicExch(&mark[p], epoch) != epoch;
-                            }
-                        } else {
-                            const unsigned long long nt = t + GEN1;
-                            if (nt < ld64(&tau[p])) push_n = atomicMin(&tau[p], nt) == TINF;
-                        }
-                    }
+                for (int k = 0; k < 27; k++) {
+                    if (!has_off<CONN>(g.smask, k)) continue;
+                    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                    const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+                    if ((uint64_t)X >= (uint64_t)g.w || (uint64_t)Y >= (uint64_t)g.h || (uint64_t)Z >= (uint64_t)g.d) continue;
+                    const uint32_t p = (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx);
+                    if ((uint32_t)C[p] != c || (uint32_t)I[p] >= c) continue;
+                    const uint32_t root = comp[p];
+                    if (root == last) continue; // (most neighbours of one voxel share a basin)
+                    last = root;
+                    if (t < ld64(&tau[root])) stamped += atomicMin(&tau[root], t) == TINF;
                 }
-                stage_push(push_c, p, sg, 0, closure, &st->n_closure);
-                stage_push(push_n, p, sg, 1, next, &st->n_next);
             }
-            steps++;
-            have = sp > 0;
-            if (have) cur = s_stack[--sp][threadIdx.x];
+        } else {
+            unsigned long long tb = TINF;
+            if (act) tb = ld64(&tau[comp[v]]);
+            act = act && (uint32_t)(tb >> 32) == gen; // stamped by this generation (earlier ones have relayed already)
+            sk_offer_plateau<CONN>(g, I, C, tau, c, act, v, tb + GEN1, sg, next, st);
         }
-        stage_flush(sg, 0, closure, &st->n_closure);
-        stage_flush(sg, 1, next, &st->n_next);
+        stage_flush(sg, next, &st->n_next);
     }
-    // the last workgroup out sets up the next round
+    if (stamped) atomicAdd(&st->n_stamped, stamped);
     __shared__ uint32_t s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -274,37 +292,34 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__re
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
     __threadfence();
-    const uint32_t ncl = __hip_atomic_load(&st->n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nst = __hip_atomic_load(&st->n_stamped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t nnx = __hip_atomic_load(&st->n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     st->ticket = 0;
     st->rounds += 1;
-    st->epoch = epoch + 1;
-    if (ncl) { // zero-cost steps still spreading inside this generation
-        st->n_in = ncl;
-        st->n_closure = 0;
-        const uint32_t oldin = st->in_sel;
-        st->in_sel = st->cla_sel; // the four roles stay a permutation of the four lists
-        st->cla_sel = st->clb_sel;
-        st->clb_sel = oldin;
+    if (phase == 0 && nst) { // basins were stamped: they relay before the generation advances
+        st->phase = 1;
+        st->n_stamped = 0;
+        st->brounds += 1;
     } else if (nnx) { // next generation
+        st->phase = 0;
         st->n_in = nnx;
         st->n_next = 0;
-        st->gen += 1;
+        st->gen = gen + 1;
         st->gens += 1;
-        const uint32_t oldin = st->in_sel;
-        st->in_sel = st->nxt_sel;
-        st->nxt_sel = oldin;
+        st->in_sel ^= 1u;
     } else {
         st->done = 1;
     }
 }
 
 template <typename MT>
-__global__ __launch_bounds__(256) void k_sk_labels(int64_t n, const unsigned long long *__restrict__ tau, const int32_t *__restrict__ runlabel,
-                                                   MT *__restrict__ out, int32_t *__restrict__ out32, uint8_t *__restrict__ out8) {
+__global__ __launch_bounds__(256) void k_sk_labels(int64_t n, const uint32_t *__restrict__ comp, const unsigned long long *__restrict__ tau,
+                                                   const int32_t *__restrict__ runlabel, MT *__restrict__ out, int32_t *__restrict__ out32,
+                                                   uint8_t *__restrict__ out8) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    const unsigned long long t = tau[p];
+    const uint32_t cp = comp[p];
+    const unsigned long long t = tau[cp == ENTRY ? (uint32_t)p : cp];
     const int32_t l = t == TINF ? 0 : runlabel[(uint32_t)(t & 0xFFFFFFFFull)];
     if (out) out[p] = (MT)l;
     if (out32) out32[p] = l;
@@ -319,7 +334,7 @@ struct SkBufs {
     uint16_t *C;
     uint8_t *kind, *dirty, *pending;
     unsigned long long *tau, *key_a, *key_b;
-    uint32_t *mark, *elist, *lists[4], *val_a, *val_b, *hist, *cursor, *bcount, *bsum, *tlist, *total;
+    uint32_t *comp, *zmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *bcount, *bsum, *tlist, *total;
     int32_t *runlabel;
     WsState *wst;
     SkState *st;
@@ -335,11 +350,15 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->C = (uint16_t *)take((size_t)g.n * 2);
     b->kind = (uint8_t *)take((size_t)g.n);
     b->tau = (unsigned long long *)take((size_t)g.n * 8);
-    b->mark = (uint32_t *)take((size_t)g.n * 4);
+    b->comp = (uint32_t *)take((size_t)g.n * 4);
+    b->zmask = (uint32_t *)take((size_t)g.n * 4);
+    b->dlist = (uint32_t *)take((size_t)g.n * 4);
     b->elist = (uint32_t *)take((size_t)g.n * 4);
-    for (int i = 0; i < 4; i++) b->lists[i] = (uint32_t *)take((size_t)g.n * 4);
+    for (int i = 0; i < 2; i++) b->lists[i] = (uint32_t *)take((size_t)g.n * 4);
     b->hist = (uint32_t *)take(65536 * 4);
     b->cursor = (uint32_t *)take(65536 * 4);
+    b->dhist = (uint32_t *)take(65536 * 4);
+    b->dcursor = (uint32_t *)take(65536 * 4);
     b->bcount = (uint32_t *)take((size_t)(nblk + 1) * 4);
     b->bsum = (uint32_t *)take((size_t)(std::max<int64_t>(cdiv(nblk, 4096), 16) + 2) * 4);
     b->tlist = (uint32_t *)take((size_t)g.ntiles * 4);
@@ -411,26 +430,35 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     if (cost_out) IVX_HIP(hipMemcpyAsync(cost_out, b.C, (size_t)g.n * 2, hipMemcpyDeviceToDevice, st));
 
     tm.mark(st);
-    // ---- 2. generation 0, bucketed by level ------------------------------------------------------------------
-    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind));
+    // ---- 2. generation 0 and the drained basins, bucketed by level ------------------------------------------
+    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind, b.comp,
+                                              b.zmask));
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ws_runs, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp, (int)((g.smask >> 12) & 1u));
+    IVX_LAUNCH_CHECK();
+    WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_union<CC>, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp));
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ws_flatten, dim3(gl), dim3(256), 0, st, g.n, b.comp);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipMemsetAsync(b.hist, 0, 65536 * 4, st));
+    IVX_HIP(hipMemsetAsync(b.dhist, 0, 65536 * 4, st));
     const unsigned gbk = (unsigned)cdiv(g.n, 256 * BK_CH);
-    hipLaunchKernelGGL((k_ws_bucket<SkGen0Pred<MT>, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkGen0Pred<MT>{b.kind}, b.hist, b.elist);
-    IVX_LAUNCH_CHECK();
-    std::vector<uint32_t> hist(65536);
-    IVX_HIP(hipMemcpyAsync(hist.data(), b.hist, 65536 * 4, hipMemcpyDeviceToHost, st));
-    IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, 65536 * 4, hipMemcpyDeviceToDevice, st));
-    {
-        const int rc = scan_u32_exclusive(b.cursor, 65536, b.bsum, b.total, st);
+    std::vector<uint32_t> hist(65536), dhist(65536);
+    for (int which = 0; which < 2; which++) { // generation 0 -> elist, drained voxels -> dlist
+        const SkKindPred pred{b.kind, which ? KIND_DRAINED : KIND_GEN0};
+        uint32_t *h = which ? b.dhist : b.hist, *cur = which ? b.dcursor : b.cursor, *lst = which ? b.dlist : b.elist;
+        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, h, lst);
+        IVX_LAUNCH_CHECK();
+        IVX_HIP(hipMemcpyAsync((which ? dhist : hist).data(), h, 65536 * 4, hipMemcpyDeviceToHost, st));
+        IVX_HIP(hipMemcpyAsync(cur, h, 65536 * 4, hipMemcpyDeviceToDevice, st));
+        const int rc = scan_u32_exclusive(cur, 65536, b.bsum, b.total, st);
         if (rc != IVX_OK) return rc;
+        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, true>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, cur, lst);
+        IVX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL((k_ws_bucket<SkGen0Pred<MT>, true>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkGen0Pred<MT>{b.kind}, b.cursor, b.elist);
-    IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sk_fill64, dim3(2048), dim3(256), 0, st, b.tau, g.n, TINF);
     IVX_LAUNCH_CHECK();
-    IVX_HIP(hipMemsetAsync(b.mark, 0, (size_t)g.n * 4, st));
-    IVX_HIP(hipStreamSynchronize(st)); // hist is on the host now
+    IVX_HIP(hipStreamSynchronize(st)); // the histograms are on the host now
     uint64_t ngen0 = 0;
     uint32_t maxcnt = 0;
     for (uint32_t c = 0; c < 65535; c++) { // (65535 = never reached: no generation 0 there)
@@ -451,15 +479,18 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
     int64_t nlevels = 0, nsorted = 0;
-    uint32_t start = 0, roff = 0, gbase = 1;
+    uint32_t start = 0, dstart = 0, roff = 0, gbase = 1;
     SkLists lists;
-    for (int i = 0; i < 4; i++) lists.l[i] = b.lists[i];
+    for (int i = 0; i < 2; i++) lists.l[i] = b.lists[i];
     for (uint32_t c = 0; c < 65535; c++) {
-        const uint32_t cnt = hist[c];
-        if (!cnt) continue;
+        const uint32_t cnt = hist[c], ndl = dhist[c];
+        if (!cnt) { // (no voxel of the level at all: a level's drained voxels hang off its generation 0)
+            dstart += ndl;
+            continue;
+        }
         nlevels++;
         const unsigned gb = (unsigned)cdiv(cnt, 256);
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, b.tau, b.elist + start, b.key_a,
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau, b.elist + start, b.key_a,
                                                   b.val_a, cnt, c));
         IVX_LAUNCH_CHECK();
         const unsigned long long *ks = b.key_a;
@@ -479,9 +510,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         uint32_t batch = 4, width = cnt;
         for (;;) {
             // the frontier can grow a lot inside one batch: the grid is sized for a large one (idle workgroups leave at once)
-            const unsigned nb = (unsigned)std::min<int64_t>(std::max<int64_t>(4 * cdiv(width, 256), 1024), 4096);
+            const unsigned nb = (unsigned)std::min<int64_t>(std::max<int64_t>(4 * cdiv(std::max(width, ndl), 256), 1024), 4096);
             for (uint32_t r = 0; r < batch; r++) {
-                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3(nb), dim3(256), 0, st, g, I, b.C, b.tau, b.mark, c, lists, b.st));
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3(nb), dim3(256), 0, st, g, I, b.C, b.comp, b.tau, c, lists, b.dlist + dstart, ndl, b.st));
                 IVX_LAUNCH_CHECK();
             }
             uint32_t seq = 0, msg[4] = {0, 0, 0, 0};
@@ -498,11 +529,12 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         IVX_REQUIRE(gbase < 0x7FFFFFF0u, IVX_EINVAL, "watershed: more than 2^31 generations");
         roff += cnt;
         start += cnt;
+        dstart += ndl;
     }
 
     tm.mark(st);
     // ---- 4. labels -------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_sk_labels<MT>, dim3(gl), dim3(256), 0, st, g.n, b.tau, b.runlabel, out, out32, out8);
+    hipLaunchKernelGGL(k_sk_labels<MT>, dim3(gl), dim3(256), 0, st, g.n, b.comp, b.tau, b.runlabel, out, out32, out8);
     IVX_LAUNCH_CHECK();
     tm.mark(st);
     SkState hs;
@@ -513,7 +545,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         stats[6] = hs.mixed; stats[7] = hs.rounds;
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] generation 0, [10] level chain, [11] labels (microseconds)
-        stats[13] = hs.gens; stats[14] = nsorted;
+        stats[12] = hs.brounds; stats[13] = hs.gens; stats[14] = nsorted;
     }
     return IVX_OK;
 }
