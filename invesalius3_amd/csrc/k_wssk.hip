@@ -68,7 +68,17 @@ struct SkState {
     uint32_t mixed;     // adjacent tied markers with different labels (see TIES)
     uint32_t gens;      // generation steps (statistics)
     uint32_t brounds;   // B rounds (statistics)
+    uint32_t pad0;
+    // what a workgroup needs to decide whether it takes part in a launch, in ONE word (read with one atomic load):
+    // bits 0..31 entries of the frontier, 32 phase, 33 which list, 34..63 sequence number of the launch it describes
+    unsigned long long ctl;
 };
+static_assert(sizeof(SkState) == 64, "ctl is 8-byte aligned");
+
+__host__ __device__ inline unsigned long long sk_ctl(uint32_t seq, uint32_t in_sel, uint32_t phase, uint32_t n_in) {
+    return ((unsigned long long)(seq & 0x3FFFFFFFu) << 34) | ((unsigned long long)(in_sel & 1u) << 33) |
+           ((unsigned long long)(phase & 1u) << 32) | n_in;
+}
 
 struct SkLists {
     uint32_t *l[2];
@@ -153,12 +163,14 @@ __global__ __launch_bounds__(256) void k_sk_keys(WsGeom g, const uint16_t *__res
 template <typename MT>
 __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
                                                    const MT *__restrict__ mk, unsigned long long *tau, int32_t *runlabel,
-                                                   uint32_t *__restrict__ front, uint32_t cnt, uint32_t roff, uint32_t gbase, SkState *st) {
+                                                   uint32_t *__restrict__ front, uint32_t cnt, uint32_t roff, uint32_t gbase, uint32_t seq,
+                                                   SkState *st) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { // the level's frontier loop starts from list 0, phase A
         st->done = 0; st->gen = gbase; st->n_in = cnt;
         st->phase = 0; st->in_sel = 0;
         st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->ctl = sk_ctl(seq, 0, 0, cnt); // the first round of this level is the host's launch number `seq`
     }
     if (i >= cnt) return;
     const uint32_t p = val[i];
@@ -239,12 +251,20 @@ __device__ __forceinline__ void sk_offer_plateau(const WsGeom &g, const uint16_t
 template <int CONN>
 __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
                                                   const uint32_t *__restrict__ comp, unsigned long long *tau, uint32_t c, SkLists L,
-                                                  const uint32_t *__restrict__ dlist, uint32_t ndl, SkState *st) {
-    if (st->done) return; // (uniform: written only between rounds)
-    const uint32_t phase = st->phase, gen = st->gen;
-    const uint32_t n_in = phase ? ndl : st->n_in;
-    const uint32_t *__restrict__ in = phase ? dlist : L.l[st->in_sel];
-    uint32_t *__restrict__ next = L.l[st->in_sel ^ 1u];
+                                                  const uint32_t *__restrict__ dlist, uint32_t ndl, uint32_t seq, SkState *st) {
+    // Only the workgroups that have list entries take part (and sign the ticket): a small frontier costs a handful of
+    // atomics, not one per launched workgroup.  A workgroup without work may start after the last working one has already
+    // set the state up for the NEXT launch -- hence one control word that names the launch it describes.
+    if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const unsigned long long ctl = __hip_atomic_load(&st->ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(ctl >> 34) != (seq & 0x3FFFFFFFu)) return;
+    const uint32_t phase = (uint32_t)(ctl >> 32) & 1u, in_sel = (uint32_t)(ctl >> 33) & 1u, n_front = (uint32_t)ctl;
+    const uint32_t n_in = phase ? ndl : n_front;
+    const uint32_t nactive = min((uint32_t)gridDim.x, (n_in + 255u) / 256u);
+    if (blockIdx.x >= nactive) return;
+    const uint32_t gen = st->gen; // (a working workgroup runs before the update: the plain fields are this launch's)
+    const uint32_t *__restrict__ in = phase ? dlist : L.l[in_sel];
+    uint32_t *__restrict__ next = L.l[in_sel ^ 1u];
     const uint32_t stride = gridDim.x * 256;
     __shared__ SkStage sg;
     if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__re
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        s_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1;
+        s_last = atomicAdd(&st->ticket, 1u) == nactive - 1;
     }
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
@@ -300,13 +320,15 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__re
         st->phase = 1;
         st->n_stamped = 0;
         st->brounds += 1;
+        __hip_atomic_store(&st->ctl, sk_ctl(seq + 1u, in_sel, 1, n_front), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (nnx) { // next generation
         st->phase = 0;
         st->n_in = nnx;
         st->n_next = 0;
         st->gen = gen + 1;
         st->gens += 1;
-        st->in_sel ^= 1u;
+        st->in_sel = in_sel ^ 1u;
+        __hip_atomic_store(&st->ctl, sk_ctl(seq + 1u, in_sel ^ 1u, 0, nnx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         st->done = 1;
     }
@@ -479,7 +501,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
     int64_t nlevels = 0, nsorted = 0;
-    uint32_t start = 0, dstart = 0, roff = 0, gbase = 1;
+    uint32_t start = 0, dstart = 0, roff = 0, gbase = 1, seq = 0;
     SkLists lists;
     for (int i = 0; i < 2; i++) lists.l[i] = b.lists[i];
     for (uint32_t c = 0; c < 65535; c++) {
@@ -504,7 +526,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             vs = b.val_b;
             nsorted += cnt;
         }
-        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, b.st);
+        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, seq, b.st);
         IVX_LAUNCH_CHECK();
         // rounds are queued in growing batches; one host read per batch (a round after the level's last returns at once)
         uint32_t batch = 4, width = cnt;
@@ -512,13 +534,13 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             // the frontier can grow a lot inside one batch: the grid is sized for a large one (idle workgroups leave at once)
             const unsigned nb = (unsigned)std::min<int64_t>(std::max<int64_t>(4 * cdiv(std::max(width, ndl), 256), 1024), 4096);
             for (uint32_t r = 0; r < batch; r++) {
-                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3(nb), dim3(256), 0, st, g, I, b.C, b.comp, b.tau, c, lists, b.dlist + dstart, ndl, b.st));
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3(nb), dim3(256), 0, st, g, I, b.C, b.comp, b.tau, c, lists, b.dlist + dstart, ndl, seq++, b.st));
                 IVX_LAUNCH_CHECK();
             }
-            uint32_t seq = 0, msg[4] = {0, 0, 0, 0};
-            int rc = mailbox_publish(&b.st->done, 4, st, &seq);
+            uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
+            int rc = mailbox_publish(&b.st->done, 4, st, &mseq);
             if (rc != IVX_OK) return rc;
-            rc = mailbox_wait(seq, st, msg, 4);
+            rc = mailbox_wait(mseq, st, msg, 4);
             if (rc != IVX_OK) return rc;
             gbase = msg[1];
             if (msg[0]) break;
