@@ -96,7 +96,7 @@ constexpr uint8_t KIND_GEN0 = 1, KIND_DRAINED = 2;
 template <int CONN, typename MT>
 __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
                                                      const MT *__restrict__ mk, uint8_t *__restrict__ kind, uint32_t *__restrict__ comp,
-                                                     uint32_t *__restrict__ zmask) {
+                                                     uint32_t *__restrict__ zmask, uint32_t *__restrict__ pmask) {
     __shared__ uint32_t s[NCELL];
     int z0, y0, x0;
     tile_origin(g, blockIdx.x, z0, y0, x0);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *_
         const int64_t p = (int64_t)(z0 + zz) * g.hw + (int64_t)(y0 + ly) * g.w + (x0 + lx);
         const bool drained = c != CINF && iv < c; // (never a marker: those sit at their own value)
         bool lower = false;
-        uint32_t zm = 0;
+        uint32_t zm = 0, pm = 0; // neighbours of the same level: drained ones (zm), those at the level's value (pm)
 #pragma unroll
         for (int k = 0; k < 27; k++) {
             if (!has_off<CONN>(g.smask, k)) continue;
@@ -120,10 +120,13 @@ __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *_
             const uint32_t qv = s[ci + (dz * BY + dy) * BX + dx]; // cells outside the volume carry CINF
             lower |= (qv >> 16) < c;
             zm |= ((qv >> 16) == c && (qv & 0xFFFFu) < c) ? 1u << k : 0u;
+            pm |= ((qv >> 16) == c && (qv & 0xFFFFu) == c) ? 1u << k : 0u;
         }
+        if (c == CINF) zm = pm = 0; // never reached: takes part in nothing
         kind[p] = (mk[p] != 0 || (c != CINF && iv == c && lower)) ? KIND_GEN0 : drained ? KIND_DRAINED : 0;
         comp[p] = drained ? (uint32_t)p : ENTRY;
-        zmask[p] = drained ? zm : 0u;
+        zmask[p] = zm; // (the union-find only follows it from drained voxels)
+        pmask[p] = pm;
     }
 }
 
@@ -222,23 +225,17 @@ __device__ __forceinline__ void stage_flush(SkStage &sg, uint32_t *__restrict__ 
     if (lane == 0) sg.n[wv] = 0;
 }
 
-// stamp the unstamped neighbours of value c of voxel `v` with `nt` (one generation after v's own stamp)
-template <int CONN>
-__device__ __forceinline__ void sk_offer_plateau(const WsGeom &g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                 unsigned long long *tau, uint32_t c, bool act, uint32_t v, unsigned long long nt,
+// stamp the unstamped neighbours of the level's value of voxel `v` (the set bits of its pmask) with `nt`, one generation
+// after v's own stamp.  Lanes walk their own bits; the staged appends take whoever is there.
+__device__ __forceinline__ void sk_offer_plateau(const WsGeom &g, unsigned long long *tau, uint32_t pm, uint32_t v, unsigned long long nt,
                                                  SkStage &sg, uint32_t *__restrict__ next, SkState *st) {
-    const int64_t z = v / g.hw, r = v - z * g.hw, y = r / g.w, x = r - y * g.w;
-#pragma unroll
-    for (int k = 0; k < 27; k++) {
-        if (!has_off<CONN>(g.smask, k)) continue;
+    while (pm) {
+        const int k = __ffs(pm) - 1;
+        pm &= pm - 1;
         const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-        const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+        const uint32_t p = (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx);
         bool push_n = false;
-        uint32_t p = 0;
-        if (act && (uint64_t)X < (uint64_t)g.w && (uint64_t)Y < (uint64_t)g.h && (uint64_t)Z < (uint64_t)g.d) {
-            p = (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx);
-            if ((uint32_t)C[p] == c && (uint32_t)I[p] == c && nt < ld64(&tau[p])) push_n = atomicMin(&tau[p], nt) == TINF;
-        }
+        if (nt < ld64(&tau[p])) push_n = atomicMin(&tau[p], nt) == TINF;
         stage_push(push_n, p, sg, next, &st->n_next);
     }
 }
@@ -248,9 +245,8 @@ __device__ __forceinline__ void sk_offer_plateau(const WsGeom &g, const uint16_t
 // one generation, and all its candidates arrive in this one launch).  Phase B: every drained voxel of the level whose basin
 // carries a stamp of generation G relays it, one generation later, to its unstamped neighbours of value c.  Fixed grid,
 // grid-stride over the list; the last workgroup out sets up the next round.
-template <int CONN>
-__global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
-                                                  const uint32_t *__restrict__ comp, unsigned long long *tau, uint32_t c, SkLists L,
+__global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
+                                                  const uint32_t *__restrict__ comp, unsigned long long *tau, SkLists L,
                                                   const uint32_t *__restrict__ dlist, uint32_t ndl, uint32_t seq, SkState *st) {
     // Only the workgroups that have list entries take part (and sign the ticket): a small frontier costs a handful of
     // atomics, not one per launched workgroup.  A workgroup without work may start after the last working one has already
@@ -276,29 +272,23 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint16_t *__re
         const uint32_t v = act ? in[i] : 0u;
         if (phase == 0) {
             const unsigned long long t = act ? ld64(&tau[v]) : TINF;
-            sk_offer_plateau<CONN>(g, I, C, tau, c, act, v, t + GEN1, sg, next, st);
-            if (ndl && act) { // the basins this voxel touches
-                const int64_t z = v / g.hw, r = v - z * g.hw, y = r / g.w, x = r - y * g.w;
-                uint32_t last = ENTRY;
-#pragma unroll
-                for (int k = 0; k < 27; k++) {
-                    if (!has_off<CONN>(g.smask, k)) continue;
-                    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-                    const int64_t Z = z + dz, Y = y + dy, X = x + dx;
-                    if ((uint64_t)X >= (uint64_t)g.w || (uint64_t)Y >= (uint64_t)g.h || (uint64_t)Z >= (uint64_t)g.d) continue;
-                    const uint32_t p = (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx);
-                    if ((uint32_t)C[p] != c || (uint32_t)I[p] >= c) continue;
-                    const uint32_t root = comp[p];
-                    if (root == last) continue; // (most neighbours of one voxel share a basin)
-                    last = root;
-                    if (t < ld64(&tau[root])) stamped += atomicMin(&tau[root], t) == TINF;
-                }
+            sk_offer_plateau(g, tau, act ? pmask[v] : 0u, v, t + GEN1, sg, next, st);
+            uint32_t zm = (ndl && act) ? zmask[v] : 0u; // the basins this voxel touches
+            uint32_t last = ENTRY;
+            while (zm) {
+                const int k = __ffs(zm) - 1;
+                zm &= zm - 1;
+                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                const uint32_t root = comp[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)];
+                if (root == last) continue; // (most neighbours of one voxel share a basin)
+                last = root;
+                if (t < ld64(&tau[root])) stamped += atomicMin(&tau[root], t) == TINF;
             }
         } else {
             unsigned long long tb = TINF;
             if (act) tb = ld64(&tau[comp[v]]);
             act = act && (uint32_t)(tb >> 32) == gen; // stamped by this generation (earlier ones have relayed already)
-            sk_offer_plateau<CONN>(g, I, C, tau, c, act, v, tb + GEN1, sg, next, st);
+            sk_offer_plateau(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
         }
         stage_flush(sg, next, &st->n_next);
     }
@@ -356,7 +346,7 @@ struct SkBufs {
     uint16_t *C;
     uint8_t *kind, *dirty, *pending;
     unsigned long long *tau, *key_a, *key_b;
-    uint32_t *comp, *zmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *bcount, *bsum, *tlist, *total;
+    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *bcount, *bsum, *tlist, *total;
     int32_t *runlabel;
     WsState *wst;
     SkState *st;
@@ -374,6 +364,7 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->tau = (unsigned long long *)take((size_t)g.n * 8);
     b->comp = (uint32_t *)take((size_t)g.n * 4);
     b->zmask = (uint32_t *)take((size_t)g.n * 4);
+    b->pmask = (uint32_t *)take((size_t)g.n * 4);
     b->dlist = (uint32_t *)take((size_t)g.n * 4);
     b->elist = (uint32_t *)take((size_t)g.n * 4);
     for (int i = 0; i < 2; i++) b->lists[i] = (uint32_t *)take((size_t)g.n * 4);
@@ -454,7 +445,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     tm.mark(st);
     // ---- 2. generation 0 and the drained basins, bucketed by level ------------------------------------------
     WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind, b.comp,
-                                              b.zmask));
+                                              b.zmask, b.pmask));
     IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ws_runs, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp, (int)((g.smask >> 12) & 1u));
     IVX_LAUNCH_CHECK();
@@ -534,7 +525,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             // the frontier can grow a lot inside one batch: the grid is sized for a large one (idle workgroups leave at once)
             const unsigned nb = (unsigned)std::min<int64_t>(std::max<int64_t>(4 * cdiv(std::max(width, ndl), 256), 1024), 4096);
             for (uint32_t r = 0; r < batch; r++) {
-                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_round<CC>, dim3(nb), dim3(256), 0, st, g, I, b.C, b.comp, b.tau, c, lists, b.dlist + dstart, ndl, seq++, b.st));
+                hipLaunchKernelGGL(k_sk_round, dim3(nb), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists, b.dlist + dstart, ndl, seq++, b.st);
                 IVX_LAUNCH_CHECK();
             }
             uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
