@@ -39,6 +39,7 @@
 //      launches in batches and reads one mailbox line per batch.
 //   4. k_sk_labels     label = label of the run in T's low word.
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
@@ -247,7 +248,7 @@ __device__ __forceinline__ void sk_offer_plateau(const WsGeom &g, unsigned long 
 // grid-stride over the list; the last workgroup out sets up the next round.
 __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
                                                   const uint32_t *__restrict__ comp, unsigned long long *tau, SkLists L,
-                                                  const uint32_t *__restrict__ dlist, uint32_t ndl, uint32_t seq, SkState *st) {
+                                                  const uint32_t *__restrict__ dlist, uint32_t ndl, uint32_t seq, uint32_t per_wg, SkState *st) {
     // Only the workgroups that have list entries take part (and sign the ticket): a small frontier costs a handful of
     // atomics, not one per launched workgroup.  A workgroup without work may start after the last working one has already
     // set the state up for the NEXT launch -- hence one control word that names the launch it describes.
@@ -256,12 +257,12 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint32_t *__re
     if ((uint32_t)(ctl >> 34) != (seq & 0x3FFFFFFFu)) return;
     const uint32_t phase = (uint32_t)(ctl >> 32) & 1u, in_sel = (uint32_t)(ctl >> 33) & 1u, n_front = (uint32_t)ctl;
     const uint32_t n_in = phase ? ndl : n_front;
-    const uint32_t nactive = min((uint32_t)gridDim.x, (n_in + 255u) / 256u);
+    const uint32_t nactive = min((uint32_t)gridDim.x, (n_in + per_wg - 1u) / per_wg); // (few signatures: several passes per workgroup)
     if (blockIdx.x >= nactive) return;
     const uint32_t gen = st->gen; // (a working workgroup runs before the update: the plain fields are this launch's)
     const uint32_t *__restrict__ in = phase ? dlist : L.l[in_sel];
     uint32_t *__restrict__ next = L.l[in_sel ^ 1u];
-    const uint32_t stride = gridDim.x * 256;
+    const uint32_t stride = nactive * 256;
     __shared__ SkStage sg;
     if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
     __syncthreads();
@@ -492,6 +493,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
     int64_t nlevels = 0, nsorted = 0;
+    const bool trace = getenv("IVX_WS_TRACE") != nullptr;
+    const char *epb = getenv("IVX_SK_PER_WG"); // list entries per working workgroup (A/B measurements)
+    const uint32_t per_wg = epb && atoi(epb) >= 256 ? (uint32_t)atoi(epb) : 1024u;
     uint32_t start = 0, dstart = 0, roff = 0, gbase = 1, seq = 0;
     SkLists lists;
     for (int i = 0; i < 2; i++) lists.l[i] = b.lists[i];
@@ -502,6 +506,8 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             continue;
         }
         nlevels++;
+        const auto lvl_t0 = std::chrono::steady_clock::now();
+        uint32_t lvl_batches = 0;
         const unsigned gb = (unsigned)cdiv(cnt, 256);
         WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau, b.elist + start, b.key_a,
                                                   b.val_a, cnt, c));
@@ -520,12 +526,13 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, seq, b.st);
         IVX_LAUNCH_CHECK();
         // rounds are queued in growing batches; one host read per batch (a round after the level's last returns at once)
-        uint32_t batch = 4, width = cnt;
+        // (a host read costs about as much as eight idle launches: the first batch is sized for a typical level)
+        uint32_t batch = 16, width = cnt;
         for (;;) {
             // the frontier can grow a lot inside one batch: the grid is sized for a large one (idle workgroups leave at once)
             const unsigned nb = (unsigned)std::min<int64_t>(std::max<int64_t>(4 * cdiv(std::max(width, ndl), 256), 1024), 4096);
             for (uint32_t r = 0; r < batch; r++) {
-                hipLaunchKernelGGL(k_sk_round, dim3(nb), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists, b.dlist + dstart, ndl, seq++, b.st);
+                hipLaunchKernelGGL(k_sk_round, dim3(nb), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists, b.dlist + dstart, ndl, seq++, per_wg, b.st);
                 IVX_LAUNCH_CHECK();
             }
             uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
@@ -534,10 +541,14 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             rc = mailbox_wait(mseq, st, msg, 4);
             if (rc != IVX_OK) return rc;
             gbase = msg[1];
+            lvl_batches++;
             if (msg[0]) break;
             width = std::max(msg[3], 1u);
             batch = std::min(batch * 2, 64u);
         }
+        if (trace)
+            fprintf(stderr, "sk level %u gen0 %u drained %u -> generation %u, %u batches, %.0f us\n", c, cnt, ndl, gbase, lvl_batches,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lvl_t0).count());
         gbase++;
         IVX_REQUIRE(gbase < 0x7FFFFFF0u, IVX_EINVAL, "watershed: more than 2^31 generations");
         roff += cnt;
