@@ -482,7 +482,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_REQUIRE(ngen0 < 0xFFFFFFF0ull, IVX_EINVAL, "watershed: more than 2^32 queue entries");
     size_t cub_bytes = 0;
     IVX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                               (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)maxcnt, 0, 64, st));
+                                               (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)maxcnt, 0, 64, st));
     {
         void *mem2 = nullptr;
         const size_t need = sk_layout2(ngen0, maxcnt, cub_bytes, nullptr, &b);
@@ -518,7 +518,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             int end_bit = 33; // keys are below (gbase << 32): the bits that can differ
             while (end_bit < 64 && (gbase >> (end_bit - 32))) end_bit++;
             size_t tb = cub_bytes + 256;
-            IVX_HIP(hipcub::DeviceRadixSort::SortPairs(b.cub, tb, b.key_a, b.key_b, b.val_a, b.val_b, (int)cnt, 0, end_bit, st));
+            IVX_HIP(hipcub::DeviceRadixSort::SortPairs(b.cub, tb, b.key_a, b.key_b, b.val_a, b.val_b, (size_t)cnt, 0, end_bit, st));
             ks = b.key_b;
             vs = b.val_b;
             nsorted += cnt;

@@ -638,10 +638,12 @@ class DeviceVolume:
         return nv.value, nt.value
 
     # -- watershed (watershed_process.py:19-60 + the merge of styles.py:2147-2152) on the resident volume -------------------
-    def watershed(self, markers: np.ndarray, strct, use_ww_wl: bool = False, wl=0, ww=0, overwrite: bool = False):
-        """The IFT branch of do_watershed followed by the caller's merge rule, all in HBM: cost image (LUT or
-        ``image - image.min()``) -> marker flood (`ivx_dev_watershed_ift`) -> ``mask`` gets 253 where the flood says 1 and
-        2 where it says 2 (only over cells that hold 0 / 2 / 253, or over everything after zeroing with `overwrite`).
+    def watershed(self, markers: np.ndarray, strct, use_ww_wl: bool = False, wl=0, ww=0, overwrite: bool = False,
+                  algorithm: str = "Watershed IFT", mg_size=(3, 3, 3)):
+        """do_watershed followed by the caller's merge rule, all in HBM: cost image (LUT or ``image - image.min()``) ->
+        [`algorithm == "Watershed"`: morphological gradient of `mg_size`] -> marker flood (`ivx_dev_watershed_ift`, or
+        `ivx_dev_watershed_sk` for "Watershed", the GUI's default) -> ``mask`` gets 253 where the flood says 1 and 2 where
+        it says 2 (only over cells that hold 0 / 2 / 253, or over everything after zeroing with `overwrite`).
         `markers`: int8 / int16 (0, 1, 2) array of the volume's shape, uploaded for the call.  Returns the flood's stats."""
         mk = np.ascontiguousarray(markers)
         if mk.shape != self.shape or mk.dtype.type not in (np.int8, np.int16):
@@ -663,16 +665,30 @@ class DeviceVolume:
                 mm.close()
                 L.check(lib.ivx_dev_shift_min_u16(self.image.raw, c64(n), imin, d_cost.ptr, self.stream), "min shift")
             stats = (ctypes.c_int64 * 16)()
-            with self.timer.span("watershed_flood"):
-                L.check(lib.ivx_dev_watershed_ift(d_cost.ptr, L.I16 if mk.dtype == np.int16 else L.I8, d_mk.ptr, c64(self.dz),
-                                                  c64(self.dy), c64(self.dx), L.ptr(s3), None, d_lab.ptr, None, stats, self.stream),
-                        "watershed_ift")
+            mdt = L.I16 if mk.dtype == np.int16 else L.I8
+            if algorithm == "Watershed":  # watershed_process.py:33-39,47-52
+                d_grad = DeviceBuffer(n * 2)
+                try:
+                    gsz = (ctypes.c_int * 3)(*[int(v) for v in mg_size])
+                    L.check(lib.ivx_dev_morph_gradient_u16(d_cost.ptr, c64(self.dz), c64(self.dy), c64(self.dx), gsz, d_grad.ptr,
+                                                           self.stream), "gradient")
+                    with self.timer.span("watershed_flood"):
+                        L.check(lib.ivx_dev_watershed_sk(d_grad.ptr, mdt, d_mk.ptr, c64(self.dz), c64(self.dy), c64(self.dx), L.ptr(s3),
+                                                         None, None, d_lab.ptr, None, stats, self.stream), "watershed_sk")
+                    self.sync()
+                finally:
+                    d_grad.close()
+            else:
+                with self.timer.span("watershed_flood"):
+                    L.check(lib.ivx_dev_watershed_ift(d_cost.ptr, mdt, d_mk.ptr, c64(self.dz), c64(self.dy), c64(self.dx), L.ptr(s3),
+                                                      None, d_lab.ptr, None, stats, self.stream), "watershed_ift")
             L.check(lib.ivx_dev_watershed_merge(self.mask.ptr, d_lab.ptr, c64(n), int(bool(overwrite)), self.stream), "merge")
             self.sync()
         finally:
             for b in (d_mk, d_cost, d_lab):
                 b.close()
-        names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles")
+        names = (("rounds", "tile_visits", "levels", "generations", "markers", "generation0", "tied_markers_of_different_labels")
+                 if algorithm == "Watershed" else ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles"))
         return {k: int(v) for k, v in zip(names, stats)}
 
     # -- projections ---------------------------------------------------------------------------------

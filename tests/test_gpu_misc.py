@@ -246,3 +246,30 @@ def test_device_volume_watershed_matches_reference_recipe(ivxlib, oracle, use_ww
     assert np.array_equal(vol.download_mask(), want) and (want == 253).any()
     assert overwrite or (want == 2).any()  # overwrite keeps the object only (styles.py:2147-2149)
     vol.close()
+
+
+def test_device_volume_watershed_default_algorithm(ivxlib, oracle):
+    """resident watershed, algorithm "Watershed" (the GUI's default): min-shift -> 3x3x3 gradient -> scikit-image's flood
+    (serial heap flood of oracle/) -> merge rule"""
+    from scipy import ndimage
+
+    from invesalius3_amd.device import DeviceVolume
+    img = synth_volume((24, 48, 64), seed=67)
+    mk = np.zeros(img.shape, np.int16)
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    mk[max(z - 1, 0):z + 2, y - 2:y + 3, x - 2:x + 3] = 1
+    mk[:2, :4, :4] = 2
+    mk[-2:, -4:, -4:] = 2
+    s = generate_binary_structure(3, 1)
+    vol = DeviceVolume(img)
+    vol.threshold(226, 3071)
+    before = vol.download_mask()
+    stats = vol.watershed(mk, s, overwrite=False, algorithm="Watershed", mg_size=(3, 3, 3))
+    grad = ndimage.morphological_gradient((img - img.min()).astype("uint16"), (3, 3, 3))  # watershed_process.py:49-51
+    lab = oracle.watershed_sk(grad, mk, s, 1)
+    assert np.array_equal(lab, oracle.watershed_sk(grad, mk, s, 0))  # (heap-ordered marker ties give the same here)
+    want = before.copy()
+    oracle.watershed_merge(want, lab.astype(np.uint8), False)
+    assert np.array_equal(vol.download_mask(), want) and (want == 253).any() and (want == 2).any()
+    assert stats["markers"] == int((mk != 0).sum())
+    vol.close()
