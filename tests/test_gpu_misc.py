@@ -270,6 +270,8 @@ def test_device_volume_watershed_default_algorithm(ivxlib, oracle):
     assert np.array_equal(lab, oracle.watershed_sk(grad, mk, s, 0))  # (heap-ordered marker ties give the same here)
     want = before.copy()
     oracle.watershed_merge(want, lab.astype(np.uint8), False)
-    assert np.array_equal(vol.download_mask(), want) and (want == 253).any() and (want == 2).any()
+    got = vol.download_mask()
+    # (the object's voxels hold 255 from the threshold here, which the merge rule leaves alone: styles.py:2150-2152)
+    assert np.array_equal(got, want) and (want == 2).any() and (got != before).any()
     assert stats["markers"] == int((mk != 0).sum())
     vol.close()
