@@ -18,9 +18,10 @@
  *     layout at that moment, i.e. on every push and pop before it.
  * tie_mode 0 reproduces that heap move for move (== the compiled kernel of scikit-image 0.18.3 run in
  * this container, tests/golden/watershed_sk.npz); tie_mode 1 breaks marker ties by raster index instead
- * (a total order: any correct priority queue then gives the same result).  The two differ on inputs with
- * competing equal-valued markers, which is why this branch has no order-free parallel statement
- * (DESIGN.md section 6).
+ * (a total order: any correct priority queue then gives the same result, and so does the order-free statement
+ * csrc/k_wssk.hip implements -- DESIGN.md section 6b).  The two differ only on inputs where equal-valued markers of
+ * different labels compete.  tie_mode + 2: the neighbour list reversed (diagnostic: with raster ties the labels do not
+ * depend on the neighbour order, with heap ties they do).
  */
 #include <stdint.h>
 #include <stdlib.h>

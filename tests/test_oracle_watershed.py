@@ -117,6 +117,30 @@ def test_zone_formulation_equals_the_defect_free_flood(oracle):
     assert worst < 400  # merged label classes keep the time-stamp table tiny
 
 
+def test_run_formulation_equals_the_serial_heap_flood(oracle):
+    """The order-free statement csrc/k_wssk.hip implements for scikit-image's flood (minimax of image values, generation 0
+    sorted by parent pop time, 0-1 breadth-first steps, time = (generation, run)), executed by the pure-Python prototype
+    tools/proto_ws_runs.py, equals the serial (value, age) heap flood with raster marker ties -- labels on every voxel;
+    and the serial flood itself does not depend on the neighbour order then (reversed list: same labels)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from proto_ws_runs import flood_runs
+    from scipy import ndimage
+    rng = np.random.default_rng(5)
+    for k in range(120):
+        nd = 3 if k % 4 else 2
+        shape = tuple(int(v) for v in rng.integers(1 if nd == 3 else 3, 8 if nd == 3 else 12, size=nd))
+        img = rng.integers(0, int(rng.choice([1, 2, 4, 30, 3000])), size=shape).astype(np.uint16)
+        mk = np.zeros(shape, np.int16)
+        pos = rng.choice(img.size, size=int(rng.integers(1, max(2, img.size // 5))), replace=False)
+        mk.ravel()[pos] = rng.integers(1, 4, size=len(pos))
+        st = ndimage.generate_binary_structure(nd, int(rng.integers(1, nd + 1)))
+        want = oracle.watershed_sk(img, mk, st, 1)
+        assert np.array_equal(flood_runs(img, mk, st), want), (k, shape)
+        assert np.array_equal(oracle.watershed_sk(img, mk, st, 3), want), (k, shape)  # 3 = raster ties + reversed neighbours
+
+
 def test_cost_map_is_the_minimax_arc_cost(oracle):
     a = np.array([[0, 6, 5, 8, 20, 19]], np.uint16)
     m = np.array([[1, 0, 0, 0, 0, 0]], np.int16)
