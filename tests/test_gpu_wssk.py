@@ -114,6 +114,23 @@ def test_brush_markers_on_a_ct_like_volume(ivxlib, oracle, conn, use_ww_wl):
     assert np.array_equal(got, want0)
 
 
+def test_odd_shaped_volume_with_wide_frontiers(ivxlib, oracle):
+    """3 M voxels, no extent a multiple of the tile (the scalar staging path, partial tiles on every face), 26 neighbours,
+    frontiers of 10^5 voxels (the per-wave staging buffers overflow into the direct path)."""
+    from invesalius3_amd import watershed_process as wp
+    img, am = _ct_like((61, 203, 237), 9)
+    mk = np.zeros(img.shape, np.int16)
+    mk[max(am[0] - 2, 0):am[0] + 3, am[1] - 4:am[1] + 5, am[2] - 4:am[2] + 5] = 1
+    mk[:3, :6, :6] = 2
+    mk[-3:, -6:, -6:] = 3
+    st = ndimage.generate_binary_structure(3, 3)
+    for use_ww_wl in (True, False):
+        grad = wp.cost_image(img, use_ww_wl, 300, 400, (3, 3, 3))
+        got, cost = wp.watershed(grad, mk, st, want_cost=True)
+        assert np.array_equal(got, oracle.watershed_sk(grad, mk, st, 1)), use_ww_wl
+        assert (cost >= grad).all() and (cost[mk != 0] == grad[mk != 0]).all()  # minimax of the values ON the path
+
+
 def test_edge_cases(ivxlib, oracle):
     from invesalius3_amd import watershed_process as wp
     s6 = ndimage.generate_binary_structure(3, 1)
