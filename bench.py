@@ -536,8 +536,10 @@ def run_watershed(args, job):
 # ----------------------------------------------------------------------------------------------------------------
 
 def run_watershed_sk(args, job):
-    """configs[2] with the GUI's DEFAULT algorithm ("Watershed"): min-shift -> 3x3x3 morphological gradient ->
-    skimage.segmentation.watershed's marker flood (csrc/k_wssk.hip) -> merge (watershed_process.py:47-52, styles.py:2147-2152)."""
+    """configs[2] with the GUI's DEFAULT settings (styles.py:1628-1634: algorithm "Watershed", 6 neighbours, gradient size 3,
+    use_ww_wl): window/level LUT -> 3x3x3 morphological gradient -> skimage.segmentation.watershed's marker flood
+    (csrc/k_wssk.hip) -> merge (watershed_process.py:33-39, styles.py:2147-2152).  --ws-raw takes the other branch
+    (watershed_process.py:47-52: image - image.min(), the harder input: a noise-dominated gradient)."""
     import ctypes
 
     from scipy.ndimage import generate_binary_structure
@@ -568,13 +570,21 @@ def run_watershed_sk(args, job):
     stats = (ctypes.c_int64 * 16)()
     gsz = (ctypes.c_int * 3)(3, 3, 3)
 
+    use_ww_wl = not args.ws_raw
+    WL, WW = 300, 400  # a bone window on the synthetic volume (values -1024 .. 3071)
+
     def step():
-        L.check(lib.ivx_dev_minmax_f32(L.I16, d_img.ptr, c64(nvox), d_mm.ptr, st))
-        L.check(lib.ivx_stream_synchronize(st))
-        imin = int(d_mm.download((2,), np.float32)[0])
-        with timer.span("cost_image"):
-            L.check(lib.ivx_dev_shift_min_u16(d_img.ptr, c64(nvox), imin, d_cost.ptr, st))
-            L.check(lib.ivx_dev_morph_gradient_u16(d_cost.ptr, c64(n), c64(n), c64(n), gsz, d_grad.ptr, st), "gradient")
+        if use_ww_wl:
+            with timer.span("cost_image"):
+                L.check(lib.ivx_dev_lut_u16(d_img.ptr, c64(nvox), ctypes.c_double(WW), ctypes.c_double(WL), 0, d_cost.ptr, st), "lut")
+                L.check(lib.ivx_dev_morph_gradient_u16(d_cost.ptr, c64(n), c64(n), c64(n), gsz, d_grad.ptr, st), "gradient")
+        else:
+            L.check(lib.ivx_dev_minmax_f32(L.I16, d_img.ptr, c64(nvox), d_mm.ptr, st))
+            L.check(lib.ivx_stream_synchronize(st))
+            imin = int(d_mm.download((2,), np.float32)[0])
+            with timer.span("cost_image"):
+                L.check(lib.ivx_dev_shift_min_u16(d_img.ptr, c64(nvox), imin, d_cost.ptr, st))
+                L.check(lib.ivx_dev_morph_gradient_u16(d_cost.ptr, c64(n), c64(n), c64(n), gsz, d_grad.ptr, st), "gradient")
         with timer.span("flood"):
             L.check(lib.ivx_dev_watershed_sk(d_grad.ptr, L.I16, d_mk.ptr, c64(n), c64(n), c64(n), L.ptr(s3), None, None, d_lab.ptr,
                                              None, stats, st), "watershed_sk")
@@ -600,16 +610,18 @@ def run_watershed_sk(args, job):
     if job.rank != 0:
         return
     names = ("rounds", "tile_visits", "levels", "generations", "markers", "generation0", "tied_markers_of_different_labels",
-             "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "basin_rounds", "generation_steps", "sorted_keys")
+             "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "basin_rounds", "generation_steps", "sorted_keys", "tile_rounds")
     flood_ms = spans.get("flood", 0.0)
     res = {
         "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
         "value": round(job.world * nvox / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",
         "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-        "config": {"workload": "configs[2]: %dx%dx%d int16, watershed segmentation, 'Watershed' branch of do_watershed (the GUI's "
-                               "default: min-shift, 3x3x3 morphological gradient, scikit-image's 6-neighbour marker flood, merge), "
-                               "markers: 5^3 cube at the maximum (1) + 8 corner cubes (2)" % shape,
+        "config": {"workload": "configs[2]: %dx%dx%d int16, watershed segmentation, 'Watershed' branch of do_watershed with %s, 3x3x3 "
+                               "morphological gradient, scikit-image's 6-neighbour marker flood, merge; markers: 5^3 cube at the "
+                               "maximum (1) + 8 corner cubes (2)"
+                               % (shape + ("the GUI's default settings (window/level LUT, ww 400 wl 300)" if use_ww_wl
+                                           else "image - image.min() (--ws-raw)",)),
                    "parallelism": "replicas only (global priority order: SURVEY.md 8e)" if job.world > 1 else "single GPU"},
         "stage_ms": {k: round(v, 3) for k, v in spans.items()},
         "flood": {k: int(v) for k, v in zip(names, stats) if k != "_"},
@@ -628,7 +640,7 @@ def run_watershed_sk(args, job):
         sl = min(n, max(8, int(1.6e7 // (n * n))))
         sub = np.ascontiguousarray(img[:sl])
         smk = ws_markers(sub).astype(np.int16)
-        grad = wp.cost_image(sub, False, 0, 0, (3, 3, 3))
+        grad = wp.cost_image(sub, use_ww_wl, WL, WW, (3, 3, 3))
         t = time.perf_counter()
         heap = orc.watershed_sk(grad, smk, strct, 0)
         ts = time.perf_counter() - t
@@ -873,6 +885,7 @@ def main():
                     help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2] (IFT branch), watershed_sk = configs[2] with the GUI's default scikit-image branch; sharded2048 = "
                          "configs[3] (strong scaling: the whole volume split over --gpus); mip = configs[4]")
     ap.add_argument("--size", type=int, default=None, help="edge of the volume (defaults: 512 / 1024 / 512 per GPU; 2048 in total for sharded2048)")
+    ap.add_argument("--ws-raw", action="store_true", help="watershed_sk: the image - image.min() branch instead of the GUI's default window/level")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false", help="skip the CPU baseline + full-size parity check")
     ap.add_argument("--cpu-slices", type=int, default=None, help="(kept for old command lines; 0 = --no-cpu)")
     args = ap.parse_args()

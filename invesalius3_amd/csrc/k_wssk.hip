@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
     const unsigned long long K = key[i];
     const int m = (int)mk[p];
     // a run's label: its marker's, or the label of the run its parent belongs to (an earlier level: final)
-    const int32_t l = m ? (int32_t)m : runlabel[(uint32_t)(K & 0xFFFFFFFFull)];
+    const int32_t l = m ? (int32_t)m : (K == TINF ? 0 : runlabel[(uint32_t)(K & 0xFFFFFFFFull)]); // (TINF cannot happen: no wild read if it does)
     runlabel[roff + i] = l;
     tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + i);
     front[i] = p;
@@ -325,6 +325,148 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint32_t *__re
     }
 }
 
+// ---- a level without basins that holds a large part of the volume (the zero plateau of a windowed gradient image): its
+// breadth-first search has hundreds of generations, each a launch with a chain of dependent gathers.  The time stamps are
+// the fixed point of  T(p) = min over neighbours q of the level (T(q) + one generation)  with generation 0 fixed, and any
+// order of relaxation reaches it: so relax tiles staged in LDS to their local fixed point, dirty tiles only, like the
+// cost map -- a tile crossing costs LDS round trips instead of launches.
+constexpr unsigned long long TNM = TINF - 1ull; // staged cell that is not a voxel of the level (never offers, never accepts)
+
+struct SkLevelPred { // every voxel that was reached
+    __device__ bool operator()(int64_t) const { return true; }
+};
+
+// the tiles that stage a generation-0 voxel (its own, and those that see it in their halo) start dirty: the voxel itself
+// never changes, so nobody else would wake the tile across the face
+__global__ __launch_bounds__(256) void k_sk_mark_tiles(WsGeom g, const uint32_t *__restrict__ list, uint32_t cnt, uint8_t *__restrict__ dirty) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    const int64_t p = list[i], z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
+    const int64_t tz = z / TZ, ty = y / TY, tx = x / TX;
+    const int lz = (int)(z - tz * TZ), ly = (int)(y - ty * TY), lx = (int)(x - tx * TX);
+    for (int dz = (lz == 0 ? -1 : 0); dz <= (lz == TZ - 1 ? 1 : 0); dz++)
+        for (int dy = (ly == 0 ? -1 : 0); dy <= (ly == TY - 1 ? 1 : 0); dy++)
+            for (int dx = (lx == 0 ? -1 : 0); dx <= (lx == TX - 1 ? 1 : 0); dx++) {
+                const int64_t Z = tz + dz, Y = ty + dy, X = tx + dx;
+                if (Z >= 0 && Z < g.ntz && Y >= 0 && Y < g.nty && X >= 0 && X < g.ntx) dirty[(Z * g.nty + Y) * g.ntx + X] = 1;
+            }
+}
+
+template <int CONN>
+__device__ __forceinline__ bool sk_plateau_eval(unsigned long long *s, uint32_t (*s_act)[TX], int lx, int ly, int zz, int nz, uint32_t smask) {
+    const int ci = ((zz + 1) * BY + (ly + 1)) * BX + (lx + 1);
+    const unsigned long long cur = s[ci];
+    if (cur == TNM) return false;
+    unsigned long long best = cur;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        if (!has_off<CONN>(smask, k)) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const unsigned long long q = s[ci + (dz * BY + dy) * BX + dx];
+        if (q < TNM) best = min(best, q + GEN1); // (stamped voxels of the level only)
+    }
+    if (best >= cur) return false;
+    s[ci] = best;
+#pragma unroll
+    for (int cy = -1; cy <= 1; cy++) {
+#pragma unroll
+        for (int cx = -1; cx <= 1; cx++) {
+            uint32_t m3 = 0;
+#pragma unroll
+            for (int dz = -1; dz <= 1; dz++)
+                if (has_off<CONN>(smask, (dz + 1) * 9 + (cy + 1) * 3 + (cx + 1))) m3 |= 1u << (dz + 1);
+            if (!m3) continue;
+            const int tx = lx + cx, ty = ly + cy;
+            if ((unsigned)tx >= (unsigned)TX || (unsigned)ty >= (unsigned)TY) continue;
+            const uint32_t bits = ((m3 << zz) >> 1) & ((1u << nz) - 1u);
+            if (bits) atomicOr(&s_act[ty][tx], bits);
+        }
+    }
+    return true;
+}
+
+template <int CONN>
+__global__ __launch_bounds__(256) void k_sk_plateau_relax(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
+                                                          unsigned long long *tau, const uint32_t *__restrict__ list, uint8_t *dirty,
+                                                          uint32_t c, SkState *st) {
+    __shared__ unsigned long long s[NCELL];
+    __shared__ uint32_t s_act[TY][TX];
+    __shared__ uint32_t s_ev2, s_gmax;
+    const int64_t tile = list[blockIdx.x];
+    int z0, y0, x0;
+    tile_origin(g, tile, z0, y0, x0);
+    constexpr int PER = (NCELL + 255) / 256;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int ce = threadIdx.x + q * 256;
+        if (ce >= NCELL) continue;
+        const int lx = ce % BX, ly = (ce / BX) % BY, lz = ce / (BX * BY);
+        const int64_t zz = z0 + lz - 1, yy = y0 + ly - 1, xx = x0 + lx - 1;
+        unsigned long long v = TNM;
+        if ((uint64_t)xx < (uint64_t)g.w && (uint64_t)yy < (uint64_t)g.h && (uint64_t)zz < (uint64_t)g.d) {
+            const int64_t Lx = zz * g.hw + yy * g.w + xx;
+            if ((uint32_t)C[Lx] == c && (uint32_t)I[Lx] == c) v = tau[Lx];
+        }
+        s[ce] = v;
+    }
+    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
+    s_act[ly][lx] = 0;
+    if (threadIdx.x == 0) { s_ev2 = 0; s_gmax = 0; }
+    __syncthreads();
+    const bool col = x0 + lx < g.w && y0 + ly < g.h;
+    const int nz = min(TZ, (int)(g.d - z0));
+    uint32_t chg = 0;
+    if (col)
+        for (int zz = 0; zz < nz; zz++)
+            if (sk_plateau_eval<CONN>(s, s_act, lx, ly, zz, nz, g.smask)) chg |= 1u << zz;
+    __syncthreads();
+    int it = 1;
+    bool more = true;
+    while (more && it < 4 * RELAX_ITCAP) {
+        bool any = false;
+        uint32_t a = col ? atomicExch(&s_act[ly][lx], 0u) : 0u;
+        while (a) {
+            const int zz = (it & 1) ? 31 - __clz(a) : __ffs(a) - 1;
+            a &= ~(1u << zz);
+            if (sk_plateau_eval<CONN>(s, s_act, lx, ly, zz, nz, g.smask)) {
+                any = true;
+                chg |= 1u << zz;
+            }
+        }
+        more = __syncthreads_or(any);
+        it++;
+    }
+    if (more && threadIdx.x == 0) dirty[tile] = 1; // iteration cap: come back
+    uint32_t dirs = 0, gmax = 0;
+    for (int zz = 0; zz < nz && chg; zz++) {
+        if (!((chg >> zz) & 1u)) continue;
+        const int z = z0 + zz, y = y0 + ly, x = x0 + lx;
+        const unsigned long long t = s[((zz + 1) * BY + (ly + 1)) * BX + (lx + 1)];
+        tau[(int64_t)z * g.hw + (int64_t)y * g.w + x] = t;
+        gmax = max(gmax, (uint32_t)(t >> 32));
+        const bool edge = lx == 0 || lx == TX - 1 || ly == 0 || ly == TY - 1 || zz == 0 || zz == TZ - 1;
+        if (!edge) continue;
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            if (!has_off<CONN>(g.smask, k)) continue;
+            const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+            const int Z = z + dz, Y = y + dy, X = x + dx;
+            if ((unsigned)X >= (unsigned)g.w || (unsigned)Y >= (unsigned)g.h || (unsigned)Z >= (unsigned)g.d) continue;
+            const int ex = X < x0 ? 0 : (X >= x0 + TX ? 2 : 1), ey = Y < y0 ? 0 : (Y >= y0 + TY ? 2 : 1), ez = Z < z0 ? 0 : (Z >= z0 + TZ ? 2 : 1);
+            dirs |= 1u << (ez * 9 + ey * 3 + ex);
+        }
+    }
+    if (dirs & ~(1u << 13)) atomicOr(&s_ev2, dirs);
+    if (gmax) atomicMax(&s_gmax, gmax);
+    __syncthreads();
+    if (threadIdx.x < 27 && threadIdx.x != 13 && ((s_ev2 >> threadIdx.x) & 1u)) {
+        const int k = threadIdx.x;
+        const int tz = z0 / TZ + k / 9 - 1, ty = y0 / TY + (k / 3) % 3 - 1, tx = x0 / TX + k % 3 - 1;
+        if (tz >= 0 && tz < g.ntz && ty >= 0 && ty < g.nty && tx >= 0 && tx < g.ntx) dirty[((int64_t)tz * g.nty + ty) * g.ntx + tx] = 1;
+    }
+    if (threadIdx.x == 0 && s_gmax > __hip_atomic_load(&st->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->gen, s_gmax);
+}
+
 template <typename MT>
 __global__ __launch_bounds__(256) void k_sk_labels(int64_t n, const uint32_t *__restrict__ comp, const unsigned long long *__restrict__ tau,
                                                    const int32_t *__restrict__ runlabel, MT *__restrict__ out, int32_t *__restrict__ out32,
@@ -347,7 +489,7 @@ struct SkBufs {
     uint16_t *C;
     uint8_t *kind, *dirty, *pending;
     unsigned long long *tau, *key_a, *key_b;
-    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *bcount, *bsum, *tlist, *total;
+    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *lhist, *bcount, *bsum, *tlist, *total;
     int32_t *runlabel;
     WsState *wst;
     SkState *st;
@@ -373,6 +515,7 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->cursor = (uint32_t *)take(65536 * 4);
     b->dhist = (uint32_t *)take(65536 * 4);
     b->dcursor = (uint32_t *)take(65536 * 4);
+    b->lhist = (uint32_t *)take(65536 * 4);
     b->bcount = (uint32_t *)take((size_t)(nblk + 1) * 4);
     b->bsum = (uint32_t *)take((size_t)(std::max<int64_t>(cdiv(nblk, 4096), 16) + 2) * 4);
     b->tlist = (uint32_t *)take((size_t)g.ntiles * 4);
@@ -470,6 +613,11 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         hipLaunchKernelGGL((k_ws_bucket<SkKindPred, true>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, cur, lst);
         IVX_LAUNCH_CHECK();
     }
+    std::vector<uint32_t> lhist(65536); // voxels per level (a level that holds much of the volume is relaxed tile-wise)
+    IVX_HIP(hipMemsetAsync(b.lhist, 0, 65536 * 4, st));
+    hipLaunchKernelGGL((k_ws_bucket<SkLevelPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkLevelPred{}, b.lhist, b.elist);
+    IVX_LAUNCH_CHECK();
+    IVX_HIP(hipMemcpyAsync(lhist.data(), b.lhist, 65536 * 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(k_sk_fill64, dim3(2048), dim3(256), 0, st, b.tau, g.n, TINF);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipStreamSynchronize(st)); // the histograms are on the host now
@@ -492,7 +640,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
 
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
-    int64_t nlevels = 0, nsorted = 0;
+    int64_t nlevels = 0, nsorted = 0, ntile_rounds = 0;
     const bool trace = getenv("IVX_WS_TRACE") != nullptr;
     const char *epb = getenv("IVX_SK_PER_WG"); // list entries per working workgroup (A/B measurements)
     const uint32_t per_wg = epb && atoi(epb) >= 256 ? (uint32_t)atoi(epb) : 1024u;
@@ -525,6 +673,39 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         }
         hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, seq, b.st);
         IVX_LAUNCH_CHECK();
+        const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
+        const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 22);
+        if (ndl == 0 && tile_min && lhist[c] >= tile_min) {
+            hipLaunchKernelGGL(k_sk_mark_tiles, dim3(gb), dim3(256), 0, st, g, b.lists[0], cnt, b.dirty);
+            IVX_LAUNCH_CHECK();
+            for (;;) {
+                IVX_HIP(hipMemsetAsync(&b.wst->nlist, 0, 4, st));
+                hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, b.dirty, b.tlist, b.wst);
+                IVX_LAUNCH_CHECK();
+                uint32_t mseq = 0, nl = 0;
+                int rc = mailbox_publish(&b.wst->nlist, 1, st, &mseq);
+                if (rc != IVX_OK) return rc;
+                rc = mailbox_wait(mseq, st, &nl, 1);
+                if (rc != IVX_OK) return rc;
+                if (!nl) break;
+                ntile_rounds++;
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(nl), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c, b.st));
+                IVX_LAUNCH_CHECK();
+            }
+            uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
+            int rc = mailbox_publish(&b.st->done, 4, st, &mseq);
+            if (rc != IVX_OK) return rc;
+            rc = mailbox_wait(mseq, st, msg, 4);
+            if (rc != IVX_OK) return rc;
+            gbase = msg[1] + 1;
+            roff += cnt;
+            start += cnt;
+            dstart += ndl;
+            if (trace)
+                fprintf(stderr, "sk level %u gen0 %u tile-wise -> generation %u, %.0f us\n", c, cnt, gbase - 1,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lvl_t0).count());
+            continue;
+        }
         // rounds are queued in growing batches; one host read per batch (a round after the level's last returns at once)
         // (a host read costs about as much as eight idle launches: the first batch is sized for a typical level)
         uint32_t batch = 16, width = cnt;
@@ -569,7 +750,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         stats[6] = hs.mixed; stats[7] = hs.rounds;
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] generation 0, [10] level chain, [11] labels (microseconds)
-        stats[12] = hs.brounds; stats[13] = hs.gens; stats[14] = nsorted;
+        stats[12] = hs.brounds; stats[13] = hs.gens; stats[14] = nsorted; stats[15] = ntile_rounds;
     }
     return IVX_OK;
 }

@@ -168,6 +168,17 @@ __global__ __launch_bounds__(256) void k_ws_init(WsGeom g, const MT *__restrict_
             neg |= m < 0;
             const int64_t z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
             dirty[((z / TZ) * g.nty + y / TY) * g.ntx + x / TX] = 1;
+            // A marker never changes, so a tile that only sees it in its halo would not be woken by it: when the marker
+            // sits on a face of its tile, wake the tiles that own its neighbours (normally the marker's in-tile
+            // neighbours on that face change and do this; a one-voxel-wide volume has none).
+            if (x % TX == 0 || x % TX == TX - 1 || y % TY == 0 || y % TY == TY - 1 || z % TZ == 0 || z % TZ == TZ - 1)
+                for (int k = 0; k < 27; k++) {
+                    if (k == 13 || !((g.smask >> k) & 1u)) continue;
+                    const int64_t Z = z + k / 9 - 1, Y = y + (k / 3) % 3 - 1, X = x + k % 3 - 1;
+                    if (SK && !((uint64_t)X < (uint64_t)g.w && (uint64_t)Y < (uint64_t)g.h && (uint64_t)Z < (uint64_t)g.d)) continue;
+                    const int64_t t = owner_tile(g, Z, Y, X);
+                    if (t >= 0) dirty[t] = 1;
+                }
         }
     }
     if (mine) atomicAdd(&s_cnt, mine);

@@ -131,6 +131,34 @@ def test_odd_shaped_volume_with_wide_frontiers(ivxlib, oracle):
         assert (cost >= grad).all() and (cost[mk != 0] == grad[mk != 0]).all()  # minimax of the values ON the path
 
 
+def test_one_voxel_wide_volumes_and_markers_on_tile_faces(ivxlib, oracle):
+    """A marker never changes, so it cannot wake the tile across the face it sits on; in a one-voxel-wide volume nothing
+    else does either (regression: the cost map stopped at the tile boundary).  Both floods, all three axes."""
+    from invesalius3_amd import watershed_process as wp
+    rng = np.random.default_rng(4)
+    for axis in range(3):
+        for pos in (15, 16, 7, 8, 31):
+            shape = [1, 1, 1]
+            shape[axis] = 70
+            img = rng.integers(0, 9, size=shape).astype(np.uint16)
+            mk = np.zeros(shape, np.int16)
+            mk.ravel()[pos] = 1
+            mk.ravel()[69] = 2
+            for conn in (1, 3):
+                st = ndimage.generate_binary_structure(3, conn)
+                assert np.array_equal(wp.watershed(img, mk, st), oracle.watershed_sk(img, mk, st, 1)), (axis, pos, conn)
+                assert np.array_equal(wp.watershed_ift(img, mk, st), oracle.watershed_ift_clean(img, mk, st)), (axis, pos, conn)
+    # a flat image: one level, no basins (the tile-wise breadth-first search when forced by IVX_SK_TILE_LEVEL=1)
+    flat = np.zeros((9, 40, 40), np.uint16)
+    mk = np.zeros(flat.shape, np.int16)
+    mk[4, 15, 15] = 1
+    mk[4, 16, 31] = 2
+    mk[0, 0, 0] = 3
+    for conn in (1, 2, 3):
+        st = ndimage.generate_binary_structure(3, conn)
+        assert np.array_equal(wp.watershed(flat, mk, st), oracle.watershed_sk(flat, mk, st, 1)), conn
+
+
 def test_edge_cases(ivxlib, oracle):
     from invesalius3_amd import watershed_process as wp
     s6 = ndimage.generate_binary_structure(3, 1)

@@ -23,6 +23,7 @@ timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o w
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o skkt -- python bench.py --config watershed_sk --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > $O/skkt.log 2>&1
 timeout -k 5 400 python bench.py --config watershed < /dev/null > $O/bench_watershed_1024.json 2> $O/bench_watershed.err
 timeout -k 5 400 python bench.py --config watershed_sk < /dev/null > $O/bench_watershed_sk_1024.json 2> $O/bench_watershed_sk.err
+timeout -k 5 400 python bench.py --config watershed_sk --ws-raw < /dev/null > $O/bench_watershed_sk_raw_1024.json 2> $O/bench_watershed_sk_raw.err
 timeout -k 5 300 python tools/bench_wssk.py 512 < /dev/null > $O/wssk_512_modes.jsonl 2>&1
 find $O -name "*_kernel_trace.csv" -size +8M -delete
 cat $O/gpu_tests.txt 2>/dev/null
