@@ -272,6 +272,70 @@ def join_surface_pieces(filenames, keep_largest_region=False):
     return verts, faces, {"volume": volume, "area": area}
 
 
+def _boundary_edges(faces):
+    """edges used by exactly one triangle (what vtkFillHolesFilter looks for)"""
+    f = np.asarray(faces, np.int64)
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    _, counts = np.unique(e[:, 0] * (int(f.max()) + 1 if len(f) else 1) + e[:, 1], return_counts=True)
+    return int((counts == 1).sum())
+
+
+def join_process_surface(filenames, algorithm, smooth_iterations, smooth_relaxation_factor, decimate_reduction, keep_largest,
+                         fill_holes, options, msg_queue=None):
+    """``invesalius.data.surface_process.join_process_surface`` (:204-472) with its own signature and return value
+    ``(filename_of_the_full_vtp, {"volume": v, "area": a})``, on the piece files `create_surface_piece` wrote:
+
+    * append + clean (vtkAppendPolyData, vtkCleanPolyData with point merging, :228-268): `join_surface_pieces`;
+    * ``algorithm == "ca_smoothing"`` (:270-322): cell normals and the context-aware smoothing on the GPU with
+      ``options["angle" | "max distance" | "min weight" | "steps"]``;
+    * decimation (:350-373): the reference's condition is inverted (``if not decimate_reduction``), so vtkQuadricDecimation
+      only ever runs with a target reduction of 0, i.e. changes nothing -- nothing to do here either (SURVEY Q7);
+    * ``keep_largest`` (:378-391) and the area / volume of :452-458 on the GPU;
+    * ``fill_holes`` (:396-416, vtkFillHolesFilter): surfaces made with ``fill_border_holes`` are closed, the filter then
+      finds no boundary edge and changes nothing; a surface WITH boundary edges raises -- hole triangulation is not built;
+    * the final vtkPolyDataNormals (:420-435: split points at feature edges + point normals for the renderer) is not
+      reproduced: the file holds the merged points and triangles the measures were taken on.
+    The reference's progress messages go to `msg_queue` unchanged."""
+    import queue as _queue
+
+    from . import invesalius_rs as rs
+
+    def send_message(msg):
+        if msg_queue is None:
+            return
+        try:
+            msg_queue.put_nowait(msg)
+        except _queue.Full as e:
+            print(e)
+
+    send_message("Joining surfaces ...")
+    send_message("Cleaning surface ...")
+    verts, faces, _ = join_surface_pieces(list(filenames))
+    if algorithm == "ca_smoothing" and len(faces):
+        send_message("Calculating normals ...")
+        send_message("Context Aware smoothing ...")
+        mesh = rs.Mesh.from_indexed(np.ascontiguousarray(verts, np.float32), faces)  # unit cell normals (:271-285)
+        rs.ca_smoothing(mesh, options["angle"], options["max distance"], options["min weight"], options["steps"])
+        verts = np.asarray(mesh.vertices, np.float32)
+    if not decimate_reduction:
+        send_message("Decimating ...")  # (target reduction 0: see above)
+    if keep_largest and len(faces):
+        send_message("Finding the largest ...")
+        verts, faces, _ = globals()["keep_largest"](verts, faces)
+    if fill_holes and len(faces):
+        send_message("Filling holes ...")
+        nb = _boundary_edges(faces)
+        if nb:
+            raise NotImplementedError("join_process_surface(fill_holes=True): the surface has %d boundary edges; "
+                                      "vtkFillHolesFilter's hole triangulation is not built" % nb)
+    send_message("Calculating area and volume ...")
+    volume, area = mass_properties(verts, faces) if len(faces) else (0.0, 0.0)
+    fd, filename = tempfile.mkstemp(suffix="_full.vtp")
+    os.close(fd)
+    write_vtp(filename, verts, faces)
+    return filename, {"volume": float(volume), "area": float(area)}
+
+
 def resize_image_array(image, resolution_percentage, as_mmap=False):
     """``imagedata_utils.resize_image_array`` (:121-130): ``scipy.ndimage.zoom(image, factor, image.dtype, order=2)``, the
     down-sampling AddNewActor applies to image AND mask for the Low / Medium quality presets (surface.py:1350-1353), on
@@ -308,9 +372,9 @@ def create_surface(image, mask_matrix, spacing, min_value, max_value, from_binar
     return np.concatenate(parts) if parts else np.empty((0, 3, 3), np.float32)
 
 
-def join_process_surface(image, mask_matrix, spacing, min_value, max_value, from_binary, fill_border_holes=True,
-                         keep_largest_region=False):
-    """The geometry of join_process_surface (surface_process.py:204-472) for the stages built here: the pieces'
+def join_process_volume(image, mask_matrix, spacing, min_value, max_value, from_binary, fill_border_holes=True,
+                        keep_largest_region=False):
+    """The geometry of join_process_surface (surface_process.py:204-472) straight from the resident arrays: the pieces'
     surfaces appended and point-merged (== one indexed marching-cubes pass over the whole volume: pieces share
     exactly one slice, so their cells partition the volume's), optionally the largest region only, then area and
     volume.  Returns ``(verts, faces, {"volume": v, "area": a})``.  Smoothing, decimation, hole filling and normals

@@ -57,7 +57,7 @@ def test_bone_mask_surface_and_stl(ivxlib, oracle, tmp_path):
     assert hi[1] <= SPACING[1] and lo[1] >= -img.shape[1] * SPACING[1]
     assert -SPACING[2] <= lo[2] and hi[2] <= img.shape[0] * SPACING[2] + SPACING[2]
     # -- merged surface, largest region, measurements ----------------------------------------------------------------------
-    verts, faces, meas = sp.join_process_surface(None, mask, SPACING, 0, 0, True, keep_largest_region=True)
+    verts, faces, meas = sp.join_process_volume(None, mask, SPACING, 0, 0, True, keep_largest_region=True)
     v0, f0 = sp.marching_cubes_indexed(mask[1:, 1:, 1:], SPACING, [127.0])
     vk, fk, nreg = oracle.mesh_keep_largest(v0, f0)
     assert np.array_equal(verts, vk) and np.array_equal(faces, fk)

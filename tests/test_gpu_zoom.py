@@ -64,10 +64,34 @@ def test_create_surface_piece_reference_signature(ivxlib, oracle, tmp_path):
             assert np.array_equal(v[f], want)
             names.append(name)
         verts, faces, m = sp.join_surface_pieces(names[::-1])      # any order in: sorted by the roi in the name
-        wv, wf, wm = sp.join_process_surface(img, mask, spacing, 226, 3071, from_binary)
+        wv, wf, wm = sp.join_process_volume(img, mask, spacing, 226, 3071, from_binary)
         key = lambda t: np.sort(np.ascontiguousarray(t).reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
         assert len(verts) == len(wv) and np.array_equal(key(verts[faces]), key(wv[wf]))
         assert m["area"] == pytest.approx(wm["area"], rel=1e-12) and m["volume"] == pytest.approx(wm["volume"], rel=1e-9)
+        # the reference's own join step, with its argument list (surface.py:1440-1452) and its queue messages
+        import queue
+        q = queue.Queue()
+        opts = {"angle": 0.7, "max distance": 3.0, "min weight": 0.5, "steps": 3}
+        full, meas = sp.join_process_surface(names, "Default", 0, 0.0, 0.0, True, True, opts, q)
+        assert full.endswith("_full.vtp")
+        fv, ff = sp.read_vtp(full)
+        lv, lf, _ = sp.keep_largest(wv, wf)
+        assert len(fv) == len(lv) and np.array_equal(key(fv[ff]), key(lv[lf]))
+        vol, area = sp.mass_properties(lv, lf)
+        assert meas["area"] == pytest.approx(area, rel=1e-12) and meas["volume"] == pytest.approx(vol, rel=1e-9)
+        msgs = []
+        while not q.empty():
+            msgs.append(q.get())
+        assert msgs == ["Joining surfaces ...", "Cleaning surface ...", "Decimating ...", "Finding the largest ...",
+                        "Filling holes ...", "Calculating area and volume ..."]
+        os.remove(full)
+        full, meas_s = sp.join_process_surface(names, "ca_smoothing", 0, 0.0, 0.0, False, False, opts, None)
+        sv, sf = sp.read_vtp(full)
+        from invesalius3_amd import invesalius_rs as rs
+        mesh = rs.Mesh.from_indexed(np.array(verts, np.float32), faces)  # (a copy: the smoothing works in place)
+        rs.ca_smoothing(mesh, 0.7, 3.0, 0.5, 3)
+        assert np.array_equal(sf, faces) and np.array_equal(sv, np.asarray(mesh.vertices, np.float32)) and not np.array_equal(sv, verts)
+        os.remove(full)
         for n in names:
             os.remove(n)
     # the "InVesalius 3.b2" value rewrite (surface_process.py:128-146), reachable only with from_binary=False
