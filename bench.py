@@ -610,7 +610,7 @@ def run_watershed_sk(args, job):
     if job.rank != 0:
         return
     names = ("rounds", "tile_visits", "levels", "generations", "markers", "generation0", "tied_markers_of_different_labels",
-             "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "basin_rounds", "generation_steps", "sorted_keys", "tile_rounds")
+             "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "basin_rounds", "generation_steps", "small_level_runs", "tile_rounds")
     flood_ms = spans.get("flood", 0.0)
     res = {
         "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",

@@ -526,7 +526,8 @@ int ivx_watershed_ift(int idtype /* IVX_U8 | IVX_U16 */, const void *input, cons
  * 0 = identical to scikit-image by construction.  cost_out (optional): the minimax map of image values.
  * stats (optional, host): [0] relaxation rounds, [1] tile visits, [2] non-empty levels, [3] generations, [4] marker
  * voxels, [5] generation-0 voxels, [6] tied markers of different labels, [7] frontier launches, [8..11] microseconds
- * of: costs, generation 0, level chain, labels, [13] generation steps, [14] sorted keys.
+ * of: costs, generation 0, level chain, labels, [12] basin relay launches, [13] generation steps, [14] launches that took a run of
+ * small levels in one workgroup, [15] tile rounds of levels relaxed tile-wise.
  * ---------------------------------------------------------------------------------------------- */
 int ivx_dev_watershed_sk(const uint16_t *image, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
                          const uint8_t strct[27], void *out_labels /* markers' dtype, may be NULL */,

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint32_t *__re
     }
 }
 
-// ---- a level without basins that holds a large part of the volume (the zero plateau of a windowed gradient image): its
+// ---- a level without basins that is not small (the zero plateau of a windowed gradient image holds most of the volume): its
 // breadth-first search has hundreds of generations, each a launch with a chain of dependent gathers.  The time stamps are
 // the fixed point of  T(p) = min over neighbours q of the level (T(q) + one generation)  with generation 0 fixed, and any
 // order of relaxation reaches it: so relax tiles staged in LDS to their local fixed point, dirty tiles only, like the
@@ -465,6 +465,148 @@ __global__ __launch_bounds__(256) void k_sk_plateau_relax(WsGeom g, const uint16
         if (tz >= 0 && tz < g.ntz && ty >= 0 && ty < g.nty && tx >= 0 && tx < g.ntx) dirty[((int64_t)tz * g.nty + ty) * g.ntx + tx] = 1;
     }
     if (threadIdx.x == 0 && s_gmax > __hip_atomic_load(&st->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->gen, s_gmax);
+}
+
+// ---- small levels: everything a level needs in ONE workgroup and ONE launch, and a run of consecutive small levels in the
+// same launch.  A slice of the GUI's 2-D mode, or the thin upper levels of a volume, are hundreds of levels of a few
+// hundred voxels each: as separate launches (keys, sort, stamps, two per generation) they cost launch latency and nothing
+// else.  Here: keys -> bitonic sort in LDS -> stamps -> the generations with workgroup barriers between their phases.
+constexpr int SMALL_GEN0 = 4096;        // generation-0 voxels of a level that still sort in LDS
+constexpr uint32_t SMALL_TOTAL = 32768; // voxels of a level one workgroup still walks
+
+struct SkSmallArgs {
+    const uint16_t *C, *I;
+    const uint32_t *comp, *pmask, *zmask, *elist, *dlist;
+    const uint32_t *hist, *cursor, *dhist, *dcursor; // counts and (after the scatter pass) segment ENDS per level
+    unsigned long long *tau;
+    int32_t *runlabel;
+    uint32_t *list0, *list1;
+    SkState *st;
+};
+
+template <typename MT>
+__global__ __launch_bounds__(1024) void k_sk_levels_small(WsGeom g, SkSmallArgs a, const MT *__restrict__ mk, uint32_t c_lo, uint32_t c_hi,
+                                                          uint32_t gbase, uint32_t roff) {
+    __shared__ unsigned long long s_key[SMALL_GEN0];
+    __shared__ uint32_t s_val[SMALL_GEN0];
+    __shared__ uint32_t s_n_next, s_stamped, s_mixed;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_mixed = 0;
+    for (uint32_t c = c_lo; c <= c_hi; c++) {
+        const uint32_t cnt = a.hist[c];
+        if (!cnt) continue; // (uniform)
+        const uint32_t ndl = a.dhist[c];
+        const uint32_t *el = a.elist + (a.cursor[c] - cnt), *dl = a.dlist + (a.dcursor[c] - ndl);
+        // keys
+        uint32_t n2 = 1;
+        while (n2 < cnt) n2 <<= 1;
+        for (uint32_t i = tid; i < n2; i += 1024) {
+            unsigned long long K = TINF;
+            uint32_t p = 0;
+            if (i < cnt) {
+                p = el[i];
+                K = p;
+                if (mk[p] == 0) {
+                    K = TINF;
+                    const int64_t z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
+                    for (int k = 0; k < 27; k++) {
+                        if (!((g.smask >> k) & 1u)) continue;
+                        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                        const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+                        if ((uint64_t)X >= (uint64_t)g.w || (uint64_t)Y >= (uint64_t)g.h || (uint64_t)Z >= (uint64_t)g.d) continue;
+                        const int64_t q = (int64_t)p + dz * g.hw + dy * g.w + dx;
+                        const uint32_t qc = a.C[q];
+                        if (qc < c) K = min(K, ld64(&a.tau[(uint32_t)a.I[q] < qc ? a.comp[q] : (uint32_t)q]));
+                    }
+                }
+            }
+            s_key[i] = K;
+            s_val[i] = p;
+        }
+        __syncthreads();
+        // bitonic sort of (key, voxel) pairs; padding keys (TINF) end up behind the real ones
+        for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1)
+            for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < (n2 >> 1); t += 1024) {
+                    const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                    const bool up = ((lo & k2) == 0);
+                    const unsigned long long ka = s_key[lo], kb = s_key[hi];
+                    if ((ka > kb) == up) {
+                        s_key[lo] = kb; s_key[hi] = ka;
+                        const uint32_t va = s_val[lo]; s_val[lo] = s_val[hi]; s_val[hi] = va;
+                    }
+                }
+                __syncthreads();
+            }
+        // stamps, run labels, first frontier
+        for (uint32_t i = tid; i < cnt; i += 1024) {
+            const uint32_t p = s_val[i];
+            const unsigned long long K = s_key[i];
+            const int m = (int)mk[p];
+            const int32_t l = m ? (int32_t)m : (K == TINF ? 0 : a.runlabel[(uint32_t)(K & 0xFFFFFFFFull)]);
+            a.runlabel[roff + i] = l;
+            a.tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + i);
+            a.list0[i] = p;
+            if (m && i > 0 && (int)mk[s_val[i - 1]] != m) atomicAdd(&s_mixed, 1u);
+        }
+        roff += cnt;
+        // generations
+        uint32_t n_in = cnt, gen = gbase;
+        uint32_t *in = a.list0, *nx = a.list1;
+        for (;;) {
+            if (tid == 0) { s_n_next = 0; s_stamped = 0; }
+            __syncthreads();
+            for (uint32_t i = tid; i < n_in; i += 1024) { // phase A
+                const uint32_t v = in[i];
+                const unsigned long long t = ld64(&a.tau[v]), nt = t + GEN1;
+                uint32_t pm = a.pmask[v];
+                while (pm) {
+                    const int k = __ffs(pm) - 1;
+                    pm &= pm - 1;
+                    const uint32_t p = (uint32_t)((int64_t)v + (k / 9 - 1) * g.hw + ((k / 3) % 3 - 1) * g.w + (k % 3 - 1));
+                    if (nt < ld64(&a.tau[p]) && atomicMin(&a.tau[p], nt) == TINF) nx[atomicAdd(&s_n_next, 1u)] = p;
+                }
+                uint32_t zm = ndl ? a.zmask[v] : 0u, last = ENTRY;
+                while (zm) {
+                    const int k = __ffs(zm) - 1;
+                    zm &= zm - 1;
+                    const uint32_t root = a.comp[(uint32_t)((int64_t)v + (k / 9 - 1) * g.hw + ((k / 3) % 3 - 1) * g.w + (k % 3 - 1))];
+                    if (root == last) continue;
+                    last = root;
+                    if (t < ld64(&a.tau[root]) && atomicMin(&a.tau[root], t) == TINF) s_stamped = 1;
+                }
+            }
+            __syncthreads();
+            if (s_stamped) { // phase B (uniform: read after the barrier)
+                for (uint32_t i = tid; i < ndl; i += 1024) {
+                    const uint32_t v = dl[i];
+                    const unsigned long long tb = ld64(&a.tau[a.comp[v]]);
+                    if ((uint32_t)(tb >> 32) != gen) continue;
+                    const unsigned long long nt = tb + GEN1;
+                    uint32_t pm = a.pmask[v];
+                    while (pm) {
+                        const int k = __ffs(pm) - 1;
+                        pm &= pm - 1;
+                        const uint32_t p = (uint32_t)((int64_t)v + (k / 9 - 1) * g.hw + ((k / 3) % 3 - 1) * g.w + (k % 3 - 1));
+                        if (nt < ld64(&a.tau[p]) && atomicMin(&a.tau[p], nt) == TINF) nx[atomicAdd(&s_n_next, 1u)] = p;
+                    }
+                }
+                __syncthreads();
+            }
+            const uint32_t nn = s_n_next;
+            __syncthreads(); // (everybody has read the counters before they are cleared)
+            if (!nn) break;
+            n_in = nn;
+            gen++;
+            uint32_t *t2 = in; in = nx; nx = t2;
+        }
+        gbase = gen + 1;
+    }
+    if (tid == 0) {
+        a.st->gen = gbase - 1; // what the host reads: the last generation used
+        a.st->done = 1;
+        if (s_mixed) atomicAdd(&a.st->mixed, s_mixed);
+    }
 }
 
 template <typename MT>
@@ -640,17 +782,48 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
 
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
-    int64_t nlevels = 0, nsorted = 0, ntile_rounds = 0;
+    int64_t nlevels = 0, nsorted = 0, ntile_rounds = 0, nsmall_runs = 0;
     const bool trace = getenv("IVX_WS_TRACE") != nullptr;
     const char *epb = getenv("IVX_SK_PER_WG"); // list entries per working workgroup (A/B measurements)
     const uint32_t per_wg = epb && atoi(epb) >= 256 ? (uint32_t)atoi(epb) : 1024u;
     uint32_t start = 0, dstart = 0, roff = 0, gbase = 1, seq = 0;
     SkLists lists;
     for (int i = 0; i < 2; i++) lists.l[i] = b.lists[i];
+    const char *senv = getenv("IVX_SK_SMALL"); // 0: never take the one-workgroup path (A/B measurements)
+    const bool small_on = !(senv && senv[0] == '0');
+    auto is_small = [&](uint32_t c) { return small_on && hist[c] <= (uint32_t)SMALL_GEN0 && lhist[c] <= SMALL_TOTAL; };
+    SkSmallArgs sa{b.C, I, b.comp, b.pmask, b.zmask, b.elist, b.dlist, b.hist, b.cursor, b.dhist, b.dcursor, b.tau, b.runlabel,
+                   b.lists[0], b.lists[1], b.st};
     for (uint32_t c = 0; c < 65535; c++) {
         const uint32_t cnt = hist[c], ndl = dhist[c];
         if (!cnt) { // (no voxel of the level at all: a level's drained voxels hang off its generation 0)
             dstart += ndl;
+            continue;
+        }
+        if (is_small(c)) { // a run of consecutive small levels: one launch
+            uint32_t c_hi = c, esum = 0, dsum = 0, nlv = 0;
+            for (uint32_t q = c; q < 65535 && (hist[q] == 0 || is_small(q)); q++)
+                if (hist[q]) c_hi = q;
+            for (uint32_t q = c; q <= c_hi; q++) {
+                nlv += hist[q] != 0;
+                esum += hist[q];
+                dsum += dhist[q];
+            }
+            hipLaunchKernelGGL(k_sk_levels_small<MT>, dim3(1), dim3(1024), 0, st, g, sa, mk, c, c_hi, gbase, roff);
+            IVX_LAUNCH_CHECK();
+            uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
+            int rc = mailbox_publish(&b.st->done, 4, st, &mseq);
+            if (rc != IVX_OK) return rc;
+            rc = mailbox_wait(mseq, st, msg, 4);
+            if (rc != IVX_OK) return rc;
+            gbase = msg[1] + 1;
+            roff += esum;
+            start += esum;
+            dstart += dsum;
+            nlevels += nlv;
+            nsmall_runs++;
+            if (trace) fprintf(stderr, "sk levels %u..%u (%u levels) in one workgroup -> generation %u\n", c, c_hi, nlv, gbase - 1);
+            c = c_hi;
             continue;
         }
         nlevels++;
@@ -674,7 +847,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, seq, b.st);
         IVX_LAUNCH_CHECK();
         const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
-        const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 22);
+        const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
         if (ndl == 0 && tile_min && lhist[c] >= tile_min) {
             hipLaunchKernelGGL(k_sk_mark_tiles, dim3(gb), dim3(256), 0, st, g, b.lists[0], cnt, b.dirty);
             IVX_LAUNCH_CHECK();
@@ -750,7 +923,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         stats[6] = hs.mixed; stats[7] = hs.rounds;
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] generation 0, [10] level chain, [11] labels (microseconds)
-        stats[12] = hs.brounds; stats[13] = hs.gens; stats[14] = nsorted; stats[15] = ntile_rounds;
+        stats[12] = hs.brounds; stats[13] = hs.gens; stats[14] = nsmall_runs; stats[15] = ntile_rounds;
     }
     return IVX_OK;
 }

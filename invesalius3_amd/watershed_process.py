@@ -130,7 +130,7 @@ def watershed(image: np.ndarray, markers: np.ndarray, connectivity=None, want_co
         res += (cost,)
     if want_stats:
         names = ("rounds", "tile_visits", "levels", "generations", "markers", "generation0", "tied_markers_of_different_labels",
-                 "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "basin_rounds", "generation_steps", "sorted_keys", "tile_rounds")
+                 "frontier_launches", "us_costs", "us_generation0", "us_levels", "us_labels", "basin_rounds", "generation_steps", "small_level_runs", "tile_rounds")
         res += ({k: int(v) for k, v in zip(names, stats) if not k.startswith("_")},)
     return res[0] if len(res) == 1 else res
 

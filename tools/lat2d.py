@@ -14,7 +14,7 @@ st = ndimage.generate_binary_structure(2, 1)
 wp.watershed(grad, mk, st)
 for _ in range(3):
     t = time.perf_counter(); lab, s = wp.watershed(grad, mk, st, want_stats=True); dt = time.perf_counter() - t
-    print("2-D 512x512 sk flood: %.1f ms" % (dt * 1e3), {k: s[k] for k in ("levels", "generations", "frontier_launches", "tile_rounds")})
+    print("2-D 512x512 sk flood: %.1f ms" % (dt * 1e3), {k: s[k] for k in ("levels", "generations", "frontier_launches", "small_level_runs", "tile_rounds")})
 t = time.perf_counter(); li = wp.watershed_ift(grad, mk.astype(np.int16), st); print("2-D IFT: %.1f ms" % ((time.perf_counter() - t) * 1e3))
 t = time.perf_counter(); li = wp.watershed_ift(grad, mk.astype(np.int16), st); print("2-D IFT: %.1f ms" % ((time.perf_counter() - t) * 1e3))
 from oracle import oracle as O
