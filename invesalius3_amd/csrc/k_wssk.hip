@@ -36,7 +36,10 @@
 //      generation and offers its own stamp to the basins it touches (atomicMin at the root); B -- only if a basin was
 //      stamped: the level's drained voxels whose basin carries this generation's stamp hand it, one generation later, to
 //      their unstamped neighbours of value c.  The last workgroup of a launch sets up the next one; the host queues
-//      launches in batches and reads one mailbox line per batch.
+//      launches in batches and reads one mailbox line per batch.  Two shortcuts: a RUN of consecutive small levels is
+//      taken by one workgroup in one launch (k_sk_levels_small: keys, LDS sort, stamps, generations behind barriers);
+//      a basin-free level that is not small (the zero plateau of a windowed gradient) is relaxed tile-wise in LDS
+//      (k_sk_plateau_relax: its stamps are a fixed point any relaxation order reaches).
 //   4. k_sk_labels     label = label of the run in T's low word.
 #include <algorithm>
 #include <chrono>
@@ -782,7 +785,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
 
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
-    int64_t nlevels = 0, nsorted = 0, ntile_rounds = 0, nsmall_runs = 0;
+    int64_t nlevels = 0, ntile_rounds = 0, nsmall_runs = 0;
     const bool trace = getenv("IVX_WS_TRACE") != nullptr;
     const char *epb = getenv("IVX_SK_PER_WG"); // list entries per working workgroup (A/B measurements)
     const uint32_t per_wg = epb && atoi(epb) >= 256 ? (uint32_t)atoi(epb) : 1024u;
@@ -842,7 +845,6 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             IVX_HIP(hipcub::DeviceRadixSort::SortPairs(b.cub, tb, b.key_a, b.key_b, b.val_a, b.val_b, (size_t)cnt, 0, end_bit, st));
             ks = b.key_b;
             vs = b.val_b;
-            nsorted += cnt;
         }
         hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, seq, b.st);
         IVX_LAUNCH_CHECK();
