@@ -272,6 +272,9 @@ def join_surface_pieces(filenames, keep_largest_region=False):
     return verts, faces, {"volume": volume, "area": area}
 
 
+_keep_largest_region = keep_largest  # (join_process_surface has a parameter of that name, like the reference)
+
+
 def _boundary_edges(faces):
     """edges used by exactly one triangle (what vtkFillHolesFilter looks for)"""
     f = np.asarray(faces, np.int64)
@@ -321,7 +324,7 @@ def join_process_surface(filenames, algorithm, smooth_iterations, smooth_relaxat
         send_message("Decimating ...")  # (target reduction 0: see above)
     if keep_largest and len(faces):
         send_message("Finding the largest ...")
-        verts, faces, _ = globals()["keep_largest"](verts, faces)
+        verts, faces, _ = _keep_largest_region(verts, faces)
     if fill_holes and len(faces):
         send_message("Filling holes ...")
         nb = _boundary_edges(faces)
