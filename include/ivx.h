@@ -536,6 +536,14 @@ int ivx_dev_watershed_sk(const uint16_t *image, int mdtype, const void *markers,
 int ivx_watershed_sk(int idtype /* IVX_U8 | IVX_U16 */, const void *input, const int64_t shape[3], int mdtype,
                      const void *markers, const uint8_t strct[27], int32_t *output, uint16_t *cost_out, int64_t stats[16]);
 
+/* do_watershed (invesalius/data/watershed_process.py:19-60) in one host call: int16 image (dense or a strided view) and
+ * markers (dense, int16 / int8) up once, uint8 labels (what `mask[:] = tmp_mask` stores) back once.  algorithm 0 =
+ * "Watershed IFT" (LUT or min-shift -> ivx_dev_watershed_ift), 1 = "Watershed" (the same, then the morphological gradient of
+ * gradient_size -> ivx_dev_watershed_sk).  stats as for the flood that ran. */
+int ivx_do_watershed(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mdtype, const void *markers,
+                     const uint8_t strct[27], int algorithm, const int gradient_size[3] /* NULL for algorithm 0 */,
+                     int use_ww_wl, double window, double level, uint8_t *out_u8, int64_t stats[16]);
+
 /* ------------------------------------------------------------------------------------------------
  * confidence-connected region growing support (do_rg_confidence, invesalius/data/styles.py:3220-3251):
  * exact integer count / sum / sum-of-squares of image[sel != 0]; dst[v] = 1 where src[v] == value.

@@ -511,6 +511,55 @@ extern "C" int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3],
     return IVX_OK;
 }
 
+// do_watershed in one host call: the image and the markers go up once, the uint8 labels come back once; the cost /
+// gradient image and the labels in the markers' width never cross PCIe (watershed_process.py:19-60 moves them through
+// host memory between its numpy / scipy / scikit-image steps).
+extern "C" int ivx_do_watershed(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mdtype, const void *markers,
+                                const uint8_t strct[27], int algorithm, const int gradient_size[3], int use_ww_wl, double window,
+                                double level, uint8_t *out_u8, int64_t stats[16]) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    IVX_REQUIRE(algorithm == 0 || algorithm == 1, IVX_EINVAL, "do_watershed: algorithm must be 0 (Watershed IFT) or 1 (Watershed)");
+    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "do_watershed: markers must be int16 or int8");
+    IVX_REQUIRE(algorithm == 0 || gradient_size, IVX_EINVAL, "do_watershed: the Watershed branch needs the gradient size");
+    const int64_t n = shape[0] * shape[1] * shape[2];
+    if (n == 0) return IVX_OK;
+    const size_t msz = mdtype == IVX_I16 ? 2 : 1;
+    void *d_img, *d_a, *d_b = nullptr, *d_mk, *d_out;
+    int rc;
+    if ((rc = ws_get(WS_IN, (size_t)n * 2, &d_img))) return rc;
+    if ((rc = ws_get(WS_AUX0, (size_t)n * 2, &d_a))) return rc;
+    if ((rc = ws_get(WS_AUX2, (size_t)n * msz, &d_mk))) return rc;
+    if ((rc = ws_get(WS_OUT, (size_t)n, &d_out))) return rc;
+    if ((rc = upload_strided(d_img, img, shape, strides, 2, WS_IN))) return rc;
+    IVX_HIP(hipMemcpy(d_mk, markers, (size_t)n * msz, hipMemcpyHostToDevice));
+    if (use_ww_wl) {
+        if ((rc = ivx_dev_lut_u16((const int16_t *)d_img, n, window, level, 0, (uint16_t *)d_a, nullptr))) return rc;
+    } else {
+        void *d_small;
+        if ((rc = ws_get(WS_SMALL, 256, &d_small))) return rc;
+        if ((rc = ivx_dev_minmax_f32(IVX_I16, d_img, n, (float *)d_small, nullptr))) return rc;
+        float h[2];
+        IVX_HIP(hipMemcpy(h, d_small, 8, hipMemcpyDeviceToHost));
+        if ((rc = ivx_dev_shift_min_u16((const int16_t *)d_img, n, (int)h[0], (uint16_t *)d_a, nullptr))) return rc;
+    }
+    const uint16_t *cost = (const uint16_t *)d_a;
+    if (algorithm == 1) { // gradient image first (watershed_process.py:36-38,49-51)
+        if ((rc = ws_get(WS_AUX1, (size_t)n * 2, &d_b))) return rc;
+        if ((rc = ivx_dev_morph_gradient_u16((const uint16_t *)d_a, shape[0], shape[1], shape[2], gradient_size, (uint16_t *)d_b, nullptr)))
+            return rc;
+        cost = (const uint16_t *)d_b;
+        rc = ivx_dev_watershed_sk(cost, mdtype, d_mk, shape[0], shape[1], shape[2], strct, nullptr, nullptr, (uint8_t *)d_out, nullptr, stats,
+                                  nullptr);
+    } else {
+        rc = ivx_dev_watershed_ift(cost, mdtype, d_mk, shape[0], shape[1], shape[2], strct, nullptr, (uint8_t *)d_out, nullptr, stats, nullptr);
+    }
+    if (rc != IVX_OK) return rc;
+    IVX_HIP(hipDeviceSynchronize());
+    IVX_HIP(hipMemcpy(out_u8, d_out, (size_t)n, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+
 extern "C" int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mst[3], const uint8_t *tmp,
                                    const int64_t tst[3], int overwrite) {
     ivx::HostCallGuard host_guard__;

@@ -139,13 +139,28 @@ def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_
     """Same signature and side effects as watershed_process.do_watershed (:19-60): writes the uint8 label volume to
     the memmap `tfile` and signals ``q.put(1)``.  Cost image and flood run on the GPU."""
     mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")
-    if algorithm == "Watershed":  # watershed_process.py:33-39,47-52: gradient image, scikit-image's flood, int16 markers
-        tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, mg_size)
-        tmp_mask = watershed(tmp_image, np.asarray(markers).astype("int16"), bstruct)
-    else:
-        tmp_image = cost_image(np.asarray(image), use_ww_wl, wl, ww, 0)
-        mk = np.asarray(markers).astype("int16" if use_ww_wl else "int8")  # watershed_process.py:45,57
-        tmp_mask = watershed_ift(tmp_image, mk, bstruct)
+    image = np.asarray(image)
+    if image.dtype != np.int16 or image.ndim not in (2, 3):
+        raise TypeError("image must be a 2-D or 3-D int16 array")
+    sk = algorithm == "Watershed"
+    # watershed_process.py:39,45,52,57: int16 markers, except for the IFT flood of the min-shifted image (int8)
+    mk = np.ascontiguousarray(np.asarray(markers).astype("int16" if (sk or use_ww_wl) else "int8"))
+    if mk.shape != image.shape:
+        raise RuntimeError("input and markers must have equal shape")
+    img3 = image if image.ndim == 3 else image[np.newaxis]
+    gs = None
+    if sk:  # int -> the same size on every axis (scipy semantics); tuple -> per axis
+        sz = tuple(int(v) for v in mg_size) if np.ndim(mg_size) else (int(mg_size),) * image.ndim
+        if len(sz) != image.ndim:
+            raise RuntimeError("size must have one entry per image axis")
+        gs = (ctypes.c_int * 3)(*((1,) * (3 - len(sz)) + sz))
+    tmp_mask = np.empty(img3.shape, np.uint8)
+    stats = (ctypes.c_int64 * 16)()
+    # one call: image and markers up, uint8 labels back (the cost / gradient image never leaves the device)
+    L.check(L.lib().ivx_do_watershed(L.ptr(img3), L.i64(img3.shape), L.i64(img3.strides), L.I16 if mk.dtype == np.int16 else L.I8,
+                                     L.ptr(mk), L.ptr(_strct27(bstruct, image.ndim)), int(sk), gs, int(bool(use_ww_wl)),
+                                     ctypes.c_double(float(ww)), ctypes.c_double(float(wl)), L.ptr(tmp_mask), stats), "do_watershed")
+    tmp_mask = tmp_mask.reshape(image.shape)
     mask[:] = tmp_mask
     mask.flush()
     if q is not None:

@@ -80,6 +80,39 @@ def test_do_watershed_default_algorithm_on_the_reference_fixture(ivxlib, tmp_pat
     assert np.array_equal(result, ref.astype(np.uint8)) and (result == 1).sum() == 109 and (result == 2).sum() == 16
 
 
+def test_do_watershed_in_one_call_equals_its_stages(ivxlib, tmp_path):
+    """do_watershed (image and markers up once, uint8 labels back once) == cost image -> flood -> uint8, for the four
+    branches of watershed_process.py:33-57, on a strided image view, and for one slice (styles.py:1958-1983)."""
+    import queue
+
+    from invesalius3_amd import watershed_process as wp
+    base, am = _ct_like((26, 70, 90), 21)
+    img = base[1:, 2:, 3:]                       # a view, like Slice.matrix[...]
+    am = (max(am[0] - 1, 0), max(am[1] - 2, 3), max(am[2] - 3, 3))
+    mk = np.zeros(img.shape, np.int16)
+    mk[max(am[0] - 1, 0):am[0] + 2, am[1] - 3:am[1] + 4, am[2] - 3:am[2] + 4] = 1
+    mk[:2, :5, :5] = 2
+    st = ndimage.generate_binary_structure(3, 1)
+    tfile = str(tmp_path / "ws.dat")
+    for algorithm in ("Watershed", "Watershed IFT"):
+        for use_ww_wl in (True, False):
+            np.memmap(tfile, shape=img.shape, dtype="uint8", mode="w+").flush()
+            q = queue.Queue()
+            wp.do_watershed(img, mk, tfile, img.shape, st, algorithm, (3, 3, 3), use_ww_wl, 300, 400, q)
+            assert q.get(timeout=2) == 1
+            got = np.array(np.memmap(tfile, shape=img.shape, dtype="uint8", mode="r"))
+            if algorithm == "Watershed":
+                want = wp.watershed(wp.cost_image(img, use_ww_wl, 300, 400, (3, 3, 3)), mk, st)
+            else:
+                want = wp.watershed_ift(wp.cost_image(img, use_ww_wl, 300, 400, 0), mk.astype("int16" if use_ww_wl else "int8"), st)
+            assert np.array_equal(got, want.astype(np.uint8)) and (got == 1).any() and (got == 2).any(), (algorithm, use_ww_wl)
+    sl, mk2, st2 = img[7], mk[max(am[0], 0)], ndimage.generate_binary_structure(2, 1)
+    np.memmap(tfile, shape=sl.shape, dtype="uint8", mode="w+").flush()
+    wp.do_watershed(sl, mk2, tfile, sl.shape, st2, "Watershed", (3, 3), True, 300, 400, None)
+    got = np.array(np.memmap(tfile, shape=sl.shape, dtype="uint8", mode="r"))
+    assert np.array_equal(got, wp.watershed(wp.cost_image(sl, True, 300, 400, (3, 3)), mk2, st2).astype(np.uint8))
+
+
 def _ct_like(shape, seed):
     rng = np.random.default_rng(seed)
     z, y, x = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")

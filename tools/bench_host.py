@@ -64,6 +64,22 @@ def main():
     o2 = np.zeros((n, n), np.int16)
     res["mida axis 0"] = timeit(lambda: rs.mida(img, 0, 300, 600, o2))
     res["project MaxIP axis 0"] = timeit(lambda: slice_.project(img, 0, slice_.PROJECTION_MaxIP))
+    # do_watershed as the reference calls it (memmap out, queue), the GUI's default settings and the IFT alternative
+    import os
+    import tempfile
+
+    from invesalius3_amd import watershed_process as wp
+    from tools.bench_wsift import markers_for
+    mk = markers_for(img).astype(np.int16)
+    fd, tfile = tempfile.mkstemp(suffix=".dat")
+    os.close(fd)
+    np.memmap(tfile, shape=img.shape, dtype="uint8", mode="w+").flush()
+    s6 = generate_binary_structure(3, 1)
+    res["do_watershed (Watershed, ww/wl, 6 neighbours)"] = timeit(
+        lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed", (3, 3, 3), True, 300, 400, None), reps=2)
+    res["do_watershed (Watershed IFT, ww/wl, 6 neighbours)"] = timeit(
+        lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed IFT", (3, 3, 3), True, 300, 400, None), reps=2)
+    os.remove(tfile)
     print(json.dumps({"size": "512^3", "triangles": int(len(tri[0])),
                       "results": {k: {"s": round(v, 4), "Mvoxel/s": round(nvox / v / 1e6, 1)} for k, v in res.items()}}, indent=1))
 
