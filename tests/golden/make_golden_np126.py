@@ -70,6 +70,22 @@ def main(path):
     d["bw"] = bw
     for c in (1, 2, 3):
         d["label_%d" % c], _ = ndimage.label(bw, ndimage.generate_binary_structure(3, c))
+    # a8: confidence-connected growing (float64 mean / std of the grown set decide the next thresholds)
+    smooth = ndimage.gaussian_filter(rng.normal(0, 1, (12, 20, 22)), 2.0)
+    cimg = (smooth / np.abs(smooth).max() * 900 + rng.normal(0, 20, smooth.shape)).astype(np.int16)
+    d["conf_img"] = cimg
+    seed = tuple(int(v) for v in np.unravel_index(int(np.argmax(smooth)), smooth.shape)[::-1])
+    d["conf_seed"] = np.array(seed)
+    for c in (1, 3):
+        d["conf_%d" % c] = O.do_rg_confidence(cimg, seed, ndimage.generate_binary_structure(3, c), 2.5, 3)
+    # Mask.fill_holes_auto (scipy label + the restated Rust fill)
+    fm = np.zeros((9, 14, 15), np.uint8)
+    fm[1:, 1:, 1:] = np.where(rng.random((8, 13, 14)) < 0.7, 255, 0)
+    d["holes_in"] = fm
+    for conn in (6, 18, 26):
+        t = fm.copy()
+        O.mask_fill_holes_auto(t, "3D", conn, "AXIAL", 0, 4)
+        d["holes_%d" % conn] = t
     np.savez_compressed(path, **d)
     print("numpy", np.__version__, "scipy", scipy.__version__, len(d), "arrays")
 

@@ -111,6 +111,14 @@ def test_restated_numpy_and_scipy_expressions_under_the_pinned_numpy(oracle):
         assert np.array_equal(ndimage.label(z["bw"], s)[0], z["label_%d" % c])
     for i, f in enumerate((0.5, 0.75)):
         assert np.array_equal(ndimage.zoom(z["zoom_in"], f, z["zoom_in"].dtype, order=2), z["zoom_%d" % i])
+    seed = tuple(int(v) for v in z["conf_seed"])
+    for c in (1, 3):
+        got = oracle.do_rg_confidence(z["conf_img"], seed, ndimage.generate_binary_structure(3, c), 2.5, 3)
+        assert np.array_equal(got, z["conf_%d" % c]) and got.any()
+    for conn in (6, 18, 26):
+        t = z["holes_in"].copy()
+        oracle.mask_fill_holes_auto(t, "3D", conn, "AXIAL", 0, 4)
+        assert np.array_equal(t, z["holes_%d" % conn])
 
 
 @pytest.mark.gpu
