@@ -121,6 +121,51 @@ def test_restated_numpy_and_scipy_expressions_under_the_pinned_numpy(oracle):
         assert np.array_equal(t, z["holes_%d" % conn])
 
 
+def _ref_ws():
+    z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
+    for nm in z["names"]:
+        alg, uw, wl, ww, mg = z["par_" + nm]
+        yield (str(nm), z["img_" + nm], z["mk_" + nm], z["st_" + nm].astype(bool), str(alg), bool(int(uw)), float(wl), float(ww),
+               tuple(int(v) for v in str(mg).split("x")), z["out_" + nm])
+
+
+def test_oracle_pipeline_equals_the_reference_do_watershed(oracle):
+    """tests/golden/ref_do_watershed.npz = outputs of the reference's OWN do_watershed (imported from /root/reference and run
+    in the build container, scikit-image's flood through the 0.18.3 build under /opt/conda: make_golden_ref_dowatershed.py),
+    all four branches, 6 / 26 neighbours, a slice, and the reference's test fixture.  The restated stages composed the same
+    way give the same bytes -- with either marker-tie rule for the scikit-image flood, with or without scipy's defect."""
+    from scipy import ndimage
+    n = 0
+    for nm, img, mk, st, alg, uw, wl, ww, mg, out in _ref_ws():
+        cost = oracle.get_LUT_value(img, ww, wl).astype("uint16") if uw else (img - img.min()).astype("uint16")
+        if alg == "Watershed":
+            grad = ndimage.morphological_gradient(cost, mg)
+            for tie in (0, 1):
+                assert np.array_equal(oracle.watershed_sk(grad, mk.astype("int16"), st, tie).astype(np.uint8), out), (nm, tie)
+        else:
+            m2 = mk.astype("int16" if uw else "int8")
+            assert np.array_equal(oracle.watershed_ift(cost, m2, st).astype(np.uint8), out), nm
+            assert np.array_equal(oracle.watershed_ift_clean(cost, m2, st).astype(np.uint8), out), nm
+        n += 1
+    assert n == 12
+
+
+@pytest.mark.gpu
+def test_gpu_do_watershed_equals_the_reference_do_watershed(ivxlib, tmp_path):
+    """the drop-in hook against the reference's own outputs (same golden file), called with the reference's argument list"""
+    import queue
+
+    from invesalius3_amd import watershed_process as wp
+    for nm, img, mk, st, alg, uw, wl, ww, mg, out in _ref_ws():
+        tfile = str(tmp_path / (nm + ".dat"))
+        np.memmap(tfile, shape=img.shape, dtype="uint8", mode="w+").flush()
+        q = queue.Queue()
+        wp.do_watershed(image=img, markers=mk, tfile=tfile, shape=img.shape, bstruct=st, algorithm=alg, mg_size=mg, use_ww_wl=uw,
+                        wl=wl, ww=ww, q=q)
+        assert q.get(timeout=2) == 1
+        assert np.array_equal(np.array(np.memmap(tfile, shape=img.shape, dtype="uint8", mode="r")), out), nm
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_the_golden_vectors(ivxlib):
     from invesalius3_amd import surface_process as sp, watershed_process as wp
