@@ -121,6 +121,51 @@ def test_restated_numpy_and_scipy_expressions_under_the_pinned_numpy(oracle):
         assert np.array_equal(t, z["holes_%d" % conn])
 
 
+def test_oracle_equals_the_reference_slice_methods(oracle):
+    """tests/golden/ref_slice.npz = what the reference's OWN Slice.do_threshold_to_a_slice / do_threshold_to_all_slices /
+    SetMaskThreshold, get_LUT_value(_255) and resize_image_array return (imported from /root/reference and called in the
+    build container: make_golden_ref_slice.py).  The restatements give the same bytes."""
+    from scipy import ndimage
+    z = np.load(os.path.join(GOLD, "ref_slice.npz"))
+    img, start = z["img"], z["mask_in"]
+    assert np.array_equal(oracle.do_threshold_to_a_slice(img[3], start[4, 1:, 1:], (226, 3071)), z["a_slice"])
+    assert np.array_equal(oracle.do_threshold_to_a_slice(img[3], start[4, 1:, 1:], (-100, 400)), z["a_slice_current"])
+    m = start.copy()
+    oracle.do_threshold_to_all_slices(m, img, (226, 3071))
+    assert np.array_equal(m, z["all_slices"])
+    m = start.copy()
+    oracle.set_mask_threshold_volume(m, img, (-200, 500))
+    assert np.array_equal(m, z["set_threshold_volume"])
+    assert np.array_equal(oracle.set_mask_threshold_slice(img[2], (-200, 500)), z["set_threshold_preview"])
+    for i, (w, l) in enumerate(z["wl"]):
+        a, b = oracle.get_LUT_value(img, int(w), int(l)), oracle.get_LUT_value_255(img, int(w), int(l))
+        assert a.dtype == z["lut_%d" % i].dtype and np.array_equal(a, z["lut_%d" % i]), (w, l)
+        assert b.dtype == z["lut255_%d" % i].dtype and np.array_equal(b, z["lut255_%d" % i]), (w, l)
+    for i, f in enumerate((0.5, 0.75)):
+        for k in ("i16", "u8"):
+            v = z["zoom_" + k]
+            assert np.array_equal(ndimage.zoom(v, f, v.dtype, order=2), z["zoom_%s_%d" % (k, i)])
+
+
+@pytest.mark.gpu
+def test_gpu_hooks_equal_the_reference_slice_methods(ivxlib):
+    from invesalius3_amd import slice_ as sl, surface_process as sp, watershed_process as wp
+    z = np.load(os.path.join(GOLD, "ref_slice.npz"))
+    img, start = z["img"], z["mask_in"]
+    assert np.array_equal(sl.do_threshold_to_a_slice(img[3], start[4, 1:, 1:], (226, 3071)), z["a_slice"])
+    m = start.copy()
+    sl.do_threshold_to_all_slices(m, img, (226, 3071))
+    assert np.array_equal(m, z["all_slices"])
+    m = start.copy()
+    sl.set_mask_threshold(m, img, (-200, 500))
+    assert np.array_equal(m, z["set_threshold_volume"])
+    for i, (w, l) in enumerate(z["wl"]):
+        assert np.array_equal(wp.cost_image(img, True, int(l), int(w), 0), z["lut_%d" % i].astype("uint16")), (w, l)
+    for i, f in enumerate((0.5, 0.75)):
+        for k in ("i16", "u8"):
+            assert np.array_equal(sp.resize_image_array(z["zoom_" + k], f), z["zoom_%s_%d" % (k, i)]), (k, f)
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
