@@ -29,7 +29,8 @@ class _Fake(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__"):
             raise AttributeError(name)
-        m = mock.MagicMock(name=self.__name__ + "." + name)
+        # VTK classes are subclassed by the reference (interactor styles): they have to be real classes
+        m = type(name, (), {}) if name.startswith("vtk") else mock.MagicMock(name=self.__name__ + "." + name)
         setattr(self, name, m)
         return m
 

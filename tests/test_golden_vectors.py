@@ -166,6 +166,62 @@ def test_gpu_hooks_equal_the_reference_slice_methods(ivxlib):
             assert np.array_equal(sp.resize_image_array(z["zoom_" + k], f), z["zoom_%s_%d" % (k, i)]), (k, f)
 
 
+HOLES = (("3D", 6, "AXIAL", 0, 4), ("3D", 26, "AXIAL", 0, 50), ("2D", 4, "AXIAL", 3, 3), ("2D", 8, "CORONAL", 5, 6),
+         ("2D", 4, "SAGITAL", 7, 2))
+
+
+def test_oracle_equals_the_reference_python_around_the_flood(oracle):
+    """tests/golden/ref_rg.npz = the reference's OWN do_rg_confidence, Mask.fill_holes_auto and invesalius_rs wrappers
+    (imported from /root/reference; the Rust entry points under them bound to oracle/'s pinned C restatement:
+    make_golden_ref_rg.py).  The restatements of that Python -- statistics loop, truncation rules, label / reshape logic --
+    give the same bytes."""
+    from scipy import ndimage
+    z = np.load(os.path.join(GOLD, "ref_rg.npz"))
+    img, seed = z["img"], tuple(int(v) for v in z["seed"])
+    for conn in (1, 3):
+        st = ndimage.generate_binary_structure(3, conn)
+        assert np.array_equal(oracle.do_rg_confidence(img, seed, st, 2.5, 3), z["conf_%d_0" % conn]) and z["conf_%d_0" % conn].any()
+        lut = oracle.get_LUT_value_255(img, 900, 200)
+        assert np.array_equal(oracle.do_rg_confidence(lut, seed, st, 2.5, 3), z["conf_%d_1" % conn])
+    o = np.zeros(img.shape, np.uint8)
+    oracle.floodfill_threshold(img, [list(seed)], 299.9, 1500.7, 1.9, ndimage.generate_binary_structure(3, 2), o)
+    assert np.array_equal(o, z["wrap_out"]) and o.any()
+    m = z["inplace_in"].copy()
+    oracle.floodfill_threshold_inplace(m[1:, 1:, 1:], [tuple(int(v) for v in z["inplace_seed"])], 253, 255, 1,
+                                       ndimage.generate_binary_structure(3, 1))
+    assert np.array_equal(m, z["inplace_out"])
+    for target, conn, orientation, index, size in HOLES:
+        t = z["holes_in"].copy()
+        oracle.mask_fill_holes_auto(t, target, conn, orientation, index, size)
+        assert np.array_equal(t, z["holes_%s_%d_%s_%d_%d" % (target, conn, orientation, index, size)]), (target, conn, orientation)
+
+
+@pytest.mark.gpu
+def test_gpu_hooks_equal_the_reference_python_around_the_flood(ivxlib):
+    from scipy import ndimage
+
+    from invesalius3_amd import invesalius_rs as rs, mask as mk, styles
+    z = np.load(os.path.join(GOLD, "ref_rg.npz"))
+    img, seed = z["img"], tuple(int(v) for v in z["seed"])
+    for conn, con_3d in ((1, 6), (3, 26)):
+        for use_ww_wl in (0, 1):
+            m = np.zeros(tuple(s + 1 for s in img.shape), np.uint8)
+            assert styles.do_3d_seg(img, m, seed, method="confidence", con_3d=con_3d, fill_value=254, use_ww_wl=bool(use_ww_wl), ww=900,
+                                    wl=200, confid_mult=2.5, confid_iters=3)
+            assert np.array_equal(m[1:, 1:, 1:] == 254, z["conf_%d_%d" % (conn, use_ww_wl)] == 1), (conn, use_ww_wl)
+    o = np.zeros(img.shape, np.uint8)
+    rs.floodfill_threshold(img, [list(seed)], 299.9, 1500.7, 1.9, ndimage.generate_binary_structure(3, 2), o)
+    assert np.array_equal(o, z["wrap_out"])
+    m = z["inplace_in"].copy()
+    rs.floodfill_threshold_inplace(m[1:, 1:, 1:], [tuple(int(v) for v in z["inplace_seed"])], 253, 255, 1,
+                                   ndimage.generate_binary_structure(3, 1))
+    assert np.array_equal(m, z["inplace_out"])
+    for target, conn, orientation, index, size in HOLES:
+        t = z["holes_in"].copy()
+        mk.fill_holes_auto(t, target, conn, orientation, index, size)
+        assert np.array_equal(t, z["holes_%s_%d_%s_%d_%d" % (target, conn, orientation, index, size)]), (target, conn, orientation)
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
