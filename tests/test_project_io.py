@@ -186,3 +186,49 @@ def test_close_never_removes_a_callers_workdir_and_failed_open_cleans_up(tmp_pat
     with pytest.raises(FileNotFoundError):
         prj.open_inv3(bad)
     assert not [d for d in set(os.listdir(tempfile.gettempdir())) - before if d.startswith("ivx3_")]
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_reader_opens_a_project_the_reference_wrote():
+    """tests/golden/ref_written.inv3 was written by the reference's OWN Project.SavePlistProject / Mask.SavePlist (imported
+    from /root/reference: make_golden_ref_inv3.py): int16 matrix, one image version, two masks with their flag border."""
+    from invesalius3_amd import project as prj
+    exp = np.load(os.path.join(GOLD, "ref_written_expect.npz"))
+    p = prj.open_inv3(os.path.join(GOLD, "ref_written.inv3"))
+    try:
+        assert p.name == "Golden^Case" and p.modality == "CT" and tuple(p.spacing) == (0.5, 0.5, 2.0)
+        assert (p.window, p.level) == (406.0, 62.0) and tuple(p.threshold_range) == (-1024, 3071)
+        assert tuple(p.matrix_shape) == (6, 8, 10) and p.matrix_dtype == "int16" and np.array_equal(np.asarray(p.matrix), exp["img"])
+        assert len(p.image_versions) == 1
+        label, mat = p.image_versions[0][0], p.image_versions[0][1]
+        assert label == "gaussian" and np.array_equal(np.asarray(mat), exp["filt"])
+        assert sorted(p.masks) == sorted(int(k) for k in p.masks) and len(p.masks) == 2
+        for i, idx in enumerate(sorted(p.masks)):
+            m = p.masks[idx]
+            assert m.name == "Mask %d" % (i + 1) and np.array_equal(np.asarray(m.matrix), exp["mask%d" % i])
+            assert tuple(m.threshold_range) == ((226, 3071), (-200, 300))[i] and bool(m.edited) == bool(i)
+            assert m.matrix[2, 0, 0] == 2 and m.matrix[1, 0, 0] == 1          # the per-slice flags travel with the matrix
+    finally:
+        p.close()
+
+
+def test_reference_reads_what_the_writer_wrote():
+    """tests/golden/ours_written.inv3 came out of save_inv3; ref_inv3_readback.npz is what the reference's OWN
+    Project.OpenPlistProject made of it.  Our reader sees the same project in the same file."""
+    from invesalius3_amd import project as prj
+    ref = np.load(os.path.join(GOLD, "ref_inv3_readback.npz"))
+    p = prj.open_inv3(os.path.join(GOLD, "ours_written.inv3"))
+    try:
+        assert str(ref["name"]) == p.name == "Ours^Case" and tuple(ref["spacing"]) == tuple(p.spacing) == (0.7, 0.7, 1.25)
+        assert tuple(ref["shape"]) == tuple(p.matrix_shape) and str(ref["dtype"]) == p.matrix_dtype
+        assert np.array_equal(ref["matrix"], np.asarray(p.matrix))
+        assert tuple(ref["window_level"]) == (p.window, p.level) and tuple(ref["threshold_range"]) == tuple(p.threshold_range)
+        (idx,) = list(p.masks)
+        m = p.masks[idx]
+        assert np.array_equal(ref["mask_%d" % idx], np.asarray(m.matrix))
+        name, thr, edited = (str(v) for v in ref["mask_%d_meta" % idx])
+        assert name == m.name == "Bone" and thr == str(tuple(m.threshold_range)) and edited == str(bool(m.edited)) == "True"
+    finally:
+        p.close()
