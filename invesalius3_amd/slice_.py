@@ -91,6 +91,47 @@ def project(slab: np.ndarray, axis: int, projection: int) -> np.ndarray:
     return out
 
 
+PROJECTION_LMIP, PROJECTION_MIDA, PROJECTION_CONTOUR_MIP, PROJECTION_CONTOUR_LMIP, PROJECTION_CONTOUR_MIDA = 4, 5, 6, 7, 8
+_AXIS = {"AXIAL": 0, "CORONAL": 1, "SAGITAL": 2}
+
+
+def get_image_slice(matrix: np.ndarray, orientation: str, slice_number: int, number_slices: int = 1, inverted: bool = False,
+                    border_size: float = 1.0, type_projection: int = PROJECTION_NORMAL, window_level=0) -> np.ndarray:
+    """The array work of ``Slice.get_image_slice`` (invesalius/data/slice_.py:832-1119) for an unrotated view: the slab
+    ``matrix[n : n + number_slices]`` along the view axis (one slice for PROJECTION_NORMAL), reversed when `inverted`, then
+    the projection -- max / min / mean, MIDA, the three contour MIPs -- with the reference's own arguments, its quirk
+    included (the window LEVEL goes in for level and width alike: :898-900,906-945).  LMIP raises AttributeError like the
+    reference (`mips.lmip` is commented out of invesalius_rs/__init__.py:83).  The buffer_slices cache stays with the caller."""
+    from . import invesalius_rs as mips
+
+    ax = _AXIS[orientation]
+    if type_projection == PROJECTION_NORMAL:
+        number_slices = 1
+    sl = [slice(None)] * 3
+    sl[ax] = slice(slice_number, slice_number + number_slices)
+    tmp = np.array(matrix[tuple(sl)])
+    oshape = tuple(s for i, s in enumerate(tmp.shape) if i != ax)
+    if type_projection == PROJECTION_NORMAL:
+        return tmp.reshape(oshape)
+    if inverted:
+        rev = [slice(None)] * 3
+        rev[ax] = slice(None, None, -1)
+        tmp = tmp[tuple(rev)]
+    if type_projection in (PROJECTION_MaxIP, PROJECTION_MinIP, PROJECTION_MeanIP):
+        return project(tmp, ax, type_projection)
+    if type_projection == PROJECTION_LMIP:
+        raise AttributeError("module 'invesalius_rs' has no attribute 'lmip'")
+    out = np.empty(oshape, tmp.dtype)
+    if type_projection == PROJECTION_MIDA:
+        mips.mida(tmp, ax, int(window_level), int(window_level), out)
+    elif type_projection in (PROJECTION_CONTOUR_MIP, PROJECTION_CONTOUR_LMIP, PROJECTION_CONTOUR_MIDA):
+        mips.fast_countour_mip(tmp, border_size, ax, window_level, window_level, type_projection - PROJECTION_CONTOUR_MIP, out)
+    else:  # (:946-947: anything else shows the plain slice)
+        sl[ax] = slice_number
+        return np.array(matrix[tuple(sl)])
+    return out
+
+
 def calc_image_area(mask_matrix: np.ndarray, spacing) -> float:
     """Slice.calc_image_area (invesalius/data/slice_.py:2296-2322) after its threshold step: the exposed-face area of
     ``mask_matrix[1:,1:,1:] > 127`` for ``spacing = (sx, sy, sz)``.  Computed from the uint8 mask on the GPU (the
