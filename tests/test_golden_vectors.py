@@ -267,6 +267,47 @@ def test_gpu_get_image_slice_equals_the_reference(ivxlib):
         sl.get_image_slice(z["img"], "AXIAL", 2, 7, False, 1.0, 4, 300)
 
 
+def test_oracle_equals_the_reference_mask_operations(oracle):
+    """tests/golden/ref_maskops.npz = the reference's OWN Slice.do_boolean_op (four operations), calc_image_density and
+    calc_mask_area (imported; make_golden_ref_maskops.py), each preceded by its do_threshold_to_all_slices."""
+    z = np.load(os.path.join(GOLD, "ref_maskops.npz"))
+    img = z["img"]
+    after = []
+    for k, rng_ in enumerate(((226, 3071), (-300, 600))):
+        m = z["mask%d_in" % k].copy()
+        oracle.do_threshold_to_all_slices(m, img, rng_)
+        assert np.array_equal(m, z["mask%d_after" % k])
+        after.append(m)
+    a, b = after[0][1:, 1:, 1:] > 2, after[1][1:, 1:, 1:] > 2
+    for op, val in ((1, a | b), (2, a ^ (a & b)), (3, a & b), (4, a ^ b)):
+        want = z["bool_%d" % op]
+        assert np.array_equal(want[1:, 1:, 1:], val * np.uint8(255)) and (want[0] == 1).all() and (want[:, 0] == 1).all() and (want[:, :, 0] == 1).all()
+    v = img[after[0][1:, 1:, 1:] > 127]
+    assert np.array_equal(z["density"], np.array([v.min(), v.max(), v.mean(), v.std()], np.float64))
+    assert not z["density_empty"].any()
+    assert float(z["area"]) == oracle.calc_image_area(after[1], (0.5, 0.75, 2.0))
+
+
+@pytest.mark.gpu
+def test_gpu_hooks_equal_the_reference_mask_operations(ivxlib):
+    from invesalius3_amd import slice_ as sl
+    z = np.load(os.path.join(GOLD, "ref_maskops.npz"))
+    img = z["img"]
+    after = []
+    for k, rng_ in enumerate(((226, 3071), (-300, 600))):
+        m = z["mask%d_in" % k].copy()
+        sl.do_threshold_to_all_slices(m, img, rng_)
+        assert np.array_equal(m, z["mask%d_after" % k])
+        after.append(m)
+    for op in (1, 2, 3, 4):
+        assert np.array_equal(sl.do_boolean_op(op, after[0], after[1]), z["bool_%d" % op]), op
+    lo, hi, mean, std = sl.calc_image_density(img, after[0])
+    assert (lo, hi) == (z["density"][0], z["density"][1])
+    assert mean == pytest.approx(z["density"][2], rel=1e-13) and std == pytest.approx(z["density"][3], rel=1e-10)
+    assert sl.calc_image_density(img, np.ones_like(after[0])) == (0, 0, 0, 0)
+    assert sl.calc_image_area(after[1], (0.5, 0.75, 2.0)) == pytest.approx(float(z["area"]), rel=1e-12)
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
