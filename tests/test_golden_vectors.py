@@ -308,6 +308,38 @@ def test_gpu_hooks_equal_the_reference_mask_operations(ivxlib):
     assert sl.calc_image_area(after[1], (0.5, 0.75, 2.0)) == pytest.approx(float(z["area"]), rel=1e-12)
 
 
+def _pad_cases():
+    z = np.load(os.path.join(GOLD, "ref_pad.npz"))
+    sp = (0.5, 0.75, 2.0)
+    for key, iso, padv in (("img", 226.5, float(np.iinfo(np.int16).min)), ("msk", 127.0, 0.0)):
+        for pb in (0, 1):
+            for pt in (0, 1):
+                yield z[key], z["%s_%d%d" % (key, pb, pt)], iso, padv, bool(pb), bool(pt), sp
+
+
+def test_virtual_padding_equals_the_reference_pad_image(oracle):
+    """The kernels never materialise create_surface_piece's padded copy (surface_process.py:52-68,112-146): they contour a
+    VIRTUALLY padded piece.  Contouring the array the reference's OWN pad_image returns (tests/golden/ref_pad.npz) gives the
+    same triangles in the same order, moved by the extent shift to_vtk(padding=(1, 1, pad_bottom)) prescribes -- one voxel in
+    x, one in the flipped y."""
+    for a, padded, iso, padv, pb, pt, sp in _pad_cases():
+        virt = oracle.marching_cubes(a, sp, [iso], 3, True, pb, pt, padv, int(pb))
+        real = oracle.marching_cubes(padded, sp, [iso], 3, False, False, False, 0.0, int(pb))
+        assert virt.shape == real.shape and len(virt)
+        # (same triangles, same order; the shift is applied in float32 here, hence the last-bit tolerance)
+        assert np.abs(virt - (real + np.array([-sp[0], sp[1], 0.0], np.float32))).max() < 2e-6, (a.dtype, pb, pt)
+
+
+@pytest.mark.gpu
+def test_gpu_virtual_padding_equals_the_reference_pad_image(ivxlib, oracle):
+    from invesalius3_amd import surface_process as sp_
+    for a, padded, iso, padv, pb, pt, sp in _pad_cases():
+        virt = sp_.marching_cubes(a, sp, [iso], 3, True, pb, pt, padv, int(pb))
+        real = sp_.marching_cubes(padded, sp, [iso], 3, False, False, False, 0.0, int(pb))
+        # (same triangles, same order; the shift is applied in float32 here, hence the last-bit tolerance)
+        assert np.abs(virt - (real + np.array([-sp[0], sp[1], 0.0], np.float32))).max() < 2e-6, (a.dtype, pb, pt)
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
