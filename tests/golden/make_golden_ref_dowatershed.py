@@ -30,7 +30,8 @@ class _Fake(types.ModuleType):
         if name.startswith("__"):
             raise AttributeError(name)
         # VTK classes are subclassed by the reference (interactor styles): they have to be real classes
-        m = type(name, (), {}) if name.startswith("vtk") else mock.MagicMock(name=self.__name__ + "." + name)
+        m = (type(name, (), {"__getattr__": lambda self_, n: (lambda *a, **k: "9.3.0" if n == "GetVTKVersion" else mock.MagicMock())}) if name.startswith("vtk")
+             else mock.MagicMock(name=self.__name__ + "." + name))
         setattr(self, name, m)
         return m
 
