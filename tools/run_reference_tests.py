@@ -57,7 +57,8 @@ def main():
             for p in started:
                 p.stop()
 
-    args = sys.argv[1:] or ["/root/reference/tests/test_segmentation_tools.py", "/root/reference/tests/test_bone_thresholding.py"]
+    args = sys.argv[1:] or ["/root/reference/tests/test_segmentation_tools.py", "/root/reference/tests/test_bone_thresholding.py",
+                            "/root/reference/tests/test_mask.py"]
     os.chdir(tmp_root)
     return pytest.main(["-q", "-p", "no:cacheprovider", "--rootdir", tmp_root] + args, plugins=[MockerPlugin()])
 
