@@ -340,6 +340,49 @@ def test_gpu_virtual_padding_equals_the_reference_pad_image(ivxlib, oracle):
         assert np.abs(virt - (real + np.array([-sp[0], sp[1], 0.0], np.float32))).max() < 2e-6, (a.dtype, pb, pt)
 
 
+def _expand_cases():
+    z = np.load(os.path.join(GOLD, "ref_expand_watershed.npz"))
+    for nm in z["names"]:
+        alg, uw, ow = str(nm).split("_")
+        yield str(nm), {"Watershed": "Watershed", "WatershedIFT": "Watershed IFT"}[alg], bool(int(uw)), bool(int(ow)), z
+
+
+def test_oracle_pipeline_equals_the_reference_expand_watershed(oracle):
+    """tests/golden/ref_expand_watershed.npz = the reference's OWN 3-D watershed tool (WaterShedInteractorStyle.expand_watershed,
+    imported; make_golden_ref_expand.py): threshold of the stale slices, do_watershed, merge rule -- both algorithms, with and
+    without window/level, overwrite on and off.  The restated stages in the same order give the same mask."""
+    from scipy import ndimage
+    st = ndimage.generate_binary_structure(3, 1)
+    for nm, alg, uw, ow, z in _expand_cases():
+        img, mk = z["img"], z["markers"]
+        m = z["mask_in"].copy()
+        oracle.do_threshold_to_all_slices(m, img, (226, 3071))
+        cost = oracle.get_LUT_value(img, 400, 300).astype("uint16") if uw else (img - img.min()).astype("uint16")
+        if alg == "Watershed":
+            lab = oracle.watershed_sk(ndimage.morphological_gradient(cost, (3, 3, 3)), mk.astype("int16"), st, 0)
+        else:
+            lab = oracle.watershed_ift(cost, mk.astype("int16" if uw else "int8"), st)
+        oracle.watershed_merge(m[1:, 1:, 1:], lab.astype(np.uint8), ow)
+        assert np.array_equal(m, z["out_" + nm]), nm
+
+
+@pytest.mark.gpu
+def test_gpu_hooks_equal_the_reference_expand_watershed(ivxlib, tmp_path):
+    from scipy import ndimage
+
+    from invesalius3_amd import slice_ as sl, watershed_process as wp
+    st = ndimage.generate_binary_structure(3, 1)
+    for nm, alg, uw, ow, z in _expand_cases():
+        img, mk = z["img"], z["markers"]
+        m = z["mask_in"].copy()
+        sl.do_threshold_to_all_slices(m, img, (226, 3071))
+        tfile = str(tmp_path / (nm + ".dat"))
+        np.memmap(tfile, shape=img.shape, dtype="uint8", mode="w+").flush()
+        wp.do_watershed(img, mk, tfile, img.shape, st, alg, (3, 3, 3), uw, 300, 400, None)
+        wp.merge(m[1:, 1:, 1:], np.array(np.memmap(tfile, shape=img.shape, dtype="uint8", mode="r")), ow)
+        assert np.array_equal(m, z["out_" + nm]), nm
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
