@@ -383,6 +383,52 @@ def test_gpu_hooks_equal_the_reference_expand_watershed(ivxlib, tmp_path):
         assert np.array_equal(m, z["out_" + nm]), nm
 
 
+def _seg_cases():
+    z = np.load(os.path.join(GOLD, "ref_3dseg.npz"))
+    for nm in z["names"]:
+        method, uw, con, _k = str(nm).split("_")
+        t0, t1, dmin, dmax = (int(v) for v in z["cfg_" + str(nm)])
+        yield str(nm), method, bool(int(uw)), int(con), t0, t1, dmin, dmax, z
+
+
+def test_oracle_composition_equals_the_reference_do_3d_seg(oracle):
+    """tests/golden/ref_3dseg.npz = six clicks through the reference's OWN FloodFillSegmentInteractorStyle.do_3d_seg (imported;
+    make_golden_ref_3dseg.py): threshold / dynamic (raw and through get_LUT_value_255) / confidence, 6 / 18 / 26 neighbours, one
+    click rejected (nothing happens, not even the threshold of the stale slices)."""
+    from scipy import ndimage
+    for nm, method, uw, con, t0, t1, dmin, dmax, z in _seg_cases():
+        img, seed = z["img"], tuple(int(v) for v in z["seed"])
+        x, y, zz = seed
+        m = z["mask_in"].copy()
+        st = ndimage.generate_binary_structure(3, {6: 1, 18: 2, 26: 3}[con])
+        fimg = oracle.get_LUT_value_255(img, 900, 400) if (uw and method != "threshold") else img
+        if method == "dynamic":
+            t0, t1 = int(fimg[zz, y, x]) - dmin, int(fimg[zz, y, x]) + dmax
+        if method != "confidence" and not (t0 <= fimg[zz, y, x] <= t1):
+            assert np.array_equal(m, z["out_" + nm]), nm
+            continue
+        oracle.do_threshold_to_all_slices(m, img, (226, 3071))
+        if method == "confidence":
+            out = oracle.do_rg_confidence(fimg, seed, st, 2.5, 3)
+        else:
+            out = np.zeros(img.shape, np.uint8)
+            oracle.floodfill_threshold(fimg, [seed], t0, t1, 1, st, out)
+        m[1:, 1:, 1:][out.astype(bool)] = 254
+        assert np.array_equal(m, z["out_" + nm]), nm
+
+
+@pytest.mark.gpu
+def test_gpu_do_3d_seg_equals_the_reference(ivxlib):
+    from invesalius3_amd import styles
+    for nm, method, uw, con, t0, t1, dmin, dmax, z in _seg_cases():
+        m = z["mask_in"].copy()
+        ok = styles.do_3d_seg(z["img"], m, tuple(int(v) for v in z["seed"]), method=method, con_3d=con, fill_value=254, t0=t0, t1=t1,
+                              dev_min=dmin, dev_max=dmax, use_ww_wl=uw, ww=900, wl=400, confid_mult=2.5, confid_iters=3,
+                              threshold_range=(226, 3071))
+        assert np.array_equal(m, z["out_" + nm]), nm
+        assert ok == (not np.array_equal(z["out_" + nm], z["mask_in"])), nm
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
