@@ -67,3 +67,37 @@ def do_3d_seg(image: np.ndarray, mask_matrix: np.ndarray, seed_xyz, method: str 
         if flood_image is not None:
             flood_image.close()
     return True
+
+
+CON2D = {4: 1, 8: 2}
+
+
+def flood_fill_mask(mask_matrix: np.ndarray, seed_xyz, target: str = "3D", orientation: str = "AXIAL", con_2d: int = 4,
+                    con_3d: int = 6, t0: int = 0, t1: int = 2, fill_value: int = 254, image: np.ndarray | None = None,
+                    threshold_range=None) -> bool:
+    """The array work of FloodFillMaskInteractorStyle.OnFFClick (invesalius/data/styles.py:2477-2569) -- the "fill holes" tool
+    (t0..t1 = 0..2 -> 254) and, with ``t0=253, t1=255, fill_value=1``, RemoveMaskPartsInteractorStyle (:2572-2589): the
+    clicked voxel must hold a value in [t0, t1] (else nothing happens: False); "3D" brings the stale slices up to date first
+    (`image` and `threshold_range` of the mask) and floods with the 6 / 18 / 26 structure, "2D" floods inside the clicked
+    slice only, with the 4 / 8 structure laid into the slice's plane (:2507-2515).  Edits `mask_matrix` in place."""
+    from . import invesalius_rs as floodfill
+    from scipy.ndimage import generate_binary_structure
+
+    if mask_matrix.dtype != np.uint8 or mask_matrix.ndim != 3:
+        raise TypeError("mask matrix must be a 3-D uint8 array")
+    x, y, z = (int(v) for v in seed_xyz)
+    mask = mask_matrix[1:, 1:, 1:]
+    if mask[z, y, x] < t0 or mask[z, y, x] > t1:
+        return False
+    if target == "3D":
+        bstruct = np.array(generate_binary_structure(3, CON3D[con_3d]), dtype="uint8")
+        if threshold_range is not None and image is not None:
+            sl.do_threshold_to_all_slices(mask_matrix, image, threshold_range)
+    else:
+        b2 = generate_binary_structure(2, CON2D[con_2d])
+        shape, where = {"AXIAL": ((1, 3, 3), (0, slice(None), slice(None))), "CORONAL": ((3, 1, 3), (slice(None), 0, slice(None))),
+                        "SAGITAL": ((3, 3, 1), (slice(None), slice(None), 0))}[orientation]
+        bstruct = np.zeros(shape, dtype="uint8")
+        bstruct[where] = b2
+    floodfill.floodfill_threshold_inplace(mask, ((x, y, z),), t0, t1, fill_value, bstruct)
+    return True

@@ -429,6 +429,45 @@ def test_gpu_do_3d_seg_equals_the_reference(ivxlib):
         assert ok == (not np.array_equal(z["out_" + nm], z["mask_in"])), nm
 
 
+def _ff_cases():
+    z = np.load(os.path.join(GOLD, "ref_ffmask.npz"))
+    for nm in z["names"]:
+        tool, target, orientation, c3, c2, _k = str(nm).split("_")
+        t0, t1, fill = (0, 2, 254) if tool == "fill" else (253, 255, 1)
+        yield str(nm), target, orientation, int(c3), int(c2), t0, t1, fill, tuple(int(v) for v in z["seed_" + str(nm)]), z
+
+
+def test_oracle_composition_equals_the_reference_fill_and_remove_tools(oracle):
+    """tests/golden/ref_ffmask.npz = nine clicks through the reference's OWN FloodFillMaskInteractorStyle.OnFFClick ("fill
+    holes": 0..2 -> 254) and RemoveMaskPartsInteractorStyle (253..255 -> 1), in 3-D and inside one slice of each orientation
+    (imported; make_golden_ref_ffmask.py); two clicks land on a value outside the tool's range and change nothing."""
+    from scipy import ndimage
+    for nm, target, orientation, c3, c2, t0, t1, fill, seed, z in _ff_cases():
+        m = z["mask_in"].copy()
+        x, y, zz = seed
+        if t0 <= m[1:, 1:, 1:][zz, y, x] <= t1:
+            if target == "3D":
+                oracle.do_threshold_to_all_slices(m, z["img"], (226, 3071))
+                st = ndimage.generate_binary_structure(3, {6: 1, 18: 2, 26: 3}[c3]).astype(np.uint8)
+            else:
+                b2 = ndimage.generate_binary_structure(2, {4: 1, 8: 2}[c2])
+                st = np.zeros({"AXIAL": (1, 3, 3), "CORONAL": (3, 1, 3), "SAGITAL": (3, 3, 1)}[orientation], np.uint8)
+                st[{"AXIAL": (0, slice(None), slice(None)), "CORONAL": (slice(None), 0, slice(None)),
+                    "SAGITAL": (slice(None), slice(None), 0)}[orientation]] = b2
+            oracle.floodfill_threshold_inplace(m[1:, 1:, 1:], [seed], t0, t1, fill, st)
+        assert np.array_equal(m, z["out_" + nm]), nm
+
+
+@pytest.mark.gpu
+def test_gpu_flood_fill_mask_equals_the_reference_tools(ivxlib):
+    from invesalius3_amd import styles
+    for nm, target, orientation, c3, c2, t0, t1, fill, seed, z in _ff_cases():
+        m = z["mask_in"].copy()
+        ok = styles.flood_fill_mask(m, seed, target, orientation, c2, c3, t0, t1, fill, image=z["img"], threshold_range=(226, 3071))
+        assert np.array_equal(m, z["out_" + nm]), nm
+        assert ok == (not np.array_equal(z["out_" + nm], z["mask_in"])), nm
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
