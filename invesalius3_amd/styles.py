@@ -101,3 +101,26 @@ def flood_fill_mask(mask_matrix: np.ndarray, seed_xyz, target: str = "3D", orien
         bstruct[where] = b2
     floodfill.floodfill_threshold_inplace(mask, ((x, y, z),), t0, t1, fill_value, bstruct)
     return True
+
+
+def select_mask_part(mask_matrix: np.ndarray, select_matrix: np.ndarray, seed_xyz, con_3d: int = 6, remove: bool = False,
+                     image: np.ndarray | None = None, threshold_range=None):
+    """The array work of SelectMaskPartsInteractorStyle.OnSelect (invesalius/data/styles.py:2883-2960): after the threshold of
+    the stale slices, a click copies the connected part of `mask_matrix` (values 253..255) that holds the clicked voxel into
+    the selection mask as 254; a Ctrl+click (`remove`) clears the connected part of the SELECTION (254..255 -> 0) that holds
+    it.  Both matrices are the padded (dz+1, dy+1, dx+1) uint8 matrices; `select_matrix` is edited in place."""
+    from . import invesalius_rs as floodfill
+    from scipy.ndimage import generate_binary_structure
+
+    x, y, z = (int(v) for v in seed_xyz)
+    shape = mask_matrix.shape
+    if x < 0 or y < 0 or z < 0 or z >= shape[0] - 1 or y >= shape[1] - 1 or x >= shape[2] - 1:
+        return
+    bstruct = np.array(generate_binary_structure(3, CON3D[con_3d]), dtype="uint8")
+    if threshold_range is not None and image is not None:
+        sl.do_threshold_to_all_slices(mask_matrix, image, threshold_range)
+    sel = select_matrix[1:, 1:, 1:]
+    if remove:
+        floodfill.floodfill_threshold(sel, ((x, y, z),), 254, 255, 0, bstruct, sel)
+    else:
+        floodfill.floodfill_threshold(mask_matrix[1:, 1:, 1:], ((x, y, z),), 253, 255, 254, bstruct, sel)

@@ -468,6 +468,36 @@ def test_gpu_flood_fill_mask_equals_the_reference_tools(ivxlib):
         assert ok == (not np.array_equal(z["out_" + nm], z["mask_in"])), nm
 
 
+def test_oracle_composition_equals_the_reference_select_parts_tool(oracle):
+    """tests/golden/ref_select.npz = three clicks through the reference's OWN SelectMaskPartsInteractorStyle.OnSelect (imported;
+    make_golden_ref_select.py): select a part, select a second one, Ctrl+click the first one away again."""
+    from scipy import ndimage
+    z = np.load(os.path.join(GOLD, "ref_select.npz"))
+    st = ndimage.generate_binary_structure(3, 1)
+    m, sel = z["mask_in"].copy(), np.zeros_like(z["mask_in"])
+    for k, (seed, remove) in enumerate(((z["seeds"][0], False), (z["seeds"][1], False), (z["seeds"][0], True))):
+        seed = tuple(int(v) for v in seed)
+        oracle.do_threshold_to_all_slices(m, z["img"], (900, 3071))
+        s3 = sel[1:, 1:, 1:]
+        if remove:
+            oracle.floodfill_threshold(s3, [seed], 254, 255, 0, st, s3)
+        else:
+            oracle.floodfill_threshold(m[1:, 1:, 1:], [seed], 253, 255, 254, st, s3)
+        assert np.array_equal(sel, z["sel_%d" % k]), k
+    assert np.array_equal(m, z["mask_after"]) and (z["sel_2"] == 254).sum() == 192
+
+
+@pytest.mark.gpu
+def test_gpu_select_mask_part_equals_the_reference_tool(ivxlib):
+    from invesalius3_amd import styles
+    z = np.load(os.path.join(GOLD, "ref_select.npz"))
+    m, sel = z["mask_in"].copy(), np.zeros_like(z["mask_in"])
+    for k, (seed, remove) in enumerate(((z["seeds"][0], False), (z["seeds"][1], False), (z["seeds"][0], True))):
+        styles.select_mask_part(m, sel, tuple(int(v) for v in seed), 6, remove, image=z["img"], threshold_range=(900, 3071))
+        assert np.array_equal(sel, z["sel_%d" % k]), k
+    assert np.array_equal(m, z["mask_after"])
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
