@@ -124,3 +124,46 @@ def select_mask_part(mask_matrix: np.ndarray, select_matrix: np.ndarray, seed_xy
         floodfill.floodfill_threshold(sel, ((x, y, z),), 254, 255, 0, bstruct, sel)
     else:
         floodfill.floodfill_threshold(mask_matrix[1:, 1:, 1:], ((x, y, z),), 253, 255, 254, bstruct, sel)
+
+
+BRUSH_FOREGROUND, BRUSH_BACKGROUND = 1, 2  # invesalius/constants.py
+
+
+def watershed_brush_release(image_matrix: np.ndarray, mask_matrix: np.ndarray, markers_matrix: np.ndarray, n: int,
+                            orientation: str = "AXIAL", algorithm: str = "Watershed", con_2d: int = 4, mg_size=3,
+                            use_ww_wl: bool = True, wl=0, ww=0, overwrite: bool = False) -> bool:
+    """The array work of WaterShedInteractorStyle.OnBrushRelease (invesalius/data/styles.py:1926-1997), the 2-D watershed of the
+    slice the brush was released on: slice `n` of the image, of the markers and of the padded mask matrix along `orientation`
+    (the AXIAL branch also sets the slice's "thresholded" flag, :1932), nothing unless both brush values are present, then the
+    cost / gradient image, the flood with the 4 / 8 structure and the merge rule of :1984-1989, in place on the mask.
+    The reference's IFT branch without window/level computes ``image - image.min().astype("uint16")`` -- not an unsigned image
+    -- and scipy refuses it: TypeError, here as there."""
+    from scipy.ndimage import generate_binary_structure
+
+    from . import watershed_process as wp
+
+    if orientation == "AXIAL":
+        image, mask, markers = image_matrix[n], mask_matrix[n + 1, 1:, 1:], markers_matrix[n]
+        mask_matrix[n + 1, 0, 0] = 1
+    elif orientation == "CORONAL":
+        image, mask, markers = image_matrix[:, n, :], mask_matrix[1:, n + 1, 1:], markers_matrix[:, n, :]
+    elif orientation == "SAGITAL":
+        image, mask, markers = image_matrix[:, :, n], mask_matrix[1:, 1:, n + 1], markers_matrix[:, :, n]
+    else:
+        raise ValueError("orientation must be AXIAL, CORONAL or SAGITAL")
+    if not ((markers == BRUSH_BACKGROUND).any() and (markers == BRUSH_FOREGROUND).any()):
+        return False
+    bstruct = generate_binary_structure(2, CON2D[con_2d])
+    image = np.ascontiguousarray(image)
+    mk = np.ascontiguousarray(markers).astype("int16")
+    if algorithm == "Watershed":
+        tmp_mask = wp.watershed(wp.cost_image(image, use_ww_wl, wl, ww, mg_size), mk, bstruct)
+    elif use_ww_wl:
+        tmp_mask = wp.watershed_ift(wp.cost_image(image, True, wl, ww, 0), mk, bstruct)
+    else:
+        raise TypeError("only 8 and 16 unsigned inputs are supported")  # scipy's message for the reference's int image (:1975-1976)
+    tmp = np.ascontiguousarray(tmp_mask.astype(np.uint8))
+    m2 = np.ascontiguousarray(mask)
+    wp.merge(m2, tmp, bool(overwrite))
+    mask[...] = m2
+    return True

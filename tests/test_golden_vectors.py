@@ -498,6 +498,57 @@ def test_gpu_select_mask_part_equals_the_reference_tool(ivxlib):
     assert np.array_equal(m, z["mask_after"])
 
 
+def _brush_cases():
+    z = np.load(os.path.join(GOLD, "ref_brush_watershed.npz"))
+    for nm in z["names"]:
+        orientation, n, alg, uw, ow = str(nm).split("_")
+        yield (str(nm), orientation, int(n), {"Watershed": "Watershed", "WatershedIFT": "Watershed IFT"}[alg], bool(int(uw)), bool(int(ow)),
+               str(z["err_" + str(nm)]), z)
+
+
+def test_oracle_composition_equals_the_reference_brush_release(oracle):
+    """tests/golden/ref_brush_watershed.npz = sixteen runs of the reference's OWN WaterShedInteractorStyle.OnBrushRelease (imported;
+    make_golden_ref_brush.py): the 2-D watershed of one slice along each orientation.  Its IFT branch without window/level
+    hands scipy a signed image and dies with scipy's TypeError (after setting the AXIAL slice flag): part of the vectors."""
+    from scipy import ndimage
+    st = ndimage.generate_binary_structure(2, 1)
+    for nm, orientation, n, alg, uw, ow, err, z in _brush_cases():
+        img, mk3, m = z["img"], z["markers"], z["mask_in"].copy()
+        if orientation == "AXIAL":
+            image, mask, mk = img[n], m[n + 1, 1:, 1:], mk3[n]
+            m[n + 1, 0, 0] = 1
+        elif orientation == "CORONAL":
+            image, mask, mk = img[:, n, :], m[1:, n + 1, 1:], mk3[:, n, :]
+        else:
+            image, mask, mk = img[:, :, n], m[1:, 1:, n + 1], mk3[:, :, n]
+        if alg == "Watershed IFT" and not uw:
+            assert err.startswith("TypeError: only 8 and 16 unsigned inputs")
+        else:
+            assert err == ""
+            cost = oracle.get_LUT_value(image, 400, 300).astype("uint16") if uw else (image - image.min()).astype("uint16")
+            if alg == "Watershed":
+                lab = oracle.watershed_sk(ndimage.morphological_gradient(cost, 3), mk.astype("int16"), st, 0)
+            else:
+                lab = oracle.watershed_ift(np.ascontiguousarray(cost), np.ascontiguousarray(mk.astype("int16")), st)
+            tmp = np.ascontiguousarray(mask)
+            oracle.watershed_merge(tmp, lab.astype(np.uint8), ow)
+            mask[...] = tmp
+        assert np.array_equal(m, z["out_" + nm]), nm
+
+
+@pytest.mark.gpu
+def test_gpu_watershed_brush_release_equals_the_reference(ivxlib):
+    from invesalius3_amd import styles
+    for nm, orientation, n, alg, uw, ow, err, z in _brush_cases():
+        m = z["mask_in"].copy()
+        if err:
+            with pytest.raises(TypeError, match="only 8 and 16 unsigned inputs"):
+                styles.watershed_brush_release(z["img"], m, z["markers"], n, orientation, alg, 4, 3, uw, 300, 400, ow)
+        else:
+            assert styles.watershed_brush_release(z["img"], m, z["markers"], n, orientation, alg, 4, 3, uw, 300, 400, ow)
+        assert np.array_equal(m, z["out_" + nm]), nm
+
+
 def _ref_ws():
     z = np.load(os.path.join(GOLD, "ref_do_watershed.npz"))
     for nm in z["names"]:
