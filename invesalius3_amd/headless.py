@@ -119,8 +119,8 @@ def run(args) -> dict:
 
 
 def _strct(conn: int) -> np.ndarray:
-    from scipy import ndimage
-    return ndimage.generate_binary_structure(3, {6: 1, 18: 2, 26: 3}[conn]).astype(np.uint8)
+    from .mask import CON3D, _structure
+    return _structure(3, CON3D[conn])
 
 
 def main(argv=None) -> int:

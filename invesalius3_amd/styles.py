@@ -81,7 +81,6 @@ def flood_fill_mask(mask_matrix: np.ndarray, seed_xyz, target: str = "3D", orien
     (`image` and `threshold_range` of the mask) and floods with the 6 / 18 / 26 structure, "2D" floods inside the clicked
     slice only, with the 4 / 8 structure laid into the slice's plane (:2507-2515).  Edits `mask_matrix` in place."""
     from . import invesalius_rs as floodfill
-    from scipy.ndimage import generate_binary_structure
 
     if mask_matrix.dtype != np.uint8 or mask_matrix.ndim != 3:
         raise TypeError("mask matrix must be a 3-D uint8 array")
@@ -90,11 +89,11 @@ def flood_fill_mask(mask_matrix: np.ndarray, seed_xyz, target: str = "3D", orien
     if mask[z, y, x] < t0 or mask[z, y, x] > t1:
         return False
     if target == "3D":
-        bstruct = np.array(generate_binary_structure(3, CON3D[con_3d]), dtype="uint8")
+        bstruct = _structure(3, CON3D[con_3d])
         if threshold_range is not None and image is not None:
             sl.do_threshold_to_all_slices(mask_matrix, image, threshold_range)
     else:
-        b2 = generate_binary_structure(2, CON2D[con_2d])
+        b2 = _structure(2, CON2D[con_2d])
         shape, where = {"AXIAL": ((1, 3, 3), (0, slice(None), slice(None))), "CORONAL": ((3, 1, 3), (slice(None), 0, slice(None))),
                         "SAGITAL": ((3, 3, 1), (slice(None), slice(None), 0))}[orientation]
         bstruct = np.zeros(shape, dtype="uint8")
@@ -110,13 +109,12 @@ def select_mask_part(mask_matrix: np.ndarray, select_matrix: np.ndarray, seed_xy
     the selection mask as 254; a Ctrl+click (`remove`) clears the connected part of the SELECTION (254..255 -> 0) that holds
     it.  Both matrices are the padded (dz+1, dy+1, dx+1) uint8 matrices; `select_matrix` is edited in place."""
     from . import invesalius_rs as floodfill
-    from scipy.ndimage import generate_binary_structure
 
     x, y, z = (int(v) for v in seed_xyz)
     shape = mask_matrix.shape
     if x < 0 or y < 0 or z < 0 or z >= shape[0] - 1 or y >= shape[1] - 1 or x >= shape[2] - 1:
         return
-    bstruct = np.array(generate_binary_structure(3, CON3D[con_3d]), dtype="uint8")
+    bstruct = _structure(3, CON3D[con_3d])
     if threshold_range is not None and image is not None:
         sl.do_threshold_to_all_slices(mask_matrix, image, threshold_range)
     sel = select_matrix[1:, 1:, 1:]
@@ -138,8 +136,6 @@ def watershed_brush_release(image_matrix: np.ndarray, mask_matrix: np.ndarray, m
     cost / gradient image, the flood with the 4 / 8 structure and the merge rule of :1984-1989, in place on the mask.
     The reference's IFT branch without window/level computes ``image - image.min().astype("uint16")`` -- not an unsigned image
     -- and scipy refuses it: TypeError, here as there."""
-    from scipy.ndimage import generate_binary_structure
-
     from . import watershed_process as wp
 
     if orientation == "AXIAL":
@@ -153,7 +149,7 @@ def watershed_brush_release(image_matrix: np.ndarray, mask_matrix: np.ndarray, m
         raise ValueError("orientation must be AXIAL, CORONAL or SAGITAL")
     if not ((markers == BRUSH_BACKGROUND).any() and (markers == BRUSH_FOREGROUND).any()):
         return False
-    bstruct = generate_binary_structure(2, CON2D[con_2d])
+    bstruct = _structure(2, CON2D[con_2d])
     image = np.ascontiguousarray(image)
     mk = np.ascontiguousarray(markers).astype("int16")
     if algorithm == "Watershed":

@@ -74,8 +74,8 @@ def watershed_ift(image: np.ndarray, markers: np.ndarray, structure=None, want_c
     if image.ndim not in (2, 3) or markers.shape != image.shape:
         raise RuntimeError("input and markers must have equal shape")
     if structure is None:
-        from scipy.ndimage import generate_binary_structure
-        structure = generate_binary_structure(image.ndim, 1)
+        from .mask import _structure
+        structure = _structure(image.ndim, 1)
     s3 = _strct27(structure, image.ndim)
     img = np.ascontiguousarray(image)
     mk = np.ascontiguousarray(markers)
@@ -113,8 +113,8 @@ def watershed(image: np.ndarray, markers: np.ndarray, connectivity=None, want_co
     if markers.shape != image.shape:  # scikit-image's message (_validate_inputs)
         raise ValueError("`markers` (shape {}) must have same shape as `image` (shape {})".format(markers.shape, image.shape))
     if connectivity is None:
-        from scipy.ndimage import generate_binary_structure
-        connectivity = generate_binary_structure(image.ndim, 1)
+        from .mask import _structure
+        connectivity = _structure(image.ndim, 1)
     s3 = _strct27(connectivity, image.ndim)
     img = np.ascontiguousarray(image)
     mk = np.ascontiguousarray(markers)
