@@ -43,12 +43,14 @@ def test_no_device_is_a_loud_error_not_a_fallback():
 
 def test_product_never_imports_oracle():
     """No line of the product package imports, dlopens, links or includes anything under oracle/, and none imports torch
-    (the communicator is RCCL behind the C ABI): checked line by line, no exceptions."""
+    (the communicator is RCCL behind the C ABI) or scipy / scikit-image / VTK (what the reference computes with on the CPU):
+    checked line by line, no exceptions."""
     import re
     pkg = os.path.join(ROOT, "invesalius3_amd")
     bad_oracle = re.compile(r"(^\s*(from|import)\s+oracle\b|^\s*from\s+\.+oracle\b|import_module\([\"']oracle|"
                             r"CDLL\([^)]*oracle|dlopen\([^)]*oracle|#\s*include\s*[<\"][^>\"]*oracle|libivx_oracle)")
     bad_torch = re.compile(r"^\s*(from|import)\s+torch\b")
+    bad_cpu_lib = re.compile(r"^\s*(from|import)\s+(scipy|skimage|sklearn|vtk|vtkmodules)\b")  # no third-party CPU arithmetic either
     seen = 0
     for dirpath, dirs, files in os.walk(pkg):
         dirs[:] = [d for d in dirs if d not in ("build", "__pycache__")]
@@ -59,6 +61,7 @@ def test_product_never_imports_oracle():
             for n, line in enumerate(open(os.path.join(dirpath, f), errors="replace"), 1):
                 assert not bad_oracle.search(line), "%s:%d reaches into oracle/: %s" % (f, n, line.strip())
                 assert not bad_torch.search(line), "%s:%d imports torch: %s" % (f, n, line.strip())
+                assert not bad_cpu_lib.search(line), "%s:%d imports a CPU library: %s" % (f, n, line.strip())
     assert seen > 20
     # build.py links only the package's own objects
     assert "oracle" not in open(os.path.join(pkg, "build.py")).read()
