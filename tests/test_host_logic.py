@@ -190,3 +190,19 @@ def test_slab_region_grow_counts_its_collectives_and_host_reads():
     be, comm = Backend([0]), Comm([1, 0])
     par.slab_region_grow(be, comm, par.slab_layout(2, 3, 8))
     assert comm.args[0][:4] == ("down", "rdown", None, None)
+
+
+def test_get_image_slice_plain_slices_and_the_missing_lmip_export():
+    """slice_.get_image_slice without a projection is pure slicing (no device needed): one slice along each orientation,
+    whatever slab thickness is asked for (slice_.py:847-848); the LMIP type dies like the reference's missing export."""
+    import numpy as np
+    import pytest
+    from invesalius3_amd import slice_ as sl
+    a = np.arange(4 * 5 * 6, dtype=np.int16).reshape(4, 5, 6)
+    assert np.array_equal(sl.get_image_slice(a, "AXIAL", 2, 3), a[2])
+    assert np.array_equal(sl.get_image_slice(a, "CORONAL", 1, 4, inverted=True), a[:, 1, :])
+    assert np.array_equal(sl.get_image_slice(a, "SAGITAL", 5), a[:, :, 5])
+    with pytest.raises(AttributeError):
+        sl.get_image_slice(a, "AXIAL", 0, 2, False, 1.0, sl.PROJECTION_LMIP, 100)
+    with pytest.raises(KeyError):
+        sl.get_image_slice(a, "OBLIQUE", 0)
