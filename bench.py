@@ -163,6 +163,7 @@ def launch_ranks(args):
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), IVX_COMM_FILE=idfile,
+                   IVX_COMM_NONCE="%d-%.6f" % (os.getpid(), time.time()),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -200,6 +201,32 @@ class CStdoutToStderr:
         os.dup2(2, 1)
 
 
+def dry_comm(world):
+    """--dry-comm: communicator up, ivx_comm_selftest on every rank, one JSON line from rank 0"""
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.comm import RcclComm, init_from_env
+
+    rank = int(os.environ.get("RANK", "0"))
+    t0 = time.perf_counter()
+    with CStdoutToStderr():
+        if world > 1:
+            comm = init_from_env()
+        else:
+            L.set_device(0)
+            comm = RcclComm(0, 1, RcclComm.unique_id())
+        t1 = time.perf_counter()
+        comm.selftest()
+        comm.barrier()
+        t2 = time.perf_counter()
+    if rank == 0:
+        print(json.dumps({"dry_comm": "ok", "n_gpus": world, "init_s": round(t1 - t0, 3), "selftest_s": round(t2 - t1, 3),
+                          "checked": "ivx_comm_exchange, _exchange_vote, _allreduce (sum/max/min), _allgather, _bcast, _send/_recv"
+                                     + (" + RCCL driven directly on the one-rank communicator" if world == 1 else ""),
+                          "device": L.device_name()}), flush=True)
+    CStdoutToStderr.stay()
+    comm.close()
+
+
 class Ranks:
     """what the timing contract needs from the job: barrier, max over ranks, sums -- over RCCL, or trivially at N = 1"""
 
@@ -212,6 +239,10 @@ class Ranks:
             from invesalius3_amd.comm import init_from_env
             with CStdoutToStderr():
                 self.comm = init_from_env()
+                # every ivx_comm_* entry point once on 4 KB buffers, checked against the analytic answer: a broken link or
+                # a wrong rank order fails HERE, in the first second, with the name of the collective -- not as a hang in
+                # the first region-growing round
+                self.comm.selftest()
 
     def barrier(self):
         from invesalius3_amd import _lib as L
@@ -373,6 +404,9 @@ def run_grow_mc(args, job):
         "mtriangles_per_s": round(ntri / (mc_ms * 1e-3) / 1e6, 2) if mc_ms > 0 else None,
         "triangles": ntri_all, "region_voxels": reached_all, "region_grow_rounds": rounds,
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "region_grow_ms_min_med_max": [round(float(f(spans["region_grow"])), 4) for f in (np.min, np.median, np.max)]
+        if len(spans.get("region_grow", [])) else None,
+        "timed_region_s": round(dt, 6),
         "stage_ms_source": "region_grow: HIP events inside the timed steps; other stages: HIP events in up to 5 extra steps "
                            "after the timed region, one stage after the other (every recorded event idles the stream for ~4 us)",
         "stage_mvoxel_per_s": {k: round(nvox / (v * 1e-3) / 1e6, 1) for k, v in stage_time.items() if v > 0},
@@ -517,13 +551,22 @@ def run_watershed(args, job):
         res["cpu_baseline"] = {"value": round(sub.size / ts / 1e6, 3), "unit": "Mvoxel/s", "cores": 1, "kind": "reference",
                                "sample": "live scipy.ndimage.watershed_ift (the call of watershed_process.py:57) on the first %d "
                                          "slices (%d voxels), %.2f s" % (sl, sub.size, ts)}
-        res["parity"] = {"ok": bool(np.array_equal(got, clean)),
-                         "mismatch_vs_defect_free_oracle": int((got != clean).sum()),
-                         "mismatch_vs_live_scipy": int((got != sci).sum()), "sample_voxels": int(sub.size),
+        # The reference IS live scipy: `ok` and `differs_from_reference` are the comparison with it.  The comparison with the
+        # defect-free statement of the same algorithm is reported next to it, and only THAT one aborts the run (a difference
+        # there is a bug here; a difference from scipy downstream of its own linked-list defect is a stated deviation).
+        n_ref, n_clean = int((got != sci).sum()), int((got != clean).sum())
+        res["differs_from_reference"] = n_ref
+        res["parity"] = {"ok": n_ref == 0, "reference": "live scipy.ndimage.watershed_ift (the reference's call)",
+                         "differs_from_reference": n_ref, "sample_voxels": int(sub.size),
+                         "equals_defect_free_statement": n_clean == 0,
+                         "mismatch_vs_defect_free_oracle": n_clean,
+                         "mismatch_vs_live_scipy": n_ref,
                          "scipy_defect_events": {"requeued_unlinked": ev[0], "popped_late": ev[1], "popped_twice": ev[2], "never_popped": ev[3]},
-                         "note": "the GPU flood equals the defect-free statement of NI_WatershedIFT bit for bit; live scipy differs from "
-                                 "that statement only downstream of its linked-list defect (ni_measure.c: `if (p->next || p->prev)`)"}
-        if not res["parity"]["ok"]:
+                         "note": "bit-exact integer masks are the contract: %d of %d sample voxels differ from the reference.  The GPU flood "
+                                 "equals the defect-free statement of NI_WatershedIFT bit for bit; live scipy leaves that statement only "
+                                 "downstream of its linked-list defect (ni_measure.c: `if (p->next || p->prev)`), whose events are "
+                                 "counted above" % (n_ref, sub.size)}
+        if n_clean:
             print(json.dumps(res), flush=True)
             raise SystemExit("bench.py: watershed differs from the defect-free oracle")
     else:
@@ -650,14 +693,20 @@ def run_watershed_sk(args, job):
                                "sample": "the (value, age) binary-heap flood of skimage.segmentation.watershed restated in C and pinned to "
                                          "scikit-image 0.18.3's compiled kernel (tests/golden/watershed_sk.npz), on the first %d slices "
                                          "(%d voxels), %.2f s" % (sl, sub.size, ts)}
-        res["parity"] = {"ok": bool(np.array_equal(got, raster)),
+        # the reference is scikit-image's heap flood (pinned move for move by `heap`): `ok` is the comparison with IT
+        n_ref = int((got != heap).sum())
+        res["differs_from_reference"] = n_ref
+        res["parity"] = {"ok": n_ref == 0, "reference": "scikit-image's (value, age) heap flood, heap-ordered marker ties "
+                                                         "(C restatement pinned to the compiled 0.18.3 kernel)",
+                         "differs_from_reference": n_ref,
+                         "equals_raster_tie_statement": bool(np.array_equal(got, raster)),
                          "mismatch_vs_serial_flood_raster_marker_ties": int((got != raster).sum()),
-                         "mismatch_vs_serial_flood_heap_marker_ties": int((got != heap).sum()),
+                         "mismatch_vs_serial_flood_heap_marker_ties": n_ref,
                          "tied_markers_of_different_labels": gst["tied_markers_of_different_labels"], "sample_voxels": int(sub.size),
                          "note": "the GPU flood equals the serial flood bit for bit when equal-valued marker voxels are taken in raster "
                                  "order; scikit-image's heap takes them in an order that depends on its array layout, which matters "
                                  "only where tied markers of different labels compete (second count)"}
-        if not res["parity"]["ok"]:
+        if not res["parity"]["equals_raster_tie_statement"]:
             print(json.dumps(res), flush=True)
             raise SystemExit("bench.py: watershed_sk differs from the serial flood")
     else:
@@ -888,6 +937,8 @@ def main():
     ap.add_argument("--ws-raw", action="store_true", help="watershed_sk: the image - image.min() branch instead of the GUI's default window/level")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false", help="skip the CPU baseline + full-size parity check")
     ap.add_argument("--cpu-slices", type=int, default=None, help="(kept for old command lines; 0 = --no-cpu)")
+    ap.add_argument("--dry-comm", action="store_true", help="bring the communicator up, run ivx_comm_selftest on every rank "
+                    "(at --gpus 1: on a one-rank RCCL communicator), print one JSON line and exit")
     args = ap.parse_args()
     if args.cpu_slices == 0:
         args.cpu = False
@@ -902,6 +953,8 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     from invesalius3_amd import _lib as L
     L.require_device()
+    if args.dry_comm:
+        return dry_comm(world)
     job = Ranks()
     {"grow_mc": run_grow_mc, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048}[args.config](args, job)
     if job.comm is not None:

@@ -370,6 +370,13 @@ int ivx_dev_flood_seed(const ivx_flood_plan *p, int dtype, const void *data, dou
 /* grow `reached` inside `cand` to the fix-point; *rounds (host, may be NULL) = global rounds used */
 int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch,
                       int *rounds, void *stream);
+/* ivx_dev_flood_clear + ivx_dev_flood_seed + ivx_dev_flood_run in one call: floodfill.rs:96-166 from `seeds` over `cand`
+ * into `reached`, whose previous contents are discarded.  With <= 16 seeds and scipy's 6 / 18 / 26 structure the clearing
+ * and the seeding ride on the coarse pass (no separate pass over the plane, two launches fewer); IVX_FLOOD_FUSED=0 runs the
+ * three calls one after the other (same bits). */
+int ivx_dev_flood_grow(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                       const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached, void *scratch,
+                       int *rounds, void *stream);
 /* Gate for background work (e.g. the next stage's mask-independent passes on a second, low-priority stream): the next
  * ivx_dev_flood_run on `scratch` stores `value` to the device word `word` from the first round that starts with fewer
  * than `below_tiles` tiles -- its throughput-bound head is over -- or when it returns, if no round did.
@@ -617,6 +624,10 @@ int ivx_comm_allgather(void *comm, const void *send, void *recv, size_t nbytes, 
 int ivx_comm_bcast(void *comm, void *buf, size_t nbytes, int root, void *stream);
 int ivx_comm_send(void *comm, const void *buf, size_t nbytes, int peer, void *stream);
 int ivx_comm_recv(void *comm, void *buf, size_t nbytes, int peer, void *stream);
+/* Every entry point above once, on 4 KB buffers, checked against the analytic answer; the error names the collective that
+ * failed.  Collective: every rank calls it.  At world 1, where the entry points never reach RCCL, it drives RCCL directly
+ * on the one-rank communicator (all-reduce, all-gather, broadcast, a grouped send + receive to itself). */
+int ivx_comm_selftest(void *comm, void *stream);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,11 @@ class RcclComm(HostArrayOps):
         L.check(L.lib().ivx_comm_allgather(self._h, _vp(send), _vp(recv), ctypes.c_size_t(int(nbytes)), stream),
                 "ivx_comm_allgather")
 
+    def selftest(self, stream=None):
+        """every ivx_comm_* entry point once on small buffers against the analytic answer (collective: all ranks call
+        it); raises RuntimeError naming the collective that failed"""
+        L.check(L.lib().ivx_comm_selftest(self._h, stream), "ivx_comm_selftest")
+
     def bcast(self, ptr, nbytes: int, root: int, stream):
         L.check(L.lib().ivx_comm_bcast(self._h, _vp(ptr), ctypes.c_size_t(int(nbytes)), int(root), stream), "ivx_comm_bcast")
 
@@ -163,6 +168,16 @@ def rendezvous_file() -> str:
                         "ivx_comm_%d_%s_%s.id" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), run))
 
 
+def _nonce() -> bytes:
+    """32 bytes every rank of ONE launch derives alike and a stale file of another launch cannot carry: the launcher's
+    pid, the rendezvous port, the elastic run id and (when the launcher exports one, as bench.py does) IVX_COMM_NONCE."""
+    import hashlib
+
+    key = "%d|%s|%s|%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", ""),
+                           os.environ.get("IVX_COMM_NONCE", ""))
+    return hashlib.sha256(key.encode()).digest()
+
+
 def init_from_env(timeout_s: float = 300.0) -> RcclComm:
     """RANK / WORLD_SIZE / LOCAL_RANK from the environment (torchrun's or bench.py's own launcher); selects the device,
     exchanges the id through `rendezvous_file()` and brings the communicator up."""
@@ -174,24 +189,31 @@ def init_from_env(timeout_s: float = 300.0) -> RcclComm:
                            % (rank, local, L.device_count()))
     L.set_device(local)
     path = rendezvous_file()
+    t_start = time.time()
     if rank == 0:
+        # a crashed run may have left an id behind under the same name: it must never be mistaken for this run's.  The
+        # file is replaced atomically (written next to it, private, then renamed) and carries this launch's nonce in
+        # front of the id; the readers below also refuse anything older than their own start.
         cid = RcclComm.unique_id()
         tmp = "%s.%d.tmp" % (path, os.getpid())
-        with open(tmp, "wb") as f:
-            f.write(cid)
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(_nonce() + cid)
         os.replace(tmp, path)
     else:
-        t0 = time.time()
+        want = _nonce()
         while True:
             try:
-                if os.path.getsize(path) == 128 and time.time() - os.path.getmtime(path) < 3600:
+                if os.path.getsize(path) == len(want) + 128 and os.path.getmtime(path) >= t_start - 120.0:
                     with open(path, "rb") as f:
-                        cid = f.read()
-                    break
+                        blob = f.read()
+                    if blob[:len(want)] == want and len(blob) == len(want) + 128:
+                        cid = blob[len(want):]
+                        break
             except OSError:
                 pass
-            if time.time() - t0 > timeout_s:
-                raise RuntimeError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout_s))
+            if time.time() - t_start > timeout_s:
+                raise RuntimeError("rank %d: no RCCL id of this launch at %s after %.0f s" % (rank, path, timeout_s))
             time.sleep(0.02)
     comm = RcclComm(rank, world, cid)
     comm.barrier()

@@ -48,6 +48,11 @@ constexpr int NT = TY * TZ;           // lanes per tile workgroup (one per word)
 constexpr int HY = TY + 2, HZ = TZ + 2;
 constexpr int BATCH = 8;              // most rounds the host may keep queued ahead (the counter ring has 2 * BATCH entries)
 constexpr int SUB = 1;                // gather/update steps per termination vote (measured: 4 doubles the tile time)
+// dirty-byte bits: bit 0 = "on (or to be put on) a round's list"; CLOSED = every candidate of the tile is reached, so no
+// news can ever change it again (sticky for the rest of the flood; the byte is then never 0 and the enlisting atomicOr of a
+// neighbour finds it "already marked": closed tiles cost no visits -- about a third of the second round's list on the bench
+// volume); ENLISTED (coarse pass) further down
+constexpr unsigned int CLOSED = 0x40u;
 
 struct Tiles {
     int64_t dz, dy, dx, wx;
@@ -281,6 +286,7 @@ struct TileLds {
     unsigned long long sD[HZ * HY];
     unsigned char sCL[HZ * HY], sCR[HZ * HY];
     unsigned int dirs;
+    unsigned int open; // some candidate of the tile is still unreached after this visit
     unsigned int vote[2]; // workgroup "anything changed" vote, double-buffered: ONE s_barrier per iteration
 };
 
@@ -425,6 +431,7 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dirs |= __shfl_xor(dirs, o, 64);
     if ((threadIdx.x & 63) == 0 && dirs) atomicOr(&L.dirs, dirs);
+    if (__any((c & ~r) != 0ull) && (threadIdx.x & 63) == 0) L.open = 1u;
 }
 
 // ---- directed tile update (floodfill_auto_threshold) -------------------------------------------------------------
@@ -510,6 +517,7 @@ __device__ __forceinline__ void tile_update_dir(const Tiles &t, const unsigned l
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dirs |= __shfl_xor(dirs, o, 64);
     if ((threadIdx.x & 63) == 0 && dirs) atomicOr(&L.dirs, dirs);
+    if (threadIdx.x == 0) L.open = 1u; // (edge planes: no candidate plane to be exhausted)
 }
 
 // diagnostic only (not part of include/ivx.h): cycle stamps written under IVX_FLOOD_DBG=1, see tools/dbg_tile.py
@@ -526,7 +534,7 @@ extern "C" int ivx_debug_read(unsigned long long *out16) {
 __global__ void k_flood_build_list(Tiles t, const uint8_t *__restrict__ dirty, unsigned int *__restrict__ list,
                                    unsigned int *__restrict__ count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < t.ntiles && dirty[i]) list[atomicAdd(count, 1u)] = (unsigned int)i;
+    if (i < t.ntiles && (dirty[i] & 1u)) list[atomicAdd(count, 1u)] = (unsigned int)i;
 }
 
 // `line` (pinned host memory, ivx::progress_line): word 0 = tag | round + 1 | tiles on this round's list, stored as the
@@ -557,6 +565,7 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
         if (threadIdx.x == 0) {
             dirty_cur[tile] = 0;
             L.dirs = 0;
+            L.open = 0;
         }
         __syncthreads();
         const bool dbg = (t.strct >> 30 & 1u) && li == 0; // IVX_FLOOD_DBG: cycle stamps of the first tile (tools/dbg_tile.py)
@@ -571,6 +580,11 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
         if (dbg && threadIdx.x == 0) g_dbg[3] = __builtin_readcyclecounter();
         const int64_t txi = tile % t.wx, r1 = tile / t.wx;
         const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+        if (threadIdx.x == 32 && !L.open) { // closed for good: nobody needs to enlist this tile again (see CLOSED)
+            const unsigned int bit = CLOSED << (8 * (unsigned int)(tile & 3));
+            atomicOr((unsigned int *)(dirty_cur + (tile & ~(int64_t)3)), bit);
+            atomicOr((unsigned int *)(dirty_next + (tile & ~(int64_t)3)), bit);
+        }
         if (threadIdx.x < 27 && (L.dirs >> threadIdx.x & 1u)) {
             const int d = threadIdx.x;
             const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
 __global__ void k_flood_enqueue(Tiles t, uint8_t *dirty, Queue *q, unsigned int *queued, unsigned int *ring,
                                 unsigned int qmask) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= t.ntiles || !dirty[i]) return;
+    if (i >= t.ntiles || !(dirty[i] & 1u)) return;
     dirty[i] = 0;
     if (atomicExch(&queued[i], 1u) == 0u) {
         atomicAdd(&q->pending, 1u);
@@ -641,6 +655,7 @@ __global__ __launch_bounds__(NT) void k_flood_persistent(Tiles t, const unsigned
             if (tile >= 0) atomicExch(&queued[tile], 0u); // cleared BEFORE staging: later changes re-queue the tile
             s_tile = tile;
             L.dirs = 0;
+            L.open = 0;
         }
         __syncthreads();
         const int tile = s_tile;
@@ -693,28 +708,90 @@ __global__ void k_flood_mark(Tiles t, int64_t tz0, int64_t tz1, uint8_t *dirty) 
 constexpr int CT = 1024, CRP = 8, CROWS_MAX = 7680; // coarse workgroup size, rows per lane, LDS rows incl. halo (60 KB)
 constexpr unsigned int ENLISTED = 0x80u;             // dirty-byte bit: "already on the round-0 list" (coarse pass only)
 
-// A row of tiles along x (tile row index g = tzi * nty + tyi) is described by two words, bit = tile x index:
-//   rowF[g]  the tile is all-candidate,   rowW[g]  the tile is wholly reached (seeded by this kernel, closed by k_flood_coarse).
+// Granularity of the coarse graph: blocks of BXS x 16 x 16 voxels, BXS = 16, 32 or 64 (a quarter, half or whole tile along
+// x; the y / z extent is the tile's, so a row of blocks along x is still one row of the tile grid).  A row of blocks is one
+// 64-bit word (bit = block index along x), so BXS is the smallest of the three with 64 / BXS * wx <= 64: 16 up to 1024
+// voxels along x, 32 up to 2048, 64 (= the tile itself) up to 4096.  Finer blocks reach closer to the region's surface:
+// on the bench volume the rounds that follow drop from 13 to 8 (tools/sim_flood.c reproduces the round structure on the CPU).
+//   rowF[g]  the block is all-candidate,   rowW[g]  the block is wholly reached (seeded here / by k_flood_coarse, closed by it).
+struct Blocks {
+    int q;   // blocks per tile along x (4, 2, 1)
+    int bxs; // voxels per block along x (16, 32, 64)
+};
+__device__ __forceinline__ unsigned long long block_mask(const Blocks &b, unsigned long long qbits) {
+    // qbits: one bit per block of a word -> the voxel bits of those blocks
+    const unsigned long long one = b.bxs == 64 ? ~0ull : ((1ull << b.bxs) - 1ull);
+    unsigned long long m = 0;
+    for (int q = 0; q < b.q; q++)
+        if (qbits >> q & 1ull) m |= one << (b.bxs * q);
+    return m;
+}
+// the blocks of tile column txi that exist (hold at least one in-bounds voxel), as a q-bit mask
+__device__ __forceinline__ unsigned int block_exist(const Tiles &t, const Blocks &b, int64_t txi) {
+    unsigned int m = 0;
+    for (int q = 0; q < b.q; q++)
+        if (txi * 64 + (int64_t)b.bxs * q < t.dx) m |= 1u << q;
+    return m;
+}
+
+__device__ __forceinline__ double load_as_double(const void *data, int dtype, int64_t i) {
+    switch (dtype) {
+    case IVX_I16: return (double)((const int16_t *)data)[i];
+    case IVX_U8: return (double)((const uint8_t *)data)[i];
+    case IVX_U16: return (double)((const uint16_t *)data)[i];
+    default: return ((const double *)data)[i];
+    }
+}
+
 // One workgroup per tile row: the 16 rows of a slice are contiguous, so the loads coalesce across the row's tiles.
-__global__ __launch_bounds__(256) void k_flood_tile_flags(Tiles t, const unsigned long long *__restrict__ cand,
-                                                          const unsigned long long *__restrict__ reached,
-                                                          const uint8_t *__restrict__ dirty,
-                                                          unsigned long long *__restrict__ rowF,
-                                                          unsigned long long *__restrict__ rowW,
-                                                          unsigned int *__restrict__ cnt, int ncnt) {
+// FRESH: the flood starts from the seeds in `sp` and nothing else -- `reached` and the dirty flags are not read (their old
+// contents are dead: k_flood_block_apply<true> rewrites every word of the plane), this kernel zeroes the dirty flags and
+// the round counters, and workgroup 0 tests the seeds (floodfill.rs:123: only in-range seeds start a flood; an accepted
+// seed is a candidate even when its barrier byte already equals `fill`) and leaves the accepted ones as a bit mask.
+template <bool FRESH>
+__global__ __launch_bounds__(256) void k_flood_block_flags(Tiles t, Blocks bk, unsigned long long *cand,
+                                                           const unsigned long long *__restrict__ reached,
+                                                           uint8_t *dirty, uint8_t *dirty1,
+                                                           unsigned long long *__restrict__ rowF,
+                                                           unsigned long long *__restrict__ rowW,
+                                                           unsigned int *__restrict__ cnt, int ncnt, SeedPack sp, int dtype,
+                                                           const void *__restrict__ data, double t0, double t1,
+                                                           unsigned int *__restrict__ seed_ok) {
     __shared__ unsigned int s_bad[64], s_has[64];
     const int64_t tyi = blockIdx.x % t.nty, tzi = blockIdx.x / t.nty;
     if (threadIdx.x < 64) {
         s_bad[threadIdx.x] = 0u;
         s_has[threadIdx.x] = 0u;
     }
-    if (blockIdx.x == 0 && (int)threadIdx.x < ncnt) cnt[threadIdx.x] = 0u; // the round counters (k_flood_coarse_apply appends)
-    __syncthreads();
+    if (blockIdx.x == 0 && (int)threadIdx.x < ncnt) cnt[threadIdx.x] = 0u; // the round counters (k_flood_block_apply appends)
     const int wx = (int)t.wx, per_z = TY * wx, nw = TZ * per_z;
-    const unsigned long long last = (t.dx & 63) ? (1ull << (t.dx & 63)) - 1ull : ~0ull;
     const int64_t tile0 = (int64_t)blockIdx.x * t.wx;
+    if (FRESH) {
+        if ((int)threadIdx.x < wx) {
+            dirty[tile0 + threadIdx.x] = 0;
+            dirty1[tile0 + threadIdx.x] = 0;
+        }
+        if (blockIdx.x == 0) {
+            __shared__ unsigned int s_ok;
+            if (threadIdx.x == 0) s_ok = 0u;
+            __syncthreads();
+            if ((int)threadIdx.x < sp.n) {
+                const int64_t x = sp.xyz[threadIdx.x][0], y = sp.xyz[threadIdx.x][1], z = sp.xyz[threadIdx.x][2];
+                const double v = load_as_double(data, dtype, (z * t.dy + y) * t.dx + x);
+                if (v >= t0 && v <= t1) {
+                    atomicOr(&cand[(z * t.dy + y) * t.wx + (x >> 6)], 1ull << (x & 63));
+                    atomicOr(&s_ok, 1u << threadIdx.x);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) *seed_ok = s_ok;
+        }
+    }
+    __syncthreads();
+    const unsigned long long last = (t.dx & 63) ? (1ull << (t.dx & 63)) - 1ull : ~0ull;
+    const unsigned long long one = bk.bxs == 64 ? ~0ull : ((1ull << bk.bxs) - 1ull);
     for (int i0 = threadIdx.x; i0 < nw; i0 += 4 * 256) { // four loads in flight per lane: the kernel is latency-bound
-        unsigned long long cv[4];
+        unsigned long long cv[4], rv[4];
         int64_t wi[4];
         int tx[4];
 #pragma unroll
@@ -725,29 +802,37 @@ __global__ __launch_bounds__(256) void k_flood_tile_flags(Tiles t, const unsigne
             const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
             wi[u] = (i < nw && z < t.dz && y < t.dy) ? (z * t.dy + y) * t.wx + tx[u] : -1;
             cv[u] = wi[u] >= 0 ? cand[wi[u]] : 0ull;
+            rv[u] = 0ull;
+            if (!FRESH && wi[u] >= 0 && (dirty[tile0 + tx[u]] & 1u)) rv[u] = reached[wi[u]]; // only freshly seeded / marked tiles start a coarse flood
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (wi[u] < 0) continue;
-            if (cv[u] != (tx[u] == wx - 1 ? last : ~0ull)) s_bad[tx[u]] = 1u;
-            else if (dirty[tile0 + tx[u]] && reached[wi[u]]) s_has[tx[u]] = 1u; // only freshly seeded / marked tiles start a coarse flood
+            const unsigned long long miss = ~cv[u] & (tx[u] == wx - 1 ? last : ~0ull); // in-bounds voxels that are no candidates
+            for (int q = 0; q < bk.q; q++) {
+                if ((miss >> (bk.bxs * q)) & one) s_bad[tx[u] * bk.q + q] = 1u;
+                else if (!FRESH && ((rv[u] >> (bk.bxs * q)) & one)) s_has[tx[u] * bk.q + q] = 1u;
+            }
         }
     }
     __syncthreads();
     if (threadIdx.x < 64) {
-        const bool in = (int)threadIdx.x < wx;
-        const unsigned long long f = __ballot(in && !s_bad[threadIdx.x]);
-        const unsigned long long h = __ballot(in && s_has[threadIdx.x]);
+        const int b = threadIdx.x, btx = b / bk.q;
+        const bool in = btx < wx && (int64_t)btx * 64 + (int64_t)bk.bxs * (b % bk.q) < t.dx; // the block exists
+        const unsigned long long f = __ballot(in && !s_bad[b]);
+        const unsigned long long h = __ballot(in && s_has[b]);
         if (threadIdx.x == 0) {
             rowF[blockIdx.x] = f;
-            rowW[blockIdx.x] = f & h;
+            rowW[blockIdx.x] = FRESH ? 0ull : (f & h);
         }
     }
 }
 
-template <int CONN>
-__global__ __launch_bounds__(CT) void k_flood_coarse(Tiles t, const unsigned long long *__restrict__ rowF,
-                                                     unsigned long long *__restrict__ rowW) {
+// SEEDED: the accepted seeds of `sp` (mask *seed_ok) that sit in an all-candidate block start the coarse flood
+template <int CONN, bool SEEDED>
+__global__ __launch_bounds__(CT) void k_flood_coarse(Tiles t, Blocks bk, const unsigned long long *__restrict__ rowF,
+                                                     unsigned long long *__restrict__ rowW, SeedPack sp,
+                                                     const unsigned int *__restrict__ seed_ok) {
     __shared__ unsigned long long sR[CROWS_MAX];
     __shared__ unsigned int vote[2];
     const int nty = (int)t.nty, ntz = (int)t.ntz, hy = nty + 2;
@@ -758,12 +843,24 @@ __global__ __launch_bounds__(CT) void k_flood_coarse(Tiles t, const unsigned lon
     for (int k = 0; k < CRP; k++) { // issue the loads before the LDS clear
         const int j = threadIdx.x + k * (int)blockDim.x;
         F[k] = j < nrows ? rowF[j] : 0ull;
-        R[k] = j < nrows ? rowW[j] : 0ull;
+        R[k] = (j < nrows && !SEEDED) ? rowW[j] : 0ull;
         me[k] = j < nrows ? (j / nty + 1) * hy + (j % nty) + 1 : 0;
     }
     for (int i = threadIdx.x; i < nh; i += blockDim.x) sR[i] = 0ull;
     if (threadIdx.x == 0) vote[0] = 0u;
     __syncthreads();
+    if (SEEDED) {
+        if ((int)threadIdx.x < sp.n && (*seed_ok >> threadIdx.x & 1u)) {
+            const int64_t x = sp.xyz[threadIdx.x][0], y = sp.xyz[threadIdx.x][1], z = sp.xyz[threadIdx.x][2];
+            const int j = (int)((z / TZ) * nty + y / TY);
+            const unsigned long long bit = 1ull << (x / bk.bxs);
+            if (rowF[j] & bit) atomicOr(&sR[(j / nty + 1) * hy + (j % nty) + 1], bit);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CRP; k++) R[k] = sR[me[k]]; // (unused slots read the all-zero corner row)
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < CRP; k++)
         if (R[k]) {
@@ -807,26 +904,43 @@ __global__ __launch_bounds__(CT) void k_flood_coarse(Tiles t, const unsigned lon
     }
 }
 
-// reached = cand for the wholly reached tiles; their not-wholly-reached neighbours (and the seeded tiles that are not
-// whole) go straight onto the round-0 list: a dirty byte is enlisted by whoever sets its ENLISTED bit first.
+// reached = cand for the wholly reached blocks; the tiles around them that are not wholly reached themselves (and the
+// seeded tiles that are not whole) go straight onto the round-0 list: a dirty byte is enlisted by whoever sets its
+// ENLISTED bit first.
 __device__ __forceinline__ void coarse_enlist(uint8_t *dirty, int64_t tile, unsigned int *list, unsigned int *count) {
     unsigned int *wp = (unsigned int *)(dirty + (tile & ~(int64_t)3));
-    const unsigned int bit = ENLISTED << (8 * (unsigned int)(tile & 3));
-    if (!(atomicOr(wp, bit) & bit)) list[atomicAdd(count, 1u)] = (unsigned int)tile;
+    const unsigned int sh = 8 * (unsigned int)(tile & 3);
+    const unsigned int old = atomicOr(wp, ENLISTED << sh);
+    if (!(old & ((ENLISTED | CLOSED) << sh))) list[atomicAdd(count, 1u)] = (unsigned int)tile;
 }
 
-__global__ __launch_bounds__(256) void k_flood_coarse_apply(Tiles t, const unsigned long long *__restrict__ cand,
-                                                            unsigned long long *__restrict__ reached,
-                                                            const unsigned long long *__restrict__ rowW, uint8_t *dirty,
-                                                            unsigned int *__restrict__ list, unsigned int *count) {
+// FRESH: every word of the plane is written (whole blocks: their candidates; the accepted seeds' bits; zero elsewhere), so
+// the plane needs no clearing pass before the flood
+template <bool FRESH>
+__global__ __launch_bounds__(256) void k_flood_block_apply(Tiles t, Blocks bk, const unsigned long long *__restrict__ cand,
+                                                           unsigned long long *__restrict__ reached,
+                                                           const unsigned long long *__restrict__ rowW, uint8_t *dirty,
+                                                           unsigned int *__restrict__ list, unsigned int *count, SeedPack sp,
+                                                           const unsigned int *__restrict__ seed_ok) {
     __shared__ unsigned int s_chg[64];
+    __shared__ unsigned int s_seeds; // FRESH: the accepted seeds that sit in this tile row
     const int64_t tyi = blockIdx.x % t.nty, tzi = blockIdx.x / t.nty;
     const int wx = (int)t.wx, per_z = TY * wx, nw = TZ * per_z;
     const int64_t tile0 = (int64_t)blockIdx.x * t.wx;
     const unsigned long long whole = rowW[blockIdx.x];
+    const unsigned int qm = (1u << bk.q) - 1u;
     if (threadIdx.x < 64) s_chg[threadIdx.x] = 0u;
-    if ((int)threadIdx.x < wx && dirty[tile0 + threadIdx.x]) {
-        if (whole >> threadIdx.x & 1ull) {
+    if (threadIdx.x == 0) s_seeds = 0u;
+    __syncthreads();
+    if (FRESH) {
+        if ((int)threadIdx.x < sp.n && (*seed_ok >> threadIdx.x & 1u) && sp.xyz[threadIdx.x][2] / TZ == tzi &&
+            sp.xyz[threadIdx.x][1] / TY == tyi) {
+            s_chg[sp.xyz[threadIdx.x][0] >> 6] = 1u; // a seed starts its tile (and wakes the tiles around it)
+            atomicOr(&s_seeds, 1u << threadIdx.x);
+        }
+    } else if ((int)threadIdx.x < wx && (dirty[tile0 + threadIdx.x] & 1u)) {
+        const unsigned int ex = block_exist(t, bk, threadIdx.x);
+        if (((unsigned int)(whole >> (bk.q * threadIdx.x)) & ex) == ex) {
             dirty[tile0 + threadIdx.x] = 0; // final: a wholly reached tile has nothing to gain
             // ... but it was marked because bits arrived in it from OUTSIDE the flood (a seed, a neighbour slab's plane
             // OR-ed into a halo slice): even when those bits already fill the tile, nobody has told its neighbours yet
@@ -835,10 +949,11 @@ __global__ __launch_bounds__(256) void k_flood_coarse_apply(Tiles t, const unsig
             coarse_enlist(dirty, tile0 + threadIdx.x, list, count);
         }
     }
-    if (!whole) return; // uniform
+    if (!FRESH && !whole) return; // uniform
     __syncthreads();
+    const unsigned int ok = FRESH ? s_seeds : 0u;
     for (int i0 = threadIdx.x; i0 < nw; i0 += 4 * 256) { // four word pairs in flight per lane
-        unsigned long long cv[4], rv[4];
+        unsigned long long cv[4], rv[4], bm[4];
         int64_t wi[4];
         int tx[4];
 #pragma unroll
@@ -847,24 +962,39 @@ __global__ __launch_bounds__(256) void k_flood_coarse_apply(Tiles t, const unsig
             const int tz = i / per_z, rem = i - tz * per_z, ty = rem / wx;
             tx[u] = rem - ty * wx;
             const int64_t z = tzi * TZ + tz, y = tyi * TY + ty;
-            wi[u] = (i < nw && (whole >> tx[u] & 1ull) && z < t.dz && y < t.dy) ? (z * t.dy + y) * t.wx + tx[u] : -1;
-            cv[u] = wi[u] >= 0 ? cand[wi[u]] : 0ull;
-            rv[u] = wi[u] >= 0 ? reached[wi[u]] : 0ull;
+            const unsigned int wq = (unsigned int)(whole >> (bk.q * tx[u])) & qm;
+            wi[u] = (i < nw && (FRESH || wq) && z < t.dz && y < t.dy) ? (z * t.dy + y) * t.wx + tx[u] : -1;
+            bm[u] = wq ? block_mask(bk, wq) : 0ull;
+            cv[u] = (wi[u] >= 0 && wq) ? cand[wi[u]] : 0ull;
+            rv[u] = (!FRESH && wi[u] >= 0) ? reached[wi[u]] : 0ull;
+            if (FRESH && wi[u] >= 0 && ok) { // the accepted seeds of this word
+                const int64_t z2 = tzi * TZ + tz, y2 = tyi * TY + ty;
+                for (int n = 0; n < sp.n; n++)
+                    if ((ok >> n & 1u) && sp.xyz[n][2] == z2 && sp.xyz[n][1] == y2 && (sp.xyz[n][0] >> 6) == tx[u])
+                        rv[u] |= 1ull << (sp.xyz[n][0] & 63);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (wi[u] >= 0 && rv[u] != cv[u]) { // the tile gained voxels: its neighbours must look again
-                reached[wi[u]] = cv[u];
+        for (int u = 0; u < 4; u++) {
+            if (wi[u] < 0) continue;
+            const unsigned long long nr = rv[u] | (cv[u] & bm[u]);
+            if (FRESH) {
+                reached[wi[u]] = nr;
+                if (bm[u]) s_chg[tx[u]] = 1u;
+            } else if (nr != rv[u]) { // the tile gained voxels: its neighbours (and its own open part) must look again
+                reached[wi[u]] = nr;
                 s_chg[tx[u]] = 1u;
             }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 27 * wx; i += 256) {
         const int txi = i / 27, d = i - txi * 27;
-        if (d == 13 || !s_chg[txi]) continue;
+        if (!s_chg[txi]) continue;
         const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
         if (nz < 0 || nz >= t.ntz || ny < 0 || ny >= t.nty || nx < 0 || nx >= t.wx) continue;
-        if (rowW[nz * t.nty + ny] >> nx & 1ull) continue;
+        const unsigned int ex = block_exist(t, bk, nx);
+        if (((unsigned int)(rowW[nz * t.nty + ny] >> (bk.q * nx)) & ex) == ex) continue; // wholly reached: nothing to gain
         coarse_enlist(dirty, (nz * t.nty + ny) * t.wx + nx, list, count);
     }
 }
@@ -954,26 +1084,40 @@ __global__ __launch_bounds__(256) void k_flood_apply(Tiles t, const uint8_t *__r
 // two bytes of reached bits -> one 16-byte store (a read-modify-write of the lane's own 16 bytes on a partial chunk)
 __global__ __launch_bounds__(256) void k_flood_apply16(const uint16_t *__restrict__ reached, int64_t nchunks,
                                                        uint4 *__restrict__ out, uint8_t fill) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
     const unsigned int f4 = 0x01010101u * fill;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
-        const unsigned int m = reached[i];
-        if (!m) continue;
-        uint4 v = make_uint4(f4, f4, f4, f4);
-        if (m != 0xffffu) {
-            const uint4 o = out[i];
-            // bit e of m -> byte e: spread 4 bits to 4 byte masks
-            auto blend = [&](unsigned int old, unsigned int bits4) {
-                const unsigned int sel = ((bits4 & 1u) * 0xffu) | ((bits4 >> 1 & 1u) * 0xff00u) |
-                                         ((bits4 >> 2 & 1u) * 0xff0000u) | ((bits4 >> 3 & 1u) * 0xff000000u);
-                return (old & ~sel) | (f4 & sel);
-            };
-            v.x = blend(o.x, m & 15u);
-            v.y = blend(o.y, m >> 4 & 15u);
-            v.z = blend(o.z, m >> 8 & 15u);
-            v.w = blend(o.w, m >> 12 & 15u);
+    // four chunks per lane, 256 apart: the four bit loads (and the loads of the partial chunks' bytes) are in flight
+    // together, and every store instruction of a wave writes 1 KB of consecutive bytes
+    for (int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; i0 < nchunks; i0 += stride) {
+        unsigned int m[4];
+        uint4 o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = i0 + u * 256;
+            m[u] = i < nchunks ? reached[i] : 0u;
+            o[u] = make_uint4(0u, 0u, 0u, 0u);
         }
-        out[i] = v;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (m[u] && m[u] != 0xffffu) o[u] = out[i0 + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!m[u]) continue;
+            uint4 v = make_uint4(f4, f4, f4, f4);
+            if (m[u] != 0xffffu) {
+                // bit e of m -> byte e: spread 4 bits to 4 byte masks
+                auto blend = [&](unsigned int old, unsigned int bits4) {
+                    const unsigned int sel = ((bits4 & 1u) * 0xffu) | ((bits4 >> 1 & 1u) * 0xff00u) |
+                                             ((bits4 >> 2 & 1u) * 0xff0000u) | ((bits4 >> 3 & 1u) * 0xff000000u);
+                    return (old & ~sel) | (f4 & sel);
+                };
+                v.x = blend(o[u].x, m[u] & 15u);
+                v.y = blend(o[u].y, m[u] >> 4 & 15u);
+                v.z = blend(o[u].z, m[u] >> 8 & 15u);
+                v.w = blend(o[u].w, m[u] >> 12 & 15u);
+            }
+            out[i0 + u * 256] = v;
+        }
     }
 }
 
@@ -1221,8 +1365,34 @@ __global__ void k_gate_set(unsigned int *word, unsigned int value) {
 
 // directed: `cand` = the six edge planes of ivx_dev_flood_edges_auto (rounds engine only: the coarse pass, the
 // union-find escape and the persistent frontier all rely on symmetric adjacency)
+// `fresh` (may be NULL): the flood starts from these seeds on a plane whose old contents are dead (ivx_dev_flood_grow) --
+// the coarse pass then does the clearing and the seeding as well
+struct Fresh {
+    int dtype;
+    const void *data;
+    double t0, t1;
+    SeedPack sp;
+};
+static int flood_mode() {
+    static const int mode_env = [] {
+        const char *e = getenv("IVX_FLOOD_MODE");
+        if (e && !strcmp(e, "ccl")) return 0;
+        if (e && !strcmp(e, "persistent")) return 2;
+        return 1;
+    }();
+    return mode_env;
+}
+static bool coarse_ok(const Tiles &t, bool directed) {
+    static const bool coarse_on = [] {
+        const char *e = getenv("IVX_FLOOD_COARSE");
+        return !(e && e[0] == '0');
+    }();
+    // standard structures only, tile grid small enough for one workgroup's LDS
+    return coarse_on && !directed && t.conn != 0 && t.wx <= 64 && (t.nty + 2) * (t.ntz + 2) <= CROWS_MAX &&
+           t.nty * t.ntz <= (int64_t)CT * CRP;
+}
 static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool directed, uint64_t *reached, void *scratch_,
-                          int *rounds, void *stream) {
+                          int *rounds, void *stream, const Fresh *fresh = nullptr) {
     Tiles t;
     int rc = make_tiles(p, &t);
     if (rc) return rc;
@@ -1254,13 +1424,7 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
     // when a flood needs more than CCL_ESCAPE_ROUNDS rounds (serpentine / maze-like regions); "ccl" = run-based
     // union-find from the start (k_ccl.hip; no frontier, flat cost); "persistent" = tile frontier, single launch +
     // device queue.  Measured at 512^3 on the bench blob (20 rounds): rounds 0.74 ms, ccl 0.86 ms, persistent 1.4 ms.
-    static const int mode_env = [] {
-        const char *e = getenv("IVX_FLOOD_MODE");
-        if (e && !strcmp(e, "ccl")) return 0;
-        if (e && !strcmp(e, "persistent")) return 2;
-        return 1;
-    }();
-    const int mode = directed ? 1 : mode_env;
+    const int mode = directed ? 1 : flood_mode();
     constexpr int CCL_ESCAPE_ROUNDS = 48;
     if (mode == 0 && ivx::ccl_supported(p->strct_bits)) {
         if (rounds) *rounds = 1;
@@ -1318,28 +1482,50 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
         const int v = e ? atoi(e) : 3;
         return v < 1 ? 1 : (v > BATCH ? BATCH : v);
     }();
-    static const bool coarse_on = [] {
-        const char *e = getenv("IVX_FLOOD_COARSE");
-        return !(e && e[0] == '0');
-    }();
-    // coarse pass (see k_flood_coarse): standard structures only, tile grid small enough for one workgroup's LDS
-    if (coarse_on && !directed && t.conn != 0 && t.wx <= 64 && (t.nty + 2) * (t.ntz + 2) <= CROWS_MAX &&
-        t.nty * t.ntz <= (int64_t)CT * CRP) {
+    // coarse pass (see k_flood_coarse): blocks of 16 / 32 / 64 x 16 x 16 voxels, the finest whose row fits one word
+    if (coarse_ok(t, directed)) {
+        static const int bxs_env = [] {
+            const char *e = getenv("IVX_FLOOD_BLOCK"); // 16 / 32 / 64: force a coarser block (A/B measurements)
+            return e ? atoi(e) : 0;
+        }();
+        Blocks bk;
+        bk.bxs = 16;
+        while (bk.bxs < 64 && ((64 / bk.bxs) * t.wx > 64 || bk.bxs < bxs_env)) bk.bxs *= 2;
+        bk.q = 64 / bk.bxs;
         unsigned long long *rowF = (unsigned long long *)(scr + s.off_full), *rowW = (unsigned long long *)(scr + s.off_whole);
+        unsigned int *seed_ok = (unsigned int *)(scr + s.off_status) + 8;
         const unsigned groups = (unsigned)(t.nty * t.ntz);
-        hipLaunchKernelGGL(k_flood_tile_flags, dim3(groups), dim3(256), 0, st, t, (const unsigned long long *)cand,
-                           (const unsigned long long *)reached, dirty[0], rowF, rowW, cnt, RING);
-        IVX_LAUNCH_CHECK();
+        SeedPack none;
+        none.n = 0;
         int ct = 64; // one row of tiles per lane up to 1024 lanes, then up to CRP rows per lane (128..1024 lanes measured equal)
         while (ct < CT && ct < t.nty * t.ntz) ct *= 2;
-        if (t.conn == 26) hipLaunchKernelGGL(k_flood_coarse<26>, dim3(1), dim3(ct), 0, st, t, rowF, rowW);
-        else if (t.conn == 18) hipLaunchKernelGGL(k_flood_coarse<18>, dim3(1), dim3(ct), 0, st, t, rowF, rowW);
-        else hipLaunchKernelGGL(k_flood_coarse<6>, dim3(1), dim3(ct), 0, st, t, rowF, rowW);
-        IVX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_flood_coarse_apply, dim3(groups), dim3(256), 0, st, t, (const unsigned long long *)cand,
-                           (unsigned long long *)reached, rowW, dirty[0], list[0], cnt);
-        IVX_LAUNCH_CHECK();
+        if (fresh) {
+            hipLaunchKernelGGL(k_flood_block_flags<true>, dim3(groups), dim3(256), 0, st, t, bk, (unsigned long long *)cand,
+                               (const unsigned long long *)reached, dirty[0], dirty[1], rowF, rowW, cnt, RING, fresh->sp,
+                               fresh->dtype, fresh->data, fresh->t0, fresh->t1, seed_ok);
+            IVX_LAUNCH_CHECK();
+            if (t.conn == 26) hipLaunchKernelGGL((k_flood_coarse<26, true>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, fresh->sp, seed_ok);
+            else if (t.conn == 18) hipLaunchKernelGGL((k_flood_coarse<18, true>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, fresh->sp, seed_ok);
+            else hipLaunchKernelGGL((k_flood_coarse<6, true>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, fresh->sp, seed_ok);
+            IVX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_flood_block_apply<true>, dim3(groups), dim3(256), 0, st, t, bk, (const unsigned long long *)cand,
+                               (unsigned long long *)reached, rowW, dirty[0], list[0], cnt, fresh->sp, seed_ok);
+            IVX_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(k_flood_block_flags<false>, dim3(groups), dim3(256), 0, st, t, bk, (unsigned long long *)cand,
+                               (const unsigned long long *)reached, dirty[0], dirty[1], rowF, rowW, cnt, RING, none, 0,
+                               (const void *)nullptr, 0.0, 0.0, seed_ok);
+            IVX_LAUNCH_CHECK();
+            if (t.conn == 26) hipLaunchKernelGGL((k_flood_coarse<26, false>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, none, seed_ok);
+            else if (t.conn == 18) hipLaunchKernelGGL((k_flood_coarse<18, false>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, none, seed_ok);
+            else hipLaunchKernelGGL((k_flood_coarse<6, false>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, none, seed_ok);
+            IVX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_flood_block_apply<false>, dim3(groups), dim3(256), 0, st, t, bk, (const unsigned long long *)cand,
+                               (unsigned long long *)reached, rowW, dirty[0], list[0], cnt, none, seed_ok);
+            IVX_LAUNCH_CHECK();
+        }
     } else {
+        IVX_REQUIRE(!fresh, IVX_EINVAL, "flood: the fused start needs the coarse pass");
         IVX_HIP(hipMemsetAsync(cnt, 0, RING * 4, st));
         hipLaunchKernelGGL(k_flood_build_list, dim3((unsigned)ivx::cdiv(t.ntiles, 256)), dim3(256), 0, st, t, dirty[0], list[0], cnt);
         IVX_LAUNCH_CHECK();
@@ -1347,7 +1533,11 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
     volatile unsigned long long *line = nullptr;
     uint32_t tag = 0;
     if ((rc = ivx::progress_line(st, &line, &tag))) return rc;
-    const unsigned grid = (unsigned)(t.ntiles < 1536 ? t.ntiles : 1536); // 6 workgroups per CU are resident (80 VGPRs)
+    const unsigned grid_max = (unsigned)(t.ntiles < 1536 ? t.ntiles : 1536); // 6 workgroups per CU are resident (80 VGPRs)
+    // The rounds queued ahead are sized by the newest list length the host has seen: the lists shrink towards the end, and
+    // dispatching 1536 workgroups that find nothing costs ~3 us more per round than dispatching 128 (a list that turns out
+    // longer than the grid is still served: workgroups stride over it).
+    unsigned grid = grid_max;
     int64_t queued = 0; // rounds launched so far
     auto queue_round = [&]() -> int {
         const int r = (int)(queued % RING), cur = (int)(queued & 1);
@@ -1391,6 +1581,7 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
         if (trace) fprintf(stderr, "ivx flood: round %lld starts with %u of %lld tiles (%lld queued)\n", (long long)seen, n_list,
                            (long long)t.ntiles, (long long)queued);
         if (n_list < arm.below) arm.word = nullptr; // that round has opened the gate: nothing left for the guard to do
+        grid = n_list >= 384u ? grid_max : (n_list >= 96u ? (grid_max < 512u ? grid_max : 512u) : (grid_max < 128u ? grid_max : 128u));
         if (n_list == 0) { // converged: word 1 holds the last round that had work (if any, and if it is ours)
             const unsigned long long u = __atomic_load_n((const unsigned long long *)line + 1, __ATOMIC_ACQUIRE);
             total_rounds = (uint32_t)(u >> 56) == tag ? (int)((u >> 32) & 0xffffffull) : 0;
@@ -1417,6 +1608,43 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
                                  int *rounds, void *stream) {
     return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream);
 }
+// clear + seed + run in one call: the flood of `seeds` over `cand` into a plane whose old contents are dead.  With at most
+// 16 seeds and a standard structuring element the clearing and the seeding ride on the coarse pass (three launches before
+// the rounds instead of five, no separate pass over the plane); otherwise the three calls run one after the other.
+extern "C" int ivx_dev_flood_grow(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                                  const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached, void *scratch_,
+                                  int *rounds, void *stream) {
+    Tiles t;
+    int rc = make_tiles(p, &t);
+    if (rc) return rc;
+    IVX_REQUIRE(ivx::dtype_size(dtype), IVX_EINVAL, "flood: unsupported dtype %d", dtype);
+    for (int64_t n = 0; n < nseeds; n++) {
+        const int64_t x = seeds_xyz[3 * n], y = seeds_xyz[3 * n + 1], z = seeds_xyz[3 * n + 2];
+        IVX_REQUIRE(x >= 0 && y >= 0 && z >= 0 && x < t.dx && y < t.dy && z < t.dz, IVX_ERANGE,
+                    "flood: seed (%lld,%lld,%lld) outside volume (%lld,%lld,%lld) [x,y,z]", (long long)x, (long long)y,
+                    (long long)z, (long long)t.dx, (long long)t.dy, (long long)t.dz);
+    }
+    static const bool fused_on = [] {
+        const char *e = getenv("IVX_FLOOD_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (!(fused_on && nseeds >= 1 && nseeds <= 16 && t.ntiles > 0 && flood_mode() == 1 && coarse_ok(t, false))) {
+        if ((rc = ivx_dev_flood_clear(p, reached, scratch_, stream))) return rc;
+        if ((rc = ivx_dev_flood_seed(p, dtype, data, t0, t1, seeds_xyz, nseeds, cand, reached, scratch_, stream))) return rc;
+        return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream);
+    }
+    ivx::ccl_invalidate(scratch_);
+    Fresh f;
+    f.dtype = dtype;
+    f.data = data;
+    f.t0 = t0;
+    f.t1 = t1;
+    f.sp.n = (int)nseeds;
+    for (int64_t n = 0; n < nseeds; n++)
+        for (int q = 0; q < 3; q++) f.sp.xyz[n][q] = seeds_xyz[3 * n + q];
+    return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream, &f);
+}
+
 extern "C" int ivx_dev_flood_run_edges(const ivx_flood_plan *p, const uint64_t *edges, uint64_t *reached, void *scratch_,
                                        int *rounds, void *stream) {
     return flood_run_impl(p, edges, true, reached, scratch_, rounds, stream);
@@ -1527,7 +1755,7 @@ extern "C" int ivx_dev_flood_apply(const ivx_flood_plan *p, const uint64_t *reac
     const uint8_t *r = (const uint8_t *)reached;
     if (dtype == IVX_U8 && t.dx % 64 == 0 && ((uintptr_t)target & 15) == 0) {
         const int64_t nchunks = t.dz * t.dy * t.dx / 16;
-        const int64_t blocks = ivx::cdiv(nchunks, 256);
+        const int64_t blocks = ivx::cdiv(nchunks, 1024);
         hipLaunchKernelGGL(k_flood_apply16, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st,
                            (const uint16_t *)reached, nchunks, (uint4 *)target, (uint8_t)fill);
         IVX_LAUNCH_CHECK();
@@ -1737,14 +1965,12 @@ static int flood_host(int dtype, void *data, const int64_t shape[3], const int64
         if ((rc = ws_get(WS_OUT, n, &d_out))) return rc;
         if ((rc = upload_strided(d_out, out, shape, ostrides, 1, WS_OUT))) return rc;
     }
-    if ((rc = ivx_dev_flood_clear(&plan, (uint64_t *)d_reach, d_scr, nullptr))) return rc;
     if ((rc = ivx_dev_flood_candidates(&plan, dtype, d_data, t0, t1, (const uint8_t *)d_out, inplace ? 2 : 1, fill,
                                        (uint64_t *)d_cand, nullptr)))
         return rc;
-    if ((rc = ivx_dev_flood_seed(&plan, dtype, d_data, t0, t1, seeds, nseeds, (uint64_t *)d_cand, (uint64_t *)d_reach,
-                                 d_scr, nullptr)))
+    if ((rc = ivx_dev_flood_grow(&plan, dtype, d_data, t0, t1, seeds, nseeds, (uint64_t *)d_cand, (uint64_t *)d_reach, d_scr,
+                                 nullptr, nullptr)))
         return rc;
-    if ((rc = ivx_dev_flood_run(&plan, (const uint64_t *)d_cand, (uint64_t *)d_reach, d_scr, nullptr, nullptr))) return rc;
     if (inplace) {
         if ((rc = ivx_dev_flood_apply(&plan, (const uint64_t *)d_reach, dtype, d_data, fill, nullptr))) return rc;
         IVX_HIP(hipDeviceSynchronize());

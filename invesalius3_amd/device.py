@@ -327,14 +327,12 @@ class DeviceVolume:
         st = self.stream
         t0, t1 = float(int(t0)), float(int(t1))  # wrapper int() truncation for integer images
         self._before_flood()
-        L.check(lib.ivx_dev_flood_clear(p, self.reached.ptr, self.flood_scratch.ptr, st))
         cand, shared = self._candidate_plane(image, t0, t1, fill)
-        L.check(lib.ivx_dev_flood_seed(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
-                                       c64(len(seeds)), cand.ptr, self.reached.ptr, self.flood_scratch.ptr, st),
-                "region_grow")  # an in-range seed is already a candidate here: the kernel's OR is a no-op on a shared plane
         rounds = ctypes.c_int(0)
-        L.check(lib.ivx_dev_flood_run(p, cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
-                                      st), "region_grow")
+        # clear + seed + run (an in-range seed is already a candidate here: the kernel's OR is a no-op on a shared plane)
+        L.check(lib.ivx_dev_flood_grow(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
+                                       c64(len(seeds)), cand.ptr, self.reached.ptr, self.flood_scratch.ptr,
+                                       ctypes.byref(rounds), st), "region_grow")
         self._gate_armed = False  # an armed gate has been opened by this flood
         self._apply_reached(fill, select_value, shared)
         return rounds.value
@@ -689,7 +687,11 @@ class DeviceVolume:
                 b.close()
         names = (("rounds", "tile_visits", "levels", "generations", "markers", "generation0", "tied_markers_of_different_labels")
                  if algorithm == "Watershed" else ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles"))
-        return {k: int(v) for k, v in zip(names, stats)}
+        res = {k: int(v) for k, v in zip(names, stats)}
+        if algorithm == "Watershed":
+            from .watershed_process import _warn_ties
+            _warn_ties(res["tied_markers_of_different_labels"], "DeviceVolume.watershed")
+        return res
 
     # -- projections ---------------------------------------------------------------------------------
     def project(self, axis: int, op: int, out: DeviceBuffer):

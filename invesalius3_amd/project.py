@@ -131,6 +131,17 @@ def compress(folder_name: str, filename, filelist: dict, gz: bool = False):
     shutil.move(tmp, filename)
 
 
+def _inside(dirpath: str, name: str) -> str:
+    """`name` (a file name taken from a plist of the project in `dirpath`) as a path, provided it stays inside that
+    folder once symlinks and `..` are resolved.  Plists come out of archives people exchange: a name such as
+    `../../home/x/.ssh/id_rsa`, or an absolute one, must never be opened -- let alone copied into the next archive."""
+    root = os.path.realpath(dirpath)
+    path = os.path.realpath(os.path.join(root, str(name)))
+    if os.path.isabs(str(name)) or os.path.commonpath([root, path]) != root:
+        raise ValueError("project file name %r leaves the project folder" % (name,))
+    return path
+
+
 def load_from_folder(dirpath: str) -> Project:
     """project.py:378-536 load_from_folder, minus the GUI objects."""
     with open(os.path.join(dirpath, "main.plist"), "rb") as f:
@@ -147,7 +158,7 @@ def load_from_folder(dirpath: str) -> Project:
     p.threshold_range = tuple(main["scalar_range"])
     p.spacing = tuple(main["spacing"])
     p.compress = main.get("compress", True)
-    p.matrix_filename = os.path.join(dirpath, main["matrix"]["filename"])
+    p.matrix_filename = _inside(dirpath, main["matrix"]["filename"])
     p.matrix_shape = tuple(int(v) for v in main["matrix"]["shape"])
     p.matrix_dtype = main["matrix"]["dtype"]
     if main.get("affine", ""):
@@ -158,13 +169,13 @@ def load_from_folder(dirpath: str) -> Project:
         raise ValueError("matrix.dat holds %d bytes, shape %s of %s needs %d" % (have, p.matrix_shape, p.matrix_dtype, need))
     p.matrix = np.memmap(p.matrix_filename, shape=p.matrix_shape, dtype=p.matrix_dtype, mode="r+")
     for version in main.get("image_versions", []):
-        vpath = os.path.join(dirpath, version["filename"])
+        vpath = _inside(dirpath, version["filename"])
         if os.path.exists(vpath):
             p.image_versions.append((version["label"], np.memmap(vpath, shape=p.matrix_shape, dtype=p.matrix_dtype, mode="r+")))
     masks = main.get("masks", {})
     for key in sorted(masks, key=lambda k: int(k)):
         try:
-            rec = open_mask_plist(os.path.join(dirpath, masks[key]))
+            rec = open_mask_plist(_inside(dirpath, masks[key]))
         except FileNotFoundError as e:  # project.py:478-487: a missing mask file is skipped with a warning
             warnings.warn("Skipping mask %r: %s" % (masks[key], e), stacklevel=2)
             continue
@@ -172,11 +183,19 @@ def load_from_folder(dirpath: str) -> Project:
         p.masks[rec.index] = rec
     surfaces = main.get("surfaces", {})
     for key in sorted(surfaces, key=lambda k: int(k)):
-        spath = os.path.join(dirpath, surfaces[key])
+        spath = _inside(dirpath, surfaces[key])
         if os.path.exists(spath):
             with open(spath, "rb") as f:
-                p.surfaces[int(key)] = plistlib.load(f, fmt=plistlib.FMT_XML)
-    mpath = os.path.join(dirpath, main.get("measurements", "measurements.plist"))
+                sd = plistlib.load(f, fmt=plistlib.FMT_XML)
+            payload = sd.get("polydata")
+            if payload:  # the reference parses this file as VTP; here it is carried along byte for byte, so it must be ours
+                try:
+                    _inside(dirpath, payload)
+                except ValueError as e:
+                    warnings.warn("surface %s: %s -- payload dropped" % (key, e), stacklevel=2)
+                    sd["polydata"] = ""
+            p.surfaces[int(key)] = sd
+    mpath = _inside(dirpath, main.get("measurements", "measurements.plist"))
     if os.path.exists(mpath):
         with open(mpath, "rb") as f:
             p.measurements = plistlib.load(f, fmt=plistlib.FMT_XML)
@@ -187,7 +206,7 @@ def open_mask_plist(filename: str) -> MaskRecord:
     """mask.py:347-366 Mask.OpenPList + _open_mask (392-401)."""
     with open(filename, "rb") as f:
         m = plistlib.load(f, fmt=plistlib.FMT_XML)
-    path = os.path.join(os.path.abspath(os.path.dirname(filename)), m["mask_file"])
+    path = _inside(os.path.dirname(os.path.abspath(filename)), m["mask_file"])
     if not os.path.exists(path):
         raise FileNotFoundError("Mask data file not found: %r" % path)
     shape = tuple(int(v) for v in m["mask_shape"])
@@ -218,7 +237,8 @@ def open_inv3(filename, workdir: str | None = None) -> Project:
 
 def save_inv3(filename, project: Project, gz: bool | None = None):
     """Project.SavePlistProject (project.py:219-345): image, filtered image versions, masks, surfaces (plist + polydata
-    file) and measurements.  A project opened with open_inv3 and written back keeps all of them."""
+    file) and measurements.  A project opened with open_inv3 and written back keeps all of them (not carried: the
+    per-version filter parameters and `active_image_version` of project.py:253-293)."""
     gz = project.compress if gz is None else gz
     tmp = tempfile.mkdtemp(prefix="ivx3_save_")
     try:
@@ -279,7 +299,9 @@ def save_inv3(filename, project: Project, gz: bool | None = None):
             sd = dict(sdict)
             payload = sd.get("polydata")
             if payload:
-                src = payload if os.path.isabs(payload) else os.path.join(project.dirpath or "", payload)
+                # a relative name belongs to the project the surface was loaded from and must stay inside its folder;
+                # an absolute one is a file the CALLER put there (load_from_folder never lets one through)
+                src = payload if os.path.isabs(payload) else _inside(project.dirpath or os.getcwd(), payload)
                 if not os.path.exists(src):
                     raise FileNotFoundError("surface %s: polydata file %r not found (looked in %r)" % (index, payload, project.dirpath))
                 ext = os.path.splitext(payload)[1] or ".vtp"

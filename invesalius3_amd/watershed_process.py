@@ -15,7 +15,23 @@ import ctypes
 
 import numpy as np
 
+import warnings
+
 from . import _lib as L
+
+
+class MarkerTieWarning(UserWarning):
+    """The scikit-image branch met adjacent marker voxels of DIFFERENT labels and EQUAL image value.  scikit-image pops
+    such markers in an order that depends on its heap's array layout (every push and pop before them), which no parallel
+    flood can reproduce; this package takes them in raster order.  Where their basins meet before the cost decides, the
+    labels may differ from scikit-image's.  Zero such pairs = identical to scikit-image by construction."""
+
+
+def _warn_ties(n: int, where: str):
+    if n > 0:
+        warnings.warn("%s: %d adjacent tied markers of different labels -- taken in raster order, scikit-image's order "
+                      "depends on its heap layout; labels can differ where those basins meet (DESIGN.md 6b)" % (where, n),
+                      MarkerTieWarning, stacklevel=3)
 
 
 def cost_image(image: np.ndarray, use_ww_wl: bool, wl, ww, gradient_size=0) -> np.ndarray:
@@ -100,8 +116,9 @@ def watershed(image: np.ndarray, markers: np.ndarray, connectivity=None, want_co
     """``skimage.segmentation.watershed(image, markers, connectivity)`` on the GPU, for the call the reference makes
     (watershed_process.py:39,52; styles.py:1958,1975): `connectivity` is the 3x3(x3) structure array, no offset, mask,
     compactness or watershed lines.  2-D or 3-D uint8 / uint16 image, int8 / int16 markers; int32 labels like
-    scikit-image.  ``stats["tied_markers_of_different_labels"] == 0`` means: identical to scikit-image by construction
-    (DESIGN.md section 6b)."""
+    scikit-image.  This is the RASTER-TIE variant of that flood: ``stats["tied_markers_of_different_labels"] == 0``
+    means identical to scikit-image by construction; otherwise a `MarkerTieWarning` is raised with the count, because
+    scikit-image's own order among such markers depends on its heap layout."""
     image = np.asarray(image)
     markers = np.asarray(markers)
     if image.dtype.type not in (np.uint8, np.uint16):
@@ -125,6 +142,7 @@ def watershed(image: np.ndarray, markers: np.ndarray, connectivity=None, want_co
     L.check(L.lib().ivx_watershed_sk(L.U8 if img.dtype == np.uint8 else L.U16, L.ptr(img), L.i64(shp),
                                      L.I16 if mk.dtype == np.int16 else L.I8, L.ptr(mk), L.ptr(s3), L.ptr(out),
                                      L.ptr(cost) if want_cost else None, stats), "watershed")
+    _warn_ties(int(stats[6]), "watershed")
     res = (out,)
     if want_cost:
         res += (cost,)
@@ -137,7 +155,9 @@ def watershed(image: np.ndarray, markers: np.ndarray, connectivity=None, want_co
 
 def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_ww_wl, wl, ww, q=None):
     """Same signature and side effects as watershed_process.do_watershed (:19-60): writes the uint8 label volume to
-    the memmap `tfile` and signals ``q.put(1)``.  Cost image and flood run on the GPU."""
+    the memmap `tfile` and signals ``q.put(1)``.  Cost image and flood run on the GPU.  With ``algorithm ==
+    "Watershed"`` this is the raster-tie variant of scikit-image's flood (see `watershed`): the number of adjacent tied
+    markers of different labels is kept in ``do_watershed.last_stats`` and a `MarkerTieWarning` says so when it is not 0."""
     mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")
     image = np.asarray(image)
     if image.dtype != np.int16 or image.ndim not in (2, 3):
@@ -160,8 +180,14 @@ def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_
     L.check(L.lib().ivx_do_watershed(L.ptr(img3), L.i64(img3.shape), L.i64(img3.strides), L.I16 if mk.dtype == np.int16 else L.I8,
                                      L.ptr(mk), L.ptr(_strct27(bstruct, image.ndim)), int(sk), gs, int(bool(use_ww_wl)),
                                      ctypes.c_double(float(ww)), ctypes.c_double(float(wl)), L.ptr(tmp_mask), stats), "do_watershed")
+    do_watershed.last_stats = {"algorithm": algorithm, "tied_markers_of_different_labels": int(stats[6]) if sk else 0}
+    if sk:
+        _warn_ties(int(stats[6]), "do_watershed")
     tmp_mask = tmp_mask.reshape(image.shape)
     mask[:] = tmp_mask
     mask.flush()
     if q is not None:
         q.put(1)
+
+
+do_watershed.last_stats = None

@@ -164,6 +164,49 @@ def test_surfaces_and_image_versions_survive_open_then_save(tmp_path):
         prj.save_inv3(tmp_path / "c.inv3", p)
 
 
+def test_a_crafted_surface_payload_never_leaves_the_project_folder(tmp_path):
+    """a surface plist naming `../../secret` (or an absolute path) as its polydata file must not make
+    open -> save copy that file into the new archive; plist file names are confined to the project folder."""
+    import plistlib
+
+    secret = tmp_path / "secret.txt"
+    secret.write_bytes(b"top secret")
+    p = _project(np.random.default_rng(4))
+    first = tmp_path / "a.inv3"
+    prj.save_inv3(first, p)
+    work = tmp_path / "w"
+    files = prj.extract(first, str(work))
+    d = os.path.dirname(files[0])
+    rel = os.path.relpath(str(secret), d)
+    for k, payload in enumerate((rel, str(secret))):
+        with open(os.path.join(d, "surface_%d.plist" % k), "wb") as f:
+            plistlib.dump({"name": "crafted", "index": k, "polydata": payload}, f)
+    with open(os.path.join(d, "main.plist"), "rb") as f:
+        main = plistlib.load(f)
+    main["surfaces"] = {"0": "surface_0.plist", "1": "surface_1.plist"}
+    with open(os.path.join(d, "main.plist"), "wb") as f:
+        plistlib.dump(main, f)
+    with pytest.warns(UserWarning, match="payload dropped"):
+        q = prj.load_from_folder(d)
+    assert q.surfaces[0]["polydata"] == "" and q.surfaces[1]["polydata"] == ""
+    second = tmp_path / "b.inv3"
+    prj.save_inv3(second, q)
+    with tarfile.open(second) as tar:
+        for m in tar.getmembers():
+            if m.isfile():
+                assert b"top secret" not in tar.extractfile(m).read()
+    # a plist that points its matrix / mask / surface plist outside the folder is refused outright
+    main["matrix"]["filename"] = rel
+    with open(os.path.join(d, "main.plist"), "wb") as f:
+        plistlib.dump(main, f)
+    with pytest.raises(ValueError, match="leaves the project folder"):
+        prj.load_from_folder(d)
+    # ... and a caller who edits a LOADED surface to point outside is stopped at save time too
+    q.surfaces[0]["polydata"] = rel
+    with pytest.raises(ValueError, match="leaves the project folder"):
+        prj.save_inv3(tmp_path / "c.inv3", q)
+
+
 def test_close_never_removes_a_callers_workdir_and_failed_open_cleans_up(tmp_path):
     rng = np.random.default_rng(4)
     p = _project(rng)
