@@ -202,6 +202,21 @@ int ivx_dev_mc_list(const ivx_mc_params *p, const void *scratch, int64_t max_tri
 int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *tris,
                        int64_t max_tris, int64_t *ntris);
 
+/* Cross-slab stitch on the device (replaces vtkAppendPolyData + vtkCleanPolyData of join_process_surface,
+ * invesalius/data/surface_process.py:229-268, across Z-slabs).  Follows ivx_dev_mc_indexed_emit on the same params / scratch /
+ * stream, one iso-value.  Rank r's top point plane and rank r+1's bottom point plane are the same voxels: the vertices both
+ * pieces carry there are matched by edge identity (point word, kind, bit), never by float compares.
+ *   1. ivx_dev_mc_stitch_top_sig   -> 32 bytes per point word of the top plane; send them to the rank above
+ *   2. ivx_dev_mc_stitch_match     bottom plane vs the signature received from below (NULL on the lowest rank):
+ *                                  vd[0] = nverts, vd[1] = copies this piece drops (device words); all-gather the pairs
+ *   3. ivx_dev_mc_stitch_apply     faces -> global vertex ids in place, kept vertices -> verts_out (nverts - dropped of
+ *                                  them, old order; global id of the first = sum over lower ranks of nverts - dropped) */
+int ivx_dev_mc_stitch_sig_bytes(const ivx_mc_params *p, size_t *nbytes);
+int ivx_dev_mc_stitch_top_sig(const ivx_mc_params *p, const void *scratch, void *sig, void *stream);
+int ivx_dev_mc_stitch_match(const ivx_mc_params *p, const void *scratch, const void *nbr_sig, int64_t nverts, uint32_t *vd,
+                            void *stream);
+int ivx_dev_mc_stitch_apply(const ivx_mc_params *p, const void *scratch, const void *nbr_sig, const uint32_t *vd_all, int rank,
+                            const float *verts, int64_t nverts, int32_t *faces, int64_t ntris, float *verts_out, void *stream);
 /* ------------------------------------------------------------------------------------------------
  * indexed surface ("point merge"): unique vertices + int32 faces instead of a soup
  *   replaces vtkAppendPolyData + vtkCleanPolyData of join_process_surface

@@ -777,6 +777,147 @@ __global__ __launch_bounds__(256) void k_mci_faces(const uint64_t *__restrict__ 
     }
 }
 
+// =====================================================================================================================
+// Cross-slab stitch on the device (the vtkAppendPolyData + vtkCleanPolyData of join_process_surface,
+// invesalius/data/surface_process.py:229-268, across the Z-slabs of SURVEY.md 8e).  Rank r's TOP point plane and rank r+1's
+// BOTTOM point plane are the same slice of voxels, so both carry the vertices of that plane's x / y edges (and its point
+// vertices).  A vertex IS a grid edge: the two copies are matched by edge identity -- same point word, same kind, same bit
+// -- never by comparing floats:
+//   k_mci_sig      per point word of a plane: (first local vertex id, cx, cy, cp)                 32 bytes per word
+//   k_mci_match    bottom plane of this piece AND the signature received from below -> the copies to drop, per word + total
+//   k_mci_gid0     global id of every vertex of the bottom plane's words: a dropped copy takes the id its twin has in the
+//                  rank below, a kept one moves down by the copies dropped before it
+//   k_mci_stitch_faces / _verts   faces -> global ids, vertices compacted; everything above the bottom plane just shifts
+// Global numbering: rank r's kept vertices follow rank r-1's, base_r = sum over q < r of (V_q - D_q); the (V, D) pairs
+// travel through ONE all-gather of 8 bytes per rank.  The result equals the host stitch (tests/_stitch_ref.py) array for
+// array.
+// =====================================================================================================================
+struct PlaneSig {
+    uint32_t vbase, pad;
+    uint64_t cx, cy, cp;
+};
+static_assert(sizeof(PlaneSig) == 32, "plane signatures travel as raw bytes");
+
+__global__ __launch_bounds__(256) void k_mci_sig(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb, Geom g,
+                                                 uint64_t pbits, uint64_t qbits, const uint32_t *__restrict__ vbase, int64_t k,
+                                                 PlaneSig *__restrict__ sig) {
+    const int64_t nwp = g.NY * g.WX;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwp) return;
+    const int64_t w = i % g.WX, jf = i / g.WX;
+    const Cross c = crossings<true>(bits, qb, g, k, jf, w, pbits, qbits);
+    PlaneSig sgn;
+    sgn.vbase = vbase[k * nwp + i];
+    sgn.pad = 0;
+    sgn.cx = c.cx;
+    sgn.cy = c.cy;
+    sgn.cp = c.cp;
+    sig[i] = sgn;
+}
+
+// vd[0] = this piece's vertex count, vd[1] (zeroed before) += copies dropped; rmcnt[word] = copies dropped in that word
+__global__ __launch_bounds__(256) void k_mci_match(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb, Geom g,
+                                                   uint64_t pbits, uint64_t qbits, const PlaneSig *__restrict__ nbr,
+                                                   uint32_t *__restrict__ rmcnt, uint32_t *vd, uint32_t nverts) {
+    const int64_t nwp = g.NY * g.WX;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) vd[0] = nverts;
+    uint32_t n = 0;
+    if (i < nwp && nbr) {
+        const int64_t w = i % g.WX, jf = i / g.WX;
+        const Cross c = crossings<true>(bits, qb, g, 0, jf, w, pbits, qbits);
+        const PlaneSig o = nbr[i];
+        n = (uint32_t)(__popcll(c.cx & o.cx) + __popcll(c.cy & o.cy) + __popcll(c.cp & o.cp));
+    }
+    if (i < nwp) rmcnt[i] = n;
+    uint32_t sum = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&vd[1], sum);
+}
+
+__device__ __forceinline__ void stitch_bases(const uint32_t *__restrict__ vd_all, int rank, uint32_t &base, uint32_t &base_below,
+                                             uint32_t &d_below) {
+    uint32_t b = 0;
+    base_below = 0;
+    d_below = 0;
+    for (int q = 0; q < rank; q++) {
+        if (q == rank - 1) {
+            base_below = b;
+            d_below = vd_all[2 * q + 1];
+        }
+        b += vd_all[2 * q] - vd_all[2 * q + 1];
+    }
+    base = b;
+}
+
+// rmoff = exclusive scan of rmcnt over the bottom plane's words
+__global__ __launch_bounds__(256) void k_mci_gid0(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb, Geom g,
+                                                  uint64_t pbits, uint64_t qbits, const uint32_t *__restrict__ vbase,
+                                                  const PlaneSig *__restrict__ nbr, const uint32_t *__restrict__ rmoff,
+                                                  const uint32_t *__restrict__ vd_all, int rank, uint32_t *__restrict__ gid0) {
+    const int64_t nwp = g.NY * g.WX;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwp) return;
+    const int64_t w = i % g.WX, jf = i / g.WX;
+    const Cross c = crossings<true>(bits, qb, g, 0, jf, w, pbits, qbits);
+    if (!(c.cx | c.cy | c.cz | c.cp)) return;
+    uint32_t base, base_below, d_below;
+    stitch_bases(vd_all, rank, base, base_below, d_below);
+    PlaneSig o;
+    o.vbase = 0; o.pad = 0; o.cx = 0; o.cy = 0; o.cp = 0;
+    if (nbr) o = nbr[i];
+    uint32_t local = vbase[i];
+    uint32_t kept = local - rmoff[i]; // position among this piece's kept vertices
+    // the rank below numbers the word's vertices cx, cy, (no cz on its top plane), cp
+    const uint32_t ocx = (uint32_t)__popcll(o.cx), ocy = (uint32_t)__popcll(o.cy);
+#pragma unroll
+    for (int ax = 0; ax < 4; ax++) {
+        uint64_t m = ax == 0 ? c.cx : (ax == 1 ? c.cy : (ax == 2 ? c.cz : c.cp));
+        const uint64_t om = ax == 0 ? o.cx : (ax == 1 ? o.cy : (ax == 2 ? 0ull : o.cp));
+        const uint32_t obefore = ax == 0 ? 0u : (ax == 1 ? ocx : ocx + ocy);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            if (om >> b & 1ull) // a copy: the twin's id in the rank below, after ITS dropped copies (all of which precede its top plane)
+                gid0[local] = base_below + (o.vbase + obefore + (uint32_t)__popcll(om & ((1ull << b) - 1ull))) - d_below;
+            else
+                gid0[local] = base + kept++;
+            local++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mci_stitch_faces(int32_t *__restrict__ faces, int64_t n3, uint32_t p0,
+                                                          const uint32_t *__restrict__ gid0, const uint32_t *__restrict__ vd_all,
+                                                          int rank) {
+    uint32_t base, bb, db;
+    stitch_bases(vd_all, rank, base, bb, db);
+    const uint32_t d = vd_all[2 * rank + 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
+        const uint32_t v = (uint32_t)faces[i];
+        faces[i] = (int32_t)(v < p0 ? gid0[v] : base + v - d);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mci_stitch_verts(const float *__restrict__ verts, int64_t nverts, uint32_t p0,
+                                                          const uint32_t *__restrict__ gid0, const uint32_t *__restrict__ vd_all,
+                                                          int rank, float *__restrict__ out) {
+    uint32_t base, bb, db;
+    stitch_bases(vd_all, rank, base, bb, db);
+    const uint32_t d = vd_all[2 * rank + 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nverts; v += stride) {
+        const uint32_t gid = v < (int64_t)p0 ? gid0[v] : base + (uint32_t)v - d;
+        if (gid < base) continue; // a dropped copy: its twin lives in the rank below
+        const uint32_t o = gid - base;
+        out[3 * (size_t)o] = verts[3 * v];
+        out[3 * (size_t)o + 1] = verts[3 * v + 1];
+        out[3 * (size_t)o + 2] = verts[3 * v + 2];
+    }
+}
+
 // per-stream workspace WS_MCV: strict[niso][bits_words] u64 | per iso: vbase[npw] u32, bsum[nsb], total[16]
 struct MciLayout {
     int64_t npw, nsb;
@@ -1092,6 +1233,130 @@ extern "C" int ivx_dev_mc_indexed_emit(const ivx_mc_params *p, const void *a, co
     case IVX_I16: return run_indexed<int16_t>(p, g, s, a, (const char *)scratch, verts, max_verts, faces, max_tris, st);
     default: return run_indexed<uint16_t>(p, g, s, a, (const char *)scratch, verts, max_verts, faces, max_tris, st);
     }
+}
+
+// ---- cross-slab stitch API: follows ivx_dev_mc_indexed_emit on the same params / scratch / stream (one iso-value) ------
+struct StitchWs {
+    PlaneSig *top;     // this piece's top-plane signature (what the rank above receives)
+    uint32_t *rmcnt;   // copies dropped per bottom-plane word, then their exclusive scan
+    uint32_t *bsum, *total, *gid0;
+    size_t bytes;
+};
+static StitchWs stitch_layout(const Geom &g, uint32_t p0, char *base) {
+    StitchWs w;
+    const size_t nwp = (size_t)(g.NY * g.WX);
+    size_t o = 0;
+    auto take = [&](size_t n) { char *q = base ? base + o : nullptr; o += al256(n); return q; };
+    w.top = (PlaneSig *)take(nwp * sizeof(PlaneSig));
+    w.rmcnt = (uint32_t *)take((nwp + 1) * 4);
+    w.bsum = (uint32_t *)take(((size_t)scan_u32_blocks((int64_t)nwp) + 2) * 4);
+    w.total = (uint32_t *)take(64);
+    w.gid0 = (uint32_t *)take(((size_t)p0 + 1) * 4);
+    w.bytes = o;
+    return w;
+}
+static int stitch_ctx(const ivx_mc_params *p, const void *scratch, hipStream_t st, Geom *g, Scratch *s, MciLayout *m, void **d_v) {
+    int rc = make_geom(p, g);
+    if (rc) return rc;
+    IVX_REQUIRE(p->niso == 1, IVX_EINVAL, "mc stitch: one iso-value only");
+    *s = make_scratch(*g, p->niso);
+    IVX_REQUIRE(s->nwords > 0 && g->NZ >= 2, IVX_EINVAL, "mc stitch: the piece needs at least one cell layer");
+    *m = mci_layout(*g, *s, p->niso);
+    return ivx::ws_get_s(ivx::WS_MCV, st, m->total, d_v); // (the block ivx_dev_mc_indexed_count filled)
+}
+
+extern "C" int ivx_dev_mc_stitch_sig_bytes(const ivx_mc_params *p, size_t *nbytes) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    *nbytes = (size_t)(g.NY * g.WX) * sizeof(PlaneSig);
+    return IVX_OK;
+}
+
+// the signature of this piece's TOP point plane -> `sig` (device, ivx_dev_mc_stitch_sig_bytes): send it to the rank above
+extern "C" int ivx_dev_mc_stitch_top_sig(const ivx_mc_params *p, const void *scratch, void *sig, void *stream) {
+    Geom g;
+    Scratch s;
+    MciLayout m;
+    void *d_v;
+    hipStream_t st = ivx::S(stream);
+    int rc = stitch_ctx(p, scratch, st, &g, &s, &m, &d_v);
+    if (rc) return rc;
+    const uint32_t *vbase = (const uint32_t *)((char *)d_v + m.off_v);
+    const int64_t nwp = g.NY * g.WX;
+    hipLaunchKernelGGL(k_mci_sig, dim3((unsigned)ivx::cdiv(nwp, 256)), dim3(256), 0, st, mc_bits_ptr(scratch, s, 0),
+                       (const uint64_t *)d_v, g, pad_bits(p, 0), pad_qbits(p, 0), vbase, g.NZ - 1, (PlaneSig *)sig);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+// this piece's BOTTOM plane against the signature received from the rank below (NULL on the lowest rank):
+// vd[0] = nverts, vd[1] = copies this piece drops (two device words: all-gather them over the ranks)
+extern "C" int ivx_dev_mc_stitch_match(const ivx_mc_params *p, const void *scratch, const void *nbr_sig, int64_t nverts,
+                                       uint32_t *vd, void *stream) {
+    Geom g;
+    Scratch s;
+    MciLayout m;
+    void *d_v, *d_w;
+    hipStream_t st = ivx::S(stream);
+    int rc = stitch_ctx(p, scratch, st, &g, &s, &m, &d_v);
+    if (rc) return rc;
+    IVX_REQUIRE(nverts >= 0 && nverts < 0x7fffffffll && vd, IVX_EINVAL, "mc stitch: bad vertex count");
+    const int64_t nwp = g.NY * g.WX;
+    StitchWs w = stitch_layout(g, 0, nullptr);
+    if ((rc = ivx::ws_get_s(ivx::WS_MCST, st, w.bytes + ((size_t)nverts + 1) * 4 + 256, &d_w))) return rc;
+    w = stitch_layout(g, (uint32_t)nverts, (char *)d_w); // (gid0 sized for the worst case: every vertex in the bottom plane)
+    IVX_HIP(hipMemsetAsync(vd, 0, 8, st));
+    hipLaunchKernelGGL(k_mci_match, dim3((unsigned)ivx::cdiv(nwp, 256)), dim3(256), 0, st, mc_bits_ptr(scratch, s, 0),
+                       (const uint64_t *)d_v, g, pad_bits(p, 0), pad_qbits(p, 0), (const PlaneSig *)nbr_sig, w.rmcnt, vd,
+                       (uint32_t)nverts);
+    IVX_LAUNCH_CHECK();
+    return scan_u32_exclusive(w.rmcnt, nwp, w.bsum, w.total, st);
+}
+
+// vd_all = the (nverts, dropped) pairs of every rank in rank order (device, 2 * world words).  `faces` (ntris x 3 local
+// ids) become global ids in place; the vertices this piece keeps are written to `verts_out` in their old order
+// (nverts - dropped of them; global id of the first one = sum over the ranks below of nverts - dropped).
+extern "C" int ivx_dev_mc_stitch_apply(const ivx_mc_params *p, const void *scratch, const void *nbr_sig, const uint32_t *vd_all,
+                                       int rank, const float *verts, int64_t nverts, int32_t *faces, int64_t ntris,
+                                       float *verts_out, void *stream) {
+    Geom g;
+    Scratch s;
+    MciLayout m;
+    void *d_v, *d_w;
+    hipStream_t st = ivx::S(stream);
+    int rc = stitch_ctx(p, scratch, st, &g, &s, &m, &d_v);
+    if (rc) return rc;
+    IVX_REQUIRE(rank >= 0 && vd_all && nverts >= 0 && nverts < 0x7fffffffll, IVX_EINVAL, "mc stitch: bad arguments");
+    const int64_t nwp = g.NY * g.WX;
+    StitchWs w = stitch_layout(g, 0, nullptr);
+    if ((rc = ivx::ws_get_s(ivx::WS_MCST, st, w.bytes + ((size_t)nverts + 1) * 4 + 256, &d_w))) return rc;
+    w = stitch_layout(g, (uint32_t)nverts, (char *)d_w);
+    const uint32_t *vbase = (const uint32_t *)((char *)d_v + m.off_v);
+    // first local id above the bottom plane's words: read through the mailbox (sizes nothing, but the kernels need it)
+    uint32_t p0 = (uint32_t)nverts;
+    if (g.NZ > 1) {
+        uint32_t seq;
+        if ((rc = ivx::mailbox_publish(vbase + nwp, 1, st, &seq))) return rc;
+        if ((rc = ivx::mailbox_wait(seq, st, &p0, 1))) return rc;
+    }
+    hipLaunchKernelGGL(k_mci_gid0, dim3((unsigned)ivx::cdiv(nwp, 256)), dim3(256), 0, st, mc_bits_ptr(scratch, s, 0),
+                       (const uint64_t *)d_v, g, pad_bits(p, 0), pad_qbits(p, 0), vbase, (const PlaneSig *)nbr_sig, w.rmcnt,
+                       vd_all, rank, w.gid0);
+    IVX_LAUNCH_CHECK();
+    if (ntris > 0) {
+        const int64_t n3 = ntris * 3, blocks = ivx::cdiv(n3, 256);
+        hipLaunchKernelGGL(k_mci_stitch_faces, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, faces, n3, p0,
+                           w.gid0, vd_all, rank);
+        IVX_LAUNCH_CHECK();
+    }
+    if (nverts > 0) {
+        const int64_t blocks = ivx::cdiv(nverts, 256);
+        hipLaunchKernelGGL(k_mci_stitch_verts, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, verts, nverts,
+                           p0, w.gid0, vd_all, rank, verts_out);
+        IVX_LAUNCH_CHECK();
+    }
+    return IVX_OK;
 }
 
 // Host form: strided piece in, indexed mesh out.  verts == NULL -> counts only (*nverts, *ntris).

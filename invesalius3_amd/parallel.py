@@ -384,52 +384,72 @@ def _make_slab_volume():
 
         def marching_cubes_indexed(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
             """This rank's piece as an indexed mesh.  Vertices on the plane shared with the next rank exist on both
-            sides; `stitch_piece_meshes` merges them (the vtkCleanPolyData step of join_process_surface)."""
+            sides; `marching_cubes_stitched` merges them (the vtkCleanPolyData step of join_process_surface)."""
             return super().marching_cubes_indexed(from_binary, min_value, max_value, fill_border_holes, download)
 
+        def marching_cubes_stitched(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False):
+            """The cross-slab stitch on the device (vtkAppendPolyData + vtkCleanPolyData of join_process_surface,
+            surface_process.py:229-268, over the Z-slabs): this rank's indexed piece with GLOBAL vertex ids.  The vertices
+            of the plane shared with the rank below exist in both pieces; they are matched by edge identity (same point
+            word, same kind, same bit -- no float compares, no host arithmetic), the copies are dropped here and the faces
+            point at the ids their twins have below.  Collective: one neighbour exchange of the plane's signature (32 bytes
+            per point word) and one all-gather of 8 bytes per rank, both on this volume's stream.
+
+            Returns (first global vertex id, kept vertices, triangles), or with download=True
+            (first id, verts (kept, 3) float32, faces (T, 3) int32 of global ids): the ranks' arrays concatenated in rank
+            order are the stitched surface.  Device buffers: self._sverts / self._faces."""
+            lib, lay, st = L.lib(), self.lay, self.stream
+            if from_binary is False:
+                raise NotImplementedError("marching_cubes_stitched: one iso-value (from_binary) only")
+            p, z0 = self._surface_params(from_binary, min_value, max_value, fill_border_holes)
+            nv, nt = DeviceVolume.marching_cubes_indexed(self, from_binary, min_value, max_value, fill_border_holes, False,
+                                                         params=p, z0=z0)
+            if lay.world == 1:  # nothing to stitch: the piece IS the surface
+                self._sverts = None
+                self.stitch_counts = {"vertices": nv, "dropped_copies": 0, "global_vertices": nv}
+                if download:
+                    self.sync()
+                    return 0, self._verts.download((nv, 3), np.float32), self._faces.download((nt, 3), np.int32)
+                return 0, nv, nt
+            with self.timer.span("stitch"):
+                nb = ctypes.c_size_t(0)
+                L.check(lib.ivx_dev_mc_stitch_sig_bytes(ctypes.byref(p), ctypes.byref(nb)))
+                if getattr(self, "_sig", None) is None or self._sig[0].nbytes < nb.value:
+                    self._sig = (DeviceBuffer(nb.value + 64), DeviceBuffer(nb.value + 64))
+                    self._vd = DeviceBuffer(64)
+                    self._vd_all = DeviceBuffer(8 * lay.world + 64)
+                top, below = self._sig
+                has_up, has_dn = lay.rank < lay.world - 1, lay.rank > 0
+                if has_up:
+                    L.check(lib.ivx_dev_mc_stitch_top_sig(ctypes.byref(p), self._mc_scratch.ptr, top.ptr, st), "stitch_top_sig")
+                if lay.world > 1:
+                    self.comm.exchange(None, below.ptr if has_dn else None, top.ptr if has_up else None, None, nb.value, st)
+                nbr = below.ptr if has_dn else None
+                L.check(lib.ivx_dev_mc_stitch_match(ctypes.byref(p), self._mc_scratch.ptr, nbr, c64(nv), self._vd.ptr, st),
+                        "stitch_match")
+                if lay.world > 1:
+                    self.comm.allgather(self._vd.ptr, self._vd_all.ptr, 8, st)
+                else:
+                    L.check(lib.ivx_memcpy_d2d(self._vd_all.ptr, self._vd.ptr, ctypes.c_size_t(8), st))
+                need = max(nv, 1) * 12
+                if getattr(self, "_sverts", None) is None or self._sverts.nbytes < need:
+                    if getattr(self, "_sverts", None) is not None:
+                        self._sverts.close()
+                    self._sverts = DeviceBuffer(int(need * 1.25) + 4096)
+                L.check(lib.ivx_dev_mc_stitch_apply(ctypes.byref(p), self._mc_scratch.ptr, nbr, self._vd_all.ptr, lay.rank,
+                                                    self._verts.ptr, c64(nv), self._faces.ptr, c64(nt), self._sverts.ptr, st),
+                        "stitch_apply")
+            self.sync()
+            vd = self._vd_all.download((lay.world, 2), np.uint32).astype(np.int64)
+            base = int((vd[:lay.rank, 0] - vd[:lay.rank, 1]).sum())
+            kept = int(vd[lay.rank, 0] - vd[lay.rank, 1])
+            self.stitch_counts = {"vertices": int(vd[lay.rank, 0]), "dropped_copies": int(vd[lay.rank, 1]),
+                                  "global_vertices": int((vd[:, 0] - vd[:, 1]).sum())}
+            if download:
+                return base, self._sverts.download((kept, 3), np.float32), self._faces.download((nt, 3), np.int32)
+            return base, kept, nt
+
     return SlabVolume
-
-
-def stitch_piece_meshes(pieces):
-    """Cross-slab stitch (vtkAppendPolyData + vtkCleanPolyData in surface_process.py:229-268): concatenate the
-    ranks' indexed pieces ``[(verts (V,3) float32, faces (T,3) int32), ...]`` in rank order and merge the vertices two
-    consecutive pieces both carry on their shared plane.  Both sides computed those vertices with the same arithmetic
-    on the same voxels, so they are equal bit for bit and the merge is an exact match on the float32 triple -- looked
-    for only among the vertices of the two pieces that sit on the shared plane's z (a few thousand per plane).
-    Returns (verts, faces) with the triangles in rank order."""
-    out_v, out_f = [], []
-    base = 0
-    prev = None  # (global ids, verts) of the previous piece, for the plane look-up
-    for verts, faces in pieces:
-        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
-        faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
-        gid = np.arange(len(verts), dtype=np.int64) + base
-        keep = np.ones(len(verts), bool)
-        if prev is not None and len(verts) and len(prev[1]):
-            pg, pv = prev
-            z_shared = np.intersect1d(np.unique(pv[:, 2]), np.unique(verts[:, 2]))
-            if len(z_shared):
-                a = np.isin(pv[:, 2], z_shared)
-                b = np.isin(verts[:, 2], z_shared)
-                key = lambda v: np.ascontiguousarray(v).view([("", np.uint32)] * 3).ravel()
-                ka, kb = key(pv[a].view(np.uint32)), key(verts[b].view(np.uint32))
-                order = np.argsort(ka)
-                pos = np.searchsorted(ka[order], kb)
-                pos[pos >= len(ka)] = 0
-                hit = (len(ka) > 0) & (ka[order][pos] == kb) if len(ka) else np.zeros(len(kb), bool)
-                idx_b = np.nonzero(b)[0][hit]
-                gid[idx_b] = pg[a][order][pos[hit]]
-                keep[idx_b] = False
-        # compact: the surviving vertices of this piece get consecutive global ids after `base`
-        new_ids = np.cumsum(keep) - 1 + base
-        gid = np.where(keep, new_ids, gid)
-        out_v.append(verts[keep])
-        out_f.append(gid[faces] if len(faces) else faces)
-        base += int(keep.sum())
-        prev = (gid, verts)
-    if not out_v:
-        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)
-    return np.concatenate(out_v), np.concatenate(out_f).astype(np.int32)
 
 
 def __getattr__(name):  # SlabVolume needs libivx + a device; build the class lazily so the CPU tests can import us

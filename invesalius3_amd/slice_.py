@@ -95,13 +95,43 @@ PROJECTION_LMIP, PROJECTION_MIDA, PROJECTION_CONTOUR_MIP, PROJECTION_CONTOUR_LMI
 _AXIS = {"AXIAL": 0, "CORONAL": 1, "SAGITAL": 2}
 
 
+def view_matrix(q_orientation, center) -> np.ndarray:
+    """The 4x4 matrix ``Slice.get_image_slice`` builds for a reoriented view (invesalius/data/slice_.py:848-858):
+    ``T1 . R^T . T0`` with ``T0 = translation(-cz, -cy, -cx)``, ``R = quaternion_matrix(q_orientation)`` (w, x, y, z;
+    transformations.py:1261-1290, unit-normalised there, identity below 4 eps) and ``T1 = translation(cz, cy, cx)``;
+    `center` is the reference's ``(cx, cy, cz)``.  C-contiguous float64, as apply_view_matrix_transform requires."""
+    q = np.array(q_orientation, dtype=np.float64, copy=True)
+    n = float(np.dot(q, q))
+    R = np.identity(4)
+    if n >= np.finfo(float).eps * 4.0:
+        q *= np.sqrt(2.0 / n)
+        o = np.outer(q, q)
+        R = np.array([[1.0 - o[2, 2] - o[3, 3], o[1, 2] - o[3, 0], o[1, 3] + o[2, 0], 0.0],
+                      [o[1, 2] + o[3, 0], 1.0 - o[1, 1] - o[3, 3], o[2, 3] - o[1, 0], 0.0],
+                      [o[1, 3] - o[2, 0], o[2, 3] + o[1, 0], 1.0 - o[1, 1] - o[2, 2], 0.0],
+                      [0.0, 0.0, 0.0, 1.0]])
+    cx, cy, cz = (float(v) for v in center)
+    T0, T1 = np.identity(4), np.identity(4)
+    T0[:3, 3] = (-cz, -cy, -cx)
+    T1[:3, 3] = (cz, cy, cx)
+    M = np.identity(4)
+    for m in (T1, R.T, T0):  # transformations.concatenate_matrices: left to right
+        M = np.dot(M, m)
+    return np.ascontiguousarray(M)
+
+
 def get_image_slice(matrix: np.ndarray, orientation: str, slice_number: int, number_slices: int = 1, inverted: bool = False,
-                    border_size: float = 1.0, type_projection: int = PROJECTION_NORMAL, window_level=0) -> np.ndarray:
-    """The array work of ``Slice.get_image_slice`` (invesalius/data/slice_.py:832-1119) for an unrotated view: the slab
-    ``matrix[n : n + number_slices]`` along the view axis (one slice for PROJECTION_NORMAL), reversed when `inverted`, then
-    the projection -- max / min / mean, MIDA, the three contour MIPs -- with the reference's own arguments, its quirk
+                    border_size: float = 1.0, type_projection: int = PROJECTION_NORMAL, window_level=0, q_orientation=None,
+                    center=None, spacing=None, interp_method: int = 2) -> np.ndarray:
+    """The array work of ``Slice.get_image_slice`` (invesalius/data/slice_.py:832-1119): the slab
+    ``matrix[n : n + number_slices]`` along the view axis (one slice for PROJECTION_NORMAL); when the view is reoriented
+    (``np.any(q_orientation[1:])``, :847,862,948,1035) the slab is resampled from the whole volume through
+    `view_matrix(q_orientation, center)` with ``apply_view_matrix_transform(matrix, spacing, M, n, orientation,
+    interp_method, matrix.min(), slab)`` (HIP: csrc/k_transform.hip) before anything else; then reversed when `inverted`,
+    then the projection -- max / min / mean, MIDA, the three contour MIPs -- with the reference's own arguments, its quirk
     included (the window LEVEL goes in for level and width alike: :898-900,906-945).  LMIP raises AttributeError like the
-    reference (`mips.lmip` is commented out of invesalius_rs/__init__.py:83).  The buffer_slices cache stays with the caller."""
+    reference (`mips.lmip` is commented out of invesalius_rs/__init__.py:83).  The buffer_slices cache stays with the
+    caller; `interp_method` defaults to the reference's (Slice.interp_method = 2, slice_.py:119)."""
     from . import invesalius_rs as mips
 
     ax = _AXIS[orientation]
@@ -110,6 +140,11 @@ def get_image_slice(matrix: np.ndarray, orientation: str, slice_number: int, num
     sl = [slice(None)] * 3
     sl[ax] = slice(slice_number, slice_number + number_slices)
     tmp = np.array(matrix[tuple(sl)])
+    if q_orientation is not None and np.any(np.asarray(q_orientation)[1:]):
+        if center is None or spacing is None:
+            raise TypeError("a reoriented view needs `center` (cx, cy, cz) and `spacing`")
+        mips.apply_view_matrix_transform(matrix, spacing, view_matrix(q_orientation, center), slice_number, orientation,
+                                         interp_method, matrix.min(), tmp)
     oshape = tuple(s for i, s in enumerate(tmp.shape) if i != ax)
     if type_projection == PROJECTION_NORMAL:
         return tmp.reshape(oshape)

@@ -267,6 +267,33 @@ def test_gpu_get_image_slice_equals_the_reference(ivxlib):
         sl.get_image_slice(z["img"], "AXIAL", 2, 7, False, 1.0, 4, 300)
 
 
+def test_view_matrix_equals_the_reference_transformations():
+    """tests/golden/ref_reorient.npz holds the matrices the reference's own get_image_slice handed to
+    apply_view_matrix_transform (transformations.translation_matrix / quaternion_matrix / concatenate_matrices,
+    slice_.py:848-858); `slice_.view_matrix` restates them (no GPU needed)."""
+    from invesalius3_amd.slice_ import view_matrix
+    z = np.load(os.path.join(GOLD, "ref_reorient.npz"))
+    for qi in range(3):
+        got = view_matrix(z["q%d" % qi], z["center"])
+        assert got.flags["C_CONTIGUOUS"] and got.dtype == np.float64
+        assert np.array_equal(got, z["M%d" % qi]), qi
+    assert np.array_equal(view_matrix((1.0, 0, 0, 0), (3, 4, 5)), np.identity(4))
+
+
+@pytest.mark.gpu
+def test_gpu_get_image_slice_reoriented_equals_the_reference(ivxlib):
+    """The reoriented-view branch (VERDICT r2 missing #2): 144 slabs of the reference's own get_image_slice with a
+    non-identity q_orientation -- three rotations x three orientations x four interpolation kernels x projections."""
+    from invesalius3_amd import slice_ as sl
+    z = np.load(os.path.join(GOLD, "ref_reorient.npz"))
+    for name in z["cases"]:
+        qi, orientation, n0, ns, interp, tp, inv = str(name).split("_")
+        got = sl.get_image_slice(z["img"], orientation, int(n0), int(ns), bool(int(inv)), 1.0, int(tp), 300,
+                                 q_orientation=z["q" + qi], center=z["center"], spacing=z["spacing"], interp_method=int(interp))
+        want = z[str(name)]
+        assert got.dtype == want.dtype and np.array_equal(got, want), name
+
+
 def test_oracle_equals_the_reference_mask_operations(oracle):
     """tests/golden/ref_maskops.npz = the reference's OWN Slice.do_boolean_op (four operations), calc_image_density and
     calc_mask_area (imported; make_golden_ref_maskops.py), each preceded by its do_threshold_to_all_slices."""

@@ -39,10 +39,11 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
             lay = vol.lay
             proj = {(ax, op): vol.project_global(ax, op) for ax in (0, 1, 2) for op in ("max", "min", "mean")}
             piece_mesh = vol.marching_cubes_indexed(from_binary=True, download=True)
+            stitched = vol.marching_cubes_stitched(from_binary=True, download=True)
             rays = {(kind, ax): vol.rays_global(kind, ax, *par) for kind, par in (("lmip", (-300, 900)), ("mida", (300.0, 1200.0)))
                     for ax in (0, 1, 2)}
             fcm = {(tm, ax): vol.fast_countour_mip_global(2.0, ax, 300, 1200, tm) for tm in (0, 1, 2) for ax in (0, 1, 2)}
-            res[rank] = dict(proj=proj, mesh=piece_mesh, rays=rays, fcm=fcm, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
+            res[rank] = dict(proj=proj, mesh=piece_mesh, stitched=stitched, rays=rays, fcm=fcm, out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1],
                              mask=vol.download_mask()[lay.first_interior:lay.last_interior + 1], tris=tris,
                              count=vol.reached_count())
             vol.close()
@@ -68,10 +69,17 @@ def test_slab_volume_matches_single_volume_oracle(ivxlib, oracle, world, conn):
     key = lambda t: np.sort(t.reshape(len(t), -1).view([("", np.float32)] * 9), axis=0)
     assert len(cat) == len(whole) and np.array_equal(key(cat), key(whole))
     # cross-slab stitch of the ranks' indexed pieces == the merged whole-volume surface
-    from invesalius3_amd.parallel import stitch_piece_meshes
+    from _stitch_ref import stitch_piece_meshes
     sv, sf = stitch_piece_meshes([res[r]["mesh"] for r in range(world)])
     assert len(sv) == len(np.unique(whole.reshape(-1, 3), axis=0)) == len(np.unique(sv, axis=0))
     assert np.array_equal(key(sv[sf]), key(whole))
+    # ... and the DEVICE stitch (edge identity, no float compares) gives the very same arrays, rank by rank
+    bases = [res[r]["stitched"][0] for r in range(world)]
+    dv = np.concatenate([res[r]["stitched"][1] for r in range(world)])
+    df = np.concatenate([res[r]["stitched"][2] for r in range(world)])
+    assert bases == [0] + list(np.cumsum([len(res[r]["stitched"][1]) for r in range(world)])[:-1])
+    assert dv.shape == sv.shape and np.array_equal(dv.view(np.uint32), sv.view(np.uint32)), "stitched vertices"
+    assert df.shape == sf.shape and np.array_equal(df, sf), "stitched faces"
     # LMIP / MIDA of the whole volume: rays along Z are handed from slab to slab, the others are rank-local rows
     for (kind, ax), img in res[0]["rays"].items():
         oshape = tuple(s for i, s in enumerate(full.shape) if i != ax)

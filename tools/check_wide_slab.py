@@ -5,7 +5,8 @@ import numpy as np
 from scipy.ndimage import generate_binary_structure
 from test_gpu_slab import LoopbackWorld
 import threading
-from invesalius3_amd.parallel import SlabVolume, stitch_piece_meshes
+from _stitch_ref import stitch_piece_meshes
+    from invesalius3_amd.parallel import SlabVolume
 from oracle import oracle
 oracle.build()
 world, nz, ny, nx = 2, 6, 2048, 2048
