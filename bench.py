@@ -98,7 +98,8 @@ def pmc_traffic(config, stage):
     """HBM bytes per step of `stage` from the rocprofv3 --pmc passes of tools/profile_round.sh, if (and only if) the
     committed summary was measured on exactly these sources; None otherwise (rocprofv3 cannot run inside the bench)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        name = "pmc_traffic.json" if config == "grow_mc" else "pmc_traffic_%s.json" % config
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             j = json.load(f)
         if j.get("src_sha16") != src_sha16() or j.get("config", "grow_mc") != config:
             return None
@@ -515,7 +516,7 @@ def run_watershed(args, job):
     if job.rank != 0:
         return
     names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "tile_sweeps", "us_costs",
-             "us_zones", "us_bucket", "us_levels", "us_labels")
+             "us_zones", "us_bucket", "us_levels", "us_labels", "cost_levels", "cost_level_rounds", "cost_level_voxels")
     flood_ms = spans.get("flood", 0.0)
     res = {
         "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
@@ -528,7 +529,7 @@ def run_watershed(args, job):
         "stage_ms": {k: round(v, 3) for k, v in spans.items()},
         "flood": {k: int(v) for k, v in zip(names, stats)},
         "object_voxels": obj,
-        "roofline": roofline("watershed flood (k_ws_*)", 7.0 * nvox, flood_ms, None, None,
+        "roofline": roofline("watershed flood (k_ws_*)", 7.0 * nvox, flood_ms, pmc_traffic("watershed", "flood") if n == 512 else None, None,
                              {"note": "7 B/voxel = cost 2 + markers 2 read, labels 2 + mask 1 written (SURVEY.md 8d); the flood is a "
                                       "multi-pass algorithm (relaxation rounds + zones + level chain), so the fraction is small by design"}),
         "device": L.device_name(),
@@ -669,7 +670,8 @@ def run_watershed_sk(args, job):
         "stage_ms": {k: round(v, 3) for k, v in spans.items()},
         "flood": {k: int(v) for k, v in zip(names, stats) if k != "_"},
         "object_voxels": obj,
-        "roofline": roofline("watershed flood (k_ws_relax + k_sk_*)", 7.0 * nvox, flood_ms, None, None,
+        "roofline": roofline("watershed flood (k_ws_relax + k_sk_*)", 7.0 * nvox, flood_ms,
+                             pmc_traffic("watershed_sk", "flood") if n == 512 and use_ww_wl else None, None,
                              {"note": "7 B/voxel = image 2 + markers 2 read, labels 2 + mask 1 written (SURVEY.md 8d; + 4 B/voxel for "
                                       "the gradient pass, timed apart); the flood is a level-ordered breadth-first search whose serial "
                                       "depth (generations) bounds it, not the bytes"}),
@@ -728,14 +730,33 @@ def run_mip(args, job):
     lib = L.lib()
     f = 2048 // n if n <= 2048 and 2048 % n == 0 else 1
     proj = DeviceBuffer(n * n * 2 + 64)
-    view = [DeviceBuffer(n * f * n * f * 2) for _ in range(3)]
+    view = {(k, a): DeviceBuffer(n * f * n * f * 2) for k in ("maxip", "mida") for a in range(3)}
+    view[("contour", 0)] = DeviceBuffer(n * f * n * f * 2)
+    mm, status, tmp = DeviceBuffer(64), DeviceBuffer(64), DeviceBuffer(nvox * 2 + 64)
+    status.zero(vol.stream)
+    WL, WW = 300.0, 300.0  # get_image_slice hands the window LEVEL in for level and width alike (slice_.py:898-900, quirk Q1)
 
     def step():
+        # MaxIP (int16-exact) + MIDA (f32, the reference's operation order) along each of the three axes,
+        # plus one contour MIP (fast_countour_mip, tmip 0) -- every image blown up to the 2048^2 viewport
         for axis in range(3):
             with vol.timer.span("maxip_axis%d" % axis):
                 L.check(lib.ivx_dev_mip_reduce(L.I16, vol.image.raw, c64(n), c64(n), c64(n), axis, L.MIP_MAX, proj.ptr, vol.stream))
-            with vol.timer.span("viewport_axis%d" % axis):
-                L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[axis].ptr, vol.stream))
+            with vol.timer.span("viewport"):
+                L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[("maxip", axis)].ptr, vol.stream))
+            with vol.timer.span("mida_axis%d" % axis):
+                # mida_internal's own pre-pass over the volume (mips.rs:113-121), then the rays
+                L.check(lib.ivx_dev_minmax_f32(L.I16, vol.image.raw, c64(nvox), mm.ptr, vol.stream))
+                L.check(lib.ivx_dev_mida(L.I16, vol.image.raw, c64(n), c64(n), c64(n), axis, ctypes.c_float(WL), ctypes.c_float(WW),
+                                         mm.ptr, L.I16, proj.ptr, status.ptr, vol.stream), "mida")
+            with vol.timer.span("viewport"):
+                L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[("mida", axis)].ptr, vol.stream))
+        with vol.timer.span("contour_mip_axis0"):
+            L.check(lib.ivx_dev_fcm_volume(L.I16, vol.image.raw, c64(n), c64(n), c64(n), ctypes.c_float(2.0), 0, tmp.ptr, status.ptr,
+                                           vol.stream), "fcm_volume")
+            L.check(lib.ivx_dev_mip_reduce(L.I16, tmp.ptr, c64(n), c64(n), c64(n), 0, L.MIP_MAX, proj.ptr, vol.stream))
+        with vol.timer.span("viewport"):
+            L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[("contour", 0)].ptr, vol.stream))
 
     def barrier():
         vol.sync()
@@ -750,44 +771,71 @@ def run_mip(args, job):
         step()
     barrier()
     dt = job.max(time.perf_counter() - t0)
-    spans = {k: float(np.mean(v)) for k, v in vol.timer.collect().items()}
+    raw = vol.timer.collect()
+    spans = {k: float(np.mean(v)) * (7 if k == "viewport" else 1) for k, v in raw.items()}  # ("viewport": seven per step)
     copy_gbs = copy_bandwidth(vol, nvox) if job.rank == 0 else None
-    got = [view[a].download((n * f, n * f), np.int16) for a in range(3)]
-    ok = all(np.array_equal(got[a], np.repeat(np.repeat(img.max(axis=a), f, axis=0), f, axis=1)) for a in range(3))
+    up = lambda a2: np.repeat(np.repeat(a2, f, axis=0), f, axis=1)
+    got = {k: view[k].download((n * f, n * f), np.int16) for k in view}
+    ok_max = all(np.array_equal(got[("maxip", a)], up(img.max(axis=a))) for a in range(3))
     if job.rank != 0:
         return
-    proj_ms = sum(v for k, v in spans.items() if k.startswith("maxip"))
-    sweep_bytes = 3 * (2.0 * nvox + 2.0 * n * n) + 3 * (2.0 * n * n + 2.0 * (n * f) ** 2)
-    worst = max((k for k in spans if k.startswith("maxip")), key=lambda k: spans[k])
+    proj_ms = sum(v for k, v in spans.items() if k != "viewport")
+    # algorithmic bytes: 2 B/voxel per projection, MIDA + 2 B/voxel for its min/max pre-pass, the contour MIP
+    # 2 B/voxel read + the contour volume written and read again (2 + 2), and the viewports
+    sweep_bytes = 3 * 2.0 * nvox + 3 * 4.0 * nvox + 6.0 * nvox + 7 * (2.0 * n * n + 2.0 * (n * f) ** 2) + 7 * 2.0 * n * n
+    worst = max((k for k in spans if k != "viewport"), key=lambda k: spans[k])
+    per_kernel_bytes = {"maxip": 2.0 * nvox, "mida": 4.0 * nvox, "contour": 6.0 * nvox}
     res = {
         "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
-        "value": round(job.world * 3 * nvox / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",
+        "value": round(job.world * 7 * nvox / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",
         "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16", "data": "synthetic",
-        "config": {"workload": "configs[4]: MaxIP of a %d^3 int16 volume along each of the 3 axes, each written to a %dx%d int16 viewport "
-                               "(%dx%d rays per voxel column, volume.py:678); int16 arithmetic: fp16 cannot hold int16 data (SURVEY H3)"
-                               % (n, n * f, n * f, f, f),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16 (MaxIP) / f32 (MIDA, contour MIP)", "data": "synthetic",
+        "config": {"workload": "configs[4]: MaxIP (int16-exact) + MIDA (f32) of a %d^3 int16 volume along each of the 3 axes and one contour "
+                               "MIP (axis 0), each image written to a %dx%d int16 viewport (%dx%d rays per voxel column, volume.py:678); "
+                               "7 projections per step; fp16 cannot hold int16 data (SURVEY H3), VTK's ray caster (volume.py:519-526,641) "
+                               "is not installed here and is not the comparator" % (n, n * f, n * f, f, f),
                    "parallelism": "replicas x%d" % job.world},
         "stage_ms": {k: round(v, 4) for k, v in spans.items()},
-        "parity": {"ok": bool(ok), "checked": "all three viewports == numpy max(axis) repeated %dx%d, bit for bit" % (f, f)},
-        "roofline": roofline("3-axis MaxIP sweep + viewports", sweep_bytes, sum(spans.values()), None, copy_gbs,
-                             {"slowest_axis": worst, "slowest_axis_frac": round(2.0 * nvox / (spans[worst] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "projection_ms": round(proj_ms, 4)}),
+        "roofline": roofline("3-axis MaxIP + MIDA sweep, contour MIP, viewports", sweep_bytes, sum(spans.values()), None, copy_gbs,
+                             {"slowest": worst, "projection_ms": round(proj_ms, 4),
+                              "per_kernel_frac": {k: round(per_kernel_bytes[k.split("_")[0]] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                  for k, v in spans.items() if k != "viewport" and v > 0}}),
         "device": L.device_name(),
     }
+    ok_rays = None
     if args.cpu:
+        # the C restatement of mips.rs on ALL host cores (OpenMP over the rays, as rayon does in the reference),
+        # the whole volume; its images double as the parity gate of the MIDA / contour viewports
+        from oracle import oracle as orc
+        orc.build()
         t = time.perf_counter()
-        ref = [np.repeat(np.repeat(np.array(img).max(axis=a), f, axis=0), f, axis=1) for a in range(3)]
-        ts = time.perf_counter() - t
-        res["cpu_baseline"] = {"value": round(3 * nvox / ts / 1e6, 2), "unit": "Mvoxel/s", "cores": 1, "kind": "reference",
-                               "sample": "numpy .max(axis) of the whole volume for the 3 axes (slice_.py:885-889,969-973,1056-1060) + "
-                                         "np.repeat to the viewport, %.2f s; VTK's ray caster is not installed" % ts}
-        del ref
+        ref_max = [np.array(img).max(axis=a) for a in range(3)]
+        t1 = time.perf_counter()
+        ref_mida = []
+        for a in range(3):
+            o = np.zeros(tuple(s for i, s in enumerate(shape) if i != a), np.int16)
+            orc.mida(img, a, int(WL), int(WW), o)
+            ref_mida.append(o)
+        t2 = time.perf_counter()
+        ref_fcm = np.zeros(shape[1:], np.int16)
+        orc.fast_countour_mip(img, 2.0, 0, int(WL), int(WW), 0, ref_fcm)
+        t3 = time.perf_counter()
+        ok_rays = all(np.array_equal(got[("mida", a)], up(ref_mida[a])) for a in range(3)) and \
+            np.array_equal(got[("contour", 0)], up(ref_fcm))
+        res["cpu_baseline"] = {"value": round(7 * nvox / (t3 - t) / 1e6, 2), "unit": "Mvoxel/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "the whole volume: numpy .max(axis) x3 %.2fs (one thread: that IS the reference, slice_.py:885-889) + "
+                                         "C MIDA x3 %.2fs + C contour MIP %.2fs with OpenMP over the rays on %d cores (rayon in the "
+                                         "reference; the Rust originals cannot be built here, VTK's ray caster is not installed)"
+                                         % (t1 - t, t2 - t1, t3 - t2, os.cpu_count())}
     else:
         res["cpu_baseline"] = None
-    if not ok:
+    res["parity"] = {"ok": bool(ok_max and ok_rays is not False),
+                     "checked": "MaxIP viewports == numpy max(axis) repeated %dx%d bit for bit%s" % (
+                         f, f, "; MIDA x3 and contour-MIP viewports == the C restatement of mips.rs bit for bit (unpinned upstream: "
+                               "no Rust toolchain, no reference test)" if ok_rays is not None else " (--no-cpu: MIDA / contour not compared)")}
+    if not res["parity"]["ok"]:
         print(json.dumps(res), flush=True)
-        raise SystemExit("bench.py: viewport differs from numpy")
+        raise SystemExit("bench.py: viewport differs from the reference")
     print(json.dumps(res), flush=True)
 
 

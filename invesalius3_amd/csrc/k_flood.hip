@@ -520,6 +520,134 @@ __device__ __forceinline__ void tile_update_dir(const Tiles &t, const unsigned l
     if (threadIdx.x == 0) L.open = 1u; // (edge planes: no candidate plane to be exhausted)
 }
 
+// ---- linear-index tile update (the IFT watershed's cost levels, ivx_dev_ws_cost_levels) --------------------------------
+// scipy's watershed_ift takes neighbours by LINEAR index (ni_measure.c: only indices outside [0, size) are refused), so the
+// last voxel of a row neighbours the first voxel of the next row, and the last row of a slice the first row of the next
+// slice.  With rows of whole 64-voxel words the volume is ONE flat bit array: the x-neighbour of a word is word +- 1, the
+// y-neighbour word +- wx, the z-neighbour word +- dy * wx, and "in bounds" means 0 <= word < nwords -- nothing else.  Arcs are
+// symmetric, so three planes suffice: bit b of Ex / Ey / Ez[word] = the arc from voxel (word, b) to its +1 / +W / +HW
+// neighbour is enabled; the arc arriving from the other side is the neighbour word's bit.  The staged halo rows are the
+// LINEAR neighbours (row index z * dy + y, taken as it comes), which is the wrap-around for free; only the wake-up of the
+// tiles that read a changed word has to look the reader up when it is not the lattice neighbour (border tiles).
+// (returns true when the reader is this very tile -- a volume one tile wide: the caller then revisits itself)
+__device__ __forceinline__ bool lin_enlist(const Tiles &t, int64_t word, int64_t self, uint8_t *dirty_next, unsigned int *list_next,
+                                           unsigned int *n_next) {
+    const int64_t row = word / t.wx, txi = word - row * t.wx, z = row / t.dy, y = row - z * t.dy;
+    const int64_t nt = ((z / TZ) * t.nty + (y >> TY_LOG)) * t.wx + txi;
+    if (nt == self) return true;
+    unsigned int *wp = (unsigned int *)(dirty_next + (nt & ~(int64_t)3));
+    const unsigned int sh = 8 * (unsigned int)(nt & 3);
+    const unsigned int old = atomicOr(wp, 1u << sh);
+    if (!((old >> sh) & 0xffu)) list_next[atomicAdd(n_next, 1u)] = (unsigned int)nt;
+    return false;
+}
+
+__device__ __forceinline__ void tile_update_lin(const Tiles &t, const unsigned long long *__restrict__ E,
+                                                unsigned long long *reached, int64_t tile, TileLds &L, uint8_t *dirty_next,
+                                                unsigned int *list_next, unsigned int *n_next) {
+    const int64_t txi = tile % t.wx, r1 = tile / t.wx;
+    const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+    const int64_t z0 = tzi * TZ, y0 = tyi * TY;
+    const int64_t nrows = t.dz * t.dy, nwords = nrows * t.wx, hwx = t.dy * t.wx;
+    const unsigned long long *Ex = E, *Ey = E + nwords, *Ez = E + 2 * nwords;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int idx = threadIdx.x + pass * NT;
+        if (idx < HZ * HY) {
+            const int yy = idx % HY, zz = idx / HY;
+            const int64_t row = (z0 + zz - 1) * t.dy + (y0 + yy - 1); // linear: row -1 of a slice IS the last row of the slice below
+            L.sN[idx] = (row >= 0 && row < nrows) ? reached[row * t.wx + txi] : 0ull;
+        }
+    }
+    const int ty = threadIdx.x & (TY - 1), tz = threadIdx.x >> TY_LOG;
+    const int64_t row = (z0 + tz) * t.dy + (y0 + ty);
+    const bool inside = row < nrows; // (dy is a multiple of TY: only whole slices can be missing)
+    const int64_t me_w = row * t.wx + txi;
+    unsigned long long exp = 0, bexm = 0, e_ym = 0, e_yp = 0, e_zm = 0, e_zp = 0, carry = 0, xgain = 0;
+    if (inside) {
+        exp = Ex[me_w];
+        bexm = __brevll(exp << 1); // stepping down from bit b needs the arc (b - 1, b) = bit b - 1 of Ex
+        if (me_w - t.wx >= 0) e_ym = Ey[me_w - t.wx];
+        if (me_w + t.wx < nwords) e_yp = Ey[me_w];
+        if (me_w - hwx >= 0) e_zm = Ez[me_w - hwx];
+        if (me_w + hwx < nwords) e_zp = Ez[me_w];
+        // steps across the word boundary come from the neighbour WORDS (other tiles): constant during this visit
+        if (me_w > 0) {
+            const unsigned long long lr = reached[me_w - 1] >> 63, le = Ex[me_w - 1] >> 63;
+            carry |= lr & le;
+            xgain |= le & ~lr;              // my bit 0 could still hand something to the left word
+        }
+        if (me_w + 1 < nwords) {
+            const unsigned long long rr = reached[me_w + 1] & 1ull, re = exp >> 63;
+            carry |= (rr & re) << 63;
+            xgain |= (re & ~rr) << 63;      // my bit 63 to the right word
+        }
+    }
+    if (threadIdx.x == 0) L.vote[0] = 0u;
+    __syncthreads();
+    const int me = (tz + 1) * HY + (ty + 1);
+    const unsigned long long r_in = L.sN[me];
+    unsigned long long r = r_in;
+    bool exhausted = true;
+    for (int it = 0; it < t.itcap; it++) {
+        unsigned long long nr = r | carry | (L.sN[me - 1] & e_ym) | (L.sN[me + 1] & e_yp) | (L.sN[me - HY] & e_zm) |
+                                (L.sN[me + HY] & e_zp);
+        nr |= (exp + (nr & exp)) ^ exp;
+        unsigned long long rn = __brevll(nr);
+        rn |= (bexm + (rn & bexm)) ^ bexm;
+        nr = __brevll(rn);
+        if (!inside) nr = 0ull;
+        const bool ch = nr != r;
+        if (ch) {
+            r = nr;
+            L.sN[me] = r;
+        }
+        if (__any(ch) && (threadIdx.x & 63) == 0) L.vote[it & 1] = 1u;
+        if (threadIdx.x == 0) L.vote[(it + 1) & 1] = 0u;
+        __syncthreads();
+        if (!L.vote[it & 1]) {
+            exhausted = false;
+            break;
+        }
+    }
+    const unsigned long long chg = r ^ r_in;
+    unsigned dirs = 0;
+    if (chg) {
+        reached[me_w] = r;
+        // A neighbour tile is woken only when one of the NEW bits has an enabled arc to a voxel of it that was not
+        // reached when this visit staged its halo (a stale halo can only wake one tile too many): in a flood near the
+        // percolation threshold most changes have nowhere to go, and most wake-ups were visits that found nothing.
+        const bool zlo = tz == 0 && (chg & e_zm & ~L.sN[me - HY]), zhi = tz == TZ - 1 && (chg & e_zp & ~L.sN[me + HY]);
+        const bool ylo = ty == 0 && (chg & e_ym & ~L.sN[me - 1]), yhi = ty == TY - 1 && (chg & e_yp & ~L.sN[me + 1]);
+        const bool xlo = chg & xgain & 1ull, xhi = (chg & xgain) >> 63;
+        // readers that ARE the lattice neighbour tile: one direction bit per workgroup (enlisted by the caller);
+        // readers across a row / slice end (border tiles only): looked up word by word
+        if (zlo) dirs |= 1u << 4;
+        if (zhi) dirs |= 1u << 22;
+        if (ylo) {
+            if (y0 > 0) dirs |= 1u << 10;
+            else if (me_w - t.wx >= 0 && lin_enlist(t, me_w - t.wx, tile, dirty_next, list_next, n_next)) dirs |= 1u << 13;
+        }
+        if (yhi) {
+            if (y0 + TY < t.dy) dirs |= 1u << 16;
+            else if (me_w + t.wx < nwords && lin_enlist(t, me_w + t.wx, tile, dirty_next, list_next, n_next)) dirs |= 1u << 13;
+        }
+        if (xlo) {
+            if (txi > 0) dirs |= 1u << 12;
+            else if (me_w > 0 && lin_enlist(t, me_w - 1, tile, dirty_next, list_next, n_next)) dirs |= 1u << 13;
+        }
+        if (xhi) {
+            if (txi + 1 < t.wx) dirs |= 1u << 14;
+            else if (me_w + 1 < nwords && lin_enlist(t, me_w + 1, tile, dirty_next, list_next, n_next)) dirs |= 1u << 13;
+        }
+        if (exhausted) dirs |= 1u << 13;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dirs |= __shfl_xor(dirs, o, 64);
+    if ((threadIdx.x & 63) == 0 && dirs) atomicOr(&L.dirs, dirs);
+    if (threadIdx.x == 0) L.open = 1u; // (arc planes change from level to level: a tile is never closed for good)
+}
+
 // diagnostic only (not part of include/ivx.h): cycle stamps written under IVX_FLOOD_DBG=1, see tools/dbg_tile.py
 extern "C" int ivx_debug_read(unsigned long long *out16) {
     IVX_HIP(hipDeviceSynchronize());
@@ -541,7 +669,9 @@ __global__ void k_flood_build_list(Tiles t, const uint8_t *__restrict__ dirty, u
 // round STARTS (everything before it in the stream is complete, so the count is final); word 1 = tag | round + 1 of the
 // last round that had any work.  The host polls word 0, keeps a few rounds queued ahead of the newest one it has seen
 // start, and stops when a round starts with an empty list.
-template <bool DIRECTED> // DIRECTED: `cand` holds the six edge planes of k_flood_edges_auto instead of a candidate plane
+// MODE 0: candidate plane; 1 (directed): `cand` holds the six edge planes of k_flood_edges_auto instead; 2 (linear): the
+// three arc planes of k_wsa_edges and scipy's linear-index neighbourhood (tile_update_lin)
+template <int MODE>
 __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsigned long long *__restrict__ cand,
                                                              unsigned long long *reached, const unsigned int *__restrict__ list_cur,
                                                              const unsigned int *__restrict__ n_cur, uint8_t *dirty_cur,
@@ -570,7 +700,8 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
         __syncthreads();
         const bool dbg = (t.strct >> 30 & 1u) && li == 0; // IVX_FLOOD_DBG: cycle stamps of the first tile (tools/dbg_tile.py)
         if (dbg && threadIdx.x == 0) g_dbg[0] = __builtin_readcyclecounter();
-        if (DIRECTED) tile_update_dir(t, cand, reached, tile, L);
+        if (MODE == 2) tile_update_lin(t, cand, reached, tile, L, dirty_next, list_next, n_next);
+        else if (MODE == 1) tile_update_dir(t, cand, reached, tile, L);
         else if (dbg) tile_update<false, 26, true>(t, cand, reached, tile, L);
         else if (t.conn == 26) tile_update<false, 26>(t, cand, reached, tile, L);
         else if (t.conn == 18) tile_update<false, 18>(t, cand, reached, tile, L);
@@ -1392,7 +1523,8 @@ static bool coarse_ok(const Tiles &t, bool directed) {
            t.nty * t.ntz <= (int64_t)CT * CRP;
 }
 static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool directed, uint64_t *reached, void *scratch_,
-                          int *rounds, void *stream, const Fresh *fresh = nullptr) {
+                          int *rounds, void *stream, const Fresh *fresh = nullptr, bool linear = false) {
+    if (linear) directed = true; // (arc planes: no coarse pass, no union-find escape, no persistent frontier)
     Tiles t;
     int rc = make_tiles(p, &t);
     if (rc) return rc;
@@ -1543,12 +1675,16 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
         const int r = (int)(queued % RING), cur = (int)(queued & 1);
         const unsigned int tr = (unsigned int)(tag << 24) | (unsigned int)((queued + 1) & 0xffffff);
         unsigned int *gw = arm.word; // every round carries the gate: the first one with a short list opens it
-        if (directed)
-            hipLaunchKernelGGL(k_flood_round_list<true>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+        if (linear)
+            hipLaunchKernelGGL(k_flood_round_list<2>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+                               (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
+                               cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr, gw, arm.value, arm.below);
+        else if (directed)
+            hipLaunchKernelGGL(k_flood_round_list<1>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
                                (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
                                cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr, gw, arm.value, arm.below);
         else
-            hipLaunchKernelGGL(k_flood_round_list<false>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+            hipLaunchKernelGGL(k_flood_round_list<0>, dim3(grid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
                                (unsigned long long *)reached, list[cur], cnt + r, dirty[cur], dirty[cur ^ 1], list[cur ^ 1],
                                cnt + (r + 1) % RING, cnt + (r + 2) % RING, (unsigned long long *)line, tr, gw, arm.value, arm.below);
         IVX_LAUNCH_CHECK();
@@ -1601,6 +1737,232 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
         IVX_REQUIRE(total_rounds < (1 << 24) - 64, IVX_EHIP, "flood: did not converge");
     }
     if (rounds) *rounds = total_rounds;
+    return IVX_OK;
+}
+
+// ---- the IFT watershed's cost map, level by level, on bit planes (ivx_dev_ws_cost_levels) ------------------------------
+// C(p) = min over paths from a marker of the largest arc |I(a) - I(b)| on the path.  {C <= c} is the set the markers reach
+// through arcs of weight <= c: a flood on bit planes with arc planes instead of a candidate plane, and {C == c} is what
+// level c adds to level c - 1.  The chaotic relaxation of the cost map (k_ws_relax) spends its time on the levels where the
+// bulk of a noise volume connects (percolation: long winding paths, every tile revisited ~15 times with 16-bit costs in
+// LDS); here those levels cost bit-parallel tile visits (64 voxels per lane and operation).  The caller stops after the
+// bulk is in and hands the rest -- isolated pockets whose cost is decided by their own few arcs -- to the relaxation,
+// which starts from exact costs and has nothing left to correct.
+namespace {
+template <typename MT>
+__global__ __launch_bounds__(256) void k_wsa_seed(const MT *__restrict__ mk, int64_t n, unsigned long long *__restrict__ R) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b = __ballot(p < n && mk[p] != 0);
+    if ((threadIdx.x & 63) == 0 && p < n) R[p >> 6] = b;
+}
+
+// Arc weights once, as bytes: wx / wy / wz[p] = min(|I(p) - I(p + 1 / W / HW)|, 127), 127 also when the neighbour's linear
+// index is >= n (levels stop far below 127: the caller caps them at 120).  Lane = 8 voxels; the ALU-heavy part of the arc
+// planes (field extraction, absolute differences) then happens once instead of once per level.
+__global__ __launch_bounds__(256) void k_wsa_weights(const uint16_t *__restrict__ I, int64_t n, int64_t W, int64_t HW,
+                                                     unsigned long long *__restrict__ wts) {
+    const int64_t nch = n >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nch; i += stride) {
+        const int64_t p0 = i << 3;
+        const bool hy = p0 + W < n, hz = p0 + HW < n;
+        const uint4 v = *reinterpret_cast<const uint4 *>(I + p0);
+        const uint4 vy = *reinterpret_cast<const uint4 *>(I + (hy ? p0 + W : p0));
+        const uint4 vz = *reinterpret_cast<const uint4 *>(I + (hz ? p0 + HW : p0));
+        const int next = p0 + 8 < n ? (int)I[p0 + 8] : -1000000;
+        const unsigned int vw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {vy.x, vy.y, vy.z, vy.w}, zw[4] = {vz.x, vz.y, vz.z, vz.w};
+        unsigned long long bx = 0, by = 0, bz = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int iv = (int)((vw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            const int nx = e < 7 ? (int)((vw[(e + 1) >> 1] >> (16 * ((e + 1) & 1))) & 0xffffu) : next;
+            const int ny = (int)((yw[e >> 1] >> (16 * (e & 1))) & 0xffffu), nz = (int)((zw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            const int dx = min(abs(iv - nx), 127), dy = hy ? min(abs(iv - ny), 127) : 127, dz = hz ? min(abs(iv - nz), 127) : 127;
+            bx |= (unsigned long long)dx << (8 * e);
+            by |= (unsigned long long)dy << (8 * e);
+            bz |= (unsigned long long)dz << (8 * e);
+        }
+        wts[i] = bx;
+        wts[nch + i] = by;
+        wts[2 * nch + i] = bz;
+    }
+}
+
+// the arc planes of level c from the weight bytes: lane = word = 8 x 8 bytes per direction; "byte <= c" for eight bytes at
+// once: (x | 0x80) - (c + 1) keeps bit 7 exactly when x >= c + 1 (x, c < 128: no borrow between bytes), and the eight
+// sign bits are gathered with one multiply
+__device__ __forceinline__ unsigned long long le8(unsigned long long x, unsigned long long c1) {
+    const unsigned long long t = (x | 0x8080808080808080ull) - c1;
+    return ((~t & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56;
+}
+__global__ __launch_bounds__(256) void k_wsa_planes(const unsigned long long *__restrict__ wts, int64_t nwords, int c,
+                                                    unsigned long long *__restrict__ E) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    const int64_t nch = nwords * 8;
+    const unsigned long long c1 = (unsigned long long)(c + 1) * 0x0101010101010101ull;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(wts + d * nch + w * 8);
+        unsigned long long m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const ulonglong2 x = src[q];
+            m |= le8(x.x, c1) << (16 * q);
+            m |= le8(x.y, c1) << (16 * q + 8);
+        }
+        E[d * nwords + w] = m;
+    }
+}
+
+// lane = word: would ONE relaxation step add a bit to this word?  Then its tile starts the level's flood.
+__global__ __launch_bounds__(256) void k_wsa_frontier(Tiles t, const unsigned long long *__restrict__ R,
+                                                      const unsigned long long *__restrict__ E, uint8_t *__restrict__ dirty) {
+    const int64_t nwords = t.dz * t.dy * t.wx, hwx = t.dy * t.wx;
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    const unsigned long long *Ex = E, *Ey = E + nwords, *Ez = E + 2 * nwords;
+    const unsigned long long r = R[w];
+    if (r == ~0ull) return;
+    const unsigned long long exp = Ex[w];
+    unsigned long long nr = r;
+    if (w > 0) nr |= (R[w - 1] & Ex[w - 1]) >> 63;
+    if (w + 1 < nwords) nr |= ((R[w + 1] & 1ull) & (exp >> 63)) << 63;
+    if (w - t.wx >= 0) nr |= R[w - t.wx] & Ey[w - t.wx];
+    if (w + t.wx < nwords) nr |= R[w + t.wx] & Ey[w];
+    if (w - hwx >= 0) nr |= R[w - hwx] & Ez[w - hwx];
+    if (w + hwx < nwords) nr |= R[w + hwx] & Ez[w];
+    nr |= ((nr & exp) << 1) | ((nr & (exp << 1)) >> 1); // one step along x inside the word is enough to see a gain
+    if (nr != r) {
+        const int64_t row = w / t.wx, txi = w - row * t.wx, z = row / t.dy, y = row - z * t.dy;
+        dirty[((z / TZ) * t.nty + (y >> TY_LOG)) * t.wx + txi] = 1;
+    }
+}
+
+// reached voxels so far (grid-stride, one atomic per workgroup)
+__global__ __launch_bounds__(256) void k_wsa_count(const unsigned long long *__restrict__ R, int64_t nwords,
+                                                   unsigned long long *__restrict__ count) {
+    __shared__ unsigned long long s_part[4];
+    unsigned long long mine = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) mine += (unsigned long long)__popcll(R[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (t) atomicAdd(count, t);
+    }
+}
+
+// After the last level: snap[l] = the reached plane as level l left it (planes nested: a bit set at level l is set at every
+// later one).  C[p] = the first level that has p; voxels no level reached keep their cost.  Lane = 16 voxels.
+__global__ __launch_bounds__(256) void k_wsa_costs(const uint16_t *__restrict__ snap, int64_t nchunks, int64_t plane_chunks, int levels,
+                                                   uint16_t *__restrict__ C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const unsigned int last = snap[(int64_t)(levels - 1) * plane_chunks + i];
+        if (!last) continue;
+        uint16_t *dst = C + i * 16;
+        unsigned int lev[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) lev[e] = 0xffffu;
+        unsigned int have = 0;
+        for (int l = 0; l < levels && have != last; l++) {
+            const unsigned int m = snap[(int64_t)l * plane_chunks + i];
+            unsigned int nw = m & ~have;
+            have |= m;
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                if (nw >> e & 1u) lev[e] = (unsigned int)l;
+        }
+        if (last == 0xffffu) {
+            reinterpret_cast<uint4 *>(dst)[0] = make_uint4(lev[0] | lev[1] << 16, lev[2] | lev[3] << 16, lev[4] | lev[5] << 16, lev[6] | lev[7] << 16);
+            reinterpret_cast<uint4 *>(dst)[1] = make_uint4(lev[8] | lev[9] << 16, lev[10] | lev[11] << 16, lev[12] | lev[13] << 16, lev[14] | lev[15] << 16);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                if (last >> e & 1u) dst[e] = (uint16_t)lev[e];
+        }
+    }
+}
+} // namespace
+
+// Levels 0, 1, 2, ... of the IFT cost map until `stop_frac` of the voxels are in (or `max_levels` are done): C[p] = level for
+// every voxel reached (the others keep what the caller put there: 0xFFFF), *levels_done = number of levels completed,
+// *reached_out = voxels with a final cost.  6-neighbour structure, scipy's linear-index neighbourhood; needs dx % 64 == 0
+// and dy % 16 == 0 (IVX_EINVAL otherwise: the caller then runs its relaxation from the markers alone).
+extern "C" int ivx_dev_ws_cost_levels(const uint16_t *I, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
+                                      uint16_t *C, int max_levels, double stop_frac, int *levels_done, int64_t *reached_out,
+                                      int64_t *rounds_out, void *stream) {
+    IVX_REQUIRE(I && markers && C && dz > 0 && dy > 0 && dx > 0, IVX_EINVAL, "ws_cost_levels: bad arguments");
+    IVX_REQUIRE(dx % 64 == 0 && dy % TY == 0, IVX_EINVAL, "ws_cost_levels: needs dx %% 64 == 0 and dy %% 16 == 0");
+    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "ws_cost_levels: markers must be int16 or int8");
+    ivx_flood_plan plan;
+    plan.dz = dz; plan.dy = dy; plan.dx = dx; plan.wx = dx / 64;
+    plan.strct_bits = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 13) | (1u << 14) | (1u << 16) | (1u << 22);
+    Tiles t;
+    int rc = make_tiles(&plan, &t);
+    if (rc) return rc;
+    hipStream_t st = ivx::S(stream);
+    const int64_t n = dz * dy * dx, nwords = n >> 6;
+    const FScratch fs = make_fscratch(t);
+    IVX_REQUIRE(max_levels >= 1, IVX_EINVAL, "ws_cost_levels: max_levels");
+    if (max_levels > 120) max_levels = 120; // (the weight bytes saturate at 127)
+    // workspace: R | arc planes Ex Ey Ez | weight bytes x y z | flood scratch | one snapshot of R per level
+    const size_t pw = (size_t)nwords * 8, o_E = al256(pw), o_W = al256(o_E + 3 * pw), o_S = al256(o_W + 3 * (size_t)n);
+    const size_t o_P = al256(o_S + fs.total);
+    void *mem;
+    if ((rc = ivx::ws_get_s(ivx::WS_WSA, st, o_P + (size_t)max_levels * pw + 256, &mem))) return rc;
+    unsigned long long *R = (unsigned long long *)mem;
+    unsigned long long *E = (unsigned long long *)((char *)mem + o_E);   // Ex | Ey | Ez, nwords each
+    unsigned long long *wts = (unsigned long long *)((char *)mem + o_W); // n bytes per direction
+    char *scr = (char *)mem + o_S;
+    char *snaps = (char *)mem + o_P;
+    unsigned long long *d_count = (unsigned long long *)(scr + fs.off_status) + 2;
+    IVX_HIP(hipMemsetAsync(scr, 0, fs.off_seeds, st)); // dirty flags, counters
+    const unsigned gv = (unsigned)ivx::cdiv(n, 256), gw = (unsigned)ivx::cdiv(nwords, 256);
+    if (mdtype == IVX_I16) hipLaunchKernelGGL(k_wsa_seed<int16_t>, dim3(gv), dim3(256), 0, st, (const int16_t *)markers, n, R);
+    else hipLaunchKernelGGL(k_wsa_seed<int8_t>, dim3(gv), dim3(256), 0, st, (const int8_t *)markers, n, R);
+    IVX_LAUNCH_CHECK();
+    {
+        const int64_t blocks = ivx::cdiv(n >> 3, 256);
+        hipLaunchKernelGGL(k_wsa_weights, dim3((unsigned)(blocks < 32768 ? blocks : 32768)), dim3(256), 0, st, I, n, dx, dy * dx, wts);
+        IVX_LAUNCH_CHECK();
+    }
+    int64_t rounds_total = 0, reached = 0;
+    int c = 0;
+    for (; c < max_levels; c++) {
+        hipLaunchKernelGGL(k_wsa_planes, dim3(gw), dim3(256), 0, st, wts, nwords, c, E);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_wsa_frontier, dim3(gw), dim3(256), 0, st, t, R, E, (uint8_t *)(scr + fs.off_dirty0));
+        IVX_LAUNCH_CHECK();
+        int rounds = 0;
+        if ((rc = flood_run_impl(&plan, (const uint64_t *)E, true, (uint64_t *)R, scr, &rounds, stream, nullptr, true))) return rc;
+        rounds_total += rounds;
+        IVX_HIP(hipMemcpyAsync(snaps + (size_t)c * pw, R, pw, hipMemcpyDeviceToDevice, st));
+        IVX_HIP(hipMemsetAsync(d_count, 0, 8, st));
+        hipLaunchKernelGGL(k_wsa_count, dim3(gw < 1024 ? gw : 1024), dim3(256), 0, st, R, nwords, d_count);
+        IVX_LAUNCH_CHECK();
+        uint32_t seq, got[2] = {0, 0};
+        if ((rc = ivx::mailbox_publish(d_count, 2, st, &seq))) return rc;
+        if ((rc = ivx::mailbox_wait(seq, st, got, 2))) return rc;
+        reached = (int64_t)(((uint64_t)got[1] << 32) | got[0]);
+        if ((double)reached >= stop_frac * (double)n) {
+            c++;
+            break;
+        }
+    }
+    {
+        const int64_t nchunks = n / 16, blocks = ivx::cdiv(nchunks, 256);
+        hipLaunchKernelGGL(k_wsa_costs, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, (const uint16_t *)snaps,
+                           nchunks, (int64_t)(pw / 2), c, C);
+        IVX_LAUNCH_CHECK();
+    }
+    if (levels_done) *levels_done = c;
+    if (reached_out) *reached_out = reached;
+    if (rounds_out) *rounds_out = rounds_total;
     return IVX_OK;
 }
 

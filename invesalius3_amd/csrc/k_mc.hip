@@ -298,34 +298,75 @@ __device__ __forceinline__ int case_of(const uint64_t *c, int b) {
 }
 
 // ---- 2. count -----------------------------------------------------------------------------------
+// Two phases per workgroup.  (a) every lane loads the eight corner words of its cell word and finds the active cells: most
+// words have none (13 % do on the bench surface).  (b) the words that have some are handed, packed, to the first lanes of
+// the workgroup, which walk their cells (one table look-up per active cell): the serial walks of a workgroup then sit in
+// ONE or two full waves instead of being scattered over four mostly idle ones (the kernel is bound by the walks, not by
+// the loads: 37 -> 2x us before / after on the bench volume).
 __global__ __launch_bounds__(256) void k_mc_count(const uint64_t *__restrict__ bits, Geom g, size_t nwords,
                                                   uint64_t pbits, uint16_t *__restrict__ counts,
                                                   uint32_t *__restrict__ bsum) {
-    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_part[4], s_wcnt[4];
     __shared__ uint8_t s_ntri[256];
-    s_ntri[threadIdx.x] = MC_NTRI[threadIdx.x];
-    __syncthreads();
-    const size_t wid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t n = 0;
+    __shared__ uint64_t s_c[256][5]; // per active word: the four even corner words + the active mask
+    __shared__ uint8_t s_hi[256];    // bit 63 of the four odd corner words (cell 63's far corners)
+    __shared__ uint16_t s_slot[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    s_ntri[tid] = MC_NTRI[tid];
+    const size_t wid = (size_t)blockIdx.x * 256 + tid;
+    uint64_t act = 0;
+    Corner8 r;
     if (wid < nwords) {
         // nwords < 2^32 (checked on the host): 32-bit divisions instead of two 64-bit ones per lane
         const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
         const uint32_t k = row / (uint32_t)(g.NY - 1), j = row - k * (uint32_t)(g.NY - 1);
-        const Corner8 r = load_corners(bits, g, (int64_t)k, (int64_t)j, (int64_t)w, pbits);
-        uint64_t act = r.active;
-        while (act) {
-            const int b = __builtin_ctzll(act);
-            act &= act - 1;
-            n += s_ntri[case_of(r.c, b)];
+        r = load_corners(bits, g, (int64_t)k, (int64_t)j, (int64_t)w, pbits);
+        act = r.active;
+        if (!act) counts[wid] = 0;
+    }
+    const unsigned long long am = __ballot(act != 0);
+    if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(am);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int q = 0; q < wv; q++) before += s_wcnt[q];
+    const uint32_t nact = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (act) {
+        const uint32_t slot = before + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+        s_slot[slot] = (uint16_t)tid;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            s_c[slot][q] = r.c[2 * q];
+            hi |= (uint32_t)(r.c[2 * q + 1] >> 63) << q;
         }
-        counts[wid] = (uint16_t)n;
+        s_c[slot][4] = act;
+        s_hi[slot] = (uint8_t)hi;
+    }
+    __syncthreads();
+    uint32_t n = 0;
+    if ((uint32_t)tid < nact) {
+        const uint64_t c0 = s_c[tid][0], c1 = s_c[tid][1], c2 = s_c[tid][2], c3 = s_c[tid][3];
+        uint64_t a2 = s_c[tid][4];
+        const uint32_t hi = s_hi[tid];
+        while (a2) {
+            const int b = __builtin_ctzll(a2);
+            a2 &= a2 - 1;
+            int idx;
+            if (b != 63)
+                idx = (int)((c0 >> b) & 3ull) | ((int)((c1 >> b) & 3ull) << 2) | ((int)((c2 >> b) & 3ull) << 4) | ((int)((c3 >> b) & 3ull) << 6);
+            else
+                idx = (int)(c0 >> 63) | ((int)(hi & 1u) << 1) | ((int)(c1 >> 63) << 2) | ((int)(hi >> 1 & 1u) << 3) | ((int)(c2 >> 63) << 4) |
+                      ((int)(hi >> 2 & 1u) << 5) | ((int)(c3 >> 63) << 6) | ((int)(hi >> 3 & 1u) << 7);
+            n += s_ntri[idx];
+        }
+        counts[(size_t)blockIdx.x * 256 + s_slot[tid]] = (uint16_t)n;
     }
     uint32_t s = n;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    if (lane == 0) s_part[wv] = s;
     __syncthreads();
-    if (threadIdx.x == 0) bsum[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (tid == 0) bsum[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
 // ---- 3. scan of workgroup sums (single workgroup of 1024) ---------------------------------------------
@@ -381,29 +422,48 @@ __device__ __forceinline__ void edge_decode(int e, int &ax, int &bx, int &by, in
 
 // 4a. list: the OWNER of each cell word writes one 64-bit descriptor per triangle into a flat global list, in output
 //     order: (cell word id << 17) | (cell bit << 11) | (case << 3) | triangle-in-case.  One case evaluation per
-//     active cell; only workgroups that own triangles do anything beyond a 256-entry scan.
+//     active cell; only workgroups that own triangles do anything beyond a 256-entry scan.  Like the count, in two
+//     phases: the words that own triangles are handed, packed, to the first lanes of the workgroup, so that the corner
+//     loads and the serial walks fill one or two waves instead of idling in four.
 __global__ __launch_bounds__(256) void k_mc_list(const uint64_t *__restrict__ bits, Geom g, size_t nwords, uint64_t pbits,
                                                  const uint16_t *__restrict__ counts, const uint64_t *__restrict__ boff,
                                                  uint64_t *__restrict__ list, uint64_t max_tris) {
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[4], s_wcnt[4];
     __shared__ uint8_t s_ntri[256];
+    __shared__ uint16_t s_slot[256];
+    __shared__ uint32_t s_pos[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     s_ntri[tid] = MC_NTRI[tid];
-    const size_t wid = (size_t)blockIdx.x * 256 + tid;
-    const uint32_t n = wid < nwords ? (uint32_t)counts[wid] : 0u;
+    const size_t wid0 = (size_t)blockIdx.x * 256;
+    const uint32_t n = wid0 + tid < nwords ? (uint32_t)counts[wid0 + tid] : 0u;
     uint32_t inc = n;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t t = __shfl_up(inc, o, 64);
         if (lane >= o) inc += t;
     }
+    const unsigned long long am = __ballot(n != 0);
     if (lane == 63) s_wave[wv] = inc;
+    if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(am);
     __syncthreads();
-    if (!n) return;
-    uint32_t wbase = 0;
-    for (int q = 0; q < wv; q++) wbase += s_wave[q];
-    uint64_t pos = boff[blockIdx.x] + wbase + inc - n;
-    if (pos + n > max_tris) return; // never write past the list the caller sized from the count
+    const uint32_t nact = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (!nact) return; // (uniform)
+    if (n) {
+        uint32_t wbase = 0, before = 0;
+        for (int q = 0; q < wv; q++) {
+            wbase += s_wave[q];
+            before += s_wcnt[q];
+        }
+        const uint32_t slot = before + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+        s_slot[slot] = (uint16_t)tid;
+        s_pos[slot] = wbase + inc - n; // first triangle of the word, relative to the block
+    }
+    __syncthreads();
+    if ((uint32_t)tid >= nact) return;
+    const size_t wid = wid0 + s_slot[tid];
+    uint64_t pos = boff[blockIdx.x] + s_pos[tid];
+    const uint32_t nmine = (uint32_t)counts[wid];
+    if (pos + nmine > max_tris) return; // never write past the list the caller sized from the count
     const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
     const uint32_t k = row / (uint32_t)(g.NY - 1), j = row - k * (uint32_t)(g.NY - 1);
     const Corner8 r = load_corners(bits, g, (int64_t)k, (int64_t)j, (int64_t)w, pbits);

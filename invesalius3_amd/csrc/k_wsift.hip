@@ -348,8 +348,26 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     tm.on = stats != nullptr;
     tm.mark(st);
     // ---- 1. costs ------------------------------------------------------------------------------------------
+    // The levels where the bulk of the volume connects go first, as floods on bit planes (ivx_dev_ws_cost_levels: exact
+    // costs for every voxel they reach); the relaxation then starts from final costs around the pockets that are left and
+    // has nothing to correct.  IVX_WS_LEVELS=0: relaxation from the markers alone (same costs).
     int64_t rounds = 0, visits = 0;
+    int levels_done = 0;
+    int64_t level_rounds = 0, level_voxels = 0;
     {
+        // (read per call: tests and A/B runs change them)  IVX_WS_LEVELS = most levels (0: off), IVX_WS_LEVELS_FRAC = stop
+        // once this share of the voxels is in, IVX_WS_LEVELS_MIN = smallest volume (voxels) that takes this path
+        const char *e1 = getenv("IVX_WS_LEVELS"), *e2 = getenv("IVX_WS_LEVELS_FRAC"), *e3 = getenv("IVX_WS_LEVELS_MIN");
+        const int lv_max = e1 ? atoi(e1) : 48;
+        const double lv_frac = e2 ? atof(e2) : 0.9;
+        const int64_t lv_min = e3 ? atoll(e3) : ((int64_t)1 << 21);
+        if (lv_max > 0 && conn == 6 && g.w % 64 == 0 && g.h % 16 == 0 && g.n >= lv_min) {
+            const int rc = ivx_dev_ws_cost_levels(I, sizeof(MT) == 2 ? IVX_I16 : IVX_I8, mk, g.d, g.h, g.w, b.C, lv_max, lv_frac,
+                                                  &levels_done, &level_voxels, &level_rounds, st);
+            if (rc != IVX_OK) return rc;
+            // every tile looks once: the pockets, and anything the levels left for it
+            IVX_HIP(hipMemsetAsync(b.dirty, 1, (size_t)g.ntiles, st));
+        }
         const int rc = ws_cost_rounds<false>(g, conn, I, b.C, b.list, b.dirty, b.pending, b.st, st, &rounds, &visits);
         if (rc != IVX_OK) return rc;
     }
@@ -425,6 +443,7 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         stats[6] = g.ntiles; stats[7] = hs.sweeps;
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] zones, [10] bucketing, [11] level chain, [12] labels (microseconds)
+        stats[13] = levels_done; stats[14] = level_rounds; stats[15] = level_voxels; // the cost map's bit-plane levels
     }
     return IVX_OK;
 }

@@ -107,7 +107,7 @@ def watershed_ift(image: np.ndarray, markers: np.ndarray, structure=None, want_c
         res += (cost,)
     if want_stats:
         names = ("rounds", "tile_visits", "levels", "time_stamps", "markers", "entries", "tiles", "tile_sweeps", "us_costs", "us_zones",
-                 "us_bucket", "us_levels", "us_labels")
+                 "us_bucket", "us_levels", "us_labels", "cost_levels", "cost_level_rounds", "cost_level_voxels")
         res += ({k: int(v) for k, v in zip(names, stats) if not k.startswith("_")},)
     return res[0] if len(res) == 1 else res
 

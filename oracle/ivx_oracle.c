@@ -321,7 +321,10 @@ int orc_mida(int dt, const void *img_, const int64_t shape[3], const int64_t s[3
     const float wl = (float)wl_, ww = (float)ww_;
     int64_t nr, nc, len, sr, sc, sl;
     ray_geom(axis > 2 ? 2 : axis, shape, s, &nr, &nc, &len, &sr, &sc, &sl);
-    int rc = ORC_OK;
+    int bad = 0;
+    /* rays are independent: the reference runs them on rayon's pool (mips.rs:123 par_iter), so does the oracle when it is
+     * built with OpenMP (bench.py's all-core CPU baseline; OMP_NUM_THREADS=1 gives the serial walk, same results) */
+#pragma omp parallel for schedule(dynamic, 8) reduction(| : bad)
     for (int64_t r = 0; r < nr; r++)
         for (int64_t c = 0; c < nc; c++) {
             const char *ray = img + r * sr + c * sc;
@@ -340,9 +343,9 @@ int orc_mida(int dt, const void *img_, const int64_t shape[3], const int64_t s[3
                 final_colour = colour;
                 if (current_alpha >= 1.0f) break;
             }
-            if (numcast_f32(odt, range * final_colour + img_min, out + r * os[0] + c * os[1])) rc = ORC_EDOM;
+            if (numcast_f32(odt, range * final_colour + img_min, out + r * os[0] + c * os[1])) bad |= 1;
         }
-    return rc;
+    return bad ? ORC_EDOM : ORC_OK;
 }
 
 /* finite_difference (:171-195) -- the subtraction happens in T and wraps for
@@ -378,14 +381,16 @@ int orc_fcm_volume(int dt, const void *img_, const int64_t shape[3], const int64
     const int64_t isz = dt == DT_F64 ? 8 : dt == DT_I16 ? 2 : 1;
     float dir[3] = {0, 0, 0};
     if (axis == 0) dir[2] = 1.0f; else if (axis == 1) dir[1] = 1.0f; else if (axis == 2) dir[0] = 1.0f;
-    int rc = ORC_OK;
+    int bad = 0;
+    /* voxels are independent (mips.rs:237-242 par_iter over the volume) */
+#pragma omp parallel for schedule(static) reduction(| : bad)
     for (int64_t z = 0; z < shape[0]; z++)
         for (int64_t y = 0; y < shape[1]; y++)
             for (int64_t x = 0; x < shape[2]; x++) {
                 float v = fcm_intensity(dt, img, shape, s, x, y, z, n, dir);
-                if (numcast_f32(dt, v, tmp + ((z * shape[1] + y) * shape[2] + x) * isz)) rc = ORC_EDOM;
+                if (numcast_f32(dt, v, tmp + ((z * shape[1] + y) * shape[2] + x) * isz)) bad |= 1;
             }
-    return rc;
+    return bad ? ORC_EDOM : ORC_OK;
 }
 
 /* fast_countour_mip_internal                  invesalius_rs/src/mips.rs:215-279 */

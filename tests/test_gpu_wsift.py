@@ -7,6 +7,8 @@ import pytest
 from scipy import ndimage
 from scipy.ndimage import generate_binary_structure
 
+from conftest import synth_volume
+
 pytestmark = pytest.mark.gpu
 
 
@@ -173,3 +175,38 @@ def test_millions_of_marker_voxels(ivxlib, oracle):
     got, st = wp.watershed_ift(cost, mk, s, want_stats=True)
     assert st["markers"] == int((mk != 0).sum()) > (1 << 22)
     assert np.array_equal(got, oracle.watershed_ift_clean(cost, mk, s))
+
+
+@pytest.mark.parametrize("shape", [(20, 16, 64), (33, 32, 128), (17, 48, 192), (40, 64, 64), (3, 16, 128)])
+@pytest.mark.parametrize("frac", ["0.9", "1.0", "0.3"])
+def test_cost_levels_on_bit_planes_equal_the_serial_flood(ivxlib, oracle, monkeypatch, shape, frac):
+    """The cost map's level floods (ivx_dev_ws_cost_levels, csrc/k_flood.hip: arc planes + scipy's linear-index
+    neighbourhood on a flat bit array) followed by the relaxation of what is left: labels AND costs equal the serial,
+    defect-free flood on volumes whose borders matter (one word / one tile wide, odd slice counts), whatever share of the
+    voxels the levels take."""
+    from invesalius3_amd import watershed_process as wp
+    monkeypatch.setenv("IVX_WS_LEVELS_MIN", "0")
+    monkeypatch.setenv("IVX_WS_LEVELS_FRAC", frac)
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    s6 = generate_binary_structure(3, 1)
+    for trial in range(3):
+        if trial == 0:
+            img = rng.integers(0, 40, shape).astype(np.uint16)               # dense noise: the bulk connects at one level
+        elif trial == 1:
+            img = (synth_volume(shape, seed=trial + shape[0]) + 1024).astype(np.uint16)
+        else:
+            img = (rng.integers(0, 6, shape) * 50).astype(np.uint16)          # plateaus and cliffs
+        mk = np.zeros(shape, np.int16)
+        for lab in (1, 2, 3):
+            for _ in range(3):
+                z, y, x = (int(rng.integers(0, s)) for s in shape)
+                mk[z, y, x] = lab
+        mk[0, 0, 0], mk[-1, -1, -1] = 1, 2                                     # the corners the wrap-around arcs start from
+        got, cost, st = wp.watershed_ift(img, mk, s6, want_cost=True, want_stats=True)
+        want, wcost = oracle.watershed_ift_clean(img, mk, s6, want_cost=True)
+        assert st["cost_levels"] > 0, st
+        assert np.array_equal(cost.astype(np.uint32), wcost), (shape, frac, trial, int((cost != wcost).sum()))
+        assert np.array_equal(got, want), (shape, frac, trial)
+    monkeypatch.setenv("IVX_WS_LEVELS", "0")                                   # the relaxation alone: same answer
+    got0 = wp.watershed_ift(img, mk, s6)
+    assert np.array_equal(got0, want)

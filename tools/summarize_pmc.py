@@ -52,7 +52,8 @@ def main():
         import json
         # steps of the kernel-trace run (warm-up + timed + the bench's instrumented extra steps); "auto" = the call count
         # of a kernel that runs exactly once per step
-        nsteps = stats["k_flood_clear<unsigned int, 4u>"][0] if sys.argv[4] == "auto" else int(sys.argv[4])
+        once = [k for k in stats if k.startswith("k_threshold16")]  # (k_flood_clear no longer runs in the fused start)
+        nsteps = stats[once[0]][0] if sys.argv[4] == "auto" else int(sys.argv[4])
         stage_of = lambda k: ("threshold" if k.startswith("k_threshold") else "marching_cubes" if k.startswith("k_mc_")
                               else "region_grow" if k.startswith(("k_flood_", "k_ccl_", "k_scan_")) and not k.startswith("k_flood_count")
                               else None)
@@ -62,7 +63,12 @@ def main():
             if st is None or not fe.get(k) or not wr.get(k):
                 continue
             per_launch = (2 * sum(fe[k]) / len(fe[k]) + sum(wr[k]) / len(wr[k])) * 1024
-            traffic[st] = traffic.get(st, 0.0) + per_launch * calls / nsteps
+            # launches per STEP: a kernel that runs once per step shows nsteps calls plus the few of bench.py's extra
+            # calls outside the steps (the end-to-end download runs marching cubes once more): those must not be spread
+            # over the steps (14 launches / 13 steps made the figure 8 % high); only kernels that run several
+            # times per step (the flood's rounds) are averaged
+            lps = calls / nsteps if (calls >= 2 * nsteps or calls < nsteps) else 1.0
+            traffic[st] = traffic.get(st, 0.0) + per_launch * lps
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import src_sha16
