@@ -516,7 +516,13 @@ int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mas
 /* The IFT cost map level by level on bit planes: C[p] = min over paths from a marker of the largest arc |I(a) - I(b)|
  * (6 neighbours, scipy's linear-index neighbourhood) for every voxel of cost < the number of levels done; levels run until
  * `stop_frac` of the voxels are in or `max_levels` are done.  Other voxels keep the caller's value (0xFFFF).  Used by
- * ivx_dev_watershed_ift before its relaxation; needs dx % 64 == 0 and dy % 16 == 0 (IVX_EINVAL otherwise). */
+ * ivx_dev_watershed_ift before its relaxation; needs dx % 64 == 0 and dy % 16 == 0 (IVX_EINVAL otherwise).
+ * ivx_dev_sk_cost_levels: the same for the scikit-image branch's cost (largest image VALUE on the path, markers cost their own
+ * value, lattice neighbours under `strct`): level c = what the markers of value <= c reach inside {image <= c}, on the
+ * region-growing engine; stops after level 0 when that level holds < 5 % of the voxels (no plateau).  Needs dx % 64 == 0. */
+int ivx_dev_sk_cost_levels(const uint16_t *image, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
+                           const uint8_t strct[27], uint16_t *C, int max_levels, double stop_frac, int *levels_done,
+                           int64_t *reached, int64_t *rounds, void *stream);
 int ivx_dev_ws_cost_levels(const uint16_t *cost_image, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
                            uint16_t *C, int max_levels, double stop_frac, int *levels_done, int64_t *reached,
                            int64_t *rounds, void *stream);

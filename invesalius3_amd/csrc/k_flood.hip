@@ -1966,6 +1966,128 @@ extern "C" int ivx_dev_ws_cost_levels(const uint16_t *I, int mdtype, const void 
     return IVX_OK;
 }
 
+// ---- the scikit-image branch's cost map, level by level (ivx_dev_sk_cost_levels) ---------------------------------------
+// There a path costs the largest image VALUE on it (markers cost their own value), so {C <= c} is what the markers of value
+// <= c reach inside the candidate plane {I <= c}: the ordinary region-growing engine, coarse pass included.  The gradient
+// of a windowed image is zero over everything the window saturates: level 0 alone is ~95 % of such a volume, one flood.
+namespace {
+// seeds of level c: marker voxels whose value is <= c (they are candidates by construction) that are not reached yet
+template <typename MT>
+__global__ __launch_bounds__(256) void k_ska_seed(Tiles t, const MT *__restrict__ mk, const unsigned long long *__restrict__ cand,
+                                                  unsigned long long *__restrict__ R, uint8_t *__restrict__ dirty) {
+    const int64_t n = t.dz * t.dy * t.dx;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b = __ballot(p < n && mk[p] != 0);
+    if ((threadIdx.x & 63) != 0 || p >= n || !b) return;
+    const int64_t w = p >> 6;
+    const unsigned long long add = b & cand[w] & ~R[w];
+    if (!add) return;
+    R[w] |= add;
+    const int64_t row = w / t.wx, txi = w - row * t.wx, z = row / t.dy, y = row - z * t.dy;
+    mark_tile_nbhd(t, dirty, z / TZ, y / TY, txi);
+}
+
+// lane = word: a candidate bit that is not reached and has a reached neighbour under the structure -> its tile (and the
+// tiles around it) start the level's flood
+__global__ __launch_bounds__(256) void k_ska_frontier(Tiles t, const unsigned long long *__restrict__ cand,
+                                                      const unsigned long long *__restrict__ R, uint8_t *__restrict__ dirty) {
+    const int64_t nwords = t.dz * t.dy * t.wx;
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    const unsigned long long open = cand[w] & ~R[w];
+    if (!open) return;
+    const int64_t row = w / t.wx, txi = w - row * t.wx, z = row / t.dy, y = row - z * t.dy;
+    unsigned long long nb = 0;
+    for (int kk = 0; kk < 3; kk++)
+        for (int jj = 0; jj < 3; jj++) {
+            const uint32_t m3 = (t.strct >> (kk * 9 + jj * 3)) & 7u;
+            if (!m3) continue;
+            // voxel q reached => q + (kk-1, jj-1, ii-1) reached: the source row of this word is (z - (kk-1), y - (jj-1))
+            const int64_t zs = z - (kk - 1), ys = y - (jj - 1);
+            if (zs < 0 || zs >= t.dz || ys < 0 || ys >= t.dy) continue;
+            const unsigned long long *rr = R + (zs * t.dy + ys) * t.wx;
+            const unsigned long long c0 = rr[txi];
+            const unsigned long long cl = txi > 0 ? rr[txi - 1] >> 63 : 0ull, cr = txi + 1 < t.wx ? rr[txi + 1] & 1ull : 0ull;
+            if (m3 & 2u) nb |= c0;
+            if (m3 & 4u) nb |= (c0 << 1) | cl;        // ii = 2: source bit x - 1
+            if (m3 & 1u) nb |= (c0 >> 1) | (cr << 63); // ii = 0: source bit x + 1
+        }
+    if (nb & open) mark_tile_nbhd(t, dirty, z / TZ, y / TY, txi);
+}
+} // namespace
+
+// Levels 0, 1, 2, ... of scikit-image's cost map (value-on-path minimax, lattice neighbours, any symmetric 3x3x3 structure)
+// until `stop_frac` of the voxels are in or `max_levels` are done; C[p] = level for every voxel reached.  Needs dx % 64 == 0.
+extern "C" int ivx_dev_sk_cost_levels(const uint16_t *I, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
+                                      const uint8_t strct[27], uint16_t *C, int max_levels, double stop_frac, int *levels_done,
+                                      int64_t *reached_out, int64_t *rounds_out, void *stream) {
+    IVX_REQUIRE(I && markers && C && strct && dz > 0 && dy > 0 && dx > 0, IVX_EINVAL, "sk_cost_levels: bad arguments");
+    IVX_REQUIRE(dx % 64 == 0, IVX_EINVAL, "sk_cost_levels: needs dx %% 64 == 0");
+    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "sk_cost_levels: markers must be int16 or int8");
+    IVX_REQUIRE(max_levels >= 1, IVX_EINVAL, "sk_cost_levels: max_levels");
+    ivx_flood_plan plan;
+    plan.dz = dz; plan.dy = dy; plan.dx = dx; plan.wx = dx / 64;
+    const int64_t s3[3] = {3, 3, 3};
+    int rc = ivx_flood_strct_bits(strct, s3, &plan.strct_bits);
+    if (rc) return rc;
+    Tiles t;
+    if ((rc = make_tiles(&plan, &t))) return rc;
+    hipStream_t st = ivx::S(stream);
+    const int64_t n = dz * dy * dx, nwords = n >> 6;
+    const FScratch fs = make_fscratch(t);
+    const size_t pw = (size_t)nwords * 8, o_C = al256(pw), o_S = al256(o_C + pw), o_P = al256(o_S + fs.total);
+    void *mem;
+    if ((rc = ivx::ws_get_s(ivx::WS_WSA, st, o_P + (size_t)max_levels * pw + 256, &mem))) return rc;
+    unsigned long long *R = (unsigned long long *)mem, *cand = (unsigned long long *)((char *)mem + o_C);
+    char *scr = (char *)mem + o_S, *snaps = (char *)mem + o_P;
+    unsigned long long *d_count = (unsigned long long *)(scr + fs.off_status) + 2;
+    if ((rc = ivx_dev_flood_clear(&plan, (uint64_t *)R, scr, stream))) return rc;
+    const unsigned gv = (unsigned)ivx::cdiv(n, 256), gw = (unsigned)ivx::cdiv(nwords, 256);
+    uint8_t *dirty = (uint8_t *)(scr + fs.off_dirty0);
+    int64_t rounds_total = 0, reached = 0;
+    int c = 0;
+    for (; c < max_levels; c++) {
+        if ((rc = ivx_dev_flood_candidates(&plan, IVX_U16, I, 0.0, (double)c, nullptr, 0, 0.0, (uint64_t *)cand, stream))) return rc;
+        if (c > 0) {
+            // "closed" tiles were closed for the previous level's candidate plane: this one has more candidates
+            IVX_HIP(hipMemsetAsync(scr + fs.off_dirty0, 0, fs.off_cnt - fs.off_dirty0, st));
+            hipLaunchKernelGGL(k_ska_frontier, dim3(gw), dim3(256), 0, st, t, cand, R, dirty);
+            IVX_LAUNCH_CHECK();
+        }
+        if (mdtype == IVX_I16) hipLaunchKernelGGL(k_ska_seed<int16_t>, dim3(gv), dim3(256), 0, st, t, (const int16_t *)markers, cand, R, dirty);
+        else hipLaunchKernelGGL(k_ska_seed<int8_t>, dim3(gv), dim3(256), 0, st, t, (const int8_t *)markers, cand, R, dirty);
+        IVX_LAUNCH_CHECK();
+        ivx::ccl_invalidate(scr);
+        int rounds = 0;
+        if ((rc = flood_run_impl(&plan, (const uint64_t *)cand, false, (uint64_t *)R, scr, &rounds, stream))) return rc;
+        rounds_total += rounds;
+        IVX_HIP(hipMemcpyAsync(snaps + (size_t)c * pw, R, pw, hipMemcpyDeviceToDevice, st));
+        IVX_HIP(hipMemsetAsync(d_count, 0, 8, st));
+        hipLaunchKernelGGL(k_wsa_count, dim3(gw < 1024 ? gw : 1024), dim3(256), 0, st, R, nwords, d_count);
+        IVX_LAUNCH_CHECK();
+        uint32_t seq, got[2] = {0, 0};
+        if ((rc = ivx::mailbox_publish(d_count, 2, st, &seq))) return rc;
+        if ((rc = ivx::mailbox_wait(seq, st, got, 2))) return rc;
+        reached = (int64_t)(((uint64_t)got[1] << 32) | got[0]);
+        // enough is in -- or level 0 shows that this image has no plateau to speak of (a raw gradient: the bulk connects
+        // dozens of levels up, and walking there level by level costs more than the relaxation it would save)
+        if ((double)reached >= stop_frac * (double)n || (c == 0 && (double)reached < 0.05 * (double)n)) {
+            c++;
+            break;
+        }
+    }
+    {
+        const int64_t nchunks = n / 16, blocks = ivx::cdiv(nchunks, 256);
+        hipLaunchKernelGGL(k_wsa_costs, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, (const uint16_t *)snaps,
+                           nchunks, (int64_t)(pw / 2), c, C);
+        IVX_LAUNCH_CHECK();
+    }
+    if (levels_done) *levels_done = c;
+    if (reached_out) *reached_out = reached;
+    if (rounds_out) *rounds_out = rounds_total;
+    return IVX_OK;
+}
+
 extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch_,
                                  int *rounds, void *stream) {
     return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream);

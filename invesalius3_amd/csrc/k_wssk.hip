@@ -726,6 +726,23 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     }
     int64_t rounds = 0, visits = 0;
     {
+        // The levels that hold the bulk of the volume first, as ordinary region-growing floods (ivx_dev_sk_cost_levels):
+        // the zero plateau of a windowed gradient -- ~95 % of the voxels -- is ONE flood; the relaxation keeps the rest.
+        // IVX_SK_LEVELS = most levels (0: off), IVX_SK_LEVELS_FRAC, IVX_SK_LEVELS_MIN (voxels) as for the IFT branch.
+        const char *e1 = getenv("IVX_SK_LEVELS"), *e2 = getenv("IVX_SK_LEVELS_FRAC"), *e3 = getenv("IVX_SK_LEVELS_MIN");
+        const int lv_max = e1 ? atoi(e1) : 3;          // (512^3, windowed: cost map 9.7 ms without, 7.6 with one level, 5.7 with three)
+        const double lv_frac = e2 ? atof(e2) : 0.99;
+        const int64_t lv_min = e3 ? atoll(e3) : ((int64_t)1 << 21);
+        if (lv_max > 0 && g.w % 64 == 0 && g.n >= lv_min) {
+            uint8_t s27[27];
+            for (int k = 0; k < 27; k++) s27[k] = (uint8_t)(k == 13 || ((g.smask >> k) & 1u));
+            int levels_done = 0;
+            int64_t lvox = 0, lrounds = 0;
+            const int rc = ivx_dev_sk_cost_levels(I, sizeof(MT) == 2 ? IVX_I16 : IVX_I8, mk, g.d, g.h, g.w, s27, b.C, lv_max, lv_frac,
+                                                  &levels_done, &lvox, &lrounds, st);
+            if (rc != IVX_OK) return rc;
+            IVX_HIP(hipMemsetAsync(b.dirty, 1, (size_t)g.ntiles, st)); // every tile looks once
+        }
         const int rc = ws_cost_rounds<true>(g, conn, I, b.C, b.tlist, b.dirty, b.pending, b.wst, st, &rounds, &visits);
         if (rc != IVX_OK) return rc;
     }

@@ -216,3 +216,37 @@ def test_edge_cases(ivxlib, oracle):
         wp.watershed(img, mk[:-1], s6)
     with pytest.raises(TypeError):
         wp.watershed(img.astype(np.float32), mk, s6)
+
+
+@pytest.mark.parametrize("conn", [1, 2, 3])
+@pytest.mark.parametrize("frac,levels", [("0.9", "8"), ("1.0", "40"), ("0.5", "3")])
+def test_cost_levels_on_the_region_growing_engine(ivxlib, oracle, monkeypatch, conn, frac, levels):
+    """The scikit-image branch's cost map with its bulk levels taken as region-growing floods (ivx_dev_sk_cost_levels:
+    candidate plane {image <= c}, markers of value <= c as seeds, coarse pass and all) before the relaxation: same cost map
+    as the relaxation alone, same labels as the serial flood -- windowed gradient (zero plateau), raw gradient (no plateau:
+    the levels give up after the first one) and a stepped image."""
+    from invesalius3_amd import watershed_process as wp
+    monkeypatch.setenv("IVX_SK_LEVELS_MIN", "0")
+    monkeypatch.setenv("IVX_SK_LEVELS_FRAC", frac)
+    monkeypatch.setenv("IVX_SK_LEVELS", levels)
+    st = ndimage.generate_binary_structure(3, conn)
+    rng = np.random.default_rng(conn * 7 + int(levels))
+    for trial, shape in enumerate([(24, 48, 64), (19, 33, 128), (40, 112, 128)]):
+        img, am = _ct_like(shape, 5 + trial)
+        if trial == 1:
+            grad = (rng.integers(0, 5, shape) * (rng.random(shape) < 0.4)).astype(np.uint16)   # a stepped image, many zeros
+        else:
+            grad = wp.cost_image(img, trial == 0 or conn != 2, 300, 400, (3, 3, 3))
+        mk = np.zeros(shape, np.int16)
+        mk[max(am[0] - 2, 0):am[0] + 3, max(am[1] - 4, 0):am[1] + 5, max(am[2] - 4, 0):am[2] + 5] = 1
+        mk[:4, :8, :8] = 2
+        mk[-4:, -8:, -8:] = 2
+        for _ in range(4):
+            z, y, x = (int(rng.integers(0, s)) for s in shape)
+            mk[z, y, x] = 3
+        got, cost = wp.watershed(grad, mk, st, want_cost=True)
+        monkeypatch.setenv("IVX_SK_LEVELS", "0")
+        ref, rcost = wp.watershed(grad, mk, st, want_cost=True)
+        monkeypatch.setenv("IVX_SK_LEVELS", levels)
+        assert np.array_equal(cost, rcost), (conn, frac, levels, trial, int((cost != rcost).sum()))
+        assert np.array_equal(got, ref) and np.array_equal(got, oracle.watershed_sk(grad, mk, st, 1)), (conn, frac, levels, trial)
