@@ -72,6 +72,10 @@ int ivx_memset(void *dptr, int value, size_t nbytes, void *stream);
 int ivx_memcpy_h2d(void *dst, const void *src, size_t nbytes);
 int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes);
 int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
+/* page-locked host memory (hipHostMalloc): arrays kept there cross PCIe at the link's rate instead of through the runtime's
+ * bounce buffers; every host pointer of this header may point into it */
+int ivx_host_alloc(void **hptr, size_t nbytes);
+int ivx_host_free(void *hptr);
 int ivx_stream_create(void **stream);
 int ivx_stream_create_low_priority(void **stream); /* yields to default-priority streams when both have work */
 int ivx_stream_destroy(void *stream);
@@ -195,6 +199,12 @@ int ivx_dev_mc_count_bits(const ivx_mc_params *p, const uint64_t *inside_bits, v
 /* emit; must follow ivx_dev_mc_count with the same params/scratch */
 int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *tris, int64_t max_tris,
                     void *stream);
+/* ivx_dev_mc_emit for a uint8 mask (from_binary) whose bytes are KNOWN: v_out outside the inside plane the count ran on
+ * (ivx_dev_mc_count_bits), v_sel where `sel_bits` (same layout) has a bit, v_in elsewhere inside -- the state a resident
+ * threshold + region growing leaves behind.  No voxel is read: which end of an edge is inside is in the case index, so a
+ * triangle costs three bit look-ups instead of six byte gathers; same arithmetic on the same numbers, same soup. */
+int ivx_dev_mc_emit_levels(const ivx_mc_params *p, const void *scratch, const uint64_t *sel_bits, double v_out, double v_in,
+                           double v_sel, float *tris, int64_t max_tris, void *stream);
 /* the list pass of ivx_dev_mc_emit on its own (it needs the counts, not the voxels): queue it early, on the stream the
  * emit will use; the emit that follows with max_tris <= this max_tris skips its own list pass */
 int ivx_dev_mc_list(const ivx_mc_params *p, const void *scratch, int64_t max_tris, void *stream);

@@ -90,6 +90,32 @@ def dtype_code(a: np.ndarray, allowed=(U8, I16, F64, U16)) -> int:
     return code
 
 
+class _Pinned:
+    """owner of one hipHostMalloc block (freed when the last numpy view of it goes away)"""
+
+    def __init__(self, nbytes: int):
+        self.ptr = ctypes.c_void_p()
+        check(lib().ivx_host_alloc(ctypes.byref(self.ptr), ctypes.c_size_t(int(nbytes))), "ivx_host_alloc")
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ptr.value:
+                lib().ivx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """np.empty in page-locked host memory: uploads from it and downloads into it run at the PCIe link's rate (a pageable
+    array goes through the runtime's bounce buffers).  For callers that can keep their volume / results there."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    own = _Pinned(max(n, 16))
+    buf = (ctypes.c_uint8 * max(n, 16)).from_address(own.ptr.value)
+    buf._ivx_owner = own  # the ctypes array keeps the block alive, numpy keeps the ctypes array alive
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
 def device_count() -> int:
     n = ctypes.c_int(0)
     lib().ivx_device_count(ctypes.byref(n))

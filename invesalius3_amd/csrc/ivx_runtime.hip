@@ -449,6 +449,17 @@ int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes) {
     if (nbytes) IVX_HIP(hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost));
     return IVX_OK;
 }
+// Page-locked host memory for callers that keep their arrays where the DMA engines can reach them directly: a pageable
+// numpy array crosses PCIe through the runtime's bounce buffers (~25-40 GB/s here), a pinned one at the link's rate.
+int ivx_host_alloc(void **hptr, size_t nbytes) {
+    IVX_REQUIRE(hptr, IVX_EINVAL, "ivx_host_alloc: null");
+    IVX_HIP(hipHostMalloc(hptr, nbytes ? nbytes : 16, hipHostMallocDefault));
+    return IVX_OK;
+}
+int ivx_host_free(void *hptr) {
+    if (hptr) IVX_HIP(hipHostFree(hptr));
+    return IVX_OK;
+}
 int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream) {
     if (nbytes) IVX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, S(stream)));
     return IVX_OK;

@@ -483,12 +483,20 @@ __global__ __launch_bounds__(256) void k_mc_list(const uint64_t *__restrict__ bi
 
 // 4b. emit: a flat, regular kernel -- one lane per triangle of the list, 256 consecutive triangles per workgroup.
 //     Nothing but the 9-KB staging buffer in LDS, so eight workgroups share a CU and hide each other's gather latency.
-template <typename T>
+// LEVELS: the voxel values are not gathered but derived -- `a` is a mask known to hold v_out outside the inside plane, v_sel
+// where `sel` has a bit and v_in elsewhere inside (a resident pipeline's threshold + region-growing result).  Which end of
+// an edge is inside is in the case index already, so a triangle costs three bit look-ups in a 16 MiB plane instead of six
+// byte gathers from the mask; the interpolation then runs on the same numbers and gives the same bits.
+struct McLevels {
+    const uint64_t *sel; // source-coordinate plane, rows of g.ws words
+    double v_out, v_in, v_sel;
+};
+template <typename T, bool LEVELS>
 __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g, double iso0, double iso1,
                                                  const uint64_t *__restrict__ split_dev,
                                                  const uint64_t *__restrict__ total_dev,
                                                  const uint64_t *__restrict__ list, uint64_t cap,
-                                                 float *__restrict__ tris) {
+                                                 float *__restrict__ tris, McLevels lv) {
     __shared__ uint8_t s_tri[256 * 16];
     __shared__ float s_out[256 * 9];
     const int tid = threadIdx.x;
@@ -533,7 +541,23 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
         int ec[3];
 #pragma unroll
         for (int v = 0; v < 3; v++) ec[v] = s_tri[idx * 16 + 3 * rel + v];
-        if (fast) { // interior cell: one base pointer, six byte/short gathers at table offsets, issued back to back
+        if (LEVELS) {
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                const int c = s_ec[ec[v]];
+                const int ax = c & 3, bx = (c >> 2) & 1, by = (c >> 3) & 1, bz = (c >> 4) & 1;
+                const int lo = bx + 2 * by + 4 * bz; // corner numbers of the edge's ends in the case index
+                const bool in0 = (idx >> lo) & 1, in1 = (idx >> (lo + (1 << ax))) & 1; // exactly one of them is inside
+                // the inside end is a source voxel (padding is never inside a from_binary piece): its bit of `sel`
+                const int32_t kk = k + bz + (in1 && ax == 2), jj = j + by + (in1 && ax == 1), ii = i + bx + (in1 && ax == 0);
+                const int64_t sk = kk - (int32_t)g.pb, sj = ((int32_t)g.NY - 1 - jj) - (int32_t)g.pxy, si = ii - (int32_t)g.pxy;
+                const uint64_t wsel = lv.sel[(sk * g.ny + sj) * g.ws + (si >> 6)];
+                const double vin = (wsel >> (si & 63)) & 1ull ? lv.v_sel : lv.v_in;
+                s0[v] = in0 ? vin : lv.v_out;
+                s1[v] = in1 ? vin : lv.v_out;
+                ec[v] = c;
+            }
+        } else if (fast) { // interior cell: one base pointer, six byte/short gathers at table offsets, issued back to back
             const T *cell = a + ((int64_t)ka * g.ny + ja) * g.nx + ia;
 #pragma unroll
             for (int v = 0; v < 3; v++) {
@@ -645,7 +669,7 @@ static int run_list(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
 
 template <typename T>
 static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, const char *scratch,
-                    float *tris, int64_t max_tris, hipStream_t st) {
+                    float *tris, int64_t max_tris, hipStream_t st, const McLevels *lv = nullptr) {
     if (s.nblocks == 0) return IVX_OK;
     IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
     const uint64_t *boff = (const uint64_t *)(scratch + s.off_boff);
@@ -658,9 +682,14 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     const size_t nb = s.nblocks * (size_t)p->niso;
     if (!list_ready(scratch, d_list, max_tris)) // not built ahead by ivx_dev_mc_list
         if ((rc = run_list(p, g, s, scratch, d_list, max_tris, st))) return rc;
-    hipLaunchKernelGGL((k_mc_emit<T>), dim3((unsigned)ivx::cdiv(max_tris, (int64_t)256)), dim3(256), 0, st, (const T *)a, g,
-                       p->iso[0], p->iso[1], boff + (p->niso == 2 ? s.nblocks : nb), boff + nb, (const uint64_t *)d_list,
-                       (uint64_t)max_tris, tris);
+    if (lv)
+        hipLaunchKernelGGL((k_mc_emit<T, true>), dim3((unsigned)ivx::cdiv(max_tris, (int64_t)256)), dim3(256), 0, st, (const T *)a, g,
+                           p->iso[0], p->iso[1], boff + (p->niso == 2 ? s.nblocks : nb), boff + nb, (const uint64_t *)d_list,
+                           (uint64_t)max_tris, tris, *lv);
+    else
+        hipLaunchKernelGGL((k_mc_emit<T, false>), dim3((unsigned)ivx::cdiv(max_tris, (int64_t)256)), dim3(256), 0, st, (const T *)a, g,
+                           p->iso[0], p->iso[1], boff + (p->niso == 2 ? s.nblocks : nb), boff + nb, (const uint64_t *)d_list,
+                           (uint64_t)max_tris, tris, McLevels{nullptr, 0.0, 0.0, 0.0});
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
@@ -1133,6 +1162,22 @@ extern "C" int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void
     case IVX_I16: return run_emit<int16_t>(p, g, s, a, (const char *)scratch, tris, max_tris, st);
     default: return run_emit<uint16_t>(p, g, s, a, (const char *)scratch, tris, max_tris, st);
     }
+}
+
+// ivx_dev_mc_emit for a uint8 mask whose values are KNOWN to be v_out outside the inside plane of the count, v_sel where
+// `sel_bits` (same layout as that plane) has a bit and v_in elsewhere inside: no voxel is read, the soup is the same.
+extern "C" int ivx_dev_mc_emit_levels(const ivx_mc_params *p, const void *scratch, const uint64_t *sel_bits, double v_out,
+                                      double v_in, double v_sel, float *tris, int64_t max_tris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    IVX_REQUIRE(p->dtype == IVX_U8 && p->niso == 1 && sel_bits, IVX_EINVAL, "mc_emit_levels: uint8 mask, one iso-value");
+    IVX_REQUIRE(v_out < p->iso[0] && v_in >= p->iso[0] && v_sel >= p->iso[0] && p->pad_value < p->iso[0], IVX_EINVAL,
+                "mc_emit_levels: v_out (and the padding) must lie below the iso-value, v_in and v_sel at or above it");
+    const Scratch s = make_scratch(g, p->niso);
+    if (s.nwords == 0 || max_tris <= 0) return IVX_OK;
+    const McLevels lv{sel_bits, v_out, v_in, v_sel};
+    return run_emit<uint8_t>(p, g, s, nullptr, (const char *)scratch, tris, max_tris, ivx::S(stream), &lv);
 }
 
 // The list pass of ivx_dev_mc_emit on its own: it needs the counts only, not the voxels, so a pipeline can queue it (on

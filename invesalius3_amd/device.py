@@ -29,8 +29,14 @@ class DeviceBuffer:
         assert a.nbytes <= self.nbytes
         L.check(L.lib().ivx_memcpy_h2d(self.ptr, L.ptr(a), ctypes.c_size_t(a.nbytes)))
 
-    def download(self, shape, dtype) -> np.ndarray:
-        out = np.empty(shape, dtype)
+    def download(self, shape, dtype, out: np.ndarray | None = None) -> np.ndarray:
+        """`out`: a C-contiguous array with room for the result (e.g. `_lib.pinned_empty`); a view of it is returned"""
+        if out is None:
+            out = np.empty(shape, dtype)
+        else:
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            assert out.flags["C_CONTIGUOUS"] and out.nbytes >= n
+            out = out.reshape(-1).view(np.uint8)[:n].view(dtype).reshape(shape)
         assert out.nbytes <= self.nbytes
         L.check(L.lib().ivx_memcpy_d2h(L.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
         return out
@@ -77,8 +83,13 @@ class TrackedBuffer(DeviceBuffer):
     def raw(self):
         return self._p
 
-    def download(self, shape, dtype) -> np.ndarray:  # reading changes nothing
-        out = np.empty(shape, dtype)
+    def download(self, shape, dtype, out=None) -> np.ndarray:  # reading changes nothing
+        if out is None:
+            out = np.empty(shape, dtype)
+        else:
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            assert out.flags["C_CONTIGUOUS"] and out.nbytes >= n
+            out = out.reshape(-1).view(np.uint8)[:n].view(dtype).reshape(shape)
         assert out.nbytes <= self.nbytes
         L.check(L.lib().ivx_memcpy_d2h(L.ptr(out), self._p, ctypes.c_size_t(out.nbytes)))
         return out
@@ -167,6 +178,9 @@ class DeviceVolume:
         # outside this class's own kernels (their .ptr / upload / zero) drops the corresponding note.
         self._mbits_valid = False   # self._mbits == (mask >= 127), the inside plane marching cubes needs at iso 127
         self._mbits_range = None    # (lo, hi) while additionally _mbits == (lo <= image <= hi)
+        # (v_in, v_sel | None) while the mask's BYTES are known: 0 outside _mbits, v_sel where self.reached has a bit (if
+        # given), v_in elsewhere inside -- marching cubes then needs no voxel at all (ivx_dev_mc_emit_levels)
+        self._mask_levels = None
         self._out_bytes_zero = False  # the BYTES of out_mask are all zero
         self._mc_params_cache = {}
         # surface_prefetch: marching cubes' count + list queued on a second stream under the region growing
@@ -209,6 +223,7 @@ class DeviceVolume:
     def _mask_touched(self):
         self._mbits_valid = False
         self._mbits_range = None
+        self._mask_levels = None
         self._mbits_version += 1
 
     # out_mask is the reference's throw-away `np.zeros_like` of styles.py:3190: the flood writes `fill` into it and the
@@ -275,9 +290,9 @@ class DeviceVolume:
         except Exception:
             pass
 
-    def download_mask(self) -> np.ndarray:
+    def download_mask(self, out: np.ndarray | None = None) -> np.ndarray:
         self.sync()
-        return self.mask.download(self.shape, np.uint8)
+        return self.mask.download(self.shape, np.uint8, out)
 
     def download_out_mask(self) -> np.ndarray:
         self._materialize_out()
@@ -297,6 +312,7 @@ class DeviceVolume:
             L.check(lib.ivx_dev_threshold_i16_bits(self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(lo), int(hi),
                                                    self.mask.raw, self._mbits.ptr, self.stream), "threshold")
             self._mbits_valid, self._mbits_range = True, (int(lo), int(hi))
+            self._mask_levels = (255, None)  # mask == 255 * plane, byte for byte
             return
         L.check(lib.ivx_dev_threshold_i16(self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(lo), int(hi),
                                           int(bool(preserve)), None, self.mask.raw, self.stream), "threshold")
@@ -338,8 +354,11 @@ class DeviceVolume:
         return rounds.value
 
     def _before_flood(self):
-        """the reached plane is about to be cleared: a deferred out_mask write that is still wanted must land first"""
+        """the reached plane is about to be cleared: a deferred out_mask write that is still wanted must land first, and a
+        note that describes the mask's bytes through that plane dies with it"""
         self._materialize_out()
+        if self._mask_levels is not None and self._mask_levels[1] is not None:
+            self._mask_levels = None
 
     def _candidate_plane(self, image, t0, t1, fill):
         """The flood's candidate plane: in range AND out_mask != fill.  With out_mask known to be zero (fill != 0) and
@@ -370,6 +389,11 @@ class DeviceVolume:
         else:
             L.check(lib.ivx_dev_flood_apply(p, self.reached.ptr, L.U8, self.out_mask.raw, ctypes.c_double(fill), st))
             self._out_bytes_zero = False
+        if select_value is not None:
+            # the mask's bytes stay known when it was 255 * plane and the selected voxels become another inside value
+            lv = self._mask_levels
+            self._mask_levels = (lv[0], int(select_value)) if (lv is not None and lv[1] is None and int(select_value) >= 127
+                                                                and self._mbits_valid) else None
         if select_value is not None and self._mbits_valid and not (shared and int(select_value) >= 127):
             # mask[reached] = select_value: keep the inside plane in step (reached is a subset of a shared plane)
             self._join_prefetch()
@@ -468,6 +492,21 @@ class DeviceVolume:
             plane = self._mbits.at(z0 * self.dy * ((self.dx + 63) // 64) * 8)
         return src, plane
 
+    def _emit(self, p, src, plane, z0, cap, stream):
+        """the triangle emit of a counted piece: from the known byte levels of the mask when the pipeline can prove them
+        (no voxel is read), else from the voxels"""
+        lib, lv = L.lib(), self._mask_levels
+        if (plane is not None and lv is not None and self._fuse and os.environ.get("IVX_MC_LEVELS", "1") != "0"):
+            if lv[1] is None:
+                sel, v_sel = plane, float(lv[0])  # (no second level: any plane will do, both values are the same)
+            else:
+                sel, v_sel = self.reached.at(z0 * self.dy * ((self.dx + 63) // 64) * 8), float(lv[1])
+            L.check(lib.ivx_dev_mc_emit_levels(ctypes.byref(p), self._mc_scratch.ptr, sel, ctypes.c_double(0.0),
+                                               ctypes.c_double(float(lv[0])), ctypes.c_double(v_sel), self._tris.ptr, c64(cap), stream),
+                    "mc_emit")
+        else:
+            L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(cap), stream), "mc_emit")
+
     def _second_stream(self):
         if self._stream2 is None:
             s = ctypes.c_void_p()
@@ -529,9 +568,10 @@ class DeviceVolume:
         return True
 
     def marching_cubes(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False,
-                       params: L.McParams | None = None, z0: int = 0):
+                       params: L.McParams | None = None, z0: int = 0, out: np.ndarray | None = None):
         """count + emit on the resident mask (from_binary, iso 127) or image (two iso-values).  Returns the triangle
-        count, or the (T,3,3) float32 soup when download=True."""
+        count, or the (T,3,3) float32 soup when download=True (written into `out` -- e.g. a `_lib.pinned_empty` array with
+        room for it -- when given)."""
         lib = L.lib()
         if params is not None:
             p = params
@@ -559,7 +599,7 @@ class DeviceVolume:
                 nt = n.value
                 if nt <= cap:
                     if download:
-                        return self._tris.download((nt, 3, 3), np.float32)
+                        return self._tris.download((nt, 3, 3), np.float32, out if out is not None and out.nbytes >= nt * 36 else None)
                     return nt
                 # the surface outgrew the buffer: take the ordinary path below (it re-counts and re-emits)
         src, plane = self._mc_setup(p, z0)
@@ -574,15 +614,13 @@ class DeviceVolume:
                 else:
                     L.check(lib.ivx_dev_mc_count_async(ctypes.byref(p), src, self._mc_scratch.ptr, self.stream), "mc_count")
             with self.timer.span("mc_emit"):
-                L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(cap), self.stream),
-                        "mc_emit")
+                self._emit(p, src, plane, z0, cap, self.stream)
             L.check(lib.ivx_dev_mc_total(ctypes.byref(p), self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_total")
             nt = n.value
             if nt > cap:  # the surface outgrew the buffer: emit again into a larger one
                 self._tris.close()
                 self._tris = DeviceBuffer(int(nt * 36 * 1.25) + 4096)
-                L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(nt), self.stream),
-                        "mc_emit")
+                self._emit(p, src, plane, z0, nt, self.stream)
         else:
             with self.timer.span("mc_count"):
                 if plane is not None:
@@ -593,11 +631,10 @@ class DeviceVolume:
             nt = n.value
             self._tris = DeviceBuffer(int(nt * 36 * 1.25) + 4096)
             with self.timer.span("mc_emit"):
-                L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(nt), self.stream),
-                        "mc_emit")
+                self._emit(p, src, plane, z0, nt, self.stream)
         if download:
             self.sync()
-            return self._tris.download((nt, 3, 3), np.float32)
+            return self._tris.download((nt, 3, 3), np.float32, out if out is not None and out.nbytes >= nt * 36 else None)
         return nt
 
     def marching_cubes_indexed(self, from_binary=True, min_value=0, max_value=0, fill_border_holes=True, download=False,
