@@ -1,30 +1,47 @@
-# One family of evidence files per call: GPU suite summary, the three bench configs, rocprofv3 kernel stats and the two PMC
-# passes of the default bench (same command line), joined by tools/summarize_pmc.py.  Usage (on the GPU box, via gpurun):
-#   bash tools/profile_round.sh r02_v2 [--tests]
+# One family of evidence files per call: GPU suite summary, every bench config, rocprofv3 kernel stats and the two PMC passes of
+# the default bench and of both 512^3 watershed floods (same command lines), joined by tools/summarize_pmc.py / summarize_ws_pmc.py.
+# Usage (on the GPU box, via gpurun):   bash tools/profile_round.sh r03_v1 [--tests]
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd $R
 if [ "$2" = "--tests" ]; then
-  timeout -k 5 1500 python -m pytest tests -m gpu -q < /dev/null > $O/gpu_tests_full.txt 2>&1
+  timeout -k 5 2400 python -m pytest tests -m gpu -q -W ignore < /dev/null > $O/gpu_tests_full.txt 2>&1
   grep -E "passed|failed|error" $O/gpu_tests_full.txt | tail -3 > $O/gpu_tests.txt
 fi
 timeout -k 5 300 python bench.py < /dev/null > $O/bench.json 2> $O/bench.err
 timeout -k 5 300 python bench.py --config mip < /dev/null > $O/bench_mip.json 2> $O/bench_mip.err
+timeout -k 5 120 python bench.py --dry-comm < /dev/null > $O/dry_comm.json 2> $O/dry_comm.err
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu < /dev/null > $O/kt.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o write -- python bench.py --steps 3 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
 D=$(dirname $(find $O -name "kt_kernel_stats.csv" | head -1))
 for f in fetch_counter_collection.csv write_counter_collection.csv; do s=$(find $O -name $f | head -1); [ -n "$s" ] && [ "$(dirname $s)" != "$D" ] && cp $s $D/; done
 python tools/summarize_pmc.py $D $O/kernels_pmc.md $O/pmc_traffic.json auto < /dev/null | head -40
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o wskt -- python bench.py --config watershed --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > $O/wskt.log 2>&1
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o skkt -- python bench.py --config watershed_sk --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > $O/skkt.log 2>&1
+for c in watershed watershed_sk; do
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${c}_kt -- python bench.py --config $c --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > $O/${c}_kt.log 2>&1
+  timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o ${c}_fetch -- python bench.py --config $c --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
+  timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o ${c}_write -- python bench.py --config $c --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
+  python tools/summarize_ws_pmc.py $c $(find $O -name "${c}_fetch_counter_collection.csv" | head -1) $(find $O -name "${c}_write_counter_collection.csv" | head -1) $O/pmc_traffic_$c.json $O/${c}_kernels_pmc.md < /dev/null | tail -12
+done
+cp $O/pmc_traffic_watershed.json $O/pmc_traffic_watershed_sk.json profiles/ 2>/dev/null  # (so that the two lines below quote them)
+timeout -k 5 400 python bench.py --config watershed --size 512 < /dev/null > $O/bench_watershed_512.json 2> $O/bench_watershed_512.err
+timeout -k 5 400 python bench.py --config watershed_sk --size 512 < /dev/null > $O/bench_watershed_sk_512.json 2> $O/bench_watershed_sk_512.err
 timeout -k 5 400 python bench.py --config watershed < /dev/null > $O/bench_watershed_1024.json 2> $O/bench_watershed.err
 timeout -k 5 400 python bench.py --config watershed_sk < /dev/null > $O/bench_watershed_sk_1024.json 2> $O/bench_watershed_sk.err
-timeout -k 5 400 python bench.py --config watershed_sk --ws-raw < /dev/null > $O/bench_watershed_sk_raw_1024.json 2> $O/bench_watershed_sk_raw.err
-timeout -k 5 300 python tools/bench_wssk.py 512 < /dev/null > $O/wssk_512_modes.jsonl 2>&1
+timeout -k 5 600 python bench.py --config sharded2048 < /dev/null > $O/bench_sharded2048_1gpu.json 2> $O/bench_sharded2048.err
 find $O -name "*_kernel_trace.csv" -size +8M -delete
+find $O -name "*_counter_collection.csv" -size +8M -delete
 cat $O/gpu_tests.txt 2>/dev/null
-cat $O/bench.json
+for f in bench bench_mip bench_watershed_512 bench_watershed_sk_512 bench_watershed_1024 bench_watershed_sk_1024 bench_sharded2048_1gpu; do
+python - $O/$f.json $f <<'PY'
+import json,sys
+try:
+    j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], "ms_per_step", j["ms_per_step"], "stage_ms", j.get("stage_ms"), "frac", j["roofline"]["frac"], "traffic", j["roofline"].get("traffic"), "parity", (j.get("parity") or {}).get("ok"), "e2e", j.get("end_to_end_ms"), j.get("end_to_end_pinned_ms"))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+done

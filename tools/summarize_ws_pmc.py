@@ -31,7 +31,8 @@ def load(path):
 
 def main():
     config, fe, wr = sys.argv[1], load(sys.argv[2]), load(sys.argv[3])
-    flood_kernels = [k for k in fe if k.startswith(("k_ws_", "k_sk_", "rocprim", "k_mscan", "k_mailbox"))]
+    # (k_wsa_* / k_ska_* / k_flood_*: the cost map's level floods on bit planes run inside the flood too)
+    flood_kernels = [k for k in fe if k.startswith(("k_ws_", "k_wsa_", "k_sk_", "k_ska_", "k_flood_", "rocprim", "k_mscan", "k_mailbox"))]
     lab = [k for k in fe if k in ("k_ws_labels", "k_sk_labels")]
     nfloods = fe[lab[0]][0]
     rows, total = [], 0.0
