@@ -43,6 +43,7 @@
 //   4. k_sk_labels     label = label of the run in T's low word.
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
@@ -72,12 +73,17 @@ struct SkState {
     uint32_t mixed;     // adjacent tied markers with different labels (see TIES)
     uint32_t gens;      // generation steps (statistics)
     uint32_t brounds;   // B rounds (statistics)
-    uint32_t pad0;
+    uint32_t gnext;     // first generation of the NEXT level (= gen + 1 when a level's loop ends): a chain of levels needs no host read
     // what a workgroup needs to decide whether it takes part in a launch, in ONE word (read with one atomic load):
     // bits 0..31 entries of the frontier, 32 phase, 33 which list, 34..63 sequence number of the launch it describes
     unsigned long long ctl;
+    uint32_t pad1[16];
+    // the resident launch (k_sk_level) polls its control word from every workgroup: a line of its own, away from the counters
+    // the working workgroups add to
+    unsigned long long pctl;
+    uint32_t pad2[30];
 };
-static_assert(sizeof(SkState) == 64, "ctl is 8-byte aligned");
+static_assert(sizeof(SkState) == 256 && offsetof(SkState, pctl) == 128, "ctl is 8-byte aligned, pctl starts a 128-byte line");
 
 __host__ __device__ inline unsigned long long sk_ctl(uint32_t seq, uint32_t in_sel, uint32_t phase, uint32_t n_in) {
     return ((unsigned long long)(seq & 0x3FFFFFFFu) << 34) | ((unsigned long long)(in_sel & 1u) << 33) |
@@ -173,11 +179,14 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
                                                    uint32_t *__restrict__ front, uint32_t cnt, uint32_t roff, uint32_t gbase, uint32_t seq,
                                                    SkState *st) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    // gbase 0: the level follows another one of the same chain on the device (nobody writes gnext during this launch)
+    if (gbase == 0) gbase = __hip_atomic_load(&st->gnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i == 0) { // the level's frontier loop starts from list 0, phase A
         st->done = 0; st->gen = gbase; st->n_in = cnt;
         st->phase = 0; st->in_sel = 0;
         st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
         st->ctl = sk_ctl(seq, 0, 0, cnt); // the first round of this level is the host's launch number `seq`
+        st->pctl = sk_ctl(0, 0, 0, cnt);  // (the resident launch counts its rounds from 0)
     }
     if (i >= cnt) return;
     const uint32_t p = val[i];
@@ -199,7 +208,7 @@ struct SkStage {
     volatile uint32_t n[4];
 };
 
-__device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, uint32_t *__restrict__ glist, uint32_t *gcnt) {
+__device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, uint32_t *glist, uint32_t *gcnt) {
     const unsigned long long b = __ballot(want);
     if (!b) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -213,26 +222,27 @@ __device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, u
     }
     base = __shfl(base, leader, 64);
     if (!want) return;
-    if (base & 0x80000000u) glist[(base & 0x7FFFFFFFu) + rank] = v;
+    if (base & 0x80000000u) __hip_atomic_store(&glist[(base & 0x7FFFFFFFu) + rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else sg.buf[wv][base + rank] = v;
 }
 
 // all lanes of the wave are here
-__device__ __forceinline__ void stage_flush(SkStage &sg, uint32_t *__restrict__ glist, uint32_t *gcnt) {
+__device__ __forceinline__ void stage_flush(SkStage &sg, uint32_t *glist, uint32_t *gcnt) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t n = sg.n[wv];
     if (!n) return;
     uint32_t off = 0;
     if (lane == 0) off = atomicAdd(gcnt, n);
     off = __shfl(off, 0, 64);
-    for (uint32_t j = lane; j < n; j += 64) glist[off + j] = sg.buf[wv][j];
+    // (agent-scope stores: inside the resident launch the next round's readers sit on other XCDs, behind other L2s)
+    for (uint32_t j = lane; j < n; j += 64) __hip_atomic_store(&glist[off + j], sg.buf[wv][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) sg.n[wv] = 0;
 }
 
 // stamp the unstamped neighbours of the level's value of voxel `v` (the set bits of its pmask) with `nt`, one generation
 // after v's own stamp.  Lanes walk their own bits; the staged appends take whoever is there.
 __device__ __forceinline__ void sk_offer_plateau(const WsGeom &g, unsigned long long *tau, uint32_t pm, uint32_t v, unsigned long long nt,
-                                                 SkStage &sg, uint32_t *__restrict__ next, SkState *st) {
+                                                 SkStage &sg, uint32_t *next, SkState *st) {
     while (pm) {
         const int k = __ffs(pm) - 1;
         pm &= pm - 1;
@@ -325,6 +335,148 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint32_t *__re
         __hip_atomic_store(&st->ctl, sk_ctl(seq + 1u, in_sel ^ 1u, 0, nnx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         st->done = 1;
+    }
+}
+
+// The same rounds in ONE launch per level: the grid stays resident (one workgroup per compute unit) and a round boundary is
+// a device-wide hand-over through the control word instead of a kernel boundary -- the last working workgroup of round r
+// publishes the control word of round r + 1 (or SEQ_DONE), everybody else polls it.  A level of the 512^3 bench has ~6
+// generations = ~10 rounds: as launches (queued 16 at a time) they cost 8.8 us each, working or not.
+// Everything that crosses workgroups inside the launch -- stamps, counters, control word AND the list entries -- is an
+// agent-scope atomic access (sc1 on gfx950: served at the point all XCDs share), so a round boundary needs no L2 write-back /
+// invalidate: a workgroup waits for its own stores (s_waitcnt) and signs the ticket.  (With __threadfence() pairs instead,
+// every round paid the write-back of eight L2s: 36 us per round, measured -- four times a launch.)
+constexpr uint32_t SEQ_DONE = 0x3FFFFFFFu;
+constexpr uint32_t SK_SPIN_LIMIT = 1u << 22; // polls of ~0.5 us: a lost hand-over ends the launch with done = 3, it never hangs
+
+__device__ __forceinline__ uint32_t ld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// the offers of one voxel with every neighbour in flight at once (the loop over the set bits in sk_offer_plateau is a chain of
+// dependent round trips, one per neighbour; inside the resident launch a round IS its chain of round trips)
+template <int CONN>
+__device__ __forceinline__ void sk_offer_plateau_wide(const WsGeom &g, unsigned long long *tau, uint32_t pm, uint32_t v, unsigned long long nt,
+                                                      SkStage &sg, uint32_t *next, SkState *st) {
+    unsigned long long old[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        old[k] = 0ull;
+        if (!has_off<CONN>(g.smask, k)) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        if ((pm >> k) & 1u) old[k] = atomicMin(&tau[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)], nt);
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        if (!has_off<CONN>(g.smask, k)) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        if (!__ballot((pm >> k) & 1u)) continue; // (wave-uniform)
+        stage_push(old[k] == TINF, (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx), sg, next, &st->n_next);
+    }
+}
+
+template <int CONN>
+__global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
+                                                  const uint32_t *__restrict__ comp, unsigned long long *tau, SkLists L,
+                                                  const uint32_t *dlist, uint32_t ndl, uint32_t per_wg, SkState *st) {
+    __shared__ SkStage sg;
+    __shared__ unsigned long long s_ctl;
+    __shared__ uint32_t s_last;
+    uint32_t gen = ld32(&st->gen); // (k_sk_assign's launch wrote it)
+    for (uint32_t r = 0;; r++) {
+        if (threadIdx.x == 0) {
+            unsigned long long c;
+            for (uint32_t spins = 0;; spins++) {
+                c = __hip_atomic_load(&st->pctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t sq = (uint32_t)(c >> 34);
+                if (sq == r || sq == SEQ_DONE) break;
+                if (spins > SK_SPIN_LIMIT) {
+                    st32(&st->done, 3u);
+                    c = sk_ctl(SEQ_DONE, 0, 0, 0);
+                    __hip_atomic_store(&st->pctl, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the others leave too)
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            s_ctl = c;
+        }
+        __syncthreads();
+        const unsigned long long ctl = s_ctl;
+        if ((uint32_t)(ctl >> 34) == SEQ_DONE) return;
+        const uint32_t phase = (uint32_t)(ctl >> 32) & 1u, in_sel = (uint32_t)(ctl >> 33) & 1u, n_front = (uint32_t)ctl;
+        if (r > 0 && phase == 0) gen++; // (every workgroup sees every control word: the generation is counted, not read)
+        const uint32_t n_in = phase ? ndl : n_front;
+        const uint32_t nactive = min((uint32_t)gridDim.x, (n_in + per_wg - 1u) / per_wg);
+        if (blockIdx.x < nactive) {
+            const uint32_t *in = phase ? dlist : L.l[in_sel];
+            uint32_t *next = L.l[in_sel ^ 1u];
+            const uint32_t stride = nactive * 256;
+            if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
+            __syncthreads();
+            uint32_t stamped = 0;
+            for (uint32_t i0 = blockIdx.x * 256; i0 < n_in; i0 += stride) {
+                const uint32_t i = i0 + threadIdx.x;
+                bool act = i < n_in;
+                const uint32_t v = act ? (phase ? in[i] : ld32(&in[i])) : 0u; // (dlist is read-only; a frontier list was written in this launch)
+                if (phase == 0) {
+                    const uint32_t pm = act ? pmask[v] : 0u, zm = (ndl && act) ? zmask[v] : 0u;
+                    const unsigned long long t = act ? ld64(&tau[v]) : TINF;
+                    uint32_t root[27]; // the basins this voxel touches: all their roots in flight, then all their stamps
+#pragma unroll
+                    for (int k = 0; k < 27; k++) {
+                        root[k] = ENTRY;
+                        if (!has_off<CONN>(g.smask, k)) continue;
+                        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                        if ((zm >> k) & 1u) root[k] = comp[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)];
+                    }
+                    sk_offer_plateau_wide<CONN>(g, tau, pm, v, t + GEN1, sg, next, st);
+                    uint32_t last = ENTRY;
+#pragma unroll
+                    for (int k = 0; k < 27; k++) {
+                        if (!has_off<CONN>(g.smask, k)) continue;
+                        if (root[k] == ENTRY || root[k] == last) continue; // (most neighbours of one voxel share a basin)
+                        last = root[k];
+                        stamped += atomicMin(&tau[root[k]], t) == TINF;
+                    }
+                } else {
+                    unsigned long long tb = TINF;
+                    if (act) tb = ld64(&tau[comp[v]]);
+                    act = act && (uint32_t)(tb >> 32) == gen;
+                    sk_offer_plateau_wide<CONN>(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
+                }
+                stage_flush(sg, next, &st->n_next);
+            }
+            if (stamped) atomicAdd(&st->n_stamped, stamped);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0); // this wave's stores and atomics have been acknowledged
+            __syncthreads();
+            if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1u) == nactive - 1;
+            __syncthreads();
+            if (s_last && threadIdx.x == 0) {
+                const uint32_t nst = ld32(&st->n_stamped), nnx = ld32(&st->n_next);
+                st32(&st->ticket, 0u);
+                atomicAdd(&st->rounds, 1u);
+                unsigned long long nctl;
+                if (phase == 0 && nst) {
+                    st32(&st->n_stamped, 0u);
+                    atomicAdd(&st->brounds, 1u);
+                    nctl = sk_ctl(r + 1u, in_sel, 1, n_front);
+                } else if (nnx) {
+                    st32(&st->n_next, 0u);
+                    st32(&st->n_stamped, 0u);
+                    atomicAdd(&st->gens, 1u);
+                    nctl = sk_ctl(r + 1u, in_sel ^ 1u, 0, nnx);
+                } else {
+                    st32(&st->gen, gen); // the last generation used (what the host reads); the next level starts one later
+                    st32(&st->gnext, gen + 1u);
+                    st32(&st->n_stamped, 0u);
+                    st32(&st->done, 1u);
+                    nctl = sk_ctl(SEQ_DONE, 0, 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __hip_atomic_store(&st->pctl, nctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads(); // (s_ctl is rewritten by the next poll)
     }
 }
 
@@ -806,7 +958,34 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const bool trace = getenv("IVX_WS_TRACE") != nullptr;
     const char *epb = getenv("IVX_SK_PER_WG"); // list entries per working workgroup (A/B measurements)
     const uint32_t per_wg = epb && atoi(epb) >= 256 ? (uint32_t)atoi(epb) : 1024u;
+    const char *erc = getenv("IVX_SK_RES_PER_CU");
+    const int64_t res_per_cu = erc && atoi(erc) >= 1 && atoi(erc) <= 4 ? atoi(erc) : 1;
     uint32_t start = 0, dstart = 0, roff = 0, gbase = 1, seq = 0;
+    // IVX_SK_PERSIST=0: a level's rounds as separate launches (k_sk_round, queued in batches; A/B measurements).  Default: one
+    // resident launch per level (k_sk_level) and no host read between consecutive levels -- the next level's first
+    // generation travels on the device (SkState::gnext); `gknown` says whether the host's gbase is current.
+    const char *penv = getenv("IVX_SK_PERSIST");
+    const bool persist = !(penv && penv[0] == '0');
+    int ncu = 0;
+    {
+        int dev = 0;
+        IVX_HIP(hipGetDevice(&dev));
+        IVX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    bool gknown = true;
+    uint64_t gbound = 1; // gbase <= gbound always (a generation stamps at least one voxel): sizes the sort's key width
+    auto sync_gbase = [&]() -> int { // the chain's last level has finished: fetch the generation counter
+        if (gknown) return IVX_OK;
+        uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
+        int rc = mailbox_publish(&b.st->done, 4, st, &mseq);
+        if (rc != IVX_OK) return rc;
+        rc = mailbox_wait(mseq, st, msg, 4);
+        if (rc != IVX_OK) return rc;
+        IVX_REQUIRE(msg[0] == 1, IVX_EINVAL, "watershed: a level's resident launch lost its hand-over (state %u)", msg[0]);
+        gbase = msg[1] + 1;
+        gknown = true;
+        return IVX_OK;
+    };
     SkLists lists;
     for (int i = 0; i < 2; i++) lists.l[i] = b.lists[i];
     const char *senv = getenv("IVX_SK_SMALL"); // 0: never take the one-workgroup path (A/B measurements)
@@ -820,7 +999,12 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             dstart += ndl;
             continue;
         }
+        gbound += (uint64_t)lhist[c] + 1u;
         if (is_small(c)) { // a run of consecutive small levels: one launch
+            {
+                const int rc = sync_gbase();
+                if (rc != IVX_OK) return rc;
+            }
             uint32_t c_hi = c, esum = 0, dsum = 0, nlv = 0;
             for (uint32_t q = c; q < 65535 && (hist[q] == 0 || is_small(q)); q++)
                 if (hist[q]) c_hi = q;
@@ -848,6 +1032,8 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         }
         nlevels++;
         const auto lvl_t0 = std::chrono::steady_clock::now();
+        static const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
+        const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
         uint32_t lvl_batches = 0;
         const unsigned gb = (unsigned)cdiv(cnt, 256);
         WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau, b.elist + start, b.key_a,
@@ -855,19 +1041,24 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         IVX_LAUNCH_CHECK();
         const unsigned long long *ks = b.key_a;
         const uint32_t *vs = b.val_a;
+        const bool tile_level = ndl == 0 && tile_min && lhist[c] >= tile_min;
+        if (tile_level || !persist || trace) {
+            const int rc = sync_gbase();
+            if (rc != IVX_OK) return rc;
+        }
         if (cnt > 1) {
             int end_bit = 33; // keys are below (gbase << 32): the bits that can differ
-            while (end_bit < 64 && (gbase >> (end_bit - 32))) end_bit++;
+            const uint64_t gtop = gknown ? (uint64_t)gbase : std::min<uint64_t>(gbound, 0x7FFFFFF0u);
+            while (end_bit < 64 && (gtop >> (end_bit - 32))) end_bit++;
             size_t tb = cub_bytes + 256;
             IVX_HIP(hipcub::DeviceRadixSort::SortPairs(b.cub, tb, b.key_a, b.key_b, b.val_a, b.val_b, (size_t)cnt, 0, end_bit, st));
             ks = b.key_b;
             vs = b.val_b;
         }
-        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gbase, seq, b.st);
+        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gknown ? gbase : 0u,
+                           persist && !tile_level ? 0u : seq, b.st);
         IVX_LAUNCH_CHECK();
-        const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
-        const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
-        if (ndl == 0 && tile_min && lhist[c] >= tile_min) {
+        if (tile_level) {
             hipLaunchKernelGGL(k_sk_mark_tiles, dim3(gb), dim3(256), 0, st, g, b.lists[0], cnt, b.dirty);
             IVX_LAUNCH_CHECK();
             for (;;) {
@@ -896,6 +1087,25 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             if (trace)
                 fprintf(stderr, "sk level %u gen0 %u tile-wise -> generation %u, %.0f us\n", c, cnt, gbase - 1,
                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lvl_t0).count());
+            continue;
+        }
+        if (persist) { // one resident launch; the host moves on without reading anything
+            // (as many workgroups as twice the first frontier asks for, at most res_per_cu per compute unit: all of them must be
+            // resident -- 256 threads, 30 registers and 16 KB of LDS each leave room for eight)
+            const unsigned nres = (unsigned)std::min<int64_t>(std::max<int64_t>(cdiv(2 * (int64_t)std::max(cnt, ndl), per_wg), 8), res_per_cu * std::max(ncu, 8));
+            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_level<CC>, dim3(nres), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists,
+                                                      b.dlist + dstart, ndl, per_wg, b.st));
+            IVX_LAUNCH_CHECK();
+            gknown = false;
+            if (trace) {
+                const int rc = sync_gbase();
+                if (rc != IVX_OK) return rc;
+                fprintf(stderr, "sk level %u gen0 %u drained %u -> generation %u, resident, %.0f us\n", c, cnt, ndl, gbase - 1,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lvl_t0).count());
+            }
+            roff += cnt;
+            start += cnt;
+            dstart += ndl;
             continue;
         }
         // rounds are queued in growing batches; one host read per batch (a round after the level's last returns at once)
@@ -929,6 +1139,11 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         dstart += ndl;
     }
 
+    {
+        const int rc = sync_gbase();
+        if (rc != IVX_OK) return rc;
+        IVX_REQUIRE(gbase < 0x7FFFFFF0u, IVX_EINVAL, "watershed: more than 2^31 generations");
+    }
     tm.mark(st);
     // ---- 4. labels -------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_sk_labels<MT>, dim3(gl), dim3(256), 0, st, g.n, b.comp, b.tau, b.runlabel, out, out32, out8);
