@@ -29,7 +29,7 @@
 #include "ivx_internal.h"
 #include "scan_u32.h"
 
-#define MC_TABLE_QUAL __device__ const
+#define MC_TABLE_QUAL __device__ __attribute__((aligned(16))) const
 #include "../../include/ivx_mc_tables.h"
 
 typedef short short8_t __attribute__((ext_vector_type(8)));
@@ -490,15 +490,27 @@ __global__ __launch_bounds__(256) void k_mc_list(const uint64_t *__restrict__ bi
 struct McLevels {
     const uint64_t *sel; // source-coordinate plane, rows of g.ws words
     double v_out, v_in, v_sel;
+    // (iso - s0) / (s1 - s0) for the four (which end is inside, which inside level) combinations, divided once on the host:
+    // IEEE double division gives the same bits there as three divisions per triangle give here
+    double tt[4]; // [in0 * 2 + sel]
 };
+static inline McLevels make_levels(const uint64_t *sel, double iso, double v_out, double v_in, double v_sel) {
+    McLevels lv{sel, v_out, v_in, v_sel, {0.0, 0.0, 0.0, 0.0}};
+    for (int in0 = 0; in0 < 2; in0++)
+        for (int q = 0; q < 2; q++) {
+            const double vin = q ? v_sel : v_in, s0 = in0 ? vin : v_out, s1 = in0 ? v_out : vin;
+            lv.tt[in0 * 2 + q] = (iso - s0) / (s1 - s0);
+        }
+    return lv;
+}
 template <typename T, bool LEVELS>
 __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g, double iso0, double iso1,
                                                  const uint64_t *__restrict__ split_dev,
                                                  const uint64_t *__restrict__ total_dev,
                                                  const uint64_t *__restrict__ list, uint64_t cap,
                                                  float *__restrict__ tris, McLevels lv) {
-    __shared__ uint8_t s_tri[256 * 16];
-    __shared__ float s_out[256 * 9];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tri[256 * 15];
+    __shared__ __attribute__((aligned(16))) float s_out[256 * 9];
     const int tid = threadIdx.x;
     // The grid covers the output CAPACITY; how many triangles there really are (and where iso 1's begin) is read from
     // the scan's result on the device, so the host can queue this kernel before it knows the count.
@@ -506,8 +518,10 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
     const uint64_t ntris = total < cap ? total : cap;
     const uint64_t T0 = (uint64_t)blockIdx.x * 256;
     if (T0 >= ntris) return;
+    // the triangle table (3 840 bytes, rows of 15) as 960 dwords, layout unchanged
 #pragma unroll
-    for (int q = 0; q < 15; q++) s_tri[tid * 16 + q] = MC_TRI[tid][q];
+    for (int q = 0; q < 4; q++)
+        if (q * 256 + tid < 960) ((uint32_t *)s_tri)[q * 256 + tid] = ((const uint32_t *)&MC_TRI[0][0])[q * 256 + tid];
     const uint64_t T_ = T0 + tid;
     const double iso = T_ < split ? iso0 : iso1;
     // per-edge constants, once per workgroup: voxel offsets of the edge's two end points relative to the cell's corner
@@ -540,7 +554,8 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
         double s0[3], s1[3];
         int ec[3];
 #pragma unroll
-        for (int v = 0; v < 3; v++) ec[v] = s_tri[idx * 16 + 3 * rel + v];
+        for (int v = 0; v < 3; v++) ec[v] = s_tri[idx * 15 + 3 * rel + v];
+        double ttl[3];
         if (LEVELS) {
 #pragma unroll
             for (int v = 0; v < 3; v++) {
@@ -552,9 +567,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
                 const int32_t kk = k + bz + (in1 && ax == 2), jj = j + by + (in1 && ax == 1), ii = i + bx + (in1 && ax == 0);
                 const int64_t sk = kk - (int32_t)g.pb, sj = ((int32_t)g.NY - 1 - jj) - (int32_t)g.pxy, si = ii - (int32_t)g.pxy;
                 const uint64_t wsel = lv.sel[(sk * g.ny + sj) * g.ws + (si >> 6)];
-                const double vin = (wsel >> (si & 63)) & 1ull ? lv.v_sel : lv.v_in;
-                s0[v] = in0 ? vin : lv.v_out;
-                s1[v] = in1 ? vin : lv.v_out;
+                ttl[v] = lv.tt[(in0 ? 2 : 0) + (int)((wsel >> (si & 63)) & 1ull)];
                 ec[v] = c;
             }
         } else if (fast) { // interior cell: one base pointer, six byte/short gathers at table offsets, issued back to back
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
 #pragma unroll
         for (int v = 0; v < 3; v++) {
             const int ax = ec[v] & 3, bx = (ec[v] >> 2) & 1, by = (ec[v] >> 3) & 1, bz = (ec[v] >> 4) & 1;
-            const double tt = (iso - s0[v]) / (s1[v] - s0[v]);
+            const double tt = LEVELS ? ttl[v] : (iso - s0[v]) / (s1[v] - s0[v]);
             double p0 = (double)(i + bx - (int32_t)g.pxy);
             double p1 = (double)(j + by - (int32_t)g.yoff);
             double p2 = (double)(k + bz + g.zoff);
@@ -594,7 +607,16 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
     __syncthreads();
     const uint32_t nt_chunk = ntris - T0 < 256 ? (uint32_t)(ntris - T0) : 256u;
     float *dst = tris + T0 * 9;
-    for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
+    if (nt_chunk == 256 && ((uintptr_t)tris & 15) == 0) { // a whole chunk (9 216 bytes, 16-byte aligned): 576 16-byte stores
+        typedef float float4_t __attribute__((ext_vector_type(4)));
+        float4_t *d4 = (float4_t *)dst;
+        const float4_t *s4 = (const float4_t *)s_out;
+        d4[tid] = s4[tid];
+        d4[tid + 256] = s4[tid + 256];
+        if (tid < 64) d4[tid + 512] = s4[tid + 512];
+    } else {
+        for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
+    }
 }
 
 static std::map<const void *, uint64_t> g_split; // scratch -> number of iso-0 triangles (two-iso pieces)
@@ -689,7 +711,7 @@ static int run_emit(const ivx_mc_params *p, const Geom &g, const Scratch &s, con
     else
         hipLaunchKernelGGL((k_mc_emit<T, false>), dim3((unsigned)ivx::cdiv(max_tris, (int64_t)256)), dim3(256), 0, st, (const T *)a, g,
                            p->iso[0], p->iso[1], boff + (p->niso == 2 ? s.nblocks : nb), boff + nb, (const uint64_t *)d_list,
-                           (uint64_t)max_tris, tris, McLevels{nullptr, 0.0, 0.0, 0.0});
+                           (uint64_t)max_tris, tris, McLevels{nullptr, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0, 0.0}});
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
@@ -1176,7 +1198,7 @@ extern "C" int ivx_dev_mc_emit_levels(const ivx_mc_params *p, const void *scratc
                 "mc_emit_levels: v_out (and the padding) must lie below the iso-value, v_in and v_sel at or above it");
     const Scratch s = make_scratch(g, p->niso);
     if (s.nwords == 0 || max_tris <= 0) return IVX_OK;
-    const McLevels lv{sel_bits, v_out, v_in, v_sel};
+    const McLevels lv = make_levels(sel_bits, p->iso[0], v_out, v_in, v_sel);
     return run_emit<uint8_t>(p, g, s, nullptr, (const char *)scratch, tris, max_tris, ivx::S(stream), &lv);
 }
 
