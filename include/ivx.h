@@ -402,6 +402,19 @@ int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *r
 int ivx_dev_flood_grow(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
                        const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached, void *scratch,
                        int *rounds, void *stream);
+/* The rounds of a flood run in ONE resident launch (k_flood_resident: round boundaries are device-wide barriers; the launch
+ * ends at the first empty round) -- IVX_FLOOD_RESIDENT=0 brings back one launch per round.  ivx_dev_flood_grow waits for the
+ * launch's last word before it returns; ivx_dev_flood_grow_async returns right behind the launch (*pending = 1; *rounds is
+ * not set then), so the stages the caller queues next start the moment the flood ends.  ivx_dev_flood_wait (same p, cand,
+ * reached, scratch) then fetches the round count; *late = 1 when the launch had ended early (round cap of a long thin
+ * region -> the union-find engine, or a timed-out barrier -> launches per round) and the flood was completed only inside
+ * ivx_dev_flood_wait: work queued between the two calls has seen an incomplete `reached` and must be queued again.
+ * With nothing pending ivx_dev_flood_wait returns at once and leaves *rounds alone. */
+int ivx_dev_flood_grow_async(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                             const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached, void *scratch,
+                             int *rounds, int *pending, void *stream);
+int ivx_dev_flood_wait(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch, int *rounds,
+                       int *late, void *stream);
 /* Gate for background work (e.g. the next stage's mask-independent passes on a second, low-priority stream): the next
  * ivx_dev_flood_run on `scratch` stores `value` to the device word `word` from the first round that starts with fewer
  * than `below_tiles` tiles -- its throughput-bound head is over -- or when it returns, if no round did.

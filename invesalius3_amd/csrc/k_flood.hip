@@ -396,6 +396,9 @@ __device__ __forceinline__ void tile_update(const Tiles &t, const unsigned long 
         // vote: __syncthreads_or() costs ~1500 cycles on gfx950 (library workgroup reduction); a wave ballot + one
         // LDS flag + one barrier does the same in ~200.  Flag it&1 is read now, flag (it+1)&1 is cleared for the next
         // iteration (nobody touches it between this barrier and the next one's writers).
+        // (Tried: one flag per wave, a wave whose own and whose neighbour waves' slices stood still in the last iteration
+        // skips its gather -- 0.192 -> 0.213 ms on the bench volume: the fronts move along y as much as along z, so all
+        // four waves stay busy, and the flag read at the loop head is one more dependent LDS round trip.)
         if (__any(changed) && (threadIdx.x & 63) == 0) L.vote[it & 1] = 1u;
         if (threadIdx.x == 0) L.vote[(it + 1) & 1] = 0u;
         __syncthreads();
@@ -732,6 +735,126 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
     }
 }
 
+#define AT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// ---- resident rounds: the same rounds, ONE launch ------------------------------------------------------------------
+// A launch per round costs ~5 us of dispatch whether the round has 1 500 tiles or none, the host has to see a round start
+// with an empty list before it stops queueing (three more empty launches are in the queue by then), and the stage that
+// follows waits behind all of them.  Here the grid stays resident (every workgroup is on a compute unit at once: the host
+// sizes the grid from the occupancy) and a round boundary is a device-wide barrier: a workgroup drains its own stores and
+// atomics (s_waitcnt), signs an arrival counter and polls it.  Everything that crosses workgroups inside the launch --
+// reached words, dirty bytes, list entries, counters -- is an agent-scope access (served where all XCDs meet), so the
+// boundary needs no L2 write-back.  Only workgroups that had a tile this round sign (the others just wait for them).
+// The kernel ends at the first empty list, or after `round_cap` rounds (the caller's escape to the union-find engine), or
+// -- every spin is bounded -- with status 3 when a barrier never completes (the caller finishes with launches per round:
+// `reached` is monotone, a partial result is valid).  The last word goes to the pinned progress line.
+// OPT-IN (IVX_FLOOD_RESIDENT=1), measured slower on the bench volume: region growing 0.27 ms with one workgroup per compute
+// unit, 0.31 / 0.42 / 0.49 ms with 2 / 4 / 6, against 0.19 ms for one launch per round -- a round inside the launch is a chain
+// of ~6 agent-scope round trips of ~1.2 us (poll, list entry, staged rows, publish, drain, arrival) and up to 10^3 pollers
+// share one address, while a kernel boundary costs ~5 us flat and its loads hit the L2.  What the launch per round cannot
+// do -- have the next stage queued before the flood ends -- ivx_dev_flood_grow_async / ivx_dev_flood_wait offer with it.
+struct ResCtl {
+    unsigned int arrive; // barrier arrivals since the launch (monotone)
+    unsigned int status; // 0 running, 1 converged, 2 round cap reached, 3 a barrier timed out
+    unsigned int rounds; // rounds that had work
+    unsigned int visits; // (statistics) tile visits
+};
+constexpr int RES_CTL_AT = 32; // dword index of ResCtl inside the counter block (cleared together with the ring)
+__global__ __launch_bounds__(NT, 6) void k_flood_resident(Tiles t, const unsigned long long *__restrict__ cand,
+                                                           unsigned long long *reached, unsigned int *list0,
+                                                           unsigned int *list1, unsigned int *cnt, uint8_t *dirty0,
+                                                           uint8_t *dirty1, ResCtl *ctl, unsigned long long *line,
+                                                           unsigned int tag, unsigned int ring, unsigned int round_cap,
+                                                           unsigned int max_spins, unsigned int *gate, unsigned int gate_val,
+                                                           unsigned int gate_below) {
+    __shared__ TileLds L;
+    __shared__ unsigned int s_n, s_abort;
+    unsigned int target = 0, round = 0, status = 1;
+    for (;; round++) {
+        const unsigned int r = round % ring, cur = round & 1u;
+        if (threadIdx.x == 0) {
+            s_n = AT_LOAD(&cnt[r]);
+            s_abort = 0u;
+        }
+        __syncthreads();
+        const unsigned int n = s_n;
+        if (n == 0u) break;
+        if (round >= round_cap) {
+            status = 2;
+            break;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            AT_STORE(&cnt[(r + 2u) % ring], 0u); // the counter the round AFTER the next one appends to
+            if (gate && n < gate_below) AT_STORE(gate, gate_val);
+        }
+        unsigned int *list_cur = cur ? list1 : list0, *list_next = cur ? list0 : list1;
+        uint8_t *dirty_cur = cur ? dirty1 : dirty0, *dirty_next = cur ? dirty0 : dirty1;
+        unsigned int *n_next = cnt + (r + 1u) % ring;
+        for (unsigned int li = blockIdx.x; li < n; li += gridDim.x) {
+            const int64_t tile = AT_LOAD(&list_cur[li]);
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&dirty_cur[tile], (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.dirs = 0;
+                L.open = 0;
+            }
+            __syncthreads();
+            if (t.conn == 26) tile_update<true, 26>(t, cand, reached, tile, L);
+            else if (t.conn == 18) tile_update<true, 18>(t, cand, reached, tile, L);
+            else if (t.conn == 6) tile_update<true, 6>(t, cand, reached, tile, L);
+            else tile_update<true, 0>(t, cand, reached, tile, L);
+            lds_barrier(); // L.dirs complete; the publishing atomics keep flying until the round's barrier
+            const int64_t txi = tile % t.wx, r1 = tile / t.wx;
+            const int64_t tyi = r1 % t.nty, tzi = r1 / t.nty;
+            if (threadIdx.x == 32 && !L.open) { // closed for good (see CLOSED)
+                const unsigned int bit = CLOSED << (8 * (unsigned int)(tile & 3));
+                atomicOr((unsigned int *)(dirty_cur + (tile & ~(int64_t)3)), bit);
+                atomicOr((unsigned int *)(dirty_next + (tile & ~(int64_t)3)), bit);
+            }
+            if (threadIdx.x < 27 && (L.dirs >> threadIdx.x & 1u)) {
+                const int d = threadIdx.x;
+                const int64_t nz = tzi + d / 9 - 1, ny = tyi + (d / 3) % 3 - 1, nx = txi + d % 3 - 1;
+                if (nz >= 0 && nz < t.ntz && ny >= 0 && ny < t.nty && nx >= 0 && nx < t.wx) {
+                    const int64_t nt = (nz * t.nty + ny) * t.wx + nx;
+                    unsigned int *wp = (unsigned int *)(dirty_next + (nt & ~(int64_t)3));
+                    const unsigned int sh = 8 * (unsigned int)(nt & 3);
+                    const unsigned int old = atomicOr(wp, 1u << sh);
+                    if (!((old >> sh) & 0xffu)) AT_STORE(&list_next[atomicAdd(n_next, 1u)], (unsigned int)nt);
+                }
+            }
+            __syncthreads(); // L is reused by the next list entry of this workgroup
+        }
+        // the round's barrier: min(n, grid) workgroups had work and sign; everybody waits for all of them
+        target += n < gridDim.x ? n : gridDim.x;
+        __builtin_amdgcn_s_waitcnt(0); // this wave's stores and atomics have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (blockIdx.x < n) atomicAdd(&ctl->arrive, 1u);
+            for (unsigned int spins = 0; (int)(AT_LOAD(&ctl->arrive) - target) < 0; spins++) {
+                if (spins > max_spins || AT_LOAD(&ctl->status) == 3u) {
+                    AT_STORE(&ctl->status, 3u);
+                    s_abort = 1u;
+                    break;
+                }
+                if (blockIdx.x < n) __builtin_amdgcn_s_sleep(2);
+                else __builtin_amdgcn_s_sleep(24); // (a workgroup without work this round: poll gently)
+            }
+        }
+        __syncthreads();
+        if (s_abort) {
+            status = 3;
+            break;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (status != 3u) AT_STORE(&ctl->status, status);
+        AT_STORE(&ctl->rounds, round);
+        if (gate) AT_STORE(gate, gate_val); // whatever happened, the gate is open when the flood is over
+        __hip_atomic_store(&line[0], ((unsigned long long)tag << 56) | ((unsigned long long)status << 48) | round, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- persistent tile frontier: ONE launch, device-side work queue ---------------------------------------
 // Same tile update as k_flood_round_list, but workgroups pull dirty tiles from a ring buffer and push the neighbour
 // tiles whose halo they changed, until nothing is queued or in flight (`pending` == 0).  Cross-workgroup traffic
@@ -739,8 +862,6 @@ __global__ __launch_bounds__(NT, 6) void k_flood_round_list(Tiles t, const unsig
 // form of the CDNA4 guide, G16): words are published with atomicOr (monotone, so two workgroups that happen to
 // own the same tile concurrently can never lose bits), drained with s_waitcnt vmcnt(0) before the push.
 // No co-residency is needed: a workgroup only ever waits for work while some OTHER running workgroup holds a tile.
-#define AT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define AT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 __global__ void k_flood_enqueue(Tiles t, uint8_t *dirty, Queue *q, unsigned int *queued, unsigned int *ring,
                                 unsigned int qmask) {
@@ -1522,8 +1643,83 @@ static bool coarse_ok(const Tiles &t, bool directed) {
     return coarse_on && !directed && t.conn != 0 && t.wx <= 64 && (t.nty + 2) * (t.ntz + 2) <= CROWS_MAX &&
            t.nty * t.ntz <= (int64_t)CT * CRP;
 }
+// a resident launch (k_flood_resident) whose last word has not been read yet, keyed by the scratch it runs on
+struct ResPending {
+    volatile unsigned long long *line;
+    uint32_t tag;
+    bool ccl_at_cap;
+};
+static std::map<const void *, ResPending> g_res_pending;
+static std::mutex g_res_mu;
 static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool directed, uint64_t *reached, void *scratch_,
-                          int *rounds, void *stream, const Fresh *fresh = nullptr, bool linear = false) {
+                          int *rounds, void *stream, const Fresh *fresh = nullptr, bool linear = false, int resident = -1);
+// Wait for the resident launch on `scratch_` (if any) and finish what it left: *late = 1 when `reached` was completed after
+// the launch had ended (round cap -> union-find engine; timed-out barrier -> launches per round), i.e. when work the caller
+// queued behind the launch has seen an incomplete plane and must be queued again.
+static int flood_wait_impl(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch_, int *rounds,
+                           int *late, void *stream) {
+    if (late) *late = 0;
+    ResPending rp;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        auto it = g_res_pending.find(scratch_);
+        if (it == g_res_pending.end()) return IVX_OK; // nothing pending: the flood completed inside its call
+        rp = it->second;
+        g_res_pending.erase(it);
+    }
+    hipStream_t st = ivx::S(stream);
+    unsigned long long v = 0;
+    bool got = false;
+    for (long spins = 0; spins < 40000000L; spins++) {
+        v = __atomic_load_n((const unsigned long long *)rp.line, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(v >> 56) == rp.tag && ((v >> 48) & 0xffull) != 0) { got = true; break; }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (!got) {
+        IVX_HIP(hipStreamSynchronize(st));
+        v = __atomic_load_n((const unsigned long long *)rp.line, __ATOMIC_ACQUIRE);
+        IVX_REQUIRE((uint32_t)(v >> 56) == rp.tag && ((v >> 48) & 0xffull) != 0, IVX_EHIP, "flood: the resident launch never reported");
+    }
+    const unsigned int status = (unsigned int)((v >> 48) & 0xffull);
+    int done_rounds = (int)(v & 0xffffffffull);
+    static const bool trace = getenv("IVX_FLOOD_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "ivx flood: resident launch ended with status %u after %d rounds\n", status, done_rounds);
+    if (status == 2u && rp.ccl_at_cap) { // long, thin region: the union-find engine completes the components reached so far
+        Tiles t;
+        int rc = make_tiles(p, &t);
+        if (rc) return rc;
+        const FScratch s = make_fscratch(t);
+        char *scr = (char *)scratch_;
+        IVX_HIP(hipMemsetAsync(scr + s.off_dirty0, 0, (size_t)t.ntiles, st));
+        IVX_HIP(hipMemsetAsync(scr + s.off_dirty1, 0, (size_t)t.ntiles, st));
+        if ((rc = ivx::ccl_run(p, cand, reached, scratch_, st))) return rc;
+        done_rounds += 1;
+        if (late) *late = 1;
+    } else if (status != 1u) { // a barrier timed out (or a cap without an escape): finish with one launch per round
+        fprintf(stderr, "ivx: resident flood launch ended with status %u after %d rounds; finishing with launches per round\n", status,
+                done_rounds);
+        Tiles t;
+        int rc = make_tiles(p, &t);
+        if (rc) return rc;
+        const FScratch s = make_fscratch(t);
+        char *scr = (char *)scratch_;
+        IVX_HIP(hipMemsetAsync(scr + s.off_dirty0, 1, (size_t)t.ntiles, st));
+        IVX_HIP(hipMemsetAsync(scr + s.off_dirty1, 0, (size_t)t.ntiles, st));
+        int more = 0;
+        if ((rc = flood_run_impl(p, cand, false, reached, scratch_, &more, stream, nullptr, false, 0))) return rc;
+        done_rounds += more;
+        if (late) *late = 1;
+    }
+    if (rounds) *rounds = done_rounds;
+    return IVX_OK;
+}
+// resident: -1 = as IVX_FLOOD_RESIDENT says, returns when the flood is complete; 0 = launches per round; 1 = resident launch
+// allowed AND the call may return right behind it (ivx_dev_flood_grow_async: the caller picks the result up with
+// ivx_dev_flood_wait)
+static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool directed, uint64_t *reached, void *scratch_,
+                          int *rounds, void *stream, const Fresh *fresh, bool linear, int resident) {
     if (linear) directed = true; // (arc planes: no coarse pass, no union-find escape, no persistent frontier)
     Tiles t;
     int rc = make_tiles(p, &t);
@@ -1633,7 +1829,7 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
         while (ct < CT && ct < t.nty * t.ntz) ct *= 2;
         if (fresh) {
             hipLaunchKernelGGL(k_flood_block_flags<true>, dim3(groups), dim3(256), 0, st, t, bk, (unsigned long long *)cand,
-                               (const unsigned long long *)reached, dirty[0], dirty[1], rowF, rowW, cnt, RING, fresh->sp,
+                               (const unsigned long long *)reached, dirty[0], dirty[1], rowF, rowW, cnt, RES_CTL_AT + 4, fresh->sp,
                                fresh->dtype, fresh->data, fresh->t0, fresh->t1, seed_ok);
             IVX_LAUNCH_CHECK();
             if (t.conn == 26) hipLaunchKernelGGL((k_flood_coarse<26, true>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, fresh->sp, seed_ok);
@@ -1645,7 +1841,7 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
             IVX_LAUNCH_CHECK();
         } else {
             hipLaunchKernelGGL(k_flood_block_flags<false>, dim3(groups), dim3(256), 0, st, t, bk, (unsigned long long *)cand,
-                               (const unsigned long long *)reached, dirty[0], dirty[1], rowF, rowW, cnt, RING, none, 0,
+                               (const unsigned long long *)reached, dirty[0], dirty[1], rowF, rowW, cnt, RES_CTL_AT + 4, none, 0,
                                (const void *)nullptr, 0.0, 0.0, seed_ok);
             IVX_LAUNCH_CHECK();
             if (t.conn == 26) hipLaunchKernelGGL((k_flood_coarse<26, false>), dim3(1), dim3(ct), 0, st, t, bk, rowF, rowW, none, seed_ok);
@@ -1658,13 +1854,50 @@ static int flood_run_impl(const ivx_flood_plan *p, const uint64_t *cand, bool di
         }
     } else {
         IVX_REQUIRE(!fresh, IVX_EINVAL, "flood: the fused start needs the coarse pass");
-        IVX_HIP(hipMemsetAsync(cnt, 0, RING * 4, st));
+        IVX_HIP(hipMemsetAsync(cnt, 0, (RES_CTL_AT + 4) * 4, st));
         hipLaunchKernelGGL(k_flood_build_list, dim3((unsigned)ivx::cdiv(t.ntiles, 256)), dim3(256), 0, st, t, dirty[0], list[0], cnt);
         IVX_LAUNCH_CHECK();
     }
     volatile unsigned long long *line = nullptr;
     uint32_t tag = 0;
     if ((rc = ivx::progress_line(st, &line, &tag))) return rc;
+    // IVX_FLOOD_RESIDENT=1: the rounds in one resident launch (opt-in: measured slower, see k_flood_resident)
+    static const bool resident_env = [] {
+        const char *e = getenv("IVX_FLOOD_RESIDENT");
+        return e && e[0] == '1';
+    }();
+    if (!directed && resident != 0 && resident_env) {
+        static int res_per_cu = 0, ncu = 0;
+        if (!ncu) {
+            int dev = 0, occ = 0, n = 0;
+            IVX_HIP(hipGetDevice(&dev));
+            IVX_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            IVX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_flood_resident, NT, 0));
+            const char *e = getenv("IVX_FLOOD_RES_PER_CU"); // workgroups per compute unit (A/B; never more than fit)
+            int want = e ? atoi(e) : 4;
+            if (want < 1) want = 1;
+            res_per_cu = occ < 1 ? 0 : (want < occ ? want : occ);
+            ncu = n > 0 ? n : 1;
+        }
+        if (res_per_cu > 0) {
+            const int64_t cap = (int64_t)res_per_cu * ncu;
+            const unsigned rgrid = (unsigned)(t.ntiles < cap ? t.ntiles : cap);
+            const bool ccl_cap = ivx::ccl_supported(p->strct_bits);
+            ResCtl *ctl = (ResCtl *)(cnt + RES_CTL_AT);
+            hipLaunchKernelGGL(k_flood_resident, dim3(rgrid), dim3(NT), 0, st, t, (const unsigned long long *)cand,
+                               (unsigned long long *)reached, list[0], list[1], cnt, dirty[0], dirty[1], ctl,
+                               (unsigned long long *)line, (unsigned int)tag, (unsigned int)RING,
+                               ccl_cap ? (unsigned int)CCL_ESCAPE_ROUNDS : 0x00ffffffu, max_spins, arm.word, arm.value, arm.below);
+            IVX_LAUNCH_CHECK();
+            arm.word = nullptr; // the launch opens the gate itself
+            {
+                std::lock_guard<std::mutex> lk(g_res_mu);
+                g_res_pending[scratch_] = ResPending{line, tag, ccl_cap};
+            }
+            if (resident == 1) return IVX_OK; // the caller collects the result (ivx_dev_flood_wait)
+            return flood_wait_impl(p, cand, reached, scratch_, rounds, nullptr, stream);
+        }
+    }
     const unsigned grid_max = (unsigned)(t.ntiles < 1536 ? t.ntiles : 1536); // 6 workgroups per CU are resident (80 VGPRs)
     // The rounds queued ahead are sized by the newest list length the host has seen: the lists shrink towards the end, and
     // dispatching 1536 workgroups that find nothing costs ~3 us more per round than dispatching 128 (a list that turns out
@@ -2095,9 +2328,9 @@ extern "C" int ivx_dev_flood_run(const ivx_flood_plan *p, const uint64_t *cand, 
 // clear + seed + run in one call: the flood of `seeds` over `cand` into a plane whose old contents are dead.  With at most
 // 16 seeds and a standard structuring element the clearing and the seeding ride on the coarse pass (three launches before
 // the rounds instead of five, no separate pass over the plane); otherwise the three calls run one after the other.
-extern "C" int ivx_dev_flood_grow(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
-                                  const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached, void *scratch_,
-                                  int *rounds, void *stream) {
+static int flood_grow_impl(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                           const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached, void *scratch_,
+                           int *rounds, void *stream, int resident) {
     Tiles t;
     int rc = make_tiles(p, &t);
     if (rc) return rc;
@@ -2115,7 +2348,7 @@ extern "C" int ivx_dev_flood_grow(const ivx_flood_plan *p, int dtype, const void
     if (!(fused_on && nseeds >= 1 && nseeds <= 16 && t.ntiles > 0 && flood_mode() == 1 && coarse_ok(t, false))) {
         if ((rc = ivx_dev_flood_clear(p, reached, scratch_, stream))) return rc;
         if ((rc = ivx_dev_flood_seed(p, dtype, data, t0, t1, seeds_xyz, nseeds, cand, reached, scratch_, stream))) return rc;
-        return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream);
+        return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream, nullptr, false, resident);
     }
     ivx::ccl_invalidate(scratch_);
     Fresh f;
@@ -2126,7 +2359,31 @@ extern "C" int ivx_dev_flood_grow(const ivx_flood_plan *p, int dtype, const void
     f.sp.n = (int)nseeds;
     for (int64_t n = 0; n < nseeds; n++)
         for (int q = 0; q < 3; q++) f.sp.xyz[n][q] = seeds_xyz[3 * n + q];
-    return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream, &f);
+    return flood_run_impl(p, cand, false, reached, scratch_, rounds, stream, &f, false, resident);
+}
+extern "C" int ivx_dev_flood_grow(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                                  const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached, void *scratch_,
+                                  int *rounds, void *stream) {
+    return flood_grow_impl(p, dtype, data, t0, t1, seeds_xyz, nseeds, cand, reached, scratch_, rounds, stream, -1);
+}
+// ivx_dev_flood_grow that may return right behind a resident launch (k_flood_resident): *pending = 1 then, and the flood is
+// complete for everything queued on `stream` after this call EXCEPT when the launch ends early (round cap, timed-out
+// barrier) -- ivx_dev_flood_wait tells, finishes the flood, and the caller queues its dependent work again.  The point: the
+// host is not in the loop while the flood runs, so the next stage is already in the queue when the last round ends.
+extern "C" int ivx_dev_flood_grow_async(const ivx_flood_plan *p, int dtype, const void *data, double t0, double t1,
+                                        const int64_t *seeds_xyz, int64_t nseeds, uint64_t *cand, uint64_t *reached,
+                                        void *scratch_, int *rounds, int *pending, void *stream) {
+    IVX_REQUIRE(pending, IVX_EINVAL, "flood_grow_async: NULL argument");
+    *pending = 0;
+    const int rc = flood_grow_impl(p, dtype, data, t0, t1, seeds_xyz, nseeds, cand, reached, scratch_, rounds, stream, 1);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    *pending = g_res_pending.count(scratch_) ? 1 : 0;
+    return IVX_OK;
+}
+extern "C" int ivx_dev_flood_wait(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, void *scratch_, int *rounds,
+                                  int *late, void *stream) {
+    return flood_wait_impl(p, cand, reached, scratch_, rounds, late, stream);
 }
 
 extern "C" int ivx_dev_flood_run_edges(const ivx_flood_plan *p, const uint64_t *edges, uint64_t *reached, void *scratch_,

@@ -344,13 +344,21 @@ class DeviceVolume:
         t0, t1 = float(int(t0)), float(int(t1))  # wrapper int() truncation for integer images
         self._before_flood()
         cand, shared = self._candidate_plane(image, t0, t1, fill)
-        rounds = ctypes.c_int(0)
-        # clear + seed + run (an in-range seed is already a candidate here: the kernel's OR is a no-op on a shared plane)
-        L.check(lib.ivx_dev_flood_grow(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
-                                       c64(len(seeds)), cand.ptr, self.reached.ptr, self.flood_scratch.ptr,
-                                       ctypes.byref(rounds), st), "region_grow")
+        rounds, pending = ctypes.c_int(0), ctypes.c_int(0)
+        # clear + seed + run (an in-range seed is already a candidate here: the kernel's OR is a no-op on a shared plane).
+        # The call may return right behind the flood's resident launch: the writes that depend on the reached plane are
+        # queued at once, so they start the moment the flood ends, and the round count is fetched afterwards.
+        L.check(lib.ivx_dev_flood_grow_async(p, L.I16, img_ptr, ctypes.c_double(t0), ctypes.c_double(t1), L.ptr(seeds),
+                                             c64(len(seeds)), cand.ptr, self.reached.ptr, self.flood_scratch.ptr,
+                                             ctypes.byref(rounds), ctypes.byref(pending), st), "region_grow")
         self._gate_armed = False  # an armed gate has been opened by this flood
         self._apply_reached(fill, select_value, shared)
+        if pending.value:
+            late = ctypes.c_int(0)
+            L.check(lib.ivx_dev_flood_wait(p, cand.ptr, self.reached.ptr, self.flood_scratch.ptr, ctypes.byref(rounds),
+                                           ctypes.byref(late), st), "region_grow")
+            if late.value:  # the launch ended early and the flood was completed only now: the dependent writes once more
+                self._apply_reached(fill, select_value, shared)
         return rounds.value
 
     def _before_flood(self):

@@ -185,9 +185,10 @@ def test_long_serpentine_escapes_to_union_find(ivxlib, oracle):
         assert (og == 9).sum() >= dx * dy // 2
 
 
-@pytest.mark.parametrize("mode", ["ccl", "persistent", "rounds"])
+@pytest.mark.parametrize("mode", ["ccl", "persistent", "rounds", "resident"])
 def test_all_flood_engines_agree(ivxlib, oracle, mode):
-    """the three engines (tile frontier per round, persistent frontier, union-find) in a fresh process each"""
+    """the engines (tile frontier per round, the same rounds in one resident launch, persistent frontier, union-find) in a
+    fresh process each"""
     import os
     import subprocess
     import sys
@@ -211,6 +212,8 @@ def test_all_flood_engines_agree(ivxlib, oracle, mode):
         "print('engines-ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                    os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, IVX_FLOOD_MODE=mode)
+    if mode == "resident":
+        env = dict(os.environ, IVX_FLOOD_MODE="rounds", IVX_FLOOD_RESIDENT="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "engines-ok" in r.stdout, r.stdout + r.stderr
 
