@@ -62,6 +62,8 @@ static int make_geom(const ivx_mc_params *p, Geom *g) {
     g->WX = ivx::cdiv(g->NX, 64);
     g->WC = g->NX > 1 ? ivx::cdiv(g->NX - 1, 64) : 0;
     g->nrows = (g->NZ > 1 && g->NY > 1) ? (g->NZ - 1) * (g->NY - 1) : 0;
+    // (the triangle list names a cell word by 16-bit slice, 16-bit row and 15-bit word-in-row)
+    IVX_REQUIRE(g->NZ <= 65536 && g->NY <= 65536 && g->WC <= 32768, IVX_EINVAL, "mc: piece too large (at most 65 535 cells along z and y, 2^21 along x)");
     g->padv = p->pad_value;
     g->sx = p->spacing[0]; g->sy = p->spacing[1]; g->sz = p->spacing[2];
     g->yoff = g->NY - 1 - g->pxy;
@@ -421,7 +423,9 @@ __device__ __forceinline__ void edge_decode(int e, int &ax, int &bx, int &by, in
 }
 
 // 4a. list: the OWNER of each cell word writes one 64-bit descriptor per triangle into a flat global list, in output
-//     order: (cell word id << 17) | (cell bit << 11) | (case << 3) | triangle-in-case.  One case evaluation per
+//     order: (k << 48) | (j << 32) | (w << 17) | (cell bit << 11) | (case << 3) | triangle-in-case, (k, j, w) = the cell
+//     word's slice, row and word in the row (the readers -- one lane per triangle -- then need no divisions: two 32-bit
+//     divisions by run-time divisors were a quarter of k_mc_emit's instructions).  One case evaluation per
 //     active cell; only workgroups that own triangles do anything beyond a 256-entry scan.  Like the count, in two
 //     phases: the words that own triangles are handed, packed, to the first lanes of the workgroup, so that the corner
 //     loads and the serial walks fill one or two waves instead of idling in four.
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256) void k_mc_list(const uint64_t *__restrict__ bi
         act &= act - 1;
         const int idx = case_of(r.c, b);
         const uint32_t nt = s_ntri[idx];
-        const uint64_t d0 = ((uint64_t)wid << 17) | ((uint64_t)b << 11) | ((uint64_t)idx << 3);
+        const uint64_t d0 = ((uint64_t)k << 48) | ((uint64_t)j << 32) | ((uint64_t)w << 17) | ((uint64_t)b << 11) | ((uint64_t)idx << 3);
 #pragma unroll
         for (uint32_t t = 0; t < MC_MAX_TRI; t++)
             if (t < nt) list[pos + t] = d0 | t;
@@ -540,11 +544,9 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
     const uint64_t d = live ? list[T_] : 0ull;
     __syncthreads();
     if (live) {
-        const uint64_t wid = d >> 17;
         const int b = (int)(d >> 11) & 63, idx = (int)(d >> 3) & 255, rel = (int)d & 7;
-        // nwords < 2^32 is checked on the host: 32-bit divisions
-        const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
-        const int32_t k = (int32_t)(row / (uint32_t)(g.NY - 1)), j = (int32_t)(row - (uint32_t)k * (uint32_t)(g.NY - 1));
+        const uint32_t w = (uint32_t)(d >> 17) & 0x7fffu;
+        const int32_t k = (int32_t)(d >> 48), j = (int32_t)((d >> 32) & 0xffffull);
         const int32_t i = (int32_t)w * 64 + b;
         const int32_t ka = k - (int32_t)g.pb, ja = ((int32_t)g.NY - 1 - j) - (int32_t)g.pxy; // source row of corner (dy=0, dz=0)
         const int32_t ia = i - (int32_t)g.pxy;
@@ -874,10 +876,9 @@ __global__ __launch_bounds__(256) void k_mci_faces(const uint64_t *__restrict__ 
     const uint64_t T_ = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (T_ >= ntris) return;
     const uint64_t d = list[T_];
-    const uint64_t wid = d >> 17;
     const int b = (int)(d >> 11) & 63, idx = (int)(d >> 3) & 255, rel = (int)d & 7;
-    const uint32_t row = (uint32_t)wid / (uint32_t)g.WC, w = (uint32_t)wid - row * (uint32_t)g.WC;
-    const int64_t k = row / (uint32_t)(g.NY - 1), j = row - (uint32_t)k * (uint32_t)(g.NY - 1);
+    const uint32_t w = (uint32_t)(d >> 17) & 0x7fffu;
+    const int64_t k = (int64_t)(d >> 48), j = (int64_t)((d >> 32) & 0xffffull);
     const int64_t i = (int64_t)w * 64 + b;
 #pragma unroll
     for (int v = 0; v < 3; v++) {

@@ -90,6 +90,14 @@ __host__ __device__ inline unsigned long long sk_ctl(uint32_t seq, uint32_t in_s
            ((unsigned long long)(phase & 1u) << 32) | n_in;
 }
 
+// control word of the resident launch: bits 0..31 entries of the frontier, 32 phase, 33 which list, 34..53 generations begun
+// since the level's first word (a solo stretch, below, begins several between two words), 54..63 sequence number of the word
+// (mod PSEQ_MOD).  A workgroup without a share in a round may miss that round's word altogether: it takes the newest one.
+constexpr uint32_t PSEQ_MOD = 0x3FFu, PSEQ_DONE = 0x3FFu, PGEN_MAX = 0xFFFFFu;
+__host__ __device__ inline unsigned long long sk_pctl(uint32_t seq, uint32_t gens, uint32_t in_sel, uint32_t phase, uint32_t n_in) {
+    return ((unsigned long long)(seq & 0x3FFu) << 54) | ((unsigned long long)(gens & 0xFFFFFu) << 34) |
+           ((unsigned long long)(in_sel & 1u) << 33) | ((unsigned long long)(phase & 1u) << 32) | n_in;
+}
 struct SkLists {
     uint32_t *l[2];
 };
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
         st->phase = 0; st->in_sel = 0;
         st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
         st->ctl = sk_ctl(seq, 0, 0, cnt); // the first round of this level is the host's launch number `seq`
-        st->pctl = sk_ctl(0, 0, 0, cnt);  // (the resident launch counts its rounds from 0)
+        st->pctl = sk_pctl(0, 0, 0, 0, cnt); // (the resident launch counts its rounds from 0)
     }
     if (i >= cnt) return;
     const uint32_t p = val[i];
@@ -374,24 +382,84 @@ __device__ __forceinline__ void sk_offer_plateau_wide(const WsGeom &g, unsigned 
     }
 }
 
+constexpr uint32_t SK_SOLO_MAX = 1024; // list entries up to which ONE workgroup takes the round without a hand-over
+
+// one round's share of a workgroup: list entries wg * 256 + k * nactive * 256 (the whole workgroup is here)
+template <int CONN>
+__device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
+                                               const uint32_t *__restrict__ comp, unsigned long long *tau, const SkLists &L,
+                                               const uint32_t *dlist, uint32_t ndl, SkState *st, SkStage &sg, uint32_t phase,
+                                               uint32_t in_sel, uint32_t n_front, uint32_t gen, uint32_t wg, uint32_t nactive) {
+    const uint32_t n_in = phase ? ndl : n_front;
+    const uint32_t *in = phase ? dlist : L.l[in_sel];
+    uint32_t *next = L.l[in_sel ^ 1u];
+    const uint32_t stride = nactive * 256;
+    if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t stamped = 0;
+    for (uint32_t i0 = wg * 256; i0 < n_in; i0 += stride) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool act = i < n_in;
+        const uint32_t v = act ? (phase ? in[i] : ld32(&in[i])) : 0u; // (dlist is read-only; a frontier list was written in this launch)
+        if (phase == 0) {
+            const uint32_t pm = act ? pmask[v] : 0u, zm = (ndl && act) ? zmask[v] : 0u;
+            const unsigned long long t = act ? ld64(&tau[v]) : TINF;
+            uint32_t root[27]; // the basins this voxel touches: all their roots in flight, then all their stamps
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                root[k] = ENTRY;
+                if (!has_off<CONN>(g.smask, k)) continue;
+                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                if ((zm >> k) & 1u) root[k] = comp[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)];
+            }
+            sk_offer_plateau_wide<CONN>(g, tau, pm, v, t + GEN1, sg, next, st);
+            uint32_t last = ENTRY;
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                if (!has_off<CONN>(g.smask, k)) continue;
+                if (root[k] == ENTRY || root[k] == last) continue; // (most neighbours of one voxel share a basin)
+                last = root[k];
+                stamped += atomicMin(&tau[root[k]], t) == TINF;
+            }
+        } else {
+            unsigned long long tb = TINF;
+            if (act) tb = ld64(&tau[comp[v]]);
+            act = act && (uint32_t)(tb >> 32) == gen;
+            sk_offer_plateau_wide<CONN>(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
+        }
+        stage_flush(sg, next, &st->n_next);
+    }
+    if (stamped) atomicAdd(&st->n_stamped, stamped);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0); // this wave's stores and atomics have been acknowledged
+    __syncthreads();
+}
+
+// SOLO: most rounds of a level are tiny -- on the 512^3 bench 670 of the 990 frontier rounds have at most 1 024 voxels, and
+// so have nearly all of the 780 basin relays -- and a hand-over (ticket, counters, control word, the others' poll) is four of
+// a round's ten dependent round trips.  The workgroup that closes a round therefore keeps going ALONE while the coming round
+// fits one workgroup (SK_SOLO_MAX entries): same lists, same counters, no ticket, no control word; the others keep polling
+// for the word that ends the stretch -- a larger frontier, or the end of the level -- which tells them how many generations
+// have begun meanwhile.
 template <int CONN>
 __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
                                                   const uint32_t *__restrict__ comp, unsigned long long *tau, SkLists L,
-                                                  const uint32_t *dlist, uint32_t ndl, uint32_t per_wg, SkState *st) {
+                                                  const uint32_t *dlist, uint32_t ndl, uint32_t per_wg, uint32_t solo_max, SkState *st) {
     __shared__ SkStage sg;
     __shared__ unsigned long long s_ctl;
-    __shared__ uint32_t s_last;
-    uint32_t gen = ld32(&st->gen); // (k_sk_assign's launch wrote it)
-    for (uint32_t r = 0;; r++) {
+    __shared__ uint32_t s_last, s_next[4]; // s_next: phase, list, entries, 1 = level exhausted
+    const uint32_t gen0 = ld32(&st->gen); // (k_sk_assign's launch wrote it)
+    uint32_t want = 0;                    // sequence number of the next word this workgroup has not seen
+    for (;;) {
         if (threadIdx.x == 0) {
             unsigned long long c;
             for (uint32_t spins = 0;; spins++) {
                 c = __hip_atomic_load(&st->pctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t sq = (uint32_t)(c >> 34);
-                if (sq == r || sq == SEQ_DONE) break;
+                const uint32_t sq = (uint32_t)(c >> 54);
+                if (sq == PSEQ_DONE || (sq + PSEQ_MOD - want) % PSEQ_MOD < PSEQ_MOD / 2) break; // `want`, or a later one
                 if (spins > SK_SPIN_LIMIT) {
                     st32(&st->done, 3u);
-                    c = sk_ctl(SEQ_DONE, 0, 0, 0);
+                    c = sk_pctl(PSEQ_DONE, 0, 0, 0, 0);
                     __hip_atomic_store(&st->pctl, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the others leave too)
                     break;
                 }
@@ -401,79 +469,66 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
         }
         __syncthreads();
         const unsigned long long ctl = s_ctl;
-        if ((uint32_t)(ctl >> 34) == SEQ_DONE) return;
-        const uint32_t phase = (uint32_t)(ctl >> 32) & 1u, in_sel = (uint32_t)(ctl >> 33) & 1u, n_front = (uint32_t)ctl;
-        if (r > 0 && phase == 0) gen++; // (every workgroup sees every control word: the generation is counted, not read)
+        if ((uint32_t)(ctl >> 54) == PSEQ_DONE) return;
+        const uint32_t seq = (uint32_t)(ctl >> 54);
+        want = (seq + 1u) % PSEQ_MOD;
+        uint32_t phase = (uint32_t)(ctl >> 32) & 1u, in_sel = (uint32_t)(ctl >> 33) & 1u, n_front = (uint32_t)ctl;
+        uint32_t cum = (uint32_t)(ctl >> 34) & PGEN_MAX; // generations begun since the level's first word
+        uint32_t gen = gen0 + cum;
         const uint32_t n_in = phase ? ndl : n_front;
         const uint32_t nactive = min((uint32_t)gridDim.x, (n_in + per_wg - 1u) / per_wg);
         if (blockIdx.x < nactive) {
-            const uint32_t *in = phase ? dlist : L.l[in_sel];
-            uint32_t *next = L.l[in_sel ^ 1u];
-            const uint32_t stride = nactive * 256;
-            if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
-            __syncthreads();
-            uint32_t stamped = 0;
-            for (uint32_t i0 = blockIdx.x * 256; i0 < n_in; i0 += stride) {
-                const uint32_t i = i0 + threadIdx.x;
-                bool act = i < n_in;
-                const uint32_t v = act ? (phase ? in[i] : ld32(&in[i])) : 0u; // (dlist is read-only; a frontier list was written in this launch)
-                if (phase == 0) {
-                    const uint32_t pm = act ? pmask[v] : 0u, zm = (ndl && act) ? zmask[v] : 0u;
-                    const unsigned long long t = act ? ld64(&tau[v]) : TINF;
-                    uint32_t root[27]; // the basins this voxel touches: all their roots in flight, then all their stamps
-#pragma unroll
-                    for (int k = 0; k < 27; k++) {
-                        root[k] = ENTRY;
-                        if (!has_off<CONN>(g.smask, k)) continue;
-                        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-                        if ((zm >> k) & 1u) root[k] = comp[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)];
-                    }
-                    sk_offer_plateau_wide<CONN>(g, tau, pm, v, t + GEN1, sg, next, st);
-                    uint32_t last = ENTRY;
-#pragma unroll
-                    for (int k = 0; k < 27; k++) {
-                        if (!has_off<CONN>(g.smask, k)) continue;
-                        if (root[k] == ENTRY || root[k] == last) continue; // (most neighbours of one voxel share a basin)
-                        last = root[k];
-                        stamped += atomicMin(&tau[root[k]], t) == TINF;
-                    }
-                } else {
-                    unsigned long long tb = TINF;
-                    if (act) tb = ld64(&tau[comp[v]]);
-                    act = act && (uint32_t)(tb >> 32) == gen;
-                    sk_offer_plateau_wide<CONN>(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
-                }
-                stage_flush(sg, next, &st->n_next);
-            }
-            if (stamped) atomicAdd(&st->n_stamped, stamped);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0); // this wave's stores and atomics have been acknowledged
-            __syncthreads();
+            sk_level_round<CONN>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, blockIdx.x, nactive);
             if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1u) == nactive - 1;
             __syncthreads();
-            if (s_last && threadIdx.x == 0) {
-                const uint32_t nst = ld32(&st->n_stamped), nnx = ld32(&st->n_next);
-                st32(&st->ticket, 0u);
-                atomicAdd(&st->rounds, 1u);
-                unsigned long long nctl;
-                if (phase == 0 && nst) {
-                    st32(&st->n_stamped, 0u);
-                    atomicAdd(&st->brounds, 1u);
-                    nctl = sk_ctl(r + 1u, in_sel, 1, n_front);
-                } else if (nnx) {
-                    st32(&st->n_next, 0u);
-                    st32(&st->n_stamped, 0u);
-                    atomicAdd(&st->gens, 1u);
-                    nctl = sk_ctl(r + 1u, in_sel ^ 1u, 0, nnx);
-                } else {
-                    st32(&st->gen, gen); // the last generation used (what the host reads); the next level starts one later
-                    st32(&st->gnext, gen + 1u);
-                    st32(&st->n_stamped, 0u);
-                    st32(&st->done, 1u);
-                    nctl = sk_ctl(SEQ_DONE, 0, 0, 0);
+            if (s_last) { // (the whole workgroup)
+                if (threadIdx.x == 0) st32(&st->ticket, 0u);
+                for (;;) {
+                    if (threadIdx.x == 0) {
+                        const uint32_t nst = ld32(&st->n_stamped), nnx = ld32(&st->n_next);
+                        atomicAdd(&st->rounds, 1u);
+                        st32(&st->n_stamped, 0u);
+                        if (phase == 0 && nst) { // basins were stamped: they relay before the generation advances
+                            atomicAdd(&st->brounds, 1u);
+                            s_next[0] = 1u; s_next[1] = in_sel; s_next[2] = n_front; s_next[3] = 0u;
+                        } else if (nnx) { // next generation
+                            st32(&st->n_next, 0u);
+                            atomicAdd(&st->gens, 1u);
+                            s_next[0] = 0u; s_next[1] = in_sel ^ 1u; s_next[2] = nnx; s_next[3] = 0u;
+                        } else {
+                            s_next[3] = 1u;
+                        }
+                        __builtin_amdgcn_s_waitcnt(0);
+                    }
+                    __syncthreads();
+                    if (s_next[3]) break;
+                    const uint32_t nph = s_next[0], nsel = s_next[1], nfr = s_next[2];
+                    __syncthreads(); // (s_next is rewritten after the next round)
+                    const bool solo = (nph ? ndl : nfr) <= solo_max;
+                    phase = nph; in_sel = nsel; n_front = nfr;
+                    if (phase == 0) {
+                        gen++;
+                        cum++;
+                    }
+                    if (!solo) break;
+                    sk_level_round<CONN>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, 0u, 1u);
                 }
-                __builtin_amdgcn_s_waitcnt(0);
-                __hip_atomic_store(&st->pctl, nctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) {
+                    unsigned long long nctl;
+                    if (s_next[3]) {
+                        st32(&st->gen, gen); // the last generation used (what the host reads); the next level starts one later
+                        st32(&st->gnext, gen + 1u);
+                        st32(&st->done, 1u);
+                        nctl = sk_pctl(PSEQ_DONE, 0, 0, 0, 0);
+                    } else if (cum > PGEN_MAX) { // (more generations in one level than the word can count: give up cleanly)
+                        st32(&st->done, 3u);
+                        nctl = sk_pctl(PSEQ_DONE, 0, 0, 0, 0);
+                    } else {
+                        nctl = sk_pctl(want, cum, in_sel, phase, n_front);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __hip_atomic_store(&st->pctl, nctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __syncthreads(); // (s_ctl is rewritten by the next poll)
@@ -958,6 +1013,8 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const bool trace = getenv("IVX_WS_TRACE") != nullptr;
     const char *epb = getenv("IVX_SK_PER_WG"); // list entries per working workgroup (A/B measurements)
     const uint32_t per_wg = epb && atoi(epb) >= 256 ? (uint32_t)atoi(epb) : 1024u;
+    const char *eso = getenv("IVX_SK_SOLO"); // most list entries one workgroup takes alone inside a resident launch (0: never; A/B)
+    const uint32_t solo_max = eso ? (uint32_t)atoi(eso) : SK_SOLO_MAX;
     const char *erc = getenv("IVX_SK_RES_PER_CU");
     const int64_t res_per_cu = erc && atoi(erc) >= 1 && atoi(erc) <= 4 ? atoi(erc) : 1;
     uint32_t start = 0, dstart = 0, roff = 0, gbase = 1, seq = 0;
@@ -1094,7 +1151,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             // resident -- 256 threads, 30 registers and 16 KB of LDS each leave room for eight)
             const unsigned nres = (unsigned)std::min<int64_t>(std::max<int64_t>(cdiv(2 * (int64_t)std::max(cnt, ndl), per_wg), 8), res_per_cu * std::max(ncu, 8));
             WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_level<CC>, dim3(nres), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists,
-                                                      b.dlist + dstart, ndl, per_wg, b.st));
+                                                      b.dlist + dstart, ndl, per_wg, solo_max, b.st));
             IVX_LAUNCH_CHECK();
             gknown = false;
             if (trace) {

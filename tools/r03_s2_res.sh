@@ -8,5 +8,5 @@ if [ "$2" != "notest" ]; then
 timeout -k 5 600 python -m pytest tests/test_gpu_flood.py tests/test_gpu_fused.py -m gpu -x -q -W ignore < /dev/null > $O/tests.txt 2>&1
 tail -4 $O/tests.txt
 fi
-bash tools/r03_s2_env.sh - IVX_FLOOD_RESIDENT=1,IVX_FLOOD_RES_PER_CU=1
+bash tools/r03_s2_env.sh IVX_FLOOD_APPLY_RIDE=0 - IVX_FLOOD_BATCH=1 IVX_FLOOD_BATCH=2
 IVX_FLOOD_TRACE=1 timeout -k 5 120 python bench.py --no-cpu --steps 2 --warmup 1 < /dev/null 2>&1 | grep "resident launch" | tail -2
