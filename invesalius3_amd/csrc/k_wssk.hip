@@ -46,7 +46,8 @@
 #include <cstddef>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ivx_internal.h"
 #include "scan_u32.h"
@@ -441,6 +442,11 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
 // fits one workgroup (SK_SOLO_MAX entries): same lists, same counters, no ticket, no control word; the others keep polling
 // for the word that ends the stretch -- a larger frontier, or the end of the level -- which tells them how many generations
 // have begun meanwhile.
+// Measured on the 512^3 bench: 64.8 -> 64.6 ms, i.e. nothing; neither did keeping the stretch's lists and counters in LDS (a
+// wave's staged pushes as its share of the next frontier, the stamped-basins count an LDS word: 64.0 -> 63.3 ms, dropped).
+// A round's time is its chain of dependent DRAM-latency accesses (~1.5 us each, agent-scope or not: pmask / zmask / comp are
+// random reads of 0.5 GB arrays) -- voxel -> masks and stamp -> basin roots -> atomics, twice per generation with the relay
+// -- and 1 742 generations times that chain is the level chain's floor; who runs the round hardly matters.
 template <int CONN>
 __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
                                                   const uint32_t *__restrict__ comp, unsigned long long *tau, SkLists L,
@@ -998,8 +1004,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     }
     IVX_REQUIRE(ngen0 < 0xFFFFFFF0ull, IVX_EINVAL, "watershed: more than 2^32 queue entries");
     size_t cub_bytes = 0;
-    IVX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                               (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)maxcnt, 0, 64, st));
+    // (rocPRIM, ROCm's own primitives library, called directly: the sizing call of its radix sort)
+    IVX_HIP(rocprim::radix_sort_pairs(nullptr, cub_bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                      (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)maxcnt, 0u, 64u, st));
     {
         void *mem2 = nullptr;
         const size_t need = sk_layout2(ngen0, maxcnt, cub_bytes, nullptr, &b);
@@ -1108,7 +1115,8 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             const uint64_t gtop = gknown ? (uint64_t)gbase : std::min<uint64_t>(gbound, 0x7FFFFFF0u);
             while (end_bit < 64 && (gtop >> (end_bit - 32))) end_bit++;
             size_t tb = cub_bytes + 256;
-            IVX_HIP(hipcub::DeviceRadixSort::SortPairs(b.cub, tb, b.key_a, b.key_b, b.val_a, b.val_b, (size_t)cnt, 0, end_bit, st));
+            IVX_HIP(rocprim::radix_sort_pairs(b.cub, tb, (const unsigned long long *)b.key_a, b.key_b, (const uint32_t *)b.val_a, b.val_b,
+                                              (size_t)cnt, 0u, (unsigned int)end_bit, st));
             ks = b.key_b;
             vs = b.val_b;
         }
