@@ -784,27 +784,33 @@ __device__ __forceinline__ Cross crossings(const uint64_t *__restrict__ S, const
     return c;
 }
 
+// The crossing words of every point word are derived ONCE (k_mci_count) and kept as 32-byte records: the vertex pass reads
+// its word's record, and a face corner is two gathers (record + vertex base) instead of six padded row pairs of the two
+// planes (a dozen loads and the masking around them) per corner -- three corners per triangle, 394 M triangles at 2048^3.
+struct __attribute__((aligned(32))) CrossRec {
+    uint64_t cx, cy, cz, cp;
+};
 __global__ __launch_bounds__(256) void k_mci_count(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb,
                                                    Geom g, int64_t npw, uint64_t pbits, uint64_t qbits,
-                                                   uint32_t *__restrict__ vcnt) {
+                                                   uint32_t *__restrict__ vcnt, CrossRec *__restrict__ rec) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npw; i += stride) {
         const int64_t w = i % g.WX, r = i / g.WX, jf = r % g.NY, k = r / g.NY;
         const Cross c = crossings<true>(bits, qb, g, k, jf, w, pbits, qbits);
         vcnt[i] = (uint32_t)(__popcll(c.cx) + __popcll(c.cy) + __popcll(c.cz) + __popcll(c.cp));
+        rec[i] = CrossRec{c.cx, c.cy, c.cz, c.cp};
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_mci_vertices(const T *__restrict__ a, const uint64_t *__restrict__ bits,
-                                                      const uint64_t *__restrict__ qb, Geom g, int64_t npw, uint64_t pbits,
-                                                      uint64_t qbits, double iso, const uint32_t *__restrict__ vbase,
+__global__ __launch_bounds__(256) void k_mci_vertices(const T *__restrict__ a, const CrossRec *__restrict__ rec, Geom g,
+                                                      int64_t npw, double iso, const uint32_t *__restrict__ vbase,
                                                       uint32_t id0, float *__restrict__ verts, uint64_t max_verts) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t pw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pw < npw; pw += stride) {
-        const int64_t w = pw % g.WX, r = pw / g.WX, jf = r % g.NY, k = r / g.NY;
-        const Cross c = crossings<true>(bits, qb, g, k, jf, w, pbits, qbits);
+        const CrossRec c = rec[pw];
         if (!(c.cx | c.cy | c.cz | c.cp)) continue;
+        const int64_t w = pw % g.WX, r = pw / g.WX, jf = r % g.NY, k = r / g.NY;
         uint64_t id = (uint64_t)id0 + vbase[pw];
 #pragma unroll
         for (int ax = 0; ax < 4; ax++) {
@@ -834,38 +840,39 @@ __global__ __launch_bounds__(256) void k_mci_vertices(const T *__restrict__ a, c
     }
 }
 
-// id of the vertex on the edge leaving point (i, jf, k) along axis ax
-__device__ __forceinline__ uint32_t vertex_id(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb,
-                                              const Geom &g, uint64_t pbits, uint64_t qbits,
-                                              const uint32_t *__restrict__ vbase, int64_t k, int64_t jf, int64_t i, int ax) {
+// id of the vertex on the edge leaving point (i, jf, k) along axis ax -- a crossing edge of a triangle, so exactly one of
+// three holds: the edge's bit is set in its point word's c{x,y,z} (a regular crossing: rank among the word's crossings);
+// or the point's bit is set in cp (the point's value IS the iso-value: the vertex is that point's, cp = e0 & "some crossing
+// leaves or reaches the point", and this very edge is such a crossing); or the far end point is the one on the iso-value.
+__device__ __forceinline__ uint32_t vertex_id(const CrossRec *__restrict__ rec, const Geom &g, const uint32_t *__restrict__ vbase,
+                                              int64_t k, int64_t jf, int64_t i, int ax) {
     int64_t w = i >> 6;
     int b = (int)(i & 63);
-    const Cross c = crossings<false>(bits, qb, g, k, jf, w, pbits, qbits);
-    const bool elo = (c.e0 >> b) & 1ull;
-    const bool ehi = ((ax == 0 ? c.ex : (ax == 1 ? c.ey : c.ez)) >> b) & 1ull;
-    if (!(elo | ehi)) {
-        const uint64_t below = (1ull << b) - 1ull;
+    int64_t pw = (k * g.NY + jf) * g.WX + w;
+    CrossRec c = rec[pw];
+    const uint64_t below = (1ull << b) - 1ull;
+    if (((ax == 0 ? c.cx : (ax == 1 ? c.cy : c.cz)) >> b) & 1ull) {
         uint32_t rank;
         if (ax == 0) rank = (uint32_t)__popcll(c.cx & below);
         else if (ax == 1) rank = (uint32_t)(__popcll(c.cx) + __popcll(c.cy & below));
         else rank = (uint32_t)(__popcll(c.cx) + __popcll(c.cy) + __popcll(c.cz & below));
-        return vbase[(k * g.NY + jf) * g.WX + w] + rank;
+        return vbase[pw] + rank;
     }
     // the vertex sits on a grid point: it is that point's vertex
-    if (!elo) {
+    if (!((c.cp >> b) & 1ull)) {
         if (ax == 0) i++;
         else if (ax == 1) jf++;
         else k++;
         w = i >> 6;
         b = (int)(i & 63);
+        pw = (k * g.NY + jf) * g.WX + w;
+        c = rec[pw];
     }
-    const Cross t = crossings<true>(bits, qb, g, k, jf, w, pbits, qbits);
-    const uint32_t rank = (uint32_t)(__popcll(t.cx) + __popcll(t.cy) + __popcll(t.cz) + __popcll(t.cp & ((1ull << b) - 1ull)));
-    return vbase[(k * g.NY + jf) * g.WX + w] + rank;
+    const uint32_t rank = (uint32_t)(__popcll(c.cx) + __popcll(c.cy) + __popcll(c.cz) + __popcll(c.cp & ((1ull << b) - 1ull)));
+    return vbase[pw] + rank;
 }
 
-__global__ __launch_bounds__(256) void k_mci_faces(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ qb,
-                                                   Geom g, uint64_t pbits, uint64_t qbits,
+__global__ __launch_bounds__(256) void k_mci_faces(const CrossRec *__restrict__ rec, Geom g,
                                                    const uint32_t *__restrict__ vbase, uint32_t id0,
                                                    const uint64_t *__restrict__ list, uint64_t ntris,
                                                    int32_t *__restrict__ faces) {
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(256) void k_mci_faces(const uint64_t *__restrict__ 
         const int e = s_tri[idx * 16 + 3 * rel + v];
         int ax, bx, by, bz;
         edge_decode(e, ax, bx, by, bz);
-        faces[T_ * 3 + v] = (int32_t)(id0 + vertex_id(bits, qb, g, pbits, qbits, vbase, k + bz, j + by, i + bx, ax));
+        faces[T_ * 3 + v] = (int32_t)(id0 + vertex_id(rec, g, vbase, k + bz, j + by, i + bx, ax));
     }
 }
 
@@ -1030,10 +1037,11 @@ __global__ __launch_bounds__(256) void k_mci_stitch_verts(const float *__restric
     }
 }
 
-// per-stream workspace WS_MCV: strict[niso][bits_words] u64 | per iso: vbase[npw] u32, bsum[nsb], total[16]
+// per-stream workspace WS_MCV: strict[niso][bits_words] u64 | per iso: vbase[npw] u32, bsum[nsb], total[16] | per iso:
+// crossing records[npw] (32 B each)
 struct MciLayout {
     int64_t npw, nsb;
-    size_t off_v, per_iso, total;
+    size_t off_v, per_iso, off_rec, per_iso_rec, total;
 };
 static MciLayout mci_layout(const Geom &g, const Scratch &s, int niso) {
     MciLayout m;
@@ -1041,7 +1049,9 @@ static MciLayout mci_layout(const Geom &g, const Scratch &s, int niso) {
     m.nsb = ivx::cdiv(m.npw, 256 * 16);
     m.off_v = al256((size_t)niso * s.bits_words * 8 + 16);
     m.per_iso = al256(((size_t)m.npw + (size_t)m.nsb + 16) * 4);
-    m.total = m.off_v + (size_t)niso * m.per_iso;
+    m.off_rec = m.off_v + (size_t)niso * m.per_iso;
+    m.per_iso_rec = al256((size_t)m.npw * sizeof(CrossRec));
+    m.total = m.off_rec + (size_t)niso * m.per_iso_rec;
     return m;
 }
 static inline uint64_t pad_qbits(const ivx_mc_params *p, int q) { return p->pad_value > p->iso[q] ? ~0ull : 0ull; }
@@ -1281,7 +1291,7 @@ extern "C" int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, c
         const uint64_t *qb = (const uint64_t *)d_v + (size_t)q * s.bits_words;
         const int64_t blocks = ivx::cdiv(m.npw, 256);
         hipLaunchKernelGGL(k_mci_count, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, bits, qb, g,
-                           m.npw, pad_bits(p, q), pad_qbits(p, q), vbase);
+                           m.npw, pad_bits(p, q), pad_qbits(p, q), vbase, (CrossRec *)((char *)d_v + m.off_rec + (size_t)q * m.per_iso_rec));
         IVX_LAUNCH_CHECK();
         if ((rc = scan_u32_exclusive(vbase, m.npw, bsum, d_total, st))) return rc;
         uint32_t seq;
@@ -1332,15 +1342,14 @@ static int run_indexed(const ivx_mc_params *p, const Geom &g, const Scratch &s, 
             IVX_LAUNCH_CHECK();
         }
         const int64_t blocks = ivx::cdiv(m.npw, 256);
+        const CrossRec *rec = (const CrossRec *)((const char *)d_v + m.off_rec + (size_t)q * m.per_iso_rec);
         hipLaunchKernelGGL((k_mci_vertices<T>), dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st,
-                           (const T *)a, bits, qb, g, m.npw, pad_bits(p, q), pad_qbits(p, q), p->iso[q], vbase, id0, verts,
-                           (uint64_t)max_verts);
+                           (const T *)a, rec, g, m.npw, p->iso[q], vbase, id0, verts, (uint64_t)max_verts);
         IVX_LAUNCH_CHECK();
         const uint64_t first = tb[q], last = tb[q + 1] < (uint64_t)max_tris ? tb[q + 1] : (uint64_t)max_tris;
         if (last > first) {
-            hipLaunchKernelGGL(k_mci_faces, dim3((unsigned)ivx::cdiv((int64_t)(last - first), 256)), dim3(256), 0, st, bits, qb,
-                               g, pad_bits(p, q), pad_qbits(p, q), vbase, id0, (const uint64_t *)d_list + first, last - first,
-                               faces + first * 3);
+            hipLaunchKernelGGL(k_mci_faces, dim3((unsigned)ivx::cdiv((int64_t)(last - first), 256)), dim3(256), 0, st, rec, g, vbase,
+                               id0, (const uint64_t *)d_list + first, last - first, faces + first * 3);
             IVX_LAUNCH_CHECK();
         }
     }
