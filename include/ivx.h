@@ -240,6 +240,14 @@ int ivx_dev_mc_stitch_apply(const ivx_mc_params *p, const void *scratch, const v
 int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, const void *scratch, int64_t *nverts, void *stream);
 int ivx_dev_mc_indexed_emit(const ivx_mc_params *p, const void *a, const void *scratch, float *verts, int64_t max_verts,
                             int32_t *faces, int64_t max_tris, void *stream);
+/* The two calls above for a uint8 mask whose bytes are KNOWN -- `v_out` outside the inside plane handed to
+ * ivx_dev_mc_count_bits (and as padding), `v_sel` where `sel_bits` has a bit, `v_in` elsewhere inside; v_out < iso < v_in,
+ * v_sel -- as a resident pipeline knows them after its threshold and region growing (see ivx_dev_mc_emit_levels): neither
+ * the strictly-inside plane nor a vertex reads a voxel.  Same vertices and faces, bit for bit. */
+int ivx_dev_mc_indexed_count_levels(const ivx_mc_params *p, const void *scratch, int64_t *nverts, void *stream);
+int ivx_dev_mc_indexed_emit_levels(const ivx_mc_params *p, const void *scratch, const uint64_t *sel_bits, double v_out,
+                                   double v_in, double v_sel, float *verts, int64_t max_verts, int32_t *faces,
+                                   int64_t max_tris, void *stream);
 int ivx_marching_cubes_indexed(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *verts,
                                int64_t max_verts, int32_t *faces, int64_t max_tris, int64_t *nverts, int64_t *ntris);
 

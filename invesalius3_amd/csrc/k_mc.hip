@@ -840,6 +840,53 @@ __global__ __launch_bounds__(256) void k_mci_vertices(const T *__restrict__ a, c
     }
 }
 
+// k_mci_vertices for a uint8 mask whose bytes are KNOWN (McLevels: v_out outside the inside plane -- the padding too --,
+// v_sel where `sel` has a bit, v_in elsewhere inside): no voxel is read.  Which end of a crossing edge is inside is the
+// point's bit of the padded inside row, the interpolation factor one of four constants, and no point sits on the iso-value
+// (no point vertices: cp is empty).  Same vertices, same order, same bits as k_mci_vertices on that mask.
+__global__ __launch_bounds__(256) void k_mci_vertices_levels(const uint64_t *__restrict__ bits, const CrossRec *__restrict__ rec,
+                                                             Geom g, int64_t npw, uint64_t pbits, McLevels lv,
+                                                             const uint32_t *__restrict__ vbase, uint32_t id0,
+                                                             float *__restrict__ verts, uint64_t max_verts) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t pw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pw < npw; pw += stride) {
+        const CrossRec c = rec[pw];
+        if (!(c.cx | c.cy | c.cz)) continue;
+        const int64_t w = pw % g.WX, r = pw / g.WX, jf = r % g.NY, k = r / g.NY;
+        uint64_t p0, p0n;
+        padded_pair(bits, g, k, jf, w, pbits, p0, p0n);
+        uint64_t id = (uint64_t)id0 + vbase[pw];
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            uint64_t m = ax == 0 ? c.cx : (ax == 1 ? c.cy : c.cz);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int64_t i = w * 64 + b;
+                const bool in0 = (p0 >> b) & 1ull;
+                int sel = 0;
+                if (lv.sel) { // the inside end is a source voxel: its bit of the selection plane
+                    const int64_t ii = i + (!in0 && ax == 0), jj = jf + (!in0 && ax == 1), kk = k + (!in0 && ax == 2);
+                    const int64_t sk = kk - g.pb, sj = (g.NY - 1 - jj) - g.pxy, si = ii - g.pxy;
+                    sel = (int)((lv.sel[(sk * g.ny + sj) * g.ws + (si >> 6)] >> (si & 63)) & 1ull);
+                }
+                const double tt = lv.tt[(in0 ? 2 : 0) + sel];
+                double q0 = (double)(i - g.pxy), q1 = (double)(jf - g.yoff), q2 = (double)(k + g.zoff);
+                if (ax == 0) q0 += tt;
+                else if (ax == 1) q1 += tt;
+                else q2 += tt;
+                if (id < max_verts) {
+                    float *o = verts + id * 3;
+                    o[0] = (float)(g.sx * q0);
+                    o[1] = (float)(g.sy * q1);
+                    o[2] = (float)(g.sz * q2);
+                }
+                id++;
+            }
+        }
+    }
+}
+
 // id of the vertex on the edge leaving point (i, jf, k) along axis ax -- a crossing edge of a triangle, so exactly one of
 // three holds: the edge's bit is set in its point word's c{x,y,z} (a regular crossing: rank among the word's crossings);
 // or the point's bit is set in cp (the point's value IS the iso-value: the vertex is that point's, cp = e0 & "some crossing
@@ -1263,8 +1310,21 @@ extern "C" int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const i
 }
 
 // ---- indexed mesh API: must follow ivx_dev_mc_count on the same params / scratch / stream --------------------------
+static int mc_indexed_count_impl(const ivx_mc_params *p, const void *a, const void *scratch_, int64_t *nverts, void *stream,
+                                 bool levels);
 extern "C" int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, const void *scratch_, int64_t *nverts,
                                         void *stream) {
+    return mc_indexed_count_impl(p, a, scratch_, nverts, stream, false);
+}
+// ivx_dev_mc_indexed_count for a mask whose bytes are known to lie strictly on either side of the iso-value (the levels of
+// ivx_dev_mc_emit_levels; follows ivx_dev_mc_count_bits): "value > iso" IS the inside plane, so the pass over the mask that
+// derives the strictly-inside plane is a copy of 1/8 byte per voxel instead of a read of the volume.
+extern "C" int ivx_dev_mc_indexed_count_levels(const ivx_mc_params *p, const void *scratch_, int64_t *nverts, void *stream) {
+    IVX_REQUIRE(p && p->dtype == IVX_U8 && p->niso == 1, IVX_EINVAL, "mc_indexed_count_levels: uint8 mask, one iso-value");
+    return mc_indexed_count_impl(p, nullptr, scratch_, nverts, stream, true);
+}
+static int mc_indexed_count_impl(const ivx_mc_params *p, const void *a, const void *scratch_, int64_t *nverts, void *stream,
+                                 bool levels) {
     Geom g;
     int rc = make_geom(p, &g);
     if (rc) return rc;
@@ -1277,12 +1337,17 @@ extern "C" int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, c
     if ((rc = ivx::ws_get_s(ivx::WS_MCV, st, m.total, &d_v))) return rc;
     // strictly-inside planes: value > iso  <=>  value >= nextafter(iso, +inf)
     const double n0 = std::nextafter(p->iso[0], HUGE_VAL), n1 = std::nextafter(p->iso[1], HUGE_VAL);
-    switch (p->dtype) {
-    case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
-    case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
-    default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
+    if (levels) {
+        IVX_REQUIRE(p->pad_value < p->iso[0], IVX_EINVAL, "mc_indexed_count_levels: the padding must lie below the iso-value");
+        IVX_HIP(hipMemcpyAsync(d_v, mc_bits_ptr(scratch_, s, 0), s.bits_words * 8, hipMemcpyDeviceToDevice, st));
+    } else {
+        switch (p->dtype) {
+        case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
+        case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
+        default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)d_v, n0, n1, st); break;
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
     uint32_t tot[2] = {0, 0};
     for (int q = 0; q < p->niso; q++) {
         uint32_t *vbase = (uint32_t *)((char *)d_v + m.off_v + (size_t)q * m.per_iso);
@@ -1308,7 +1373,8 @@ extern "C" int ivx_dev_mc_indexed_count(const ivx_mc_params *p, const void *a, c
 
 template <typename T>
 static int run_indexed(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, const char *scratch,
-                       float *verts, int64_t max_verts, int32_t *faces, int64_t max_tris, hipStream_t st) {
+                       float *verts, int64_t max_verts, int32_t *faces, int64_t max_tris, hipStream_t st,
+                       const McLevels *lv = nullptr) {
     IVX_REQUIRE(s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for 32-bit cell-word ids");
     const MciLayout m = mci_layout(g, s, p->niso);
     void *d_v, *d_list;
@@ -1343,8 +1409,12 @@ static int run_indexed(const ivx_mc_params *p, const Geom &g, const Scratch &s, 
         }
         const int64_t blocks = ivx::cdiv(m.npw, 256);
         const CrossRec *rec = (const CrossRec *)((const char *)d_v + m.off_rec + (size_t)q * m.per_iso_rec);
-        hipLaunchKernelGGL((k_mci_vertices<T>), dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st,
-                           (const T *)a, rec, g, m.npw, p->iso[q], vbase, id0, verts, (uint64_t)max_verts);
+        if (lv)
+            hipLaunchKernelGGL(k_mci_vertices_levels, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, bits, rec,
+                               g, m.npw, pad_bits(p, q), *lv, vbase, id0, verts, (uint64_t)max_verts);
+        else
+            hipLaunchKernelGGL((k_mci_vertices<T>), dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st,
+                               (const T *)a, rec, g, m.npw, p->iso[q], vbase, id0, verts, (uint64_t)max_verts);
         IVX_LAUNCH_CHECK();
         const uint64_t first = tb[q], last = tb[q + 1] < (uint64_t)max_tris ? tb[q + 1] : (uint64_t)max_tris;
         if (last > first) {
@@ -1370,6 +1440,24 @@ extern "C" int ivx_dev_mc_indexed_emit(const ivx_mc_params *p, const void *a, co
     case IVX_I16: return run_indexed<int16_t>(p, g, s, a, (const char *)scratch, verts, max_verts, faces, max_tris, st);
     default: return run_indexed<uint16_t>(p, g, s, a, (const char *)scratch, verts, max_verts, faces, max_tris, st);
     }
+}
+
+// ivx_dev_mc_indexed_emit after ivx_dev_mc_indexed_count_levels: the vertices from the mask's known byte levels (see
+// ivx_dev_mc_emit_levels), no voxel is read; same vertices and faces, bit for bit, as the voxel path gives on that mask.
+extern "C" int ivx_dev_mc_indexed_emit_levels(const ivx_mc_params *p, const void *scratch, const uint64_t *sel_bits, double v_out,
+                                              double v_in, double v_sel, float *verts, int64_t max_verts, int32_t *faces,
+                                              int64_t max_tris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    IVX_REQUIRE(p->dtype == IVX_U8 && p->niso == 1, IVX_EINVAL, "mc_indexed_emit_levels: uint8 mask, one iso-value");
+    IVX_REQUIRE(v_out < p->iso[0] && v_in > p->iso[0] && v_sel > p->iso[0] && p->pad_value == v_out, IVX_EINVAL,
+                "mc_indexed_emit_levels: v_out (= the padding) must lie below the iso-value, v_in and v_sel above it");
+    const Scratch s = make_scratch(g, p->niso);
+    if (s.nwords == 0 || max_tris <= 0) return IVX_OK;
+    IVX_REQUIRE(max_verts < 0x7fffffffll, IVX_EINVAL, "mc: more than 2^31 vertices do not fit int32 face indices");
+    const McLevels lv = make_levels(sel_bits, p->iso[0], v_out, v_in, v_sel);
+    return run_indexed<uint8_t>(p, g, s, nullptr, (const char *)scratch, verts, max_verts, faces, max_tris, ivx::S(stream), &lv);
 }
 
 // ---- cross-slab stitch API: follows ivx_dev_mc_indexed_emit on the same params / scratch / stream (one iso-value) ------

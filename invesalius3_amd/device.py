@@ -663,9 +663,18 @@ class DeviceVolume:
                         "mc_count")
             else:
                 L.check(lib.ivx_dev_mc_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nt), self.stream), "mc_count")
+        # the mask's bytes known through the pipeline's planes (see _emit): neither the strictly-inside plane nor a vertex
+        # needs a voxel
+        lv = self._mask_levels
+        levels = (plane is not None and lv is not None and self._fuse and os.environ.get("IVX_MC_LEVELS", "1") != "0"
+                  and float(p.pad_value) == 0.0 and lv[0] > 127 and (lv[1] is None or lv[1] > 127))
         with self.timer.span("mci_count"):
-            L.check(lib.ivx_dev_mc_indexed_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nv), self.stream),
-                    "mc_indexed_count")
+            if levels:
+                L.check(lib.ivx_dev_mc_indexed_count_levels(ctypes.byref(p), self._mc_scratch.ptr, ctypes.byref(nv), self.stream),
+                        "mc_indexed_count")
+            else:
+                L.check(lib.ivx_dev_mc_indexed_count(ctypes.byref(p), src, self._mc_scratch.ptr, ctypes.byref(nv), self.stream),
+                        "mc_indexed_count")
         for name, need in (("_verts", nv.value * 12), ("_faces", nt.value * 12)):
             buf = getattr(self, name)
             if buf is None or buf.nbytes < need:
@@ -673,8 +682,18 @@ class DeviceVolume:
                     buf.close()
                 setattr(self, name, DeviceBuffer(int(need * 1.25) + 4096))
         with self.timer.span("mci_emit"):
-            L.check(lib.ivx_dev_mc_indexed_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._verts.ptr, c64(nv.value),
-                                                self._faces.ptr, c64(nt.value), self.stream), "mc_indexed_emit")
+            if levels:
+                if lv[1] is None:
+                    sel, v_sel = None, float(lv[0])
+                else:
+                    sel, v_sel = self.reached.at(z0 * self.dy * ((self.dx + 63) // 64) * 8), float(lv[1])
+                L.check(lib.ivx_dev_mc_indexed_emit_levels(ctypes.byref(p), self._mc_scratch.ptr, sel, ctypes.c_double(0.0),
+                                                           ctypes.c_double(float(lv[0])), ctypes.c_double(v_sel), self._verts.ptr,
+                                                           c64(nv.value), self._faces.ptr, c64(nt.value), self.stream),
+                        "mc_indexed_emit")
+            else:
+                L.check(lib.ivx_dev_mc_indexed_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._verts.ptr, c64(nv.value),
+                                                    self._faces.ptr, c64(nt.value), self.stream), "mc_indexed_emit")
         if download:
             self.sync()
             return self._verts.download((nv.value, 3), np.float32), self._faces.download((nt.value, 3), np.int32)

@@ -221,3 +221,27 @@ def test_surface_prefetch_gives_the_same_surface_and_is_voided_by_plane_changes(
         assert vol._prefetch is None
         n_ref = vol.marching_cubes(from_binary=True)
         assert n_ref > 0
+
+
+@pytest.mark.parametrize("select", [254, None])
+def test_indexed_mesh_from_known_mask_levels_equals_the_voxel_path(ivxlib, oracle, monkeypatch, select):
+    """ivx_dev_mc_indexed_count_levels / _emit_levels (no voxel read: strictly-inside plane = inside plane, interpolation
+    factors = four constants) give the vertices and faces of the voxel path bit for bit, and verts[faces] is the soup"""
+    from invesalius3_amd.device import DeviceVolume
+    img = synth_volume((24, 40, 128), seed=43)
+    lo, hi = 150, 3071
+    z, y, x = (int(v[0]) for v in np.nonzero((img >= lo) & (img <= hi)))
+    vol = DeviceVolume(img, spacing=(0.5, 0.5, 1.0))
+    vol.zero_out_mask()
+    vol.threshold(lo, hi)
+    if select is not None:
+        vol.region_grow([(x, y, z)], lo, hi, S26, fill=1, select_value=select)
+    assert vol._mask_levels is not None
+    v1, f1 = vol.marching_cubes_indexed(download=True)          # levels path
+    monkeypatch.setenv("IVX_MC_LEVELS", "0")
+    v0, f0 = vol.marching_cubes_indexed(download=True)          # voxel path
+    assert v1.shape == v0.shape and f1.shape == f0.shape and len(f1) > 0
+    assert np.array_equal(v1.view(np.uint32), v0.view(np.uint32)) and np.array_equal(f1, f0)
+    mask0, _ = _oracle_step(oracle, img, lo, hi, (x, y, z), lo, hi, select)
+    assert np.array_equal(v1[f1], _soup(oracle, mask0, (0.5, 0.5, 1.0)))
+    vol.close()
