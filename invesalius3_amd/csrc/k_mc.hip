@@ -372,6 +372,8 @@ __global__ __launch_bounds__(256) void k_mc_count(const uint64_t *__restrict__ b
 }
 
 // ---- 3. scan of workgroup sums (single workgroup of 1024) ---------------------------------------------
+// (Tried in round 3: the scan in k_mc_count's tail, done by the last workgroup to sign a ticket -- one launch less, but the
+// 9 259 same-address agent-scope atomics of the ticket serialise at ~8 ns each: mc_count 44 -> 124 us.  Dropped.)
 __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ bsum, size_t n,
                                                   uint64_t *__restrict__ boff) {
     __shared__ uint64_t s_wave[16];
