@@ -53,6 +53,10 @@ constexpr int SUB = 1;                // gather/update steps per termination vot
 // neighbour finds it "already marked": closed tiles cost no visits -- about a third of the second round's list on the bench
 // volume); ENLISTED (coarse pass) further down
 constexpr unsigned int CLOSED = 0x40u;
+// (Tried in round 3: the round's list as 8 sublists with a counter each on its own 128-byte line.  ~10^3 appends that arrive
+// together serialise on one counter at 5 - 10 ns each -- tools/micro/atomic_tail.hip: 1 024 workgroups x 1 append cost 5.5 us
+// more than none, x 4 appends 40 us more, spread over 8 counters 0.3 / 1.3 us -- but the rounds' appends do not arrive
+// together: region growing 0.192 -> 0.195 ms, the IFT cost levels 13.8 -> 14.3 ms.  Dropped.)
 
 struct Tiles {
     int64_t dz, dy, dx, wx;
