@@ -495,3 +495,39 @@ def test_seed_on_a_tile_face_reaches_the_next_tile(ivxlib, oracle, axis):
         rs.floodfill_threshold(img, [seed], 500, 2000, 1, s, g)
         oracle.floodfill_threshold(img, [seed], 500, 2000, 1, s, r)
         assert r.sum() == 21 and np.array_equal(g, r)
+
+
+def test_resident_launch_behind_the_async_grow_of_the_resident_pipeline(ivxlib, oracle):
+    """IVX_FLOOD_RESIDENT=1 in a fresh process: DeviceVolume.region_grow returns right behind the resident launch
+    (ivx_dev_flood_grow_async), queues `mask[reached] = 254` at once and fetches the round count afterwards
+    (ivx_dev_flood_wait): same mask, same out_mask, a positive round count"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import synth_volume\n"
+        "from scipy.ndimage import generate_binary_structure\n"
+        "from invesalius3_amd.device import DeviceVolume\n"
+        "from oracle import oracle as orc\n"
+        "img = synth_volume((40, 72, 136), seed=93)\n"
+        "s26 = generate_binary_structure(3, 3).astype(np.uint8)\n"
+        "lo, hi = 150, 3071\n"
+        "z, y, x = np.unravel_index(np.argmax(np.where(img <= hi, img, -4000)), img.shape)\n"
+        "vol = DeviceVolume(img, spacing=(1.0, 1.0, 1.0))\n"
+        "for _ in range(2):\n"
+        "    vol.zero_out_mask(); vol.threshold(lo, hi)\n"
+        "    rounds = vol.region_grow([(int(x), int(y), int(z))], lo, hi, s26, fill=1, select_value=254)\n"
+        "    assert rounds >= 1, rounds\n"
+        "mask = np.where((img >= lo) & (img <= hi), 255, 0).astype(np.uint8)\n"
+        "out = np.zeros(img.shape, np.uint8)\n"
+        "orc.floodfill_threshold(img, [(int(x), int(y), int(z))], lo, hi, 1, s26, out)\n"
+        "mask[out.astype(bool)] = 254\n"
+        "assert np.array_equal(vol.download_mask(), mask) and np.array_equal(vol.download_out_mask(), out)\n"
+        "assert (mask == 254).sum() > 1000\n"
+        "print('resident-ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IVX_FLOOD_RESIDENT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "resident-ok" in r.stdout, r.stdout + r.stderr
