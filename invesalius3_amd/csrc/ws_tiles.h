@@ -435,28 +435,22 @@ __global__ __launch_bounds__(256) void k_ws_bucket(int64_t n, const uint16_t *__
     for (int i = threadIdx.x; i < BK_LB; i += 256) sh[i] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
-    const int lane = threadIdx.x & 63;
+    // One LDS atomic per voxel that goes into a list: the hardware serialises lanes that hit the same counter inside the
+    // instruction, and its return value IS the voxel's slot.  (Before: a match-any loop per wave -- shuffle, ballot, one LDS
+    // atomic by a leader lane per distinct level among the wave's voxels, ~20 - 30 dependent iterations on a noise volume --
+    // which made these streaming passes 5 - 10x slower than their bytes: 2.2 + 0.8 ms at 512^3 for 0.9 GB.)
     for (int pass = 0; pass < (SCATTER ? 2 : 1); pass++) {
         for (int j = 0; j < BK_CH; j++) {
             const int64_t p = b0 + (int64_t)j * 256 + threadIdx.x;
             const bool e = p < n && pred(p);
-            const uint32_t c = e ? C[p] : 0;
-            unsigned long long act = __ballot(e);
-            while (act) {
-                const int leader = __ffsll((long long)act) - 1;
-                const uint32_t lc = __shfl(c, leader, 64);
-                const unsigned long long same = __ballot(e && c == lc);
-                const uint32_t cnt = (uint32_t)__popcll(same);
-                uint32_t off = 0;
-                if (lane == leader) {
-                    if (lc < BK_LB) off = atomicAdd(&sh[lc], cnt);
-                    else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[lc], cnt);
-                }
-                if (SCATTER && pass == 1) {
-                    off = __shfl(off, leader, 64);
-                    if (e && c == lc) elist[off + __popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)p;
-                }
-                act &= ~same;
+            if (!e) continue;
+            const uint32_t c = C[p];
+            if (c < BK_LB) {
+                const uint32_t off = atomicAdd(&sh[c], 1u);
+                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
+            } else if (!SCATTER || pass == 1) {
+                const uint32_t off = atomicAdd(&hist_or_cursor[c], 1u);
+                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
             }
         }
         __syncthreads();
