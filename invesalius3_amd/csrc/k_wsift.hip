@@ -359,7 +359,9 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         // once this share of the voxels is in, IVX_WS_LEVELS_MIN = smallest volume (voxels) that takes this path
         const char *e1 = getenv("IVX_WS_LEVELS"), *e2 = getenv("IVX_WS_LEVELS_FRAC"), *e3 = getenv("IVX_WS_LEVELS_MIN");
         const int lv_max = e1 ? atoi(e1) : 48;
-        const double lv_frac = e2 ? atof(e2) : 0.7; // (0.6 .. 0.8 measure the same at 512^3; later levels cost more than they save)
+        // (0.6 .. 0.8 measure the same at 512^3; at 1024^3 0.5 / 0.7 / 0.8 / 0.9 give 215 / 223 / 231 / 255 ms: the later levels'
+        // floods cross a volume whose planes no longer fit the caches, and cost more than the relaxation they save)
+        const double lv_frac = e2 ? atof(e2) : (g.n >= ((int64_t)1 << 29) ? 0.5 : 0.7);
         const int64_t lv_min = e3 ? atoll(e3) : ((int64_t)1 << 21);
         if (lv_max > 0 && conn == 6 && g.w % 64 == 0 && g.h % 16 == 0 && g.n >= lv_min) {
             const int rc = ivx_dev_ws_cost_levels(I, sizeof(MT) == 2 ? IVX_I16 : IVX_I8, mk, g.d, g.h, g.w, b.C, lv_max, lv_frac,
