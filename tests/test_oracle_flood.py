@@ -10,7 +10,8 @@ variant and fill_holes_automatically.
   generic_floodfill_threshold          floodfill.rs:96-166
   generic_floodfill_threshold_inplace  floodfill.rs:168-237
   floodfill_internal                   floodfill.rs:5-49
-  fill_holes_automatically_internal    floodfill.rs:51-94"""
+  fill_holes_automatically_internal    floodfill.rs:51-94
+  floodfill_auto_threshold             floodfill_py.rs:12-85"""
 import numpy as np
 import pytest
 
@@ -128,3 +129,49 @@ def test_fill_holes_automatically_second_restatement(oracle):
         if small.any():  # note: label 0 (the mask itself) takes part like any other label, as in the Rust loop
             want[small[labels]] = 254
         assert modified == bool(small.any()) and np.array_equal(got, want), trial
+
+
+def _sat_i16(f):
+    """Rust's `as i16` from f32: saturating, NaN -> 0"""
+    if f != f:
+        return 0
+    return int(max(-32768.0, min(32767.0, float(np.trunc(f)))))
+
+
+def test_floodfill_auto_threshold_second_restatement(oracle):
+    """floodfill_py.rs:12-85: a FIFO walk (pop_front) over the 6-neighbourhood in which the admissible range of a step depends on
+    the voxel it LEAVES -- [ceil(v * (1 - p)), floor(v * (1 + p))] in f32, cast to i16 the way `as` does -- so reachability is
+    directed; seeds are painted unconditionally"""
+    from collections import deque
+    rng = np.random.default_rng(31)
+    F = np.float32
+    grew = 0
+    for trial in range(150):
+        shape = tuple(int(v) for v in rng.integers(2, 9, 3))
+        base = int(rng.integers(-300, 300))
+        data = (base + rng.integers(-40, 41, shape)).astype(np.int16)
+        if trial % 10 == 0:
+            data.flat[int(rng.integers(0, data.size))] = 32767  # saturating casts
+        p = F(rng.choice([0.05, 0.1, 0.3, 0.0]))
+        fill = int(rng.integers(1, 255))
+        seeds = [(int(rng.integers(0, shape[2])), int(rng.integers(0, shape[1])), int(rng.integers(0, shape[0]))) for _ in range(int(rng.integers(1, 3)))]
+        pre = (rng.random(shape) < 0.05).astype(np.uint8) * fill
+        got, want = pre.copy(), pre.copy()
+        oracle.floodfill_auto_threshold(data, seeds, float(p), fill, got)
+        q = deque()
+        for (i, j, k) in seeds:
+            q.append((i, j, k))
+            want[k, j, i] = fill
+        while q:
+            x, y, z = q.popleft()
+            val = F(data[z, y, x])
+            t0 = _sat_i16(np.ceil(F(val * F(F(1.0) - p))))
+            t1 = _sat_i16(np.floor(F(val * F(F(1.0) + p))))
+            for xo, yo, zo in ((x, y, z + 1), (x, y, z - 1), (x, y + 1, z), (x, y - 1, z), (x + 1, y, z), (x - 1, y, z)):
+                if 0 <= xo < shape[2] and 0 <= yo < shape[1] and 0 <= zo < shape[0] and want[zo, yo, xo] != fill:
+                    if t0 <= int(data[zo, yo, xo]) <= t1:
+                        want[zo, yo, xo] = fill
+                        q.append((xo, yo, zo))
+        assert np.array_equal(got, want), (trial, float(p))
+        grew += int((want != pre).sum() > len(seeds))
+    assert grew > 40
