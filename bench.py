@@ -149,6 +149,14 @@ def cpu_grow_mc(img, seed_xyz):
     return rec, {"region_voxels": int(out_mask.sum()), "triangles": int(ntri), "mask_crc32": zlib.crc32(interior)}
 
 
+def rank_envs(world, idfile):
+    """the environments of the N ranks of one launch: ONE nonce for all of them (comm._nonce() hashes it into the id file's
+    header, and a rank only accepts an id file that carries its own launch's nonce)"""
+    nonce = "%d-%.6f" % (os.getpid(), time.time())
+    return [dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), IVX_COMM_FILE=idfile, IVX_COMM_NONCE=nonce,
+                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")) for r in range(world)]
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (fresh processes, one GPU each), relay rank 0's line."""
     import subprocess
@@ -162,10 +170,8 @@ def launch_ranks(args):
         raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible -- one GPU per rank is required" % (args.gpus, have))
     idfile = os.path.join(tempfile.mkdtemp(prefix="ivx_bench_"), "comm.id")
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), IVX_COMM_FILE=idfile,
-                   IVX_COMM_NONCE="%d-%.6f" % (os.getpid(), time.time()),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for env in rank_envs(args.gpus, idfile):
+        r = int(env["RANK"])
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out = procs[0].communicate()[0].decode()

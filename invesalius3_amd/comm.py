@@ -178,6 +178,40 @@ def _nonce() -> bytes:
     return hashlib.sha256(key.encode()).digest()
 
 
+def exchange_id(rank: int, path: str, make_id, timeout_s: float = 300.0) -> bytes:
+    """The rendezvous itself (no device needed, so the CPU suite runs it with the launcher's own environments): rank 0 makes
+    the 128-byte id and leaves it at `path` behind this launch's nonce, every other rank polls for a file carrying that nonce."""
+    t_start = time.time()
+    if rank == 0:
+        # a crashed run may have left an id behind under the same name: it must never be mistaken for this run's.  The
+        # file is replaced atomically (written next to it, private, then renamed) and carries this launch's nonce in
+        # front of the id.
+        cid = make_id()
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(_nonce() + cid)
+        os.replace(tmp, path)
+        return cid
+    want = _nonce()
+    # A launcher-made IVX_COMM_NONCE is unique per launch, so a matching file IS this launch's however late this rank
+    # arrives (a slow first import on one rank must not time it out).  Without one (torchrun: launcher pid + port + run
+    # id, which a recycled pid could repeat) the file must also be no older than this rank's own patience.
+    oldest = -1.0 if os.environ.get("IVX_COMM_NONCE") else t_start - max(timeout_s, 120.0)
+    while True:
+        try:
+            if os.path.getsize(path) == len(want) + 128 and os.path.getmtime(path) >= oldest:
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if blob[:len(want)] == want and len(blob) == len(want) + 128:
+                    return blob[len(want):]
+        except OSError:
+            pass
+        if time.time() - t_start > timeout_s:
+            raise RuntimeError("rank %d: no RCCL id of this launch at %s after %.0f s" % (rank, path, timeout_s))
+        time.sleep(0.02)
+
+
 def init_from_env(timeout_s: float = 300.0) -> RcclComm:
     """RANK / WORLD_SIZE / LOCAL_RANK from the environment (torchrun's or bench.py's own launcher); selects the device,
     exchanges the id through `rendezvous_file()` and brings the communicator up."""
@@ -189,32 +223,7 @@ def init_from_env(timeout_s: float = 300.0) -> RcclComm:
                            % (rank, local, L.device_count()))
     L.set_device(local)
     path = rendezvous_file()
-    t_start = time.time()
-    if rank == 0:
-        # a crashed run may have left an id behind under the same name: it must never be mistaken for this run's.  The
-        # file is replaced atomically (written next to it, private, then renamed) and carries this launch's nonce in
-        # front of the id; the readers below also refuse anything older than their own start.
-        cid = RcclComm.unique_id()
-        tmp = "%s.%d.tmp" % (path, os.getpid())
-        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
-        with os.fdopen(fd, "wb") as f:
-            f.write(_nonce() + cid)
-        os.replace(tmp, path)
-    else:
-        want = _nonce()
-        while True:
-            try:
-                if os.path.getsize(path) == len(want) + 128 and os.path.getmtime(path) >= t_start - 120.0:
-                    with open(path, "rb") as f:
-                        blob = f.read()
-                    if blob[:len(want)] == want and len(blob) == len(want) + 128:
-                        cid = blob[len(want):]
-                        break
-            except OSError:
-                pass
-            if time.time() - t_start > timeout_s:
-                raise RuntimeError("rank %d: no RCCL id of this launch at %s after %.0f s" % (rank, path, timeout_s))
-            time.sleep(0.02)
+    cid = exchange_id(rank, path, RcclComm.unique_id, timeout_s)
     comm = RcclComm(rank, world, cid)
     comm.barrier()
     if rank == 0:

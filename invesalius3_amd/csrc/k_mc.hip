@@ -1254,8 +1254,10 @@ extern "C" int ivx_dev_mc_emit_levels(const ivx_mc_params *p, const void *scratc
     int rc = make_geom(p, &g);
     if (rc) return rc;
     IVX_REQUIRE(p->dtype == IVX_U8 && p->niso == 1 && sel_bits, IVX_EINVAL, "mc_emit_levels: uint8 mask, one iso-value");
-    IVX_REQUIRE(v_out < p->iso[0] && v_in >= p->iso[0] && v_sel >= p->iso[0] && p->pad_value < p->iso[0], IVX_EINVAL,
-                "mc_emit_levels: v_out (and the padding) must lie below the iso-value, v_in and v_sel at or above it");
+    // (every OUTSIDE end of an edge, the virtual padding included, is interpolated as v_out: a pad value that is merely below
+    // the iso-value would give silently different border vertices, so it has to BE v_out -- as the indexed variant requires)
+    IVX_REQUIRE(v_out < p->iso[0] && v_in >= p->iso[0] && v_sel >= p->iso[0] && (double)p->pad_value == v_out, IVX_EINVAL,
+                "mc_emit_levels: v_out must lie below the iso-value and equal the padding value, v_in and v_sel at or above it");
     const Scratch s = make_scratch(g, p->niso);
     if (s.nwords == 0 || max_tris <= 0) return IVX_OK;
     const McLevels lv = make_levels(sel_bits, p->iso[0], v_out, v_in, v_sel);

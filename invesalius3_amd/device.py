@@ -504,7 +504,10 @@ class DeviceVolume:
         """the triangle emit of a counted piece: from the known byte levels of the mask when the pipeline can prove them
         (no voxel is read), else from the voxels"""
         lib, lv = L.lib(), self._mask_levels
-        if (plane is not None and lv is not None and self._fuse and os.environ.get("IVX_MC_LEVELS", "1") != "0"):
+        # (the same predicate as marching_cubes_indexed: a caller's own `params` may carry another padding value or levels
+        # that do not straddle the iso-value the way the constants assume)
+        if (plane is not None and lv is not None and self._fuse and os.environ.get("IVX_MC_LEVELS", "1") != "0"
+                and float(p.pad_value) == 0.0 and lv[0] > 127 and (lv[1] is None or lv[1] > 127)):
             if lv[1] is None:
                 sel, v_sel = plane, float(lv[0])  # (no second level: any plane will do, both values are the same)
             else:

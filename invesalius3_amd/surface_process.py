@@ -298,6 +298,41 @@ def boundary_edges(faces):
     return e[~np.isin(fwd, bwd)]
 
 
+def boundary_loops(be):
+    """The directed boundary edges ordered into simple closed loops, every edge consumed exactly once.  A vertex where two
+    rims touch (a pinch point) has two outgoing rim edges: the walk keeps a list of successors per vertex and closes a loop
+    the moment it returns to a vertex of its own path, so pinched rims come out as separate simple loops instead of one
+    merged or truncated one.  Edges that cannot be ordered into a loop (open chains of a non-manifold rim) are left alone,
+    as VTK leaves what it cannot order."""
+    succ = {}
+    for a, b in np.asarray(be).reshape(-1, 2).tolist():
+        succ.setdefault(a, []).append(b)
+    loops = []
+    for start in list(succ):
+        while succ[start]:
+            path, pos = [start], {start: 0}
+            while path:
+                cur = path[-1]
+                out = succ.get(cur)
+                if not out:  # dead end: the edge that led here belongs to no loop
+                    del pos[path.pop()]
+                    continue
+                nx = out.pop()
+                i = pos.get(nx)
+                if i is None:
+                    pos[nx] = len(path)
+                    path.append(nx)
+                    continue
+                if len(path) - i >= 3:
+                    loops.append(path[i:])
+                for u in path[i + 1:]:
+                    del pos[u]
+                del path[i + 1:]
+                if i == 0 and not succ[start]:
+                    break
+    return loops
+
+
 def fill_holes(verts, faces, hole_size=300.0):
     """The hole-filling step of join_process_surface (vtkFillHolesFilter with SetHoleSize(300),
     invesalius/data/surface_process.py:396-416): every closed loop of boundary edges whose bounding sphere (half the
@@ -312,20 +347,8 @@ def fill_holes(verts, faces, hole_size=300.0):
     be = boundary_edges(f)
     if not len(be):
         return v, f, 0
-    nxt = {}
-    for a, b in be.tolist():  # (a vertex where two rims touch keeps the last one: the loops then merge, which is harmless)
-        nxt[a] = b
-    new_v, new_f, seen, holes = [], [], set(), 0
-    for start in list(nxt):
-        if start in seen:
-            continue
-        loop, cur = [], start
-        while cur in nxt and cur not in seen:
-            seen.add(cur)
-            loop.append(cur)
-            cur = nxt[cur]
-        if cur != start or len(loop) < 3:
-            continue  # an open chain (non-manifold rim): left alone, as VTK leaves what it cannot order into a loop
+    new_v, new_f, holes = [], [], 0
+    for loop in boundary_loops(be):
         pts = v[loop].astype(np.float64)
         if 0.5 * float(np.linalg.norm(pts.max(0) - pts.min(0))) > hole_size:
             continue

@@ -181,13 +181,15 @@ def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_
                                      L.ptr(mk), L.ptr(_strct27(bstruct, image.ndim)), int(sk), gs, int(bool(use_ww_wl)),
                                      ctypes.c_double(float(ww)), ctypes.c_double(float(wl)), L.ptr(tmp_mask), stats), "do_watershed")
     do_watershed.last_stats = {"algorithm": algorithm, "tied_markers_of_different_labels": int(stats[6]) if sk else 0}
-    if sk:
-        _warn_ties(int(stats[6]), "do_watershed")
     tmp_mask = tmp_mask.reshape(image.shape)
     mask[:] = tmp_mask
     mask.flush()
     if q is not None:
         q.put(1)
+    # the warning comes LAST: with warnings promoted to errors (-W error) the labels are written and the caller waiting on
+    # `q` (styles.py:2116-2134) has its signal before anything can raise
+    if sk:
+        _warn_ties(int(stats[6]), "do_watershed")
 
 
 do_watershed.last_stats = None

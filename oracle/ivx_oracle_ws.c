@@ -28,8 +28,11 @@ typedef struct ws_el {
 
 /* input: uint8 (idt=0) or uint16 (idt=3), C-contiguous, rank 3 (use shape[0]=1 for 2-D).
  * markers/output: int16 (mdt=1) or int8 (mdt=4), C-contiguous.  strct: 3x3x3 uint8. */
+/* flags (optional, one byte per voxel): 1 = popped LATE (from a bucket above its cost), 2 = reachable but never popped,
+ * 4 = the defect's trigger (sole element of a bucket re-queued without being unlinked), 8 = popped twice.
+ * lvl (optional, 3 x 65536 counters): pops / late pops / triggers per bucket level. */
 static int ws_ift_impl(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
-                       const uint8_t *strct, void *output, int64_t *ev) {
+                       const uint8_t *strct, void *output, int64_t *ev, uint8_t *flags, int64_t *lvl) {
     const int64_t dims[3] = {shape[0], shape[1], shape[2]};
     const int64_t size = dims[0] * dims[1] * dims[2];
     const int64_t strides[3] = {dims[1] * dims[2], dims[2], 1};
@@ -75,6 +78,8 @@ static int ws_ift_impl(int idt, const void *input, const int64_t shape[3], int m
         while (first[jj]) {
             ws_el *v = first[jj];
             if (ev) { if (v->done) ev[2]++; else if (v->cost != jj) ev[1]++; }
+            if (flags) { if (v->done) flags[v->index] |= 8; else if (v->cost != jj) flags[v->index] |= 1; }
+            if (lvl) { lvl[jj]++; if (!v->done && v->cost != jj) lvl[65536 + jj]++; }
             first[jj] = first[jj]->next;
             if (first[jj]) first[jj]->prev = NULL;
             v->prev = NULL; v->next = NULL;
@@ -103,7 +108,11 @@ static int ws_ift_impl(int idt, const void *input, const int64_t shape[3], int m
                     p->cost = max;
                     int32_t label = OUT(v_index);
                     SETOUT(p_index, label);
-                    if (ev && !(p->next || p->prev) && first[pcost] == p) ev[0]++;
+                    if (pcost <= maxval && !(p->next || p->prev) && first[pcost] == p) {
+                        if (ev) ev[0]++;
+                        if (flags) flags[p_index] |= 4;
+                        if (lvl) lvl[2 * 65536 + jj]++;
+                    }
                     if (p->next || p->prev) {
                         ws_el *prev = p->prev, *next = p->next;
                         if (first[pcost] == p) first[pcost] = next;
@@ -126,8 +135,8 @@ static int ws_ift_impl(int idt, const void *input, const int64_t shape[3], int m
             }
         }
     }
-    if (ev)
-        for (int64_t i = 0; i < size; i++) if (!temp[i].done && temp[i].cost <= maxval) ev[3]++;
+    if (ev || flags)
+        for (int64_t i = 0; i < size; i++) if (!temp[i].done && temp[i].cost <= maxval) { if (ev) ev[3]++; if (flags) flags[i] |= 2; }
     free(temp); free(first); free(last);
     return ORC_OK;
 #undef IN
@@ -138,7 +147,7 @@ static int ws_ift_impl(int idt, const void *input, const int64_t shape[3], int m
 
 int orc_watershed_ift(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
                       const uint8_t *strct, void *output) {
-    return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, NULL);
+    return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, NULL, NULL, NULL);
 }
 
 /* Same flood, plus what scipy's linked-list defect did on this input:
@@ -148,5 +157,12 @@ int orc_watershed_ift(int idt, const void *input, const int64_t shape[3], int md
 int orc_watershed_ift_events(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
                              const uint8_t *strct, void *output, int64_t ev[4]) {
     ev[0] = ev[1] = ev[2] = ev[3] = 0;
-    return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, ev);
+    return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, ev, NULL, NULL);
+}
+
+/* The same, plus WHERE: per-voxel event flags and per-level counters (tools/ift_defect_confinement.py). */
+int orc_watershed_ift_trace(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
+                            const uint8_t *strct, void *output, int64_t ev[4], uint8_t *flags, int64_t *lvl) {
+    ev[0] = ev[1] = ev[2] = ev[3] = 0;
+    return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, ev, flags, lvl);
 }

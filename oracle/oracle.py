@@ -639,6 +639,19 @@ def watershed_ift_events(image, markers, strct):
     return out, tuple(int(v) for v in ev)
 
 
+def watershed_ift_trace(image, markers, strct):
+    """watershed_ift_events plus WHERE: per-voxel flags (1 popped late, 2 never popped, 4 trigger, 8 popped twice) and
+    per-level counters (pops, late pops, triggers), each of length 65536."""
+    image, markers, s3, shp = _ws_args(image, markers, strct)
+    out = np.empty_like(markers)
+    ev = (ctypes.c_int64 * 4)()
+    flags = np.zeros(image.shape, np.uint8)
+    lvl = np.zeros((3, 65536), np.int64)
+    _check(lib().orc_watershed_ift_trace(0 if image.dtype == np.uint8 else 3, _p(image), _i64(shp),
+                                         1 if markers.dtype == np.int16 else 4, _p(markers), _p(s3), _p(out), ev, _p(flags), _p(lvl)))
+    return out, tuple(int(v) for v in ev), flags, lvl
+
+
 def watershed_ift_clean(image, markers, strct, want_cost=False):
     """The algorithm watershed_ift documents, without the linked-list defect (ivx_oracle_wsz.c)."""
     image, markers, s3, shp = _ws_args(image, markers, strct)

@@ -281,3 +281,58 @@ def test_fill_holes_caps_the_rims_up_to_the_hole_size():
     bottom = sv[sf].mean(axis=1)[:, 2] < -0.8
     v3, f3, n3 = sp.fill_holes(sv, sf[~top & ~bottom])                         # two rims: two caps
     assert n3 == 2 and len(sp.boundary_edges(f3)) == 0
+
+
+def test_bench_launcher_gives_every_rank_the_same_nonce_and_the_rendezvous_completes(tmp_path):
+    """`python bench.py --gpus N` outside a launcher: the N rank environments must share ONE
+    IVX_COMM_NONCE, otherwise ranks > 0 never accept rank 0's id file.  Runs the rendezvous itself (comm.exchange_id, no
+    device) in three fresh processes with exactly the environments bench.rank_envs() hands to its ranks; rank 2 arrives late."""
+    import os
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    idfile = str(tmp_path / "comm.id")
+    envs = bench.rank_envs(3, idfile)
+    assert len({e["IVX_COMM_NONCE"] for e in envs}) == 1 and [e["RANK"] for e in envs] == ["0", "1", "2"]
+    code = ("import os, sys, time; sys.path.insert(0, %r); from invesalius3_amd import comm; r = int(os.environ['RANK']); "
+            "time.sleep(1.0 if r == 2 else 0.0); "
+            "print(comm.exchange_id(r, comm.rendezvous_file(), lambda: bytes(range(128)), timeout_s=20.0).hex())"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE) for e in envs]
+    outs = [p.communicate(timeout=60)[0].decode().strip() for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0]
+    assert outs == [bytes(range(128)).hex()] * 3
+    # a file of ANOTHER launch (different nonce) under the same name is never accepted
+    other = dict(bench.rank_envs(2, idfile)[1])
+    code2 = code.replace("timeout_s=20.0", "timeout_s=0.5")
+    p = subprocess.run([sys.executable, "-c", code2], env=other, capture_output=True)
+    assert p.returncode != 0 and b"no RCCL id of this launch" in p.stderr
+
+
+def test_fill_holes_at_a_pinch_point_closes_both_rims():
+    """two holes that touch in ONE vertex: that vertex has two outgoing rim edges; every rim edge must be
+    consumed exactly once and no boundary edge may remain after capping"""
+    from invesalius3_amd import surface_process as sp
+    n = 6
+    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    verts = np.stack([ii.ravel(), jj.ravel(), np.zeros(ii.size)], axis=1).astype(np.float32)
+    vid = lambda i, j: i * (n + 1) + j
+    faces = []
+    for i in range(n):
+        for j in range(n):
+            if (i, j) in ((1, 1), (2, 2)):  # two missing cells sharing the corner (2, 2)
+                continue
+            faces += [[vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)], [vid(i, j), vid(i + 1, j + 1), vid(i, j + 1)]]
+    faces = np.asarray(faces, np.int32)
+    be = sp.boundary_edges(faces)
+    loops = sp.boundary_loops(be)
+    assert sorted(len(l) for l in loops) == [4, 4, 4 * n]             # two square rims + the sheet's outer rim, each simple
+    assert sum(len(l) for l in loops) == len(be)                       # every rim edge consumed exactly once
+    v, f, holes = sp.fill_holes(verts, faces, hole_size=1.0)           # (the outer rim is larger than the hole size)
+    assert holes == 2 and len(v) == len(verts) + 2
+    left = sp.boundary_edges(f)
+    assert len(left) == 4 * n                                          # only the outer rim stays open
+    assert not np.isin(left.ravel(), [vid(2, 2)]).any()
