@@ -758,7 +758,7 @@ def run_mip(args, job):
     proj = DeviceBuffer(n * n * 2 + 64)
     view = {(k, a): DeviceBuffer(n * f * n * f * 2) for k in ("maxip", "mida") for a in range(3)}
     view[("contour", 0)] = DeviceBuffer(n * f * n * f * 2)
-    mm, status, tmp = DeviceBuffer(64), DeviceBuffer(64), DeviceBuffer(nvox * 2 + 64)
+    mm, status = DeviceBuffer(64), DeviceBuffer(64)
     status.zero(vol.stream)
     WL, WW = 300.0, 300.0  # get_image_slice hands the window LEVEL in for level and width alike (slice_.py:898-900, quirk Q1)
 
@@ -778,9 +778,9 @@ def run_mip(args, job):
             with vol.timer.span("viewport"):
                 L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[("mida", axis)].ptr, vol.stream))
         with vol.timer.span("contour_mip_axis0"):
-            L.check(lib.ivx_dev_fcm_volume(L.I16, vol.image.raw, c64(n), c64(n), c64(n), ctypes.c_float(2.0), 0, tmp.ptr, status.ptr,
-                                           vol.stream), "fcm_volume")
-            L.check(lib.ivx_dev_mip_reduce(L.I16, tmp.ptr, c64(n), c64(n), c64(n), 0, L.MIP_MAX, proj.ptr, vol.stream))
+            # fast_countour_mip(tmip 0) = max fold of the contour volume (mips.rs:237-247): folded as it is computed, no temp
+            L.check(lib.ivx_dev_fcm_maxip(L.I16, vol.image.raw, c64(n), c64(n), c64(n), ctypes.c_float(2.0), 0, proj.ptr, status.ptr,
+                                          vol.stream), "fcm_maxip")
         with vol.timer.span("viewport"):
             L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[("contour", 0)].ptr, vol.stream))
 
@@ -807,10 +807,10 @@ def run_mip(args, job):
         return
     proj_ms = sum(v for k, v in spans.items() if k != "viewport")
     # algorithmic bytes: 2 B/voxel per projection, MIDA + 2 B/voxel for its min/max pre-pass, the contour MIP
-    # 2 B/voxel read + the contour volume written and read again (2 + 2), and the viewports
-    sweep_bytes = 3 * 2.0 * nvox + 3 * 4.0 * nvox + 6.0 * nvox + 7 * (2.0 * n * n + 2.0 * (n * f) ** 2) + 7 * 2.0 * n * n
+    # 2 B/voxel (fused: no contour volume is written or read back), and the viewports
+    sweep_bytes = 3 * 2.0 * nvox + 3 * 4.0 * nvox + 2.0 * nvox + 7 * (2.0 * n * n + 2.0 * (n * f) ** 2) + 7 * 2.0 * n * n
     worst = max((k for k in spans if k != "viewport"), key=lambda k: spans[k])
-    per_kernel_bytes = {"maxip": 2.0 * nvox, "mida": 4.0 * nvox, "contour": 6.0 * nvox}
+    per_kernel_bytes = {"maxip": 2.0 * nvox, "mida": 4.0 * nvox, "contour": 2.0 * nvox}
     res = {
         "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
         "value": round(job.world * 7 * nvox / (dt / args.steps) / 1e6, 2), "unit": "Mvoxel/s",

@@ -149,6 +149,12 @@ int ivx_dev_rays_z_slab(int kind, int dtype, const void *vol, int64_t dz, int64_
                         int *status, void *stream);
 int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
                        void *tmp /* same dtype/shape */, int *status, void *stream);
+/* fast_countour_mip_internal with tmip == 0 (invesalius_rs/src/mips.rs:237-247: tmp = contour volume, out = fold_axis max):
+ * the contour value is folded into the running maximum as it is computed -- no temp volume -- for int16 rows of whole
+ * 16-byte chunks; other inputs materialise the volume in this stream's workspace.  int16 / uint8 images; `out` has the
+ * image's dtype and the shape of the projection; *status receives IVX_EDOM where the reference's NumCast would panic. */
+int ivx_dev_fcm_maxip(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis, void *out,
+                      int *status, void *stream);
 int ivx_mida(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,
              double wl, double ww, int out_dtype, void *out, const int64_t out_strides[2]);
 int ivx_lmip(int dtype, const void *img, const int64_t shape[3], const int64_t strides[3], int axis,

@@ -392,6 +392,129 @@ __global__ __launch_bounds__(256) void k_fcm_volume_i16x8(const int16_t *__restr
     }
 }
 
+// ---- fused contour MaxIP (fast_countour_mip with tmip == 0, mips.rs:237-247) ------------------------------------------
+// The reference materialises tmp[z, y, x] = T(calc_fcm_intensity) and folds it with max along the axis.  NumCast's
+// truncation is monotone, so max over T(v) == T(max over v): the contour value is folded in f32 as it is computed and cast
+// once per pixel -- no 2 B/voxel temp written and read back.  A value NumCast would refuse (the reference panics while
+// building tmp) is reported through `status` exactly as k_fcm_volume does.
+// int16, rows of whole 16-byte chunks.  Lane = 8 consecutive voxels of a row.
+//   AXIS 0 / 1: the lane walks a segment of the ray axis with a 3-chunk sliding window in registers (previous, centre,
+//               next along the ray axis); per step it loads the next chunk, the two chunks of the OTHER in-slice axis
+//               (neighbour lanes' centre chunks: L1 / L2 hits) and the two 2-byte x-neighbours across the chunk edge.
+//   AXIS 2:     a wave per row: each lane folds its chunks' 8 values, then a shuffle tree.
+__device__ __forceinline__ float fcm_value(int16_t xm, int16_t xp, int16_t ym, int16_t yp, int16_t zm, int16_t zp, float n,
+                                           int axis, int pmode) {
+    const float g0 = fd_sub<int16_t>(xp, xm) / (2.0f * 1.0f);
+    const float g1 = fd_sub<int16_t>(yp, ym) / (2.0f * 1.0f);
+    const float g2 = fd_sub<int16_t>(zp, zm) / (2.0f * 1.0f);
+    const float gm = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+    float v = 0.0f;
+    if (gm != 0.0f) {
+        const float d = axis == 0 ? g2 : axis == 1 ? g1 : g0;
+        const float base = 1.0f - fabsf(d / gm);
+        // powf: n == 1 is the identity; n == 2 is ONE correctly rounded f32 product (the double product of two floats is
+        // exact, so this is what rounding pow's exact result once gives); anything else in double, rounded once
+        const float sf = pmode == 1 ? base : pmode == 2 ? base * base : (float)pow((double)base, (double)n);
+        v = gm * sf;
+    }
+    return v;
+}
+
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
+                                                      float n, int pmode, int64_t seg, float *__restrict__ partial,
+                                                      int *__restrict__ status) {
+    // output pixel row r = y (AXIS 0) or z (AXIS 1); the ray runs along l = z (AXIS 0) or y (AXIS 1)
+    const int64_t cpr = sx / 8;
+    const int64_t nr = AXIS == 0 ? sy : sz, len = AXIS == 0 ? sz : sy;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nr * cpr) return;
+    const int64_t r = t / cpr, x0 = (t - r * cpr) * 8;
+    const int64_t l0 = (int64_t)blockIdx.y * seg, l1 = l0 + seg < len ? l0 + seg : len;
+    // strides of the ray axis (sl) and of the other in-slice axis (so), in voxels; o = this lane's fixed coordinate there
+    const int64_t sl = AXIS == 0 ? sy * sx : sx, so = AXIS == 0 ? sx : sy * sx, no = nr;
+    const int64_t om = r == 0 ? 0 : r - 1, op = r == no - 1 ? no - 1 : r + 1;
+    const int16_t *col = img + r * so + x0;             // + l * sl
+    const int16_t *colm = img + om * so + x0, *colp = img + op * so + x0;
+    auto ld = [](const int16_t *p) { return *reinterpret_cast<const rshort8_t *>(p); };
+    rshort8_t prev = ld(col + (l0 == 0 ? 0 : l0 - 1) * sl), cur = ld(col + l0 * sl);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = -INFINITY;
+    bool bad = false;
+#pragma unroll 2
+    for (int64_t l = l0; l < l1; l++) {
+        const int64_t ln = l == len - 1 ? len - 1 : l + 1;
+        const rshort8_t next = ld(col + ln * sl);
+        const rshort8_t am = ld(colm + l * sl), ap = ld(colp + l * sl);
+        const int16_t *row = col + l * sl - x0;
+        const int16_t left = x0 == 0 ? (int16_t)cur[0] : row[x0 - 1];
+        const int16_t right = x0 + 8 == sx ? (int16_t)cur[7] : row[x0 + 8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int16_t xm = e == 0 ? left : (int16_t)cur[e - 1], xp = e == 7 ? right : (int16_t)cur[e + 1];
+            const float v = AXIS == 0 ? fcm_value(xm, xp, (int16_t)am[e], (int16_t)ap[e], (int16_t)prev[e], (int16_t)next[e], n, 0, pmode)
+                                      : fcm_value(xm, xp, (int16_t)prev[e], (int16_t)next[e], (int16_t)am[e], (int16_t)ap[e], n, 1, pmode);
+            bad |= !(v > -32769.0f && v < 32768.0f);
+            acc[e] = v > acc[e] ? v : acc[e];
+        }
+        prev = cur;
+        cur = next;
+    }
+    if (bad) atomicMin(status, IVX_EDOM);
+    float *o = partial + ((int64_t)blockIdx.y * nr + r) * sx + x0;
+    *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+__global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx, float n,
+                                                      int pmode, int16_t *__restrict__ out, int *__restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= sz * sy) return;
+    const int64_t z = ray / sy, y = ray - z * sy;
+    const int64_t py = y == 0 ? 0 : y - 1, fy = y == sy - 1 ? sy - 1 : y + 1;
+    const int64_t pz = z == 0 ? 0 : z - 1, fz = z == sz - 1 ? sz - 1 : z + 1;
+    const int16_t *row = img + (z * sy + y) * sx;
+    const int16_t *rym = img + (z * sy + py) * sx, *ryp = img + (z * sy + fy) * sx;
+    const int16_t *rzm = img + (pz * sy + y) * sx, *rzp = img + (fz * sy + y) * sx;
+    float acc = -INFINITY;
+    bool bad = false;
+    for (int64_t x0 = (int64_t)lane * 8; x0 < sx; x0 += 512) {
+        const rshort8_t c = *reinterpret_cast<const rshort8_t *>(row + x0);
+        const rshort8_t ym = *reinterpret_cast<const rshort8_t *>(rym + x0), yp = *reinterpret_cast<const rshort8_t *>(ryp + x0);
+        const rshort8_t zm = *reinterpret_cast<const rshort8_t *>(rzm + x0), zp = *reinterpret_cast<const rshort8_t *>(rzp + x0);
+        const int16_t left = x0 == 0 ? (int16_t)c[0] : row[x0 - 1];
+        const int16_t right = x0 + 8 == sx ? (int16_t)c[7] : row[x0 + 8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int16_t xm = e == 0 ? left : (int16_t)c[e - 1], xp = e == 7 ? right : (int16_t)c[e + 1];
+            const float v = fcm_value(xm, xp, (int16_t)ym[e], (int16_t)yp[e], (int16_t)zm[e], (int16_t)zp[e], n, 2, pmode);
+            bad |= !(v > -32769.0f && v < 32768.0f);
+            acc = v > acc ? v : acc;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float b = __shfl_xor(acc, o, 64);
+        acc = b > acc ? b : acc;
+    }
+    if (bad) atomicMin(status, IVX_EDOM);
+    if (lane == 0) out[ray] = (int16_t)acc; // (sx >= 8 here, so acc is a real value; out of range only with `bad` set)
+}
+
+__global__ __launch_bounds__(256) void k_fcm_max_combine(const float *__restrict__ partial, int64_t npix, int split,
+                                                         int16_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float acc = partial[i];
+    for (int s = 1; s < split; s++) {
+        const float b = partial[(int64_t)s * npix + i];
+        acc = b > acc ? b : acc;
+    }
+    out[i] = (int16_t)acc;
+}
+
 template <typename T, typename U, int MODE>
 static int launch_rays(const void *vol, int64_t dz, int64_t dy, int64_t dx, int axis, double p0, double p1,
                        const float *minmax, void *out, int *status, hipStream_t st, const double *state_in = nullptr,
@@ -517,6 +640,54 @@ extern "C" int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_
     return IVX_OK;
 }
 
+// fast_countour_mip with tmip == 0 (mips.rs:237-247) without the contour volume: fused for int16 rows of whole 16-byte
+// chunks (every volume the GUI holds), through a materialised temp from this stream's workspace otherwise.  Same bits.
+extern "C" int ivx_dev_fcm_maxip(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
+                                 void *out, int *status, void *stream) {
+    hipStream_t st = ivx::S(stream);
+    IVX_REQUIRE(axis >= 0 && axis <= 2, IVX_EINVAL, "fast_countour_mip: axis %d", axis);
+    IVX_REQUIRE(dtype == IVX_I16 || dtype == IVX_U8, IVX_EINVAL, "fcm_maxip: int16 or uint8 images (float64 takes the LMIP fold)");
+    const int64_t total = dz * dy * dx;
+    if (!total) return IVX_OK;
+    static const bool fused_ok = []() { const char *e = getenv("IVX_FCM_FUSED"); return !(e && e[0] == '0'); }();
+    int rc;
+    if (fused_ok && dtype == IVX_I16 && dx % 8 == 0 && (((uintptr_t)vol) & 15) == 0) {
+        const int pmode = n == 1.0f ? 1 : n == 2.0f ? 2 : 0;
+        const int16_t *img = (const int16_t *)vol;
+        if (axis == 2) {
+            hipLaunchKernelGGL(k_fcm_max_rows, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,
+                               (int16_t *)out, status);
+            IVX_LAUNCH_CHECK();
+            return IVX_OK;
+        }
+        const int64_t nr = axis == 0 ? dy : dz, len = axis == 0 ? dz : dy, npix = nr * dx;
+        const int64_t nblk = ivx::cdiv(nr * (dx / 8), 256);
+        // segments of the ray: enough workgroups to fill the chip, each long enough to amortise its two window chunks
+        int64_t split = ivx::cdiv(2048, nblk);
+        if (split > len / 32) split = len / 32;
+        if (split < 1) split = 1;
+        const int64_t seg = ivx::cdiv(len, split);
+        split = ivx::cdiv(len, seg);
+        void *part;
+        if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * sizeof(float) * split + 64, &part))) return rc;
+        if (axis == 0)
+            hipLaunchKernelGGL(k_fcm_max_walk<0>, dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+                               (float *)part, status);
+        else
+            hipLaunchKernelGGL(k_fcm_max_walk<1>, dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+                               (float *)part, status);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_fcm_max_combine, dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st, (const float *)part, npix,
+                           (int)split, (int16_t *)out);
+        IVX_LAUNCH_CHECK();
+        return IVX_OK;
+    }
+    void *tmp;
+    if ((rc = ivx::ws_get_s(ivx::WS_AUX0, st, (size_t)total * ivx::dtype_size(dtype) + 64, &tmp))) return rc;
+    if ((rc = ivx_dev_fcm_volume(dtype, vol, dz, dy, dx, n, axis, tmp, status, stream))) return rc;
+    return ivx_dev_mip_reduce(dtype, tmp, dz, dy, dx, axis, IVX_MIP_MAX, out, stream);
+}
+
 // ---- host forms -----------------------------------------------------------------------------------------------
 namespace {
 struct HostRay {
@@ -595,10 +766,18 @@ extern "C" int ivx_fast_countour_mip(int dtype, const void *img, const int64_t s
     int rc = host_prep(dtype, img, shape, strides, axis, dtype_size(dtype), &h);
     if (rc) return rc;
     if (nvox == 0) return tmip == 2 ? IVX_EDOM : IVX_OK;
-    void *d_tmp;
-    if ((rc = ws_get(WS_AUX0, (size_t)nvox * h.isz, &d_tmp))) return rc;
     float *mm = (float *)h.d_small;
     int *status = (int *)((char *)h.d_small + 64);
+    if (tmip == 0 && dtype != IVX_F64 && axis >= 0 && axis <= 2) {
+        // max fold: the contour value is folded as it is computed (no temp volume); a NumCast failure anywhere in the volume
+        // is reported like the reference's panic while it builds tmp
+        if ((rc = ivx_dev_fcm_maxip(dtype, h.d_in, shape[0], shape[1], shape[2], n, axis, h.d_out, status, nullptr))) return rc;
+        IVX_HIP(hipDeviceSynchronize());
+        if ((rc = host_status(h))) return rc;
+        return download_strided2(out, h.osh, out_strides, h.d_out, h.isz, WS_OUT);
+    }
+    void *d_tmp;
+    if ((rc = ws_get(WS_AUX0, (size_t)nvox * h.isz, &d_tmp))) return rc;
     if ((rc = ivx_dev_fcm_volume(dtype, h.d_in, shape[0], shape[1], shape[2], n, axis, d_tmp, status, nullptr))) return rc;
     if ((rc = host_status(h))) return rc; // the reference panics while building tmp, before any projection
     if (tmip == 0) {

@@ -167,6 +167,45 @@ def get_image_slice(matrix: np.ndarray, orientation: str, slice_number: int, num
     return out
 
 
+def apply_reorientation(matrix: np.ndarray, spacing, q_orientation, center, interp_method: int = 2, masks=()):
+    """The array work of ``Slice.apply_reorientation`` (invesalius/data/slice_.py:1969-2068): bake the view's rotation into
+    the data.  `matrix` (the int16 image, e.g. the ``matrix.dat`` memmap) is resampled IN PLACE from a copy of itself
+    through ``M = view_matrix(q_orientation, center)`` -- ``apply_view_matrix_transform(copy, spacing, M, 0, "AXIAL",
+    interp_method, copy.min(), matrix)`` (:1979-1988; HIP: csrc/k_transform.hip) -- and flushed.  Then every mask of `masks`
+    (objects with ``.matrix``, the padded ``(dz+1, dy+1, dx+1)`` uint8 array, and ``.was_edited``): an edited mask goes
+    through the SAME call with nearest-neighbour interpolation and cval 0 (:2034-2043) -- on the whole padded matrix, flag
+    planes included, exactly as the reference does (its voxel (z, y, x) sits at matrix index (z+1, y+1, x+1), so the mask
+    turns about a point one voxel off the image's: a reference quirk, kept) -- a threshold mask is cleared (:2055-2062);
+    ``mask.clear_history()`` is called where it exists.  Returns the view state the reference leaves behind:
+    ``(q_orientation, center) = ((1, 0, 0, 0), [s * d / 2 for d, s in zip(shape[::-1], spacing)])`` (:2002-2003)."""
+    from . import invesalius_rs as mips
+
+    if matrix.ndim != 3:
+        raise TypeError("matrix must be a 3-D array")
+    M = view_matrix(q_orientation, center)
+    mcopy = np.array(matrix)  # (the reference's temporary memmap copy)
+    mips.apply_view_matrix_transform(mcopy, spacing, M, 0, "AXIAL", int(interp_method), mcopy.min(), matrix)
+    del mcopy
+    if hasattr(matrix, "flush"):
+        matrix.flush()
+    new_mask_shape = tuple(s + 1 for s in matrix.shape)
+    for mask in masks:
+        mm = mask.matrix
+        if tuple(mm.shape) != new_mask_shape:  # (:2028-2030 would recreate it; the image's shape never changes here)
+            raise ValueError("mask matrix must be image shape + 1 per axis (invesalius/data/mask.py:422-431)")
+        if getattr(mask, "was_edited", False):
+            mask_copy = np.array(mm)
+            mips.apply_view_matrix_transform(mask_copy, spacing, M, 0, "AXIAL", 0, 0, mm)
+            del mask_copy
+        else:
+            mm[:] = 0
+        if hasattr(mm, "flush"):
+            mm.flush()
+        if hasattr(mask, "clear_history"):
+            mask.clear_history()
+    return np.array((1, 0, 0, 0)), [(s * d / 2.0) for (d, s) in zip(matrix.shape[::-1], spacing)]
+
+
 def calc_image_area(mask_matrix: np.ndarray, spacing) -> float:
     """Slice.calc_image_area (invesalius/data/slice_.py:2296-2322) after its threshold step: the exposed-face area of
     ``mask_matrix[1:,1:,1:] > 127`` for ``spacing = (sx, sy, sz)``.  Computed from the uint8 mask on the GPU (the

@@ -105,3 +105,38 @@ def test_fcm_u8_f64_and_errors(ivxlib, oracle):
         mips.mida(img, 0, 40000, 1, _out(img, 0))
     # (the wrapped T-subtraction of finite_difference bounds |g| <= 2^15/2 per axis, so the contour intensity
     #  always fits the image dtype: the NumCast panic of mips.rs:241 is unreachable for integer images)
+
+
+@pytest.mark.parametrize("shape", [(70, 48, 64), (40, 96, 64), (9, 10, 520), (33, 5, 8), (64, 64, 128), (5, 7, 30)])
+def test_fused_contour_maxip_equals_the_materialised_contour_volume(ivxlib, oracle, shape):
+    """ivx_dev_fcm_maxip (contour value folded into the running maximum, ray split into segments, no temp volume) ==
+    ivx_dev_fcm_volume + MaxIP == the C restatement of mips.rs:237-247, every axis, n = 1 / 2 (exact products) and 3.3;
+    the last shape has ragged rows and takes the materialised route inside the same entry point"""
+    import ctypes
+
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceBuffer, c64
+    img = synth_volume(shape, seed=57)
+    img[0, 0, :4] = [-32768, 32767, -32768, 32767]  # the T-subtraction of finite_difference wraps (quirk Q3)
+    dz, dy, dx = shape
+    lib = L.lib()
+    d_img, d_tmp, d_st = DeviceBuffer(img.nbytes), DeviceBuffer(img.nbytes), DeviceBuffer(64)
+    d_img.upload(img)
+    d_st.zero()
+    for n in (1.0, 2.0, 3.3):
+        for axis in range(3):
+            oshp = tuple(d for i, d in enumerate(shape) if i != axis)
+            d_a, d_b = DeviceBuffer(int(np.prod(oshp)) * 2 + 64), DeviceBuffer(int(np.prod(oshp)) * 2 + 64)
+            L.check(lib.ivx_dev_fcm_maxip(L.I16, d_img.ptr, c64(dz), c64(dy), c64(dx), ctypes.c_float(n), axis, d_a.ptr, d_st.ptr, None))
+            L.check(lib.ivx_dev_fcm_volume(L.I16, d_img.ptr, c64(dz), c64(dy), c64(dx), ctypes.c_float(n), axis, d_tmp.ptr, d_st.ptr, None))
+            L.check(lib.ivx_dev_mip_reduce(L.I16, d_tmp.ptr, c64(dz), c64(dy), c64(dx), axis, L.MIP_MAX, d_b.ptr, None))
+            L.synchronize()
+            a, b = d_a.download(oshp, np.int16), d_b.download(oshp, np.int16)
+            assert np.array_equal(a, b), (n, axis)
+            if n != 3.3:  # (glibc's powf may differ from the correctly rounded power by an ulp: test_fcm_volume_other_exponents)
+                r = np.zeros(oshp, np.int16)
+                oracle.fast_countour_mip(img, n, axis, 300, 300, 0, r)
+                assert np.array_equal(a, r), (n, axis)
+            d_a.close()
+            d_b.close()
+    assert int(d_st.download((1,), np.int32)[0]) == 0
