@@ -40,7 +40,21 @@ BONE = (226, 3071)  # invesalius/presets.py:37
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+_VOLUMES = {}
+
+
 def synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
+    """(cached per process: the default run times several configs on the same 512^3 volume)"""
+    key = (tuple(shape), seed, z_offset, z_total or shape[0])
+    if key not in _VOLUMES:
+        if len(_VOLUMES) >= 1 and int(np.prod(shape)) >= 2 ** 29:
+            _VOLUMES.clear()
+        _VOLUMES[key] = _synth_v512(shape, seed, z_offset, z_total)
+        _VOLUMES[key].setflags(write=False)
+    return _VOLUMES[key]
+
+
+def _synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
     """V512 of SURVEY.md 8(d): 6 Gaussian 'bone' blobs (peak 1800) + low-frequency sinusoid + N(0,25) noise,
     offset -1000, clipped to [-1024, 3071].  Built separably, slab by slab, in float32.
 
@@ -405,7 +419,7 @@ def run_grow_mc(args, job):
     dt = job.max(dt)
     ntri_all, reached_all = job.sum(ntri), job.sum(reached)
     if rank != 0:
-        return
+        return None
     ms_per_step = dt / args.steps * 1e3
     stage_ms = {k: float(np.mean(v)) for k, v in spans.items()}
     mc_ms = stage_ms.get("mc_count", 0.0) + stage_ms.get("mc_emit", 0.0)
@@ -458,7 +472,7 @@ def run_grow_mc(args, job):
             raise SystemExit("bench.py: GPU result differs from the CPU oracle: %s vs %s" % (got, orc_out))
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res), flush=True)
+    return res
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -477,6 +491,83 @@ def ws_markers(img):
                 mk[cz:cz + 5, cy:cy + 5, cx:cx + 5] = 2
     mk[z - 2:z + 3, y - 2:y + 3, x - 2:x + 3] = 1
     return mk
+
+
+def full_volume_fixture(n, img):
+    """tests/golden/ws{n}_full.npz (made by tests/golden/make_golden_ws_full.py from live scipy and the serial oracles on THIS
+    volume), or None when there is none for this size or the synthetic volume of this box differs from the one it was made on"""
+    import zlib
+    path = os.path.join(ROOT, "tests", "golden", "ws%d_full.npz" % n)
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    if tuple(z["shape"]) != tuple(img.shape) or int(z["image_crc32"]) != zlib.crc32(img):
+        return None
+    return z
+
+
+def ift_parity(args, img, mk, strct, lab, n):
+    """`differs_from_reference` for the IFT flood, on the volume and markers the bench TIMED (`lab` = its labels).
+
+    The reference is live scipy.ndimage.watershed_ift (watershed_process.py:57).  512^3 and 1024^3: scipy's labels on exactly
+    this volume are on file (tests/golden/ws{n}_full.npz: CRC-32 of scipy's labels, CRC-32 of the defect-free statement's, and
+    the voxels where the two differ) -- the timed labels are compared with both, whole volume, in a second.  Other sizes, a box
+    whose synthetic volume differs, or --live-reference: scipy and the serial oracle run here on the whole volume (minutes).
+    `cpu_baseline` = live scipy timed on a bounded slab of the same cost image (that slab's flood is not the timed one and
+    is not used for parity)."""
+    import zlib
+
+    from scipy import ndimage
+
+    from oracle import oracle as orc
+    orc.build()
+    nvox = img.size
+    cost = (img - img.min()).astype(np.uint16)
+    # (a) the reference's speed: live scipy, one core like the reference's worker process, bounded sample
+    sl = min(n, max(16, int(2.5e7 // (n * n))))
+    sub, smk = np.ascontiguousarray(cost[:sl]), np.ascontiguousarray(mk[:sl])
+    t = time.perf_counter()
+    ndimage.watershed_ift(sub, smk, strct)
+    ts = time.perf_counter() - t
+    out = {"cpu_baseline": {"value": round(sub.size / ts / 1e6, 3), "unit": "Mvoxel/s", "cores": 1, "kind": "reference",
+                            "sample": "live scipy.ndimage.watershed_ift (the call of watershed_process.py:57) on the first %d slices of "
+                                      "the timed cost image with the timed markers (%d voxels), %.2f s" % (sl, sub.size, ts)}}
+    fx = None if args.live_reference else full_volume_fixture(n, img)
+    lab = np.ascontiguousarray(lab, dtype=np.uint8)
+    if fx is not None:
+        at = np.cumsum(fx["differs_at"].astype(np.int64))
+        n_clean = 0 if zlib.crc32(lab) == int(fx["clean_crc32"]) else None
+        if n_clean == 0:
+            ref = lab.copy().reshape(-1)
+            ref[at] = 3 - ref[at]  # labels are 1 / 2: scipy's volume is the defect-free one flipped at these places
+            if zlib.crc32(ref) != int(fx["scipy_crc32"]):
+                raise SystemExit("bench.py: tests/golden/ws%d_full.npz is inconsistent (rebuilt reference labels miss their CRC)" % n)
+            n_ref = len(at)
+            how = ("tests/golden/ws%d_full.npz: live scipy (%s) and the defect-free serial statement on this very volume; the timed "
+                   "labels' CRC-32 equals the statement's, and flipping them at the %d recorded voxels gives scipy's CRC-32"
+                   % (n, ", ".join(str(v) for v in fx["versions"]), n_ref))
+            ev = None
+    if fx is None or n_clean is None:
+        # live, whole volume: the reference itself, the defect-free statement and the defect's event counts
+        sci = ndimage.watershed_ift(cost, mk, strct)
+        clean = orc.watershed_ift_clean(cost, mk, strct)
+        _, ev = orc.watershed_ift_events(cost, mk, strct)
+        n_ref, n_clean = int((lab != sci.astype(np.uint8)).sum()), int((lab != clean.astype(np.uint8)).sum())
+        how = "live scipy.ndimage.watershed_ift and oracle/ivx_oracle_wsz.c run on the whole timed volume in this process"
+    out["differs_from_reference"] = n_ref
+    out["parity"] = {"ok": n_ref == 0, "reference": "live scipy.ndimage.watershed_ift (the reference's call)",
+                     "differs_from_reference": n_ref, "compared_voxels": int(nvox), "compared": "the whole timed volume, the timed flood's own labels",
+                     "how": how, "equals_defect_free_statement": n_clean == 0, "mismatch_vs_defect_free_oracle": n_clean,
+                     "scipy_defect_events": None if ev is None else {"requeued_unlinked": ev[0], "popped_late": ev[1], "popped_twice": ev[2],
+                                                                     "never_popped": ev[3]},
+                     "note": "bit-exact integer masks are the contract: %d of %d voxels (%.4f %%) differ from the reference.  The GPU flood "
+                             "equals the defect-free statement of NI_WatershedIFT bit for bit; live scipy leaves that statement only downstream "
+                             "of its linked-list defect (ni_measure.c: `if (p->next || p->prev)`); profiles/r04_ift_defect_confinement.json "
+                             "has where and why a parallel replay is not possible" % (n_ref, nvox, 100.0 * n_ref / nvox)}
+    if n_clean:
+        print(json.dumps(dict(out, error="watershed differs from the defect-free oracle")), flush=True)
+        raise SystemExit("bench.py: watershed differs from the defect-free oracle")
+    return out
 
 
 def run_watershed(args, job):
@@ -561,44 +652,10 @@ def run_watershed(args, job):
         "device": L.device_name(),
     }
     if args.cpu:
-        # the reference's own flood, live: scipy.ndimage.watershed_ift on a bounded sample of the same volume (its first
-        # slices with the same marker rule), one core like the reference's worker process
-        sl = min(n, max(16, int(1.0e8 // (n * n))))
-        sub = np.ascontiguousarray(img[:sl])
-        smk = ws_markers(sub)
-        cost = (sub - sub.min()).astype(np.uint16)
-        t = time.perf_counter()
-        sci = ndimage.watershed_ift(cost, smk, strct)
-        ts = time.perf_counter() - t
-        got = wp.watershed_ift(cost, smk, strct)
-        from oracle import oracle as orc
-        orc.build()
-        clean = orc.watershed_ift_clean(cost, smk, strct)
-        _, ev = orc.watershed_ift_events(cost, smk, strct)
-        res["cpu_baseline"] = {"value": round(sub.size / ts / 1e6, 3), "unit": "Mvoxel/s", "cores": 1, "kind": "reference",
-                               "sample": "live scipy.ndimage.watershed_ift (the call of watershed_process.py:57) on the first %d "
-                                         "slices (%d voxels), %.2f s" % (sl, sub.size, ts)}
-        # The reference IS live scipy: `ok` and `differs_from_reference` are the comparison with it.  The comparison with the
-        # defect-free statement of the same algorithm is reported next to it, and only THAT one aborts the run (a difference
-        # there is a bug here; a difference from scipy downstream of its own linked-list defect is a stated deviation).
-        n_ref, n_clean = int((got != sci).sum()), int((got != clean).sum())
-        res["differs_from_reference"] = n_ref
-        res["parity"] = {"ok": n_ref == 0, "reference": "live scipy.ndimage.watershed_ift (the reference's call)",
-                         "differs_from_reference": n_ref, "sample_voxels": int(sub.size),
-                         "equals_defect_free_statement": n_clean == 0,
-                         "mismatch_vs_defect_free_oracle": n_clean,
-                         "mismatch_vs_live_scipy": n_ref,
-                         "scipy_defect_events": {"requeued_unlinked": ev[0], "popped_late": ev[1], "popped_twice": ev[2], "never_popped": ev[3]},
-                         "note": "bit-exact integer masks are the contract: %d of %d sample voxels differ from the reference.  The GPU flood "
-                                 "equals the defect-free statement of NI_WatershedIFT bit for bit; live scipy leaves that statement only "
-                                 "downstream of its linked-list defect (ni_measure.c: `if (p->next || p->prev)`), whose events are "
-                                 "counted above" % (n_ref, sub.size)}
-        if n_clean:
-            print(json.dumps(res), flush=True)
-            raise SystemExit("bench.py: watershed differs from the defect-free oracle")
+        res.update(ift_parity(args, img, mk, strct, lab, n))
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res), flush=True)
+    return res
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -723,23 +780,41 @@ def run_watershed_sk(args, job):
                                          "(%d voxels), %.2f s" % (sl, sub.size, ts)}
         # the reference is scikit-image's heap flood (pinned move for move by `heap`): `ok` is the comparison with IT
         n_ref = int((got != heap).sum())
-        res["differs_from_reference"] = n_ref
-        res["parity"] = {"ok": n_ref == 0, "reference": "scikit-image's (value, age) heap flood, heap-ordered marker ties "
-                                                         "(C restatement pinned to the compiled 0.18.3 kernel)",
-                         "differs_from_reference": n_ref,
-                         "equals_raster_tie_statement": bool(np.array_equal(got, raster)),
-                         "mismatch_vs_serial_flood_raster_marker_ties": int((got != raster).sum()),
-                         "mismatch_vs_serial_flood_heap_marker_ties": n_ref,
-                         "tied_markers_of_different_labels": gst["tied_markers_of_different_labels"], "sample_voxels": int(sub.size),
+        sample = {"sample_voxels": int(sub.size), "sample": "first %d slices, markers re-derived on the sample (a different flood from the timed one)" % sl,
+                  "equals_raster_tie_statement": bool(np.array_equal(got, raster)),
+                  "mismatch_vs_serial_flood_raster_marker_ties": int((got != raster).sum()),
+                  "mismatch_vs_serial_flood_heap_marker_ties": n_ref,
+                  "tied_markers_of_different_labels": gst["tied_markers_of_different_labels"]}
+        # ... and the TIMED flood, whole volume, against the serial floods run on this very volume when their CRCs are on file
+        # (tests/golden/ws{n}_full.npz, GUI-default settings only): cost image, raster-tie statement, heap-ordered reference
+        import zlib
+        fx = full_volume_fixture(n, img) if use_ww_wl else None
+        whole = None
+        if fx is not None:
+            grad_ok = zlib.crc32(d_grad.download(shape, np.uint16)) == int(fx["grad_crc32"])
+            lab_ok = zlib.crc32(np.ascontiguousarray(lab)) == int(fx["sk_raster_crc32"])
+            whole = {"compared_voxels": int(nvox), "how": "CRC-32 of the timed cost image and labels vs tests/golden/ws%d_full.npz (numpy LUT + "
+                     "scipy morphological_gradient + oracle/ivx_oracle_wssk.c on this very volume)" % n,
+                     "cost_image_equals_numpy_scipy": bool(grad_ok), "equals_raster_tie_statement": bool(lab_ok),
+                     "differs_from_reference": int(fx["sk_differs"]) if lab_ok else None}
+            if lab_ok and int(fx["sk_differs"]) == 0 and zlib.crc32(np.ascontiguousarray(lab)) != int(fx["sk_heap_crc32"]):
+                raise SystemExit("bench.py: tests/golden/ws%d_full.npz is inconsistent" % n)
+        res["differs_from_reference"] = whole["differs_from_reference"] if whole is not None else None
+        res["parity"] = {"ok": (whole["differs_from_reference"] == 0 and whole["cost_image_equals_numpy_scipy"]) if whole is not None else n_ref == 0,
+                         "reference": "scikit-image's (value, age) heap flood, heap-ordered marker ties (C restatement pinned to the "
+                                      "compiled 0.18.3 kernel)",
+                         "differs_from_reference": res["differs_from_reference"],
+                         "compared": "the whole timed volume" if whole is not None else "a sample only (no full-volume record for this size / these settings)",
+                         "whole_volume": whole, "sample": sample, "equals_raster_tie_statement": sample["equals_raster_tie_statement"] and (whole is None or whole["equals_raster_tie_statement"]),
                          "note": "the GPU flood equals the serial flood bit for bit when equal-valued marker voxels are taken in raster "
                                  "order; scikit-image's heap takes them in an order that depends on its array layout, which matters "
-                                 "only where tied markers of different labels compete (second count)"}
+                                 "only where tied markers of different labels compete"}
         if not res["parity"]["equals_raster_tie_statement"]:
             print(json.dumps(res), flush=True)
             raise SystemExit("bench.py: watershed_sk differs from the serial flood")
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res), flush=True)
+    return res
 
 def run_mip(args, job):
     import ctypes
@@ -862,7 +937,7 @@ def run_mip(args, job):
     if not res["parity"]["ok"]:
         print(json.dumps(res), flush=True)
         raise SystemExit("bench.py: viewport differs from the reference")
-    print(json.dumps(res), flush=True)
+    return res
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -987,7 +1062,35 @@ def run_sharded2048(args, job):
             raise SystemExit("bench.py: sharded2048 sample differs from the CPU oracle")
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res), flush=True)
+    return res
+
+
+def other_configs(args, job, runners):
+    """After the headline's timed region (default run, one GPU): BASELINE configs[2] at 512^3 (both branches of do_watershed),
+    configs[4] and configs[3] on this one GPU, once each with a short timed region, so that the driver's own run carries
+    their numbers and parity -- {name: {ms, frac, parity_ok, differs_from_reference, ...}}.  Full lines: `--config <name>`."""
+    import copy
+    plan = (("watershed_ift_512", "watershed", 512, 2, 1), ("watershed_gui_default_512", "watershed_sk", 512, 2, 1),
+            ("mip_sweep_512", "mip", None, 10, 2), ("sharded2048_on_one_gpu", "sharded2048", None, 3, 1))
+    out = {}
+    for name, cfg, size, steps, warmup in plan:
+        a = copy.copy(args)
+        a.config, a.size, a.steps, a.warmup, a.ws_raw = cfg, size, steps, warmup, False
+        t = time.perf_counter()
+        try:
+            r = runners[cfg](a, job)
+            par = r.get("parity") or {}
+            out[name] = {"workload": r["config"]["workload"], "ms": r["ms_per_step"], "steps": steps, "mvoxel_per_s": r["value"],
+                         "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"], "stage_ms": r.get("stage_ms"),
+                         "parity_ok": par.get("ok"), "differs_from_reference": r.get("differs_from_reference", 0 if par.get("ok") else None),
+                         "parity_compared": par.get("compared") or par.get("checked"),
+                         "cpu_baseline": {k: (r.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
+                         "wall_s": round(time.perf_counter() - t, 1)}
+        except BaseException as e:  # (SystemExit of a failed parity gate included: the headline line still goes out, with the failure in it)
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e), "parity_ok": False, "wall_s": round(time.perf_counter() - t, 1)}
+    return out
 
 
 def main():
@@ -1001,6 +1104,12 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="edge of the volume (defaults: 512 / 1024 / 512 per GPU; 2048 in total for sharded2048)")
     ap.add_argument("--ws-raw", action="store_true", help="watershed_sk: the image - image.min() branch instead of the GUI's default window/level")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false", help="skip the CPU baseline + full-size parity check")
+    ap.add_argument("--no-others", dest="others", action="store_false",
+                    help="default config only: do not run configs[2] (both branches, 512^3), configs[4] and configs[3] (one GPU) once each "
+                         "after the headline's timed region (`other_configs` of the JSON line)")
+    ap.add_argument("--live-reference", action="store_true",
+                    help="watershed: run live scipy and the serial oracle on the WHOLE timed volume instead of quoting "
+                         "tests/golden/ws{512,1024}_full.npz (512^3: ~3 min of one core; 1024^3: ~25 min and ~50 GB of RAM)")
     ap.add_argument("--cpu-slices", type=int, default=None, help="(kept for old command lines; 0 = --no-cpu)")
     ap.add_argument("--dry-comm", action="store_true", help="bring the communicator up, run ivx_comm_selftest on every rank "
                     "(at --gpus 1: on a one-rank RCCL communicator), print one JSON line and exit")
@@ -1021,7 +1130,13 @@ def main():
     if args.dry_comm:
         return dry_comm(world)
     job = Ranks()
-    {"grow_mc": run_grow_mc, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048}[args.config](args, job)
+    runners = {"grow_mc": run_grow_mc, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048}
+    res = runners[args.config](args, job)
+    if res is not None and args.config == "grow_mc" and args.others and args.cpu and world == 1 and args.size is None \
+            and os.environ.get("IVX_FORCE_SLAB") != "1":
+        res["other_configs"] = other_configs(args, job, runners)
+    if res is not None:
+        print(json.dumps(res), flush=True)
     if job.comm is not None:
         CStdoutToStderr.stay()  # the JSON line is out; whatever RCCL still has to say goes to stderr
         job.comm.barrier()

@@ -69,6 +69,11 @@ struct HostCallGuard {
 // pinned host staging (grow-only)
 int hs_get(int slot, size_t nbytes, void **hptr);
 
+// dense host <-> device copies, synchronous like hipMemcpy; pageable memory of >= 4 MB goes through page-locked lane buffers
+// filled / drained by a few host threads (ivx_runtime.hip)
+int copy_h2d(void *dst_dev, const void *src, size_t n);
+int copy_d2h(void *dst, const void *src_dev, size_t n);
+
 // strided host <-> dense device helpers (host side gather / scatter + one hipMemcpy)
 int upload_strided(void *dst_dev, const void *src, const int64_t shape[3], const int64_t strides[3], size_t isz,
                    int hslot);

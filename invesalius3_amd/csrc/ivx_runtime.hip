@@ -107,6 +107,138 @@ int hs_get(int slot, size_t nbytes, void **hptr) {
     return IVX_OK;
 }
 
+// ---- pageable host memory at (nearly) the link's rate ----------------------------------------------------------------
+// The reference hands np.memmap / plain numpy arrays over (invesalius/data/mask.py:422-431, slice_.py:192): pageable memory.
+// hipMemcpy moves such memory through the runtime's single bounce buffer at ~15 GB/s (bench.py: 43 ms for one step's
+// 630 MB against 12.5 ms from page-locked arrays).  Here a copy of >= 4 MB is cut into chunks that a few host threads
+// ("lanes") move through their own page-locked double buffers on their own streams: while the DMA engine carries chunk k of
+// a lane, the lane's thread memcpy's chunk k + lanes (upload) / unpacks chunk k - lanes (download, which also spreads the
+// page faults of a fresh destination array over the lanes).  A pointer that is already page-locked (ivx_host_alloc,
+// hipHostRegister) goes straight to hipMemcpy.  Synchronous like hipMemcpy: the bytes are in place on return.
+namespace {
+constexpr size_t STAGE_CHUNK = 4u << 20;
+constexpr size_t STAGE_MIN = 4u << 20;
+constexpr int STAGE_MAX_LANES = 8;
+struct StageLane {
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+};
+struct StageCtx {
+    int nl = 0;
+    StageLane lane[STAGE_MAX_LANES];
+};
+static std::mutex g_stage_mu; // one staged copy at a time (the lanes are the parallelism)
+static std::map<int, StageCtx> g_stage;
+
+static int stage_lanes() {
+    static const int n = []() {
+        const char *e = getenv("IVX_STAGE_THREADS");
+        int v = e ? atoi(e) : 0;
+        if (!e) {
+            const unsigned hc = std::thread::hardware_concurrency();
+            v = hc >= 16 ? 6 : hc >= 8 ? 4 : hc >= 4 ? 2 : 0;
+        }
+        return v < 0 ? 0 : v > STAGE_MAX_LANES ? STAGE_MAX_LANES : v;
+    }();
+    return n;
+}
+
+static bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // unregistered memory: the query fails, and that failure must not linger
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int stage_ctx(int dev, StageCtx **out) {
+    StageCtx &c = g_stage[dev];
+    const int want = stage_lanes();
+    while (c.nl < want) {
+        StageLane &l = c.lane[c.nl];
+        IVX_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+        for (int q = 0; q < 2; q++) {
+            IVX_HIP(hipHostMalloc(&l.buf[q], STAGE_CHUNK, hipHostMallocDefault));
+            IVX_HIP(hipEventCreateWithFlags(&l.ev[q], hipEventDisableTiming));
+        }
+        c.nl++;
+    }
+    *out = &c;
+    return IVX_OK;
+}
+
+// to_device: dev <- host, else host <- dev
+static int staged_copy(void *dev_p, void *host_p, size_t n, bool to_device) {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    int dev = 0;
+    IVX_HIP(hipGetDevice(&dev));
+    StageCtx *c;
+    int rc = stage_ctx(dev, &c);
+    if (rc) return rc;
+    IVX_HIP(hipStreamSynchronize(nullptr));
+    const size_t nchunks = (n + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    const int nl = (size_t)c->nl < nchunks ? c->nl : (int)nchunks;
+    std::vector<hipError_t> err((size_t)nl, hipSuccess);
+    auto work = [&](int t) {
+        hipError_t e = hipSetDevice(dev);
+        StageLane &l = c->lane[t];
+        char *d = (char *)dev_p, *h = (char *)host_p;
+        size_t prev = 0, prev_len = 0;
+        int k = 0;
+        for (size_t i = (size_t)t; i < nchunks && e == hipSuccess; i += (size_t)nl, k++) {
+            const int q = k & 1;
+            const size_t off = i * STAGE_CHUNK, len = n - off < STAGE_CHUNK ? n - off : STAGE_CHUNK;
+            if (to_device) {
+                if (k >= 2) e = hipEventSynchronize(l.ev[q]); // the DMA that last read this buffer
+                if (e != hipSuccess) break;
+                memcpy(l.buf[q], h + off, len);
+                e = hipMemcpyAsync(d + off, l.buf[q], len, hipMemcpyHostToDevice, l.st);
+                if (e == hipSuccess) e = hipEventRecord(l.ev[q], l.st);
+            } else {
+                e = hipMemcpyAsync(l.buf[q], d + off, len, hipMemcpyDeviceToHost, l.st);
+                if (e == hipSuccess) e = hipEventRecord(l.ev[q], l.st);
+                if (k >= 1 && e == hipSuccess) { // unpack the previous chunk while this one is in flight
+                    e = hipEventSynchronize(l.ev[q ^ 1]);
+                    if (e == hipSuccess) memcpy(h + prev, l.buf[q ^ 1], prev_len);
+                }
+                prev = off;
+                prev_len = len;
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(l.st);
+        if (!to_device && e == hipSuccess && k >= 1) memcpy(h + prev, l.buf[(k - 1) & 1], prev_len);
+        err[(size_t)t] = e;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nl; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int t = 0; t < nl; t++)
+        if (err[(size_t)t] != hipSuccess) {
+            set_error("staged %s copy of %zu bytes: %s", to_device ? "host-to-device" : "device-to-host", n, hipGetErrorString(err[(size_t)t]));
+            return err[(size_t)t] == hipErrorOutOfMemory ? IVX_ENOMEM : IVX_EHIP;
+        }
+    return IVX_OK;
+}
+} // namespace
+
+int copy_h2d(void *dst_dev, const void *src, size_t n) {
+    if (!n) return IVX_OK;
+    if (n >= STAGE_MIN && stage_lanes() > 0 && !host_is_pinned(src)) return staged_copy(dst_dev, const_cast<void *>(src), n, true);
+    IVX_HIP(hipMemcpy(dst_dev, src, n, hipMemcpyHostToDevice));
+    return IVX_OK;
+}
+int copy_d2h(void *dst, const void *src_dev, size_t n) {
+    if (!n) return IVX_OK;
+    if (n >= STAGE_MIN && stage_lanes() > 0 && !host_is_pinned(dst)) return staged_copy(const_cast<void *>(src_dev), dst, n, false);
+    IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
+    return IVX_OK;
+}
+
 static inline bool dense3(const int64_t shape[3], const int64_t st[3], size_t isz) {
     return st[2] == (int64_t)isz && st[1] == shape[2] * (int64_t)isz && st[0] == shape[1] * shape[2] * (int64_t)isz;
 }
@@ -194,16 +326,13 @@ int upload_strided(void *dst_dev, const void *src, const int64_t shape[3], const
                    int hslot) {
     const size_t n = (size_t)shape[0] * shape[1] * shape[2] * isz;
     if (n == 0) return IVX_OK;
-    if (dense3(shape, st, isz)) {
-        IVX_HIP(hipMemcpy(dst_dev, src, n, hipMemcpyHostToDevice));
-        return IVX_OK;
-    }
+    if (dense3(shape, st, isz)) return copy_h2d(dst_dev, src, n);
     size_t span = 0;
     if (hslot >= 0 && hslot < WS_COUNT && span_of(shape, st, isz, &span)) {
         SpanSlot *sp;
         int rc = span_buffer(hslot, span, &sp);
         if (rc) return rc;
-        IVX_HIP(hipMemcpy(sp->d, src, span, hipMemcpyHostToDevice));
+        if ((rc = copy_h2d(sp->d, src, span))) return rc;
         sp->host = src;
         sp->nbytes = span;
         sp->epoch = g_host_depth > 0 ? g_host_epoch : 0;
@@ -238,22 +367,20 @@ int download_strided(void *dst, const int64_t shape[3], const int64_t st[3], con
                      int hslot) {
     const size_t n = (size_t)shape[0] * shape[1] * shape[2] * isz;
     if (n == 0) return IVX_OK;
-    if (dense3(shape, st, isz)) {
-        IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
-        return IVX_OK;
-    }
+    if (dense3(shape, st, isz)) return copy_d2h(dst, src_dev, n);
     size_t span = 0;
     if (hslot >= 0 && hslot < WS_COUNT && span_of(shape, st, isz, &span)) {
         SpanSlot *sp;
         int rc = span_buffer(hslot, span, &sp);
         if (rc) return rc;
         const bool fresh = sp->host == dst && sp->nbytes == span && sp->epoch != 0 && sp->epoch == g_host_epoch && g_host_depth > 0;
-        if (!fresh) IVX_HIP(hipMemcpy(sp->d, dst, span, hipMemcpyHostToDevice)); // the bytes between the view's rows
+        if (!fresh && (rc = copy_h2d(sp->d, dst, span))) return rc; // the bytes between the view's rows
         const int64_t row = shape[2] * (int64_t)isz, chunks = (row + 15) / 16;
         hipLaunchKernelGGL(k_repitch<true>, dim3((unsigned)cdiv(shape[0] * shape[1] * chunks, 256)), dim3(256), 0, 0,
                            (uint8_t *)sp->d, st[0], st[1], (uint8_t *)const_cast<void *>(src_dev), shape[0], shape[1], row);
         IVX_LAUNCH_CHECK();
-        IVX_HIP(hipMemcpy(dst, sp->d, span, hipMemcpyDeviceToHost));
+        IVX_HIP(hipStreamSynchronize(nullptr)); // (the kernel above runs on the null stream; the staged copy on its own streams)
+        if ((rc = copy_d2h(dst, sp->d, span))) return rc;
         sp->epoch = 0; // the host copy is the truth again
         return IVX_OK;
     }
@@ -284,8 +411,7 @@ int download_strided2(void *dst, const int64_t shape[2], const int64_t st[2], co
     const int64_t st3[3] = {0, st[0], st[1]};
     if (st[1] == (int64_t)isz && st[0] == shape[1] * (int64_t)isz) {
         const size_t n = (size_t)shape[0] * shape[1] * isz;
-        if (n) IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
-        return IVX_OK;
+        return copy_d2h(dst, src_dev, n);
     }
     return download_strided(dst, sh3, st3, src_dev, isz, hslot);
 }
@@ -441,14 +567,9 @@ int ivx_memset(void *dptr, int value, size_t nbytes, void *stream) {
     if (nbytes) IVX_HIP(hipMemsetAsync(dptr, value, nbytes, S(stream)));
     return IVX_OK;
 }
-int ivx_memcpy_h2d(void *dst, const void *src, size_t nbytes) {
-    if (nbytes) IVX_HIP(hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice));
-    return IVX_OK;
-}
-int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes) {
-    if (nbytes) IVX_HIP(hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost));
-    return IVX_OK;
-}
+// (pageable host memory of >= 4 MB travels through the page-locked lane buffers above; IVX_STAGE_THREADS=0: plain hipMemcpy)
+int ivx_memcpy_h2d(void *dst, const void *src, size_t nbytes) { return copy_h2d(dst, src, nbytes); }
+int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes) { return copy_d2h(dst, src, nbytes); }
 // Page-locked host memory for callers that keep their arrays where the DMA engines can reach them directly: a pageable
 // numpy array crosses PCIe through the runtime's bounce buffers (~25-40 GB/s here), a pinned one at the link's rate.
 int ivx_host_alloc(void **hptr, size_t nbytes) {

@@ -275,3 +275,38 @@ def test_device_volume_watershed_default_algorithm(ivxlib, oracle):
     assert np.array_equal(got, want) and (want == 2).any() and (got != before).any()
     assert stats["markers"] == int((mk != 0).sum())
     vol.close()
+
+
+def test_pageable_copies_through_the_lane_buffers_round_trip(ivxlib, tmp_path):
+    """ivx_memcpy_h2d / _d2h with pageable host memory (numpy arrays, np.memmap: what the reference hands over) go through
+    page-locked lane buffers on several threads and streams (csrc/ivx_runtime.hip staged_copy): every byte arrives, for sizes
+    around the chunk and lane boundaries, unaligned host pointers, a read-only memmap source and a fresh destination; a
+    page-locked array (ivx_host_alloc) takes the direct path and must agree."""
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceBuffer
+    rng = np.random.default_rng(5)
+    chunk = 4 << 20
+    for n in (chunk - 1, chunk, chunk + 3, 2 * chunk + 1, 7 * chunk + 12345, 13 * chunk, 37 * chunk + 5):
+        src = rng.integers(0, 256, n + 7, dtype=np.uint8)[3:3 + n]  # (an unaligned view)
+        d = DeviceBuffer(n)
+        d.upload(src)
+        back = np.empty(n + 5, np.uint8)[5:]
+        assert np.array_equal(d.download((n,), np.uint8, out=np.ascontiguousarray(back)), src), n
+        pin = L.pinned_empty((n,), np.uint8)
+        d.download((n,), np.uint8, out=pin)
+        assert np.array_equal(pin, src), n
+        pin[:] = pin[::-1].copy()
+        d.upload(pin)
+        assert np.array_equal(d.download((n,), np.uint8), src[::-1]), n
+        d.close()
+    n = 9 * chunk + 77
+    m = np.memmap(str(tmp_path / "v.dat"), dtype=np.uint8, mode="w+", shape=(n,))
+    m[:] = rng.integers(0, 256, n, dtype=np.uint8)
+    m.flush()
+    ro = np.memmap(str(tmp_path / "v.dat"), dtype=np.uint8, mode="r", shape=(n,))
+    d = DeviceBuffer(n)
+    d.upload(ro)
+    out = np.memmap(str(tmp_path / "o.dat"), dtype=np.uint8, mode="w+", shape=(n,))
+    d.download((n,), np.uint8, out=out)
+    assert np.array_equal(out, ro)
+    d.close()
