@@ -380,10 +380,15 @@ def run_grow_mc(args, job):
     step()  # the sequential path's own one-time work (its triangle-list workspace) stays out of the table
     barrier()
     vol.timer.collect()
-    for _ in range(max(1, min(args.steps, 5))):
+    n_extra = max(1, min(args.steps, 5))
+    for _ in range(n_extra):
         step()
     barrier()
     spans = vol.timer.collect()
+    # N > 1: device time of the collectives per step (HIP events around every ivx_comm_* call of the bracketed steps), so that
+    # the 1 -> 8 curve arrives with its communication share attached
+    comm_ms = {k[5:]: {"ms_per_step": round(float(np.sum(v)) / n_extra, 4), "calls_per_step": round(len(v) / n_extra, 2)}
+               for k, v in spans.items() if k.startswith("comm_")}
     spans["region_grow"] = spans_timed.get("region_grow", spans.get("region_grow", []))
     reached = vol.reached_count()
     copy_gbs = copy_bandwidth(vol, nvox) if rank == 0 else None
@@ -443,6 +448,7 @@ def run_grow_mc(args, job):
         "mtriangles_per_s": round(ntri / (mc_ms * 1e-3) / 1e6, 2) if mc_ms > 0 else None,
         "triangles": ntri_all, "region_voxels": reached_all, "region_grow_rounds": rounds,
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "comm_ms_per_step": comm_ms or None,
         "region_grow_ms_min_med_max": [round(float(f(spans["region_grow"])), 4) for f in (np.min, np.median, np.max)]
         if len(spans.get("region_grow", [])) else None,
         "timed_region_s": round(dt, 6),
@@ -990,7 +996,10 @@ def run_sharded2048(args, job):
         ntri = step()
     barrier()
     dt = job.max(time.perf_counter() - t0)
-    spans = {k: float(np.mean(v)) for k, v in vol.timer.collect().items()}
+    raw_spans = vol.timer.collect()
+    spans = {k: float(np.mean(v)) for k, v in raw_spans.items()}
+    comm_ms = {k[5:]: {"ms_per_step": round(float(np.sum(v)) / max(args.steps, 1), 4), "calls_per_step": round(len(v) / max(args.steps, 1), 2)}
+               for k, v in raw_spans.items() if k.startswith("comm_")}
     sc = vol.stitch_counts
     nverts, merged = sc["vertices"] - sc["dropped_copies"], sc["dropped_copies"]
     ntri_all, nverts_all, merged_all = job.sum(ntri), job.sum(nverts), job.sum(merged)
@@ -1011,6 +1020,7 @@ def run_sharded2048(args, job):
                    "collectives": "RCCL via libivx ivx_comm_* (one image-halo slice per neighbour, once)" if world > 1 else "none"},
         "triangles": ntri_all, "mtriangles_per_s": round(ntri / (mc_ms * 1e-3) / 1e6, 2) if mc_ms > 0 else None,
         "stage_ms": {k: round(v, 4) for k, v in spans.items()},
+        "comm_ms_per_step": comm_ms or None,
         "stitch": {"ms_per_step_inside_the_timed_steps": round(spans.get("stitch", 0.0), 4), "stitched_vertices": nverts_all,
                    "merged_on_shared_planes": merged_all,
                    "note": "device kernels (k_mci_sig / _match / _gid0 / _stitch_*): the shared planes' vertices are matched by edge "
@@ -1069,6 +1079,7 @@ def other_configs(args, job, runners):
     """After the headline's timed region (default run, one GPU): BASELINE configs[2] at 512^3 (both branches of do_watershed),
     configs[4] and configs[3] on this one GPU, once each with a short timed region, so that the driver's own run carries
     their numbers and parity -- {name: {ms, frac, parity_ok, differs_from_reference, ...}}.  Full lines: `--config <name>`."""
+    import contextlib
     import copy
     plan = (("watershed_ift_512", "watershed", 512, 2, 1), ("watershed_gui_default_512", "watershed_sk", 512, 2, 1),
             ("mip_sweep_512", "mip", None, 10, 2), ("sharded2048_on_one_gpu", "sharded2048", None, 3, 1))
@@ -1078,7 +1089,8 @@ def other_configs(args, job, runners):
         a.config, a.size, a.steps, a.warmup, a.ws_raw = cfg, size, steps, warmup, False
         t = time.perf_counter()
         try:
-            r = runners[cfg](a, job)
+            with contextlib.redirect_stdout(sys.stderr):  # (a failing gate prints its own record: keep stdout to ONE line)
+                r = runners[cfg](a, job)
             par = r.get("parity") or {}
             out[name] = {"workload": r["config"]["workload"], "ms": r["ms_per_step"], "steps": steps, "mvoxel_per_s": r["value"],
                          "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"], "stage_ms": r.get("stage_ms"),

@@ -72,6 +72,17 @@ def local_seeds(lay: SlabLayout, seeds_xyz_global):
     return out
 
 
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
 def slab_region_grow(backend, comm, lay: SlabLayout) -> int:
     """Iterate local fix-point + halo exchange to the global fix-point; returns the number of exchange rounds.
 
@@ -93,8 +104,11 @@ def slab_region_grow(backend, comm, lay: SlabLayout) -> int:
             backend.flood_run()
         backend.stage_vote()
         to_down, from_down, to_up, from_up, nbytes, vote, stream = backend.round_ptrs()
-        comm.exchange_vote(to_down if lay.hb else None, from_down if lay.hb else None, to_up if lay.ht else None,
-                           from_up if lay.ht else None, nbytes, vote, 1, stream)
+        # (HIP events around the collective when the backend brackets stages: `comm_exchange_vote` of the per-stage table is
+        # the device time of the plane exchange + vote all-reduce, summed over the rounds of one flood)
+        with (backend.comm_span("comm_exchange_vote") if hasattr(backend, "comm_span") else _NOSPAN):
+            comm.exchange_vote(to_down if lay.hb else None, from_down if lay.hb else None, to_up if lay.ht else None,
+                               from_up if lay.ht else None, nbytes, vote, 1, stream)
         backend.or_planes()
         rounds += 1
         total_prev, changed = backend.read_votes()
@@ -188,6 +202,9 @@ def _make_slab_volume():
             super().close()
 
         # -- backend protocol of slab_region_grow ---------------------------------------------------------------
+        def comm_span(self, name):
+            return self.timer.span(name)
+
         def flood_run(self):
             r = ctypes.c_int(0)
             L.check(L.lib().ivx_dev_flood_run(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr,
@@ -423,12 +440,14 @@ def _make_slab_volume():
                 if has_up:
                     L.check(lib.ivx_dev_mc_stitch_top_sig(ctypes.byref(p), self._mc_scratch.ptr, top.ptr, st), "stitch_top_sig")
                 if lay.world > 1:
-                    self.comm.exchange(None, below.ptr if has_dn else None, top.ptr if has_up else None, None, nb.value, st)
+                    with self.timer.span("comm_stitch_exchange"):
+                        self.comm.exchange(None, below.ptr if has_dn else None, top.ptr if has_up else None, None, nb.value, st)
                 nbr = below.ptr if has_dn else None
                 L.check(lib.ivx_dev_mc_stitch_match(ctypes.byref(p), self._mc_scratch.ptr, nbr, c64(nv), self._vd.ptr, st),
                         "stitch_match")
                 if lay.world > 1:
-                    self.comm.allgather(self._vd.ptr, self._vd_all.ptr, 8, st)
+                    with self.timer.span("comm_stitch_allgather"):
+                        self.comm.allgather(self._vd.ptr, self._vd_all.ptr, 8, st)
                 else:
                     L.check(lib.ivx_memcpy_d2d(self._vd_all.ptr, self._vd.ptr, ctypes.c_size_t(8), st))
                 need = max(nv, 1) * 12
