@@ -116,9 +116,18 @@ int hs_get(int slot, size_t nbytes, void **hptr) {
 // page faults of a fresh destination array over the lanes).  A pointer that is already page-locked (ivx_host_alloc,
 // hipHostRegister) goes straight to hipMemcpy.  Synchronous like hipMemcpy: the bytes are in place on return.
 namespace {
-constexpr size_t STAGE_CHUNK = 4u << 20;
 constexpr size_t STAGE_MIN = 4u << 20;
-constexpr int STAGE_MAX_LANES = 8;
+constexpr int STAGE_MAX_LANES = 16;
+static size_t stage_chunk() { // bytes per lane buffer (IVX_STAGE_CHUNK_MB: 1 .. 64, default 4)
+    static const size_t n = []() {
+        const char *e = getenv("IVX_STAGE_CHUNK_MB");
+        long v = e ? atol(e) : 4;
+        if (v < 1) v = 1;
+        if (v > 64) v = 64;
+        return (size_t)v << 20;
+    }();
+    return n;
+}
 struct StageLane {
     void *buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -162,7 +171,7 @@ static int stage_ctx(int dev, StageCtx **out) {
         StageLane &l = c.lane[c.nl];
         IVX_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
         for (int q = 0; q < 2; q++) {
-            IVX_HIP(hipHostMalloc(&l.buf[q], STAGE_CHUNK, hipHostMallocDefault));
+            IVX_HIP(hipHostMalloc(&l.buf[q], stage_chunk(), hipHostMallocDefault));
             IVX_HIP(hipEventCreateWithFlags(&l.ev[q], hipEventDisableTiming));
         }
         c.nl++;
@@ -180,6 +189,7 @@ static int staged_copy(void *dev_p, void *host_p, size_t n, bool to_device) {
     int rc = stage_ctx(dev, &c);
     if (rc) return rc;
     IVX_HIP(hipStreamSynchronize(nullptr));
+    const size_t STAGE_CHUNK = stage_chunk();
     const size_t nchunks = (n + STAGE_CHUNK - 1) / STAGE_CHUNK;
     const int nl = (size_t)c->nl < nchunks ? c->nl : (int)nchunks;
     std::vector<hipError_t> err((size_t)nl, hipSuccess);
