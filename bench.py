@@ -393,16 +393,19 @@ def run_grow_mc(args, job):
     reached = vol.reached_count()
     copy_gbs = copy_bandwidth(vol, nvox) if rank == 0 else None
     # one step the way a caller without a resident volume pays for it: host -> HBM, the step, mask + triangles -> host
-    e2e_ms = None
+    e2e_ms = e2e_first_ms = None
     if world == 1 and not force_slab:
-        t = time.perf_counter()
-        vol.image.upload(img)
-        step()
-        mask_host = vol.download_mask()
-        tris_host = vol.marching_cubes(from_binary=True, download=True)
-        e2e_ms = (time.perf_counter() - t) * 1e3
-        mask_crc, ntri_dl = zlib.crc32(mask_host), len(tris_host)
-        del tris_host
+        for k in range(2):  # the first pass also pays the process's first pageable copies (page locking set-up, lane buffers)
+            t = time.perf_counter()
+            vol.image.upload(img)
+            step()
+            mask_host = vol.download_mask()  # (fresh np.empty arrays every pass, like a caller's)
+            tris_host = vol.marching_cubes(from_binary=True, download=True)
+            e2e_ms = (time.perf_counter() - t) * 1e3
+            if k == 0:
+                e2e_first_ms = e2e_ms
+            mask_crc, ntri_dl = zlib.crc32(mask_host), len(tris_host)
+            del tris_host, mask_host
     # ... and the same with the caller's arrays in page-locked host memory (invesalius3_amd._lib.pinned_empty): the DMA
     # engines then reach them directly instead of through the runtime's bounce buffers
     e2e_pinned_ms = None
@@ -456,10 +459,13 @@ def run_grow_mc(args, job):
                            "after the timed region, one stage after the other (every recorded event idles the stream for ~4 us)",
         "stage_mvoxel_per_s": {k: round(nvox / (v * 1e-3) / 1e6, 1) for k, v in stage_time.items() if v > 0},
         "end_to_end_ms": round(e2e_ms, 2) if e2e_ms else None,
+        "end_to_end_first_call_ms": round(e2e_first_ms, 2) if e2e_first_ms else None,
         "end_to_end_pinned_ms": round(e2e_pinned_ms, 2) if e2e_pinned_ms else None,
         "end_to_end_note": "host int16 volume -> HBM, one step, dense uint8 mask and float32 triangle soup back to the host: "
-                           "`end_to_end_ms` with pageable numpy arrays, `end_to_end_pinned_ms` with the caller's three arrays in "
-                           "page-locked memory (_lib.pinned_empty); first upload at start-up took %.1f ms" % upload_ms,
+                           "`end_to_end_ms` with pageable numpy arrays (results into fresh np.empty arrays; second pass -- "
+                           "`end_to_end_first_call_ms` is the first, which also sets up the process's page-locking and lane buffers), "
+                           "`end_to_end_pinned_ms` with the caller's three arrays in page-locked memory (_lib.pinned_empty); first upload "
+                           "at start-up took %.1f ms" % upload_ms,
         "roofline": roofline(dom, stage_bytes[dom], stage_time[dom], traffic, copy_gbs,
                              {"per_stage_frac": {k: round(stage_bytes[k] / (stage_time[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                  for k in stage_time if stage_time[k] > 0}}),

@@ -4,6 +4,7 @@
 #include <signal.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <map>
@@ -109,12 +110,13 @@ int hs_get(int slot, size_t nbytes, void **hptr) {
 
 // ---- pageable host memory at (nearly) the link's rate ----------------------------------------------------------------
 // The reference hands np.memmap / plain numpy arrays over (invesalius/data/mask.py:422-431, slice_.py:192): pageable memory.
-// hipMemcpy moves such memory through the runtime's single bounce buffer at ~15 GB/s (bench.py: 43 ms for one step's
-// 630 MB against 12.5 ms from page-locked arrays).  Here a copy of >= 4 MB is cut into chunks that a few host threads
-// ("lanes") move through their own page-locked double buffers on their own streams: while the DMA engine carries chunk k of
-// a lane, the lane's thread memcpy's chunk k + lanes (upload) / unpacks chunk k - lanes (download, which also spreads the
-// page faults of a fresh destination array over the lanes).  A pointer that is already page-locked (ivx_host_alloc,
-// hipHostRegister) goes straight to hipMemcpy.  Synchronous like hipMemcpy: the bytes are in place on return.
+// What that costs was measured per direction (see copy_h2d / copy_d2h below): a warm pageable upload already runs at the
+// link's rate (the runtime locks the user pages), a download into pages that were never touched -- the np.empty result array
+// of every call -- does not: one thread takes every page fault and the copy crawls at 25 GB/s.  For that case a copy of
+// >= 4 MB is cut into chunks that a few host threads ("lanes") move through their own page-locked double buffers on their own
+// streams: while the DMA engine carries chunk k of a lane, the lane's thread unpacks chunk k - lanes, so the page faults of the
+// fresh array are spread over the lanes (46 GB/s).  A pointer that is already page-locked (ivx_host_alloc, hipHostRegister)
+// goes straight to hipMemcpy.  Synchronous like hipMemcpy: the bytes are in place on return.
 namespace {
 constexpr size_t STAGE_MIN = 4u << 20;
 constexpr int STAGE_MAX_LANES = 16;
@@ -146,7 +148,7 @@ static int stage_lanes() {
         int v = e ? atoi(e) : 0;
         if (!e) {
             const unsigned hc = std::thread::hardware_concurrency();
-            v = hc >= 16 ? 6 : hc >= 8 ? 4 : hc >= 4 ? 2 : 0;
+            v = hc >= 16 ? 8 : hc >= 8 ? 4 : hc >= 4 ? 2 : 0;
         }
         return v < 0 ? 0 : v > STAGE_MAX_LANES ? STAGE_MAX_LANES : v;
     }();
@@ -236,15 +238,40 @@ static int staged_copy(void *dev_p, void *host_p, size_t n, bool to_device) {
 }
 } // namespace
 
+// fraction of a sample of the range's pages that are not resident yet (a fresh np.empty / a new memmap): writing into such a
+// range is bound by its page faults, which the lanes take in parallel
+static bool mostly_untouched(const void *p, size_t n) {
+    const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t a0 = ((uintptr_t)p + pg - 1) & ~(uintptr_t)(pg - 1), a1 = ((uintptr_t)p + n) & ~(uintptr_t)(pg - 1);
+    if (a1 <= a0 + 32 * pg) return false;
+    const size_t npages = (a1 - a0) / pg;
+    int missing = 0;
+    constexpr int SAMPLES = 32;
+    for (int q = 0; q < SAMPLES; q++) {
+        unsigned char v = 0;
+        const uintptr_t a = a0 + (npages - 1) * (size_t)q / (SAMPLES - 1) * pg;
+        if (mincore((void *)a, pg, &v) != 0) return false;
+        missing += !(v & 1);
+    }
+    return missing * 2 > SAMPLES;
+}
+
+// Measured on the MI355X box (tools/bench_stage.py, profiles/r04_stage_copies.txt; 630 MB of one bench step):
+//   host -> device, pageable, warm: hipMemcpy 55.7 GB/s (the runtime locks the user pages itself), lanes 22 - 50 GB/s  -> hipMemcpy
+//   device -> host into pages never touched (np.empty): hipMemcpy 24.9 GB/s (faults taken by one thread), lanes 46 GB/s -> lanes
+//   device -> host into touched pages: hipMemcpy 55 GB/s, lanes 47 GB/s                                                 -> hipMemcpy
+// IVX_STAGE_THREADS=0 never uses the lanes; IVX_STAGE_UP=1 sends uploads through them as well (A/B).
 int copy_h2d(void *dst_dev, const void *src, size_t n) {
     if (!n) return IVX_OK;
-    if (n >= STAGE_MIN && stage_lanes() > 0 && !host_is_pinned(src)) return staged_copy(dst_dev, const_cast<void *>(src), n, true);
+    static const bool up = []() { const char *e = getenv("IVX_STAGE_UP"); return e && e[0] == '1'; }();
+    if (up && n >= STAGE_MIN && stage_lanes() > 0 && !host_is_pinned(src)) return staged_copy(dst_dev, const_cast<void *>(src), n, true);
     IVX_HIP(hipMemcpy(dst_dev, src, n, hipMemcpyHostToDevice));
     return IVX_OK;
 }
 int copy_d2h(void *dst, const void *src_dev, size_t n) {
     if (!n) return IVX_OK;
-    if (n >= STAGE_MIN && stage_lanes() > 0 && !host_is_pinned(dst)) return staged_copy(const_cast<void *>(src_dev), dst, n, false);
+    if (n >= STAGE_MIN && stage_lanes() > 0 && mostly_untouched(dst, n) && !host_is_pinned(dst))
+        return staged_copy(const_cast<void *>(src_dev), dst, n, false);
     IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
     return IVX_OK;
 }
