@@ -275,6 +275,24 @@ int ivx_dev_mesh_mass_properties(const float *verts, const int32_t *faces, int64
 int ivx_mesh_keep_largest(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, float *out_verts,
                           int32_t *out_faces, int64_t *out_nverts, int64_t *out_ntris, int64_t *nregions);
 int ivx_mesh_mass_properties(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, double *out8);
+/* The last two filters of join_process_surface (invesalius/data/surface_process.py:396-435), host arrays in and out:
+ *   ivx_mesh_fill_holes     replaces vtkFillHolesFilter + SetHoleSize(hole_size) (:396-416): every closed rim of boundary
+ *                           edges whose bounding sphere (half the diagonal of the rim's bounding box) has a radius <= hole_size
+ *                           is capped by a fan from its centroid -- ONE new point per hole (index nverts + hole), cap triangles
+ *                           wound so that the patch continues the surface.  Rims ordered by their smallest directed edge
+ *                           3 f + k, triangles inside a rim in walking order from that edge.
+ *   ivx_mesh_point_normals  replaces vtkPolyDataNormals (:420-435: FeatureAngle, SplittingOn, AutoOrientNormalsOn,
+ *                           ComputeCellNormalsOn): unit cell normals; corners joined across edges whose cell normals' dot
+ *                           product exceeds cos_feature_angle form fans, a vertex's smallest fan keeps the point, the others get
+ *                           copies appended in (vertex, fan) order; point normal = normalised sum of the fan's cell normals;
+ *                           with auto_orient a surface whose signed volume is negative is turned inside out first.
+ * Both are two-call: with NULL output arrays the sizes come back (*n_new_verts / *n_new_tris, *out_nverts); the second call
+ * passes the capacities in through the same arguments.  PARITY UNPINNED vs VTK 9.3 (third party, not installable here). */
+int ivx_mesh_fill_holes(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, double hole_size,
+                        float *new_verts, int32_t *new_faces, int64_t *n_new_verts, int64_t *n_new_tris);
+int ivx_mesh_point_normals(const float *verts, int64_t nverts, const int32_t *faces, int64_t ntris, double cos_feature_angle,
+                           int splitting, int auto_orient, float *out_verts, int32_t *out_faces, float *point_normals,
+                           float *cell_normals /* may be NULL */, int64_t *out_nverts);
 
 /* ------------------------------------------------------------------------------------------------
  * context-aware smoothing of the indexed surface

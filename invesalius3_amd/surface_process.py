@@ -282,158 +282,53 @@ def join_surface_pieces(filenames, keep_largest_region=False):
 _keep_largest_region = keep_largest  # (join_process_surface has a parameter of that name, like the reference)
 
 
-def _directed_edges(faces):
-    f = np.asarray(faces, np.int64).reshape(-1, 3)
-    return np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
-
-
-def boundary_edges(faces):
-    """The directed edges (a -> b) of the triangles whose opposite (b -> a) belongs to no triangle: the rims of the holes
-    vtkFillHolesFilter looks for (an edge used by exactly one polygon)."""
-    e = _directed_edges(faces)
-    if not len(e):
-        return e
-    n = int(e.max()) + 1
-    fwd, bwd = e[:, 0] * n + e[:, 1], e[:, 1] * n + e[:, 0]
-    return e[~np.isin(fwd, bwd)]
-
-
-def boundary_loops(be):
-    """The directed boundary edges ordered into simple closed loops, every edge consumed exactly once.  A vertex where two
-    rims touch (a pinch point) has two outgoing rim edges: the walk keeps a list of successors per vertex and closes a loop
-    the moment it returns to a vertex of its own path, so pinched rims come out as separate simple loops instead of one
-    merged or truncated one.  Edges that cannot be ordered into a loop (open chains of a non-manifold rim) are left alone,
-    as VTK leaves what it cannot order."""
-    succ = {}
-    for a, b in np.asarray(be).reshape(-1, 2).tolist():
-        succ.setdefault(a, []).append(b)
-    loops = []
-    for start in list(succ):
-        while succ[start]:
-            path, pos = [start], {start: 0}
-            while path:
-                cur = path[-1]
-                out = succ.get(cur)
-                if not out:  # dead end: the edge that led here belongs to no loop
-                    del pos[path.pop()]
-                    continue
-                nx = out.pop()
-                i = pos.get(nx)
-                if i is None:
-                    pos[nx] = len(path)
-                    path.append(nx)
-                    continue
-                if len(path) - i >= 3:
-                    loops.append(path[i:])
-                for u in path[i + 1:]:
-                    del pos[u]
-                del path[i + 1:]
-                if i == 0 and not succ[start]:
-                    break
-    return loops
-
-
 def fill_holes(verts, faces, hole_size=300.0):
     """The hole-filling step of join_process_surface (vtkFillHolesFilter with SetHoleSize(300),
-    invesalius/data/surface_process.py:396-416): every closed loop of boundary edges whose bounding sphere (half the
-    diagonal of the loop's bounding box) has a radius <= `hole_size` is closed with new triangles, appended after the old
-    ones and wound so that the patch continues the surface's orientation.  VTK triangulates the loop's polygon without
-    new points; here the loop is fanned from its centroid (ONE new point per hole), which closes any loop -- planar or not,
-    convex or not -- without a geometric predicate.  PARITY UNPINNED: VTK is third party and not installed; what the tests
-    pin is that the result is closed, consistently oriented and that its volume is the open surface's plus the caps'.
-    Returns (verts, faces, number of holes filled)."""
+    invesalius/data/surface_process.py:396-416) on the GPU (csrc/k_meshtail.hip): every closed rim of boundary edges whose
+    bounding sphere (half the diagonal of the rim's bounding box) has a radius <= `hole_size` is closed with new triangles,
+    appended after the old ones and wound so that the patch continues the surface's orientation.  VTK triangulates the rim's
+    polygon without new points; here the rim is fanned from its centroid (ONE new point per hole), which closes any rim --
+    planar or not, convex or not -- without a geometric predicate.  Rims that touch in one vertex (pinch points) are walked
+    apart, open chains of a non-manifold rim are left alone.  PARITY UNPINNED: VTK is third party and not installed; the tests
+    pin that the result is closed and consistently oriented, and compare the kernels array for array with the same rules in
+    plain Python (tests/_mesh_tail_ref.py).  Returns (verts, faces, number of holes filled)."""
     v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
-    f = np.asarray(faces, np.int32).reshape(-1, 3)
-    be = boundary_edges(f)
-    if not len(be):
+    f = np.ascontiguousarray(np.asarray(faces, np.int32).reshape(-1, 3))
+    nv, nt = ctypes.c_int64(0), ctypes.c_int64(0)
+    lib = L.lib()
+    L.check(lib.ivx_mesh_fill_holes(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), ctypes.c_double(float(hole_size)),
+                                    None, None, ctypes.byref(nv), ctypes.byref(nt)), "mesh_fill_holes")
+    if nv.value == 0:
         return v, f, 0
-    new_v, new_f, holes = [], [], 0
-    for loop in boundary_loops(be):
-        pts = v[loop].astype(np.float64)
-        if 0.5 * float(np.linalg.norm(pts.max(0) - pts.min(0))) > hole_size:
-            continue
-        c = len(v) + len(new_v)
-        new_v.append(pts.mean(0).astype(np.float32))
-        a = np.asarray(loop, np.int64)
-        b = np.roll(a, -1)
-        new_f.append(np.stack([b, a, np.full(len(a), c)], axis=1))  # the rim edge a -> b is walked b -> a by its cap triangle
-        holes += 1
-    if not holes:
-        return v, f, 0
-    return (np.concatenate([v, np.stack(new_v)]).astype(np.float32),
-            np.concatenate([f, np.concatenate(new_f).astype(np.int32)]), holes)
+    new_v, new_f = np.empty((nv.value, 3), np.float32), np.empty((nt.value, 3), np.int32)
+    L.check(lib.ivx_mesh_fill_holes(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), ctypes.c_double(float(hole_size)),
+                                    L.ptr(new_v), L.ptr(new_f), ctypes.byref(nv), ctypes.byref(nt)), "mesh_fill_holes")
+    return np.concatenate([v, new_v]), np.concatenate([f, new_f]), int(nv.value)
 
 
 def point_normals(verts, faces, feature_angle=80.0, splitting=True, auto_orient=True):
     """The last filter of join_process_surface (vtkPolyDataNormals: FeatureAngle 80, SplittingOn, AutoOrientNormalsOn,
-    ComputeCellNormalsOn, invesalius/data/surface_process.py:420-435): unit cell normals; points on an edge sharper than
-    the feature angle are duplicated, one copy per fan of triangles joined by smooth edges (the first fan keeps the point,
-    the copies follow the old points); a point's normal is the normalised sum of its fan's unit cell normals; with
-    auto-orientation the (consistently wound) surface is turned so that its normals point out of the enclosed volume.
-    PARITY UNPINNED (VTK absent): pinned here by properties -- unit length, no copy without a sharp edge, a cube gets
-    24 points, a smooth sphere none extra, normals of a closed surface point outwards.
+    ComputeCellNormalsOn, invesalius/data/surface_process.py:420-435) on the GPU (csrc/k_meshtail.hip): unit cell normals;
+    points on an edge sharper than the feature angle are duplicated, one copy per fan of triangles joined by smooth edges (the
+    fan of the vertex's smallest corner keeps the point, the copies follow the old points in (vertex, fan) order); a point's
+    normal is the normalised sum of its fan's unit cell normals; with auto-orientation the (consistently wound) surface is
+    turned so that its normals point out of the enclosed volume.  PARITY UNPINNED (VTK absent): pinned by properties -- unit
+    length, no copy without a sharp edge, a cube gets 24 points, a smooth sphere none extra, normals of a closed surface point
+    outwards -- and array for array against the same rules in plain Python (tests/_mesh_tail_ref.py).
     Returns (verts, faces, point normals float32, cell normals float32)."""
     v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
-    f = np.asarray(faces, np.int64).reshape(-1, 3)
+    f = np.ascontiguousarray(np.asarray(faces, np.int32).reshape(-1, 3))
     if not len(f):
-        return v, f.astype(np.int32), np.zeros((len(v), 3), np.float32), np.zeros((0, 3), np.float32)
-    p = v.astype(np.float64)
-    if auto_orient:
-        a, b, c = p[f[:, 0]], p[f[:, 1]], p[f[:, 2]]
-        if float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum()) < 0.0:  # signed volume: inside out
-            f = f[:, ::-1].copy()
-    cn = np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]])
-    ln = np.linalg.norm(cn, axis=1, keepdims=True)
-    cn = np.divide(cn, ln, out=np.zeros_like(cn), where=ln > 0)
-    nf, nv = len(f), len(v)
-    corner_v = f.reshape(-1)                      # corner 3 * face + k sits at vertex f[face, k]
-    label = np.arange(3 * nf, dtype=np.int64)     # fan of a corner = smallest corner id it is joined to
-    if splitting:
-        # the two triangles of an interior edge: (a -> b) in one, (b -> a) in the other
-        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
-        face_of = np.tile(np.arange(nf, dtype=np.int64), 3)
-        ca = np.concatenate([3 * np.arange(nf) + 0, 3 * np.arange(nf) + 1, 3 * np.arange(nf) + 2])  # corner at the edge's START
-        cb = np.concatenate([3 * np.arange(nf) + 1, 3 * np.arange(nf) + 2, 3 * np.arange(nf) + 0])  # corner at its END
-        key = e[:, 0] * nv + e[:, 1]
-        okey = e[:, 1] * nv + e[:, 0]
-        order = np.argsort(key, kind="stable")
-        pos = np.searchsorted(key[order], okey)
-        pos[pos >= len(key)] = 0
-        mate = order[pos]
-        has = key[mate] == okey
-        smooth = has & (np.einsum("ij,ij->i", cn[face_of], cn[face_of[mate]]) > np.cos(np.deg2rad(feature_angle)))
-        i1, i2 = np.nonzero(smooth)[0], mate[smooth]
-        # the edge's start corner here meets the mate's END corner (same vertex), its end corner the mate's START corner
-        pa = np.concatenate([ca[i1], cb[i1]])
-        pb = np.concatenate([cb[i2], ca[i2]])
-        for _ in range(64):
-            m = np.minimum(label[pa], label[pb])
-            changed = (m < label[pa]).any() or (m < label[pb]).any()
-            np.minimum.at(label, pa, m)
-            np.minimum.at(label, pb, m)
-            label = label[label]
-            if not changed:
-                break
-    else:
-        first = np.full(nv, 3 * nf, np.int64)
-        np.minimum.at(first, corner_v, np.arange(3 * nf))
-        label = first[corner_v]
-    # one point per (vertex, fan): the fan with the smallest label keeps the vertex, the others are appended
-    pair = corner_v * (3 * nf + 1) + label
-    upair, inv = np.unique(pair, return_inverse=True)
-    uv = upair // (3 * nf + 1)
-    first_of_v = np.r_[True, uv[1:] != uv[:-1]]
-    new_id = np.empty(len(upair), np.int64)
-    new_id[first_of_v] = uv[first_of_v]
-    extra = ~first_of_v
-    new_id[extra] = nv + np.arange(int(extra.sum()))
-    out_v = np.concatenate([v, v[uv[extra]]]) if extra.any() else v
-    out_f = new_id[inv].reshape(-1, 3)
-    pn = np.zeros((len(out_v), 3), np.float64)
-    np.add.at(pn, out_f.reshape(-1), np.repeat(cn, 3, axis=0))
-    l2 = np.linalg.norm(pn, axis=1, keepdims=True)
-    pn = np.divide(pn, l2, out=np.zeros_like(pn), where=l2 > 0)
-    return out_v.astype(np.float32), out_f.astype(np.int32), pn.astype(np.float32), cn.astype(np.float32)
+        return v, f, np.zeros((len(v), 3), np.float32), np.zeros((0, 3), np.float32)
+    lib = L.lib()
+    cosang = ctypes.c_double(float(np.cos(np.deg2rad(feature_angle))))
+    n = ctypes.c_int64(0)
+    args = (L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), cosang, int(bool(splitting)), int(bool(auto_orient)))
+    L.check(lib.ivx_mesh_point_normals(*args, None, None, None, None, ctypes.byref(n)), "mesh_point_normals")
+    out_v, out_f = np.empty((n.value, 3), np.float32), np.empty((len(f), 3), np.int32)
+    pn, cn = np.empty((n.value, 3), np.float32), np.empty((len(f), 3), np.float32)
+    L.check(lib.ivx_mesh_point_normals(*args, L.ptr(out_v), L.ptr(out_f), L.ptr(pn), L.ptr(cn), ctypes.byref(n)), "mesh_point_normals")
+    return out_v, out_f, pn, cn
 
 
 def join_process_surface(filenames, algorithm, smooth_iterations, smooth_relaxation_factor, decimate_reduction, keep_largest,

@@ -209,80 +209,6 @@ def test_get_image_slice_plain_slices_and_the_missing_lmip_export():
         sl.get_image_slice(a, "OBLIQUE", 0)
 
 
-def _sphere(levels=3, inside_out=False):
-    """an octahedron subdivided `levels` times onto the unit sphere: closed, outward wound, all dihedral angles small"""
-    v = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
-    f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
-    v = [np.array(p, np.float64) for p in v]
-    for _ in range(levels):
-        mid, nf = {}, []
-
-        def m(a, b):
-            k = (min(a, b), max(a, b))
-            if k not in mid:
-                p = v[a] + v[b]
-                v.append(p / np.linalg.norm(p))
-                mid[k] = len(v) - 1
-            return mid[k]
-        for a, b, c in f:
-            ab, bc, ca = m(a, b), m(b, c), m(c, a)
-            nf += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
-        f = nf
-    f = np.array(f, np.int32)
-    return np.array(v, np.float32), (f[:, ::-1].copy() if inside_out else f)
-
-
-def test_point_normals_split_at_feature_edges_and_point_outwards():
-    """the vtkPolyDataNormals step of join_process_surface (surface_process.py:420-435), pinned by properties (VTK absent)"""
-    from invesalius3_amd import surface_process as sp
-    cube_v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
-    cube_f = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6],
-                       [3, 0, 4], [3, 4, 7]], np.int32)
-    v, f, pn, cn = sp.point_normals(cube_v, cube_f)
-    assert len(v) == 24 and len(f) == 12 and pn.dtype == np.float32        # every corner is three points, one per face
-    assert np.allclose(np.linalg.norm(pn, axis=1), 1.0) and np.allclose(np.linalg.norm(cn, axis=1), 1.0)
-    assert np.array_equal(v[f].reshape(-1, 3), cube_v[cube_f].reshape(-1, 3))  # same triangles in space
-    assert np.allclose(pn[f[:, 0]], cn) and np.allclose(pn[f[:, 2]], cn)       # a face's points carry the face normal
-    centre = v[f].mean(axis=(0, 1))
-    assert (np.einsum("ij,ij->i", cn, v[f].mean(axis=1) - centre) > 0).all()      # outwards
-    vi, fi, pni, cni = sp.point_normals(cube_v, cube_f[:, ::-1])                  # wound inside out: turned around
-    assert (np.einsum("ij,ij->i", cni, vi[fi].mean(axis=1) - centre) > 0).all()
-    v0, f0, pn0, _ = sp.point_normals(cube_v, cube_f, splitting=False)
-    assert len(v0) == 8 and np.array_equal(f0, cube_f)
-    sv, sf = _sphere(3)
-    v, f, pn, cn = sp.point_normals(sv, sf)
-    assert len(v) == len(sv) and np.array_equal(f, sf)                         # smooth everywhere: nothing is split
-    assert np.einsum("ij,ij->i", pn, sv).min() > 0.99                          # the sphere's normals are its points
-    v, f, pn, cn = sp.point_normals(*_sphere(3, inside_out=True))
-    assert np.einsum("ij,ij->i", pn, sv).min() > 0.99
-
-
-def test_fill_holes_caps_the_rims_up_to_the_hole_size():
-    """the vtkFillHolesFilter step (surface_process.py:396-416, hole size 300), pinned by properties"""
-    from invesalius3_amd import surface_process as sp
-    sv, sf = _sphere(3)
-    assert len(sp.boundary_edges(sf)) == 0
-    v, f, n = sp.fill_holes(sv, sf)
-    assert n == 0 and v is not None and np.array_equal(f, sf)                  # closed: unchanged
-    top = sv[sf].mean(axis=1)[:, 2] > 0.8
-    open_f = sf[~top]                                                          # a cap cut off
-    rim = sp.boundary_edges(open_f)
-    assert len(rim) > 0
-    v, f, n = sp.fill_holes(sv, open_f)
-    assert n == 1 and len(v) == len(sv) + 1 and len(f) == len(open_f) + len(rim)
-    assert len(sp.boundary_edges(f)) == 0                                      # closed again, every edge twice
-    assert np.array_equal(f[:len(open_f)], open_f)                             # the new triangles follow the old ones
-    p = v.astype(np.float64)
-    signed = np.einsum("ij,ij->i", p[f[:, 0]], np.cross(p[f[:, 1]], p[f[:, 2]])).sum() / 6
-    full = np.einsum("ij,ij->i", sv[sf[:, 0]].astype(np.float64), np.cross(sv[sf[:, 1]], sv[sf[:, 2]])).sum() / 6
-    assert 0.8 * full < signed < full                                          # the flat cap cuts a little of the ball off
-    v2, f2, n2 = sp.fill_holes(sv * 1000.0, open_f)                            # the same rim, 1000x larger: above the hole size
-    assert n2 == 0 and len(f2) == len(open_f)
-    bottom = sv[sf].mean(axis=1)[:, 2] < -0.8
-    v3, f3, n3 = sp.fill_holes(sv, sf[~top & ~bottom])                         # two rims: two caps
-    assert n3 == 2 and len(sp.boundary_edges(f3)) == 0
-
-
 def test_bench_launcher_gives_every_rank_the_same_nonce_and_the_rendezvous_completes(tmp_path):
     """`python bench.py --gpus N` outside a launcher: the N rank environments must share ONE
     IVX_COMM_NONCE, otherwise ranks > 0 never accept rank 0's id file.  Runs the rendezvous itself (comm.exchange_id, no
@@ -310,29 +236,3 @@ def test_bench_launcher_gives_every_rank_the_same_nonce_and_the_rendezvous_compl
     code2 = code.replace("timeout_s=20.0", "timeout_s=0.5")
     p = subprocess.run([sys.executable, "-c", code2], env=other, capture_output=True)
     assert p.returncode != 0 and b"no RCCL id of this launch" in p.stderr
-
-
-def test_fill_holes_at_a_pinch_point_closes_both_rims():
-    """two holes that touch in ONE vertex: that vertex has two outgoing rim edges; every rim edge must be
-    consumed exactly once and no boundary edge may remain after capping"""
-    from invesalius3_amd import surface_process as sp
-    n = 6
-    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
-    verts = np.stack([ii.ravel(), jj.ravel(), np.zeros(ii.size)], axis=1).astype(np.float32)
-    vid = lambda i, j: i * (n + 1) + j
-    faces = []
-    for i in range(n):
-        for j in range(n):
-            if (i, j) in ((1, 1), (2, 2)):  # two missing cells sharing the corner (2, 2)
-                continue
-            faces += [[vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)], [vid(i, j), vid(i + 1, j + 1), vid(i, j + 1)]]
-    faces = np.asarray(faces, np.int32)
-    be = sp.boundary_edges(faces)
-    loops = sp.boundary_loops(be)
-    assert sorted(len(l) for l in loops) == [4, 4, 4 * n]             # two square rims + the sheet's outer rim, each simple
-    assert sum(len(l) for l in loops) == len(be)                       # every rim edge consumed exactly once
-    v, f, holes = sp.fill_holes(verts, faces, hole_size=1.0)           # (the outer rim is larger than the hole size)
-    assert holes == 2 and len(v) == len(verts) + 2
-    left = sp.boundary_edges(f)
-    assert len(left) == 4 * n                                          # only the outer rim stays open
-    assert not np.isin(left.ravel(), [vid(2, 2)]).any()

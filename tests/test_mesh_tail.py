@@ -1,0 +1,211 @@
+"""Hole filling and point normals of join_process_surface (invesalius/data/surface_process.py:396-435: vtkFillHolesFilter with
+hole size 300, vtkPolyDataNormals with feature angle 80 / splitting / auto-orientation).  VTK is third party and not installed:
+PARITY UNPINNED vs VTK.  Two layers of tests:
+  * the documented behaviour as PROPERTIES, on the plain-Python statement of the rules (tests/_mesh_tail_ref.py, CPU) and on the
+    HIP kernels (csrc/k_meshtail.hip through invesalius3_amd.surface_process, GPU) alike;
+  * the kernels against that statement, array for array (same points, same triangles, same float32 bits)."""
+import numpy as np
+import pytest
+
+import _mesh_tail_ref as ref
+
+
+def _sphere(levels=3, inside_out=False):
+    """an octahedron subdivided `levels` times onto the unit sphere: closed, outward wound, all dihedral angles small"""
+    v = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    v = [np.array(p, np.float64) for p in v]
+    for _ in range(levels):
+        mid, nf = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+        f = nf
+    f = np.array(f, np.int32)
+    return np.array(v, np.float32), (f[:, ::-1].copy() if inside_out else f)
+
+
+CUBE_V = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.float32)
+CUBE_F = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6],
+                   [3, 0, 4], [3, 4, 7]], np.int32)
+
+
+def _pinched_sheet(n=6):
+    """a flat sheet of n x n cells with two cells missing that share ONE corner: the vertex (2, 2) has two rims"""
+    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    verts = np.stack([ii.ravel(), jj.ravel(), np.zeros(ii.size)], axis=1).astype(np.float32)
+    vid = lambda i, j: i * (n + 1) + j
+    faces = []
+    for i in range(n):
+        for j in range(n):
+            if (i, j) in ((1, 1), (2, 2)):
+                continue
+            faces += [[vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)], [vid(i, j), vid(i + 1, j + 1), vid(i, j + 1)]]
+    return verts, np.asarray(faces, np.int32), vid(2, 2)
+
+
+def _impl(name):
+    if name == "ref":
+        return ref
+    from invesalius3_amd import surface_process as sp
+    return sp
+
+
+IMPLS = [pytest.param("ref", id="rules-in-python"), pytest.param("hip", marks=pytest.mark.gpu, id="hip-kernels")]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_point_normals_split_at_feature_edges_and_point_outwards(impl, request):
+    if impl == "hip":
+        request.getfixturevalue("ivxlib")
+    sp = _impl(impl)
+    v, f, pn, cn = sp.point_normals(CUBE_V, CUBE_F)
+    assert len(v) == 24 and len(f) == 12 and pn.dtype == np.float32        # every corner is three points, one per face
+    assert np.allclose(np.linalg.norm(pn, axis=1), 1.0) and np.allclose(np.linalg.norm(cn, axis=1), 1.0)
+    assert np.array_equal(v[f].reshape(-1, 3), CUBE_V[CUBE_F].reshape(-1, 3))  # same triangles in space
+    assert np.allclose(pn[f[:, 0]], cn) and np.allclose(pn[f[:, 2]], cn)       # a face's points carry the face normal
+    centre = v[f].mean(axis=(0, 1))
+    assert (np.einsum("ij,ij->i", cn, v[f].mean(axis=1) - centre) > 0).all()      # outwards
+    vi, fi, pni, cni = sp.point_normals(CUBE_V, CUBE_F[:, ::-1])                  # wound inside out: turned around
+    assert (np.einsum("ij,ij->i", cni, vi[fi].mean(axis=1) - centre) > 0).all()
+    v0, f0, pn0, _ = sp.point_normals(CUBE_V, CUBE_F, splitting=False)
+    assert len(v0) == 8 and np.array_equal(f0, CUBE_F)
+    sv, sf = _sphere(3)
+    v, f, pn, cn = sp.point_normals(sv, sf)
+    assert len(v) == len(sv) and np.array_equal(f, sf)                         # smooth everywhere: nothing is split
+    assert np.einsum("ij,ij->i", pn, sv).min() > 0.99                          # the sphere's normals are its points
+    v, f, pn, cn = sp.point_normals(*_sphere(3, inside_out=True))
+    assert np.einsum("ij,ij->i", pn, sv).min() > 0.99
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_fill_holes_caps_the_rims_up_to_the_hole_size(impl, request):
+    if impl == "hip":
+        request.getfixturevalue("ivxlib")
+    sp = _impl(impl)
+    sv, sf = _sphere(3)
+    assert len(ref.boundary_edges(sf)) == 0
+    v, f, n = sp.fill_holes(sv, sf)
+    assert n == 0 and v is not None and np.array_equal(f, sf)                  # closed: unchanged
+    top = sv[sf].mean(axis=1)[:, 2] > 0.8
+    open_f = sf[~top]                                                          # a cap cut off
+    rim = ref.boundary_edges(open_f)
+    assert len(rim) > 0
+    v, f, n = sp.fill_holes(sv, open_f)
+    assert n == 1 and len(v) == len(sv) + 1 and len(f) == len(open_f) + len(rim)
+    assert len(ref.boundary_edges(f)) == 0                                     # closed again, every edge twice
+    assert np.array_equal(f[:len(open_f)], open_f)                             # the new triangles follow the old ones
+    p = v.astype(np.float64)
+    signed = np.einsum("ij,ij->i", p[f[:, 0]], np.cross(p[f[:, 1]], p[f[:, 2]])).sum() / 6
+    full = np.einsum("ij,ij->i", sv[sf[:, 0]].astype(np.float64), np.cross(sv[sf[:, 1]], sv[sf[:, 2]])).sum() / 6
+    assert 0.8 * full < signed < full                                          # the flat cap cuts a little of the ball off
+    v2, f2, n2 = sp.fill_holes(sv * 1000.0, open_f)                            # the same rim, 1000x larger: above the hole size
+    assert n2 == 0 and len(f2) == len(open_f)
+    bottom = sv[sf].mean(axis=1)[:, 2] < -0.8
+    v3, f3, n3 = sp.fill_holes(sv, sf[~top & ~bottom])                         # two rims: two caps
+    assert n3 == 2 and len(ref.boundary_edges(f3)) == 0
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_fill_holes_at_a_pinch_point_closes_both_rims(impl, request):
+    """two holes that touch in ONE vertex: that vertex has two incoming and two outgoing rim edges.  The rim is
+    followed by turning about the vertex through the faces that hang together, so each of the two fans of faces wedged between
+    the holes continues its own boundary: topologically the boundary of this surface is ONE closed curve through the pinch
+    point twice (a figure of eight around both holes).  Every rim edge is consumed exactly once, and after capping no boundary
+    edge is left at the pinch."""
+    if impl == "hip":
+        request.getfixturevalue("ivxlib")
+    sp = _impl(impl)
+    n = 6
+    verts, faces, pinch = _pinched_sheet(n)
+    loops = ref.rim_loops(faces)
+    assert sorted(len(l) for l in loops) == [8, 4 * n]                        # the figure of eight + the sheet's outer rim
+    assert sum(len(l) for l in loops) == len(ref.boundary_edges(faces)) == len(set(sum(loops, [])))  # every rim edge exactly once
+    e = ref.directed_edges(faces)
+    eight = min(loops, key=len)
+    assert [int(e[i, 1]) for i in eight] == [int(e[i, 0]) for i in eight[1:] + eight[:1]]            # a closed walk, edge to edge
+    assert sum(int(e[i, 0]) == pinch for i in eight) == 2                                            # through the pinch point twice
+    v, f, holes = sp.fill_holes(verts, faces, hole_size=2.0)                  # (the outer rim is larger than the hole size)
+    assert holes == 1 and len(v) == len(verts) + 1 and len(f) == len(faces) + 8
+    left = ref.directed_edges(f)[ref.boundary_edges(f)]
+    assert len(left) == 4 * n and not np.isin(left.ravel(), [pinch]).any()    # only the outer rim stays open
+    v1, f1, holes1 = sp.fill_holes(verts, faces, hole_size=1.0)               # the figure of eight's bounding sphere: radius 1.41
+    assert holes1 == 0 and np.array_equal(f1, faces)
+
+
+def _mc_surface(shape, seed, closed):
+    """an indexed marching-cubes surface of a noisy phantom: thousands of triangles, open at the volume's faces when the
+    border holes are not filled"""
+    from conftest import synth_volume
+    from invesalius3_amd import surface_process as sp
+    img = synth_volume(shape, seed=seed)
+    mask = np.zeros(tuple(s + 1 for s in shape), np.uint8)
+    mask[1:, 1:, 1:] = np.where((img >= 226) & (img <= 3071), 255, 0)
+    v, f, _ = sp.join_process_volume(None, mask, (1.0, 0.9, 1.3), 0, 0, True, fill_border_holes=closed)
+    return v, f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sphere-caps", "pinch", "cube", "mc-open", "mc-closed", "inside-out", "non-manifold"])
+def test_kernels_equal_the_rules_array_for_array(ivxlib, case):
+    from invesalius3_amd import surface_process as sp
+    rng = np.random.default_rng(3)
+    if case == "sphere-caps":
+        sv, sf = _sphere(4)
+        c = sv[sf].mean(axis=1)
+        v, f = sv * np.float32(40.0), sf[(c[:, 2] < 0.8) & (c[:, 2] > -0.7) & ~((c[:, 0] > 0.9))]  # three rims of different sizes
+        hole = 25.0                                                                                   # ... one of them too large
+    elif case == "pinch":
+        v, f, _ = _pinched_sheet(7)
+        hole = 2.0
+    elif case == "cube":
+        v, f, hole = CUBE_V, CUBE_F[:-2], 300.0                                                      # one face missing
+    elif case == "mc-open":
+        v, f = _mc_surface((24, 40, 48), 11, closed=False)
+        hole = 12.0
+    elif case == "mc-closed":
+        v, f = _mc_surface((20, 32, 40), 12, closed=True)
+        hole = 300.0
+    elif case == "inside-out":
+        v, f = _sphere(3, inside_out=True)
+        f = f[5:]
+        hole = 300.0
+    else:  # three triangles on one edge, a repeated triangle and a degenerate one: nothing may hang or differ
+        v = rng.normal(0, 1, (12, 3)).astype(np.float32)
+        f = np.array([[0, 1, 2], [1, 0, 3], [0, 1, 4], [0, 1, 2], [5, 5, 6], [7, 8, 9], [8, 7, 10], [9, 8, 10]], np.int32)
+        hole = 300.0
+    gv, gf, gn = sp.fill_holes(v, f, hole)
+    rv, rf, rn = ref.fill_holes(v, f, hole)
+    assert gn == rn and np.array_equal(gf, rf) and np.array_equal(gv.view(np.uint32), rv.view(np.uint32)), case
+    for splitting in (True, False):
+        for angle in (80.0, 30.0):
+            g = sp.point_normals(gv, gf, angle, splitting, True)
+            r = ref.point_normals(rv, rf, angle, splitting, True)
+            assert np.array_equal(g[1], r[1]), (case, splitting, angle, "faces")
+            for k in (0, 2, 3):
+                assert g[k].shape == r[k].shape and np.array_equal(g[k].view(np.uint32), r[k].view(np.uint32)), (case, splitting, angle, k)
+
+
+@pytest.mark.gpu
+def test_join_process_surface_tail_on_a_large_open_surface(ivxlib):
+    """the two filters on a surface of ~10^5 triangles with hundreds of rims (a thresholded phantom without border filling):
+    every rim up to the hole size is closed, the new triangles continue the orientation, the split points carry unit normals"""
+    from invesalius3_amd import surface_process as sp
+    v, f = _mc_surface((48, 96, 96), 21, closed=False)
+    assert len(f) > 50000
+    fv, ff, holes = sp.fill_holes(v, f, 300.0)
+    assert holes > 0 and len(ref.boundary_edges(ff)) < len(ref.boundary_edges(f))
+    loops_left = ref.rim_loops(ff)
+    assert not loops_left                                                      # every closed rim was within the hole size here
+    nv, nf, pn, cn = sp.point_normals(fv, ff)
+    assert np.array_equal(nv[nf].reshape(-1, 3), fv[ff].reshape(-1, 3)) or np.array_equal(nv[nf[:, ::-1]].reshape(-1, 3), fv[ff].reshape(-1, 3))
+    used = np.unique(nf)
+    assert np.allclose(np.linalg.norm(pn[used], axis=1), 1.0, atol=1e-5)
