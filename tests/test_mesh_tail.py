@@ -196,11 +196,11 @@ def test_kernels_equal_the_rules_array_for_array(ivxlib, case):
 
 @pytest.mark.gpu
 def test_join_process_surface_tail_on_a_large_open_surface(ivxlib):
-    """the two filters on a surface of ~10^5 triangles with hundreds of rims (a thresholded phantom without border filling):
+    """the two filters on a surface of > 10^5 triangles with many rims (a thresholded phantom without border filling):
     every rim up to the hole size is closed, the new triangles continue the orientation, the split points carry unit normals"""
     from invesalius3_amd import surface_process as sp
-    v, f = _mc_surface((48, 96, 96), 21, closed=False)
-    assert len(f) > 50000
+    v, f = _mc_surface((96, 160, 160), 21, closed=False)
+    assert len(f) > 100000
     fv, ff, holes = sp.fill_holes(v, f, 300.0)
     assert holes > 0 and len(ref.boundary_edges(ff)) < len(ref.boundary_edges(f))
     loops_left = ref.rim_loops(ff)
