@@ -379,12 +379,10 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     // ---- 2. entries and zones ------------------------------------------------------------------------------
     WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_entries<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.comp, b.pmask, b.zmask));
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ws_runs, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp, (int)((g.smask >> 12) & 1u));
-    IVX_LAUNCH_CHECK();
-    WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_union<CC>, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp));
-    IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ws_flatten, dim3(gl), dim3(256), 0, st, g.n, b.comp);
-    IVX_LAUNCH_CHECK();
+    {
+        const int rc = ws_zone_union(g, conn, b.zmask, b.comp, st);
+        if (rc != IVX_OK) return rc;
+    }
 
     tm.mark(st);
     // ---- 3. entries by level -------------------------------------------------------------------------------

@@ -966,12 +966,10 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind, b.comp,
                                               b.zmask, b.pmask));
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ws_runs, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp, (int)((g.smask >> 12) & 1u));
-    IVX_LAUNCH_CHECK();
-    WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_union<CC>, dim3(gl), dim3(256), 0, st, g, b.zmask, b.comp));
-    IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ws_flatten, dim3(gl), dim3(256), 0, st, g.n, b.comp);
-    IVX_LAUNCH_CHECK();
+    {
+        const int rc = ws_zone_union(g, conn, b.zmask, b.comp, st);
+        if (rc != IVX_OK) return rc;
+    }
     IVX_HIP(hipMemsetAsync(b.hist, 0, 65536 * 4, st));
     IVX_HIP(hipMemsetAsync(b.dhist, 0, 65536 * 4, st));
     const unsigned gbk = (unsigned)cdiv(g.n, 256 * BK_CH);

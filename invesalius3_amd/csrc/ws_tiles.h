@@ -567,12 +567,149 @@ __global__ __launch_bounds__(256) void k_ws_union(WsGeom g, const uint32_t *__re
     }
 }
 
+// ---- the same union-find, tile-local first (round 4) -------------------------------------------------------------------
+// (measured, no gain -- see ws_zone_union.)  k_ws_union hooks every forward link of every voxel through
+// global atomics (4.3 ms at 512^3, 28 ms at 1024^3).  Here a workgroup first closes a 64 x 8 x 8 block of voxels in LDS -- the
+// same min-index hooking on a 4 096-entry local table -- and writes every member's local root (the block-local minimum, which
+// is also the smallest linear index of its local set); a second launch then hooks only the links that LEAVE a block
+// (1/64 of the x-links, 1/8 of the y- and z-links, and scipy's row / plane wrap-around links) through the global table.
+// Final roots are the sets' minima either way: comp[] after k_ws_flatten is identical to the one-level version's.
+constexpr int UX = 64, UY = 8, UZ = 8, UN = UX * UY * UZ;
+__device__ __forceinline__ uint32_t ws_lfind(uint32_t *lp, uint32_t a) {
+    uint32_t r = __hip_atomic_load(&lp[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (r != a) {
+        a = r;
+        r = __hip_atomic_load(&lp[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return a;
+}
+__device__ __forceinline__ void ws_lunite(uint32_t *lp, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = ws_lfind(lp, a);
+        b = ws_lfind(lp, b);
+        if (a == b) return;
+        if (a > b) { const uint32_t t = a; a = b; b = t; }
+        const uint32_t old = atomicMin(&lp[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+// does the forward link k (14 .. 26) of the voxel at block-local (lx, ly, lz) / global (x, y, z) stay inside its block (and
+// inside the volume as a LATTICE neighbour)?  Everything else -- links into another block, scipy's wrap-around neighbours --
+// belongs to the second launch.  Both launches call this, so every link is taken exactly once.
+__device__ __forceinline__ bool ws_link_is_local(const WsGeom &g, int k, int lx, int ly, int lz, int64_t x, int64_t y, int64_t z, int &lj) {
+    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+    const int lx2 = lx + dx, ly2 = ly + dy, lz2 = lz + dz;
+    if (lx2 < 0 || lx2 >= UX || ly2 < 0 || ly2 >= UY || lz2 < 0 || lz2 >= UZ) return false;
+    if (x + dx >= g.w || y + dy >= g.h || z + dz >= g.d) return false;
+    lj = (lz2 * UY + ly2) * UX + lx2;
+    return true;
+}
+__global__ __launch_bounds__(256) void k_ws_union_local(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp) {
+    __shared__ uint32_t lp[UN];
+    const int nux = (int)((g.w + UX - 1) / UX), nuy = (int)((g.h + UY - 1) / UY);
+    const int64_t t = blockIdx.x;
+    const int tx = (int)(t % nux);
+    const int64_t r0 = t / nux;
+    const int64_t x0 = (int64_t)tx * UX, y0 = (r0 % nuy) * UY, z0 = (r0 / nuy) * UZ;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t x = x0 + lane;
+    constexpr int PER = UY * UZ / 4; // rows per wave
+    uint32_t zm[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int r = wv * PER + i, ly = r % UY, lz = r / UY;
+        const int64_t y = y0 + ly, z = z0 + lz;
+        const uint32_t li = (uint32_t)(r * UX + lane);
+        uint32_t m = 0;
+        bool member = false;
+        if (x < g.w && y < g.h && z < g.d) {
+            const int64_t p = z * g.hw + y * g.w + x;
+            member = comp[p] != ENTRY;
+            if (member) m = (zmask[p] >> 14) | 0x80000000u; // (bit 31: "member", forward links in bits 0 .. 12)
+        }
+        lp[li] = member ? li : NONE;
+        zm[i] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        uint32_t m = zm[i] & 0x1FFFu;
+        if (!m) continue;
+        const int r = wv * PER + i, ly = r % UY, lz = r / UY;
+        const uint32_t li = (uint32_t)(r * UX + lane);
+        while (m) {
+            const int k = 14 + __ffs(m) - 1;
+            m &= m - 1;
+            int lj;
+            if (!ws_link_is_local(g, k, lane, ly, lz, x, y0 + ly, z0 + lz, lj)) continue;
+            if (__hip_atomic_load(&lp[lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == NONE) continue;
+            ws_lunite(lp, li, (uint32_t)lj);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        if (!(zm[i] >> 31)) continue;
+        const int r = wv * PER + i, ly = r % UY, lz = r / UY;
+        const uint32_t root = ws_lfind(lp, (uint32_t)(r * UX + lane));
+        const int rx = (int)(root % UX), rr = (int)(root / UX), ry = rr % UY, rz = rr / UY;
+        comp[(z0 + lz) * g.hw + (y0 + ly) * g.w + x] = (uint32_t)((z0 + rz) * g.hw + (y0 + ry) * g.w + x0 + rx);
+    }
+}
+__global__ __launch_bounds__(256) void k_ws_union_cross(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp) {
+    const int64_t p64 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p64 >= g.n) return;
+    const uint32_t p = (uint32_t)p64;
+    if (__hip_atomic_load(&comp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) return;
+    uint32_t zm = (zmask[p] >> 14) & 0x1FFFu;
+    if (!zm) return;
+    const uint32_t w = (uint32_t)g.w, hw = (uint32_t)g.hw; // (n < 2^32: 32-bit divisions)
+    const uint32_t z = p / hw, rem = p - z * hw, y = rem / w, x = rem - y * w;
+    const int lx = (int)(x % UX), ly = (int)(y % UY), lz = (int)(z % UZ);
+    while (zm) {
+        const int k = 14 + __ffs(zm) - 1;
+        zm &= zm - 1;
+        int lj;
+        if (ws_link_is_local(g, k, lx, ly, lz, (int64_t)x, (int64_t)y, (int64_t)z, lj)) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const int64_t q = (int64_t)p + dz * g.hw + dy * g.w + dx;
+        if (__hip_atomic_load(&comp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) continue;
+        ws_unite(comp, p, (uint32_t)q);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ws_flatten(int64_t n, uint32_t *comp) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t c = comp[p];
     if (c == ENTRY || c == (uint32_t)p) return;
     comp[p] = ws_find(comp, c);
+}
+
+// zones / basins: comp[] from "ENTRY or self" to "ENTRY or the smallest index of the voxel's set"
+static int ws_zone_union(const WsGeom &g, int conn, const uint32_t *zmask, uint32_t *comp, hipStream_t st) {
+    // measured (profiles/r04_ws_union_ab.txt): block-local phase 1.85 ms + cross links 3.11 ms + flatten 0.73 ms against x-runs 0.55 +
+    // one-level hooks 4.24 + flatten 0.86 ms at 512^3 -- the same 5.7 ms.  The 27 % of the links that leave a block are the ones
+    // whose two ends lie on different cache lines (+y / +z neighbours), i.e. they were the cost all along; the links a block
+    // closes in LDS shared lines anyway.  Same bits, same time: the one-level path stays the default, IVX_WS_UNION_LOCAL=1 opts in.
+    static const bool two_level = []() { const char *e = getenv("IVX_WS_UNION_LOCAL"); return e && e[0] == '1'; }();
+    const unsigned gl = (unsigned)cdiv(g.n, 256);
+    if (two_level) {
+        const int64_t nblk = cdiv(g.w, UX) * cdiv(g.h, UY) * cdiv(g.d, UZ);
+        hipLaunchKernelGGL(k_ws_union_local, dim3((unsigned)nblk), dim3(256), 0, st, g, zmask, comp);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_ws_union_cross, dim3(gl), dim3(256), 0, st, g, zmask, comp);
+        IVX_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_ws_runs, dim3(gl), dim3(256), 0, st, g, zmask, comp, (int)((g.smask >> 12) & 1u));
+        IVX_LAUNCH_CHECK();
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_union<CC>, dim3(gl), dim3(256), 0, st, g, zmask, comp));
+        IVX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_ws_flatten, dim3(gl), dim3(256), 0, st, g.n, comp);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
 }
 
 // The cost map: rounds of dirty-tile visits until nothing changes (one host read per round through the mailbox).
