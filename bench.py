@@ -108,14 +108,15 @@ def src_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(config, stage):
+def pmc_traffic(config, stage, size=512):
     """HBM bytes per step of `stage` from the rocprofv3 --pmc passes of tools/profile_round.sh, if (and only if) the
-    committed summary was measured on exactly these sources; None otherwise (rocprofv3 cannot run inside the bench)."""
+    committed summary was measured on exactly these sources (and this size); None otherwise (rocprofv3 cannot run inside
+    the bench)."""
     try:
-        name = "pmc_traffic.json" if config == "grow_mc" else "pmc_traffic_%s.json" % config
+        name = "pmc_traffic.json" if config == "grow_mc" else "pmc_traffic_%s%s.json" % (config, "" if size == 512 else "_%d" % size)
         with open(os.path.join(ROOT, "profiles", name)) as f:
             j = json.load(f)
-        if j.get("src_sha16") != src_sha16() or j.get("config", "grow_mc") != config:
+        if j.get("src_sha16") != src_sha16() or j.get("config", "grow_mc") != config or j.get("size", 512) != size:
             return None
         return j["traffic_bytes_per_step"].get(stage)
     except (OSError, ValueError, KeyError):
@@ -658,7 +659,7 @@ def run_watershed(args, job):
         "stage_ms": {k: round(v, 3) for k, v in spans.items()},
         "flood": {k: int(v) for k, v in zip(names, stats)},
         "object_voxels": obj,
-        "roofline": roofline("watershed flood (k_ws_*)", 7.0 * nvox, flood_ms, pmc_traffic("watershed", "flood") if n == 512 else None, None,
+        "roofline": roofline("watershed flood (k_ws_*)", 7.0 * nvox, flood_ms, pmc_traffic("watershed", "flood", n), None,
                              {"note": "7 B/voxel = cost 2 + markers 2 read, labels 2 + mask 1 written (SURVEY.md 8d); the flood is a "
                                       "multi-pass algorithm (relaxation rounds + zones + level chain), so the fraction is small by design"}),
         "device": L.device_name(),
@@ -766,7 +767,7 @@ def run_watershed_sk(args, job):
         "flood": {k: int(v) for k, v in zip(names, stats) if k != "_"},
         "object_voxels": obj,
         "roofline": roofline("watershed flood (k_ws_relax + k_sk_*)", 7.0 * nvox, flood_ms,
-                             pmc_traffic("watershed_sk", "flood") if n == 512 and use_ww_wl else None, None,
+                             pmc_traffic("watershed_sk", "flood", n) if use_ww_wl else None, None,
                              {"note": "7 B/voxel = image 2 + markers 2 read, labels 2 + mask 1 written (SURVEY.md 8d; + 4 B/voxel for "
                                       "the gradient pass, timed apart); the flood is a level-ordered breadth-first search whose serial "
                                       "depth (generations) bounds it, not the bytes"}),

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
         s_ec[tid] = ax | (bx << 2) | (by << 3) | (bz << 4);
     }
     const bool live = T_ < ntris;
-    const uint64_t d = live ? list[T_] : 0ull;
+    const uint64_t d = live ? list[T_] : 0ull; // (a non-temporal load here measured the same)
     __syncthreads();
     if (live) {
         const int b = (int)(d >> 11) & 63, idx = (int)(d >> 3) & 255, rel = (int)d & 7;
@@ -615,9 +615,11 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
         typedef float float4_t __attribute__((ext_vector_type(4)));
         float4_t *d4 = (float4_t *)dst;
         const float4_t *s4 = (const float4_t *)s_out;
-        d4[tid] = s4[tid];
-        d4[tid + 256] = s4[tid + 256];
-        if (tid < 64) d4[tid + 512] = s4[tid + 512];
+        // non-temporal: the soup is written once and never read by the pipeline -- keeping it out of the L2 leaves the cache to the
+        // list and the planes (k_mc_list + k_mc_emit 120 -> 105 us on the bench surface, step 0.440 -> 0.419 ms)
+        __builtin_nontemporal_store(s4[tid], &d4[tid]);
+        __builtin_nontemporal_store(s4[tid + 256], &d4[tid + 256]);
+        if (tid < 64) __builtin_nontemporal_store(s4[tid + 512], &d4[tid + 512]);
     } else {
         for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
     }

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_threshold16_bits(const short8_t *__rest
             m |= (in0 ? 1u : 0u) << i;
             m |= (in1 ? 1u : 0u) << (8 + i);
         }
-        mask[c] = r;
+        mask[c] = r; // (a non-temporal store measured slower for the step: mask[reached] = 254 reads these bytes back)
         bits[c] = (uint16_t)m;
     }
 }

@@ -9,8 +9,12 @@ cp $O/kt_kernel_stats.csv $P/${R}_bench_kernel_stats.csv; cp $O/kernels_pmc.md $
 f=$(find $O -name "fetch_counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_bench_pmc_fetch.csv
 f=$(find $O -name "write_counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_bench_pmc_write.csv
 cp $O/pmc_traffic.json $O/pmc_traffic_watershed.json $O/pmc_traffic_watershed_sk.json $P/
+cp $O/pmc_traffic_watershed_1024.json $O/pmc_traffic_watershed_sk_1024.json $P/ 2>/dev/null || true
+cp $O/watershed_1024_kernels_pmc.md $P/${R}_wsift_1024_kernels_pmc.md 2>/dev/null || true; cp $O/watershed_sk_1024_kernels_pmc.md $P/${R}_wssk_1024_kernels_pmc.md 2>/dev/null || true
 cp $O/watershed_kt_kernel_stats.csv $P/${R}_wsift_512_kernel_stats.csv; cp $O/watershed_kernels_pmc.md $P/${R}_wsift_512_kernels_pmc.md
 cp $O/watershed_sk_kt_kernel_stats.csv $P/${R}_wssk_512_kernel_stats.csv; cp $O/watershed_sk_kernels_pmc.md $P/${R}_wssk_512_kernels_pmc.md
 for f in bench_watershed_512 bench_watershed_sk_512 bench_watershed_1024 bench_watershed_sk_1024 bench_sharded2048_1gpu; do cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/gpu_tests.txt ] && cp $O/gpu_tests.txt $P/${R}_gpu_tests.txt
+[ -f $O/force_slab.json ] && cp $O/force_slab.json $P/${R}_force_slab.json
+for k in slab_kt mip_kt stitch_kt; do f=$(find $O -name "${k}_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_${k}_kernel_stats.csv; done
 echo "copied $O -> $P/${R}_*  (re-run 'python bench.py' afterwards for a line that quotes the new pmc_traffic.json)"

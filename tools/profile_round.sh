@@ -11,22 +11,35 @@ if [ "$2" = "--tests" ]; then
   timeout -k 5 2400 python -m pytest tests -m gpu -q -W ignore < /dev/null > $O/gpu_tests_full.txt 2>&1
   grep -E "passed|failed|error" $O/gpu_tests_full.txt | tail -3 > $O/gpu_tests.txt
 fi
-timeout -k 5 300 python bench.py < /dev/null > $O/bench.json 2> $O/bench.err
-timeout -k 5 300 python bench.py --config mip < /dev/null > $O/bench_mip.json 2> $O/bench_mip.err
-timeout -k 5 120 python bench.py --dry-comm < /dev/null > $O/dry_comm.json 2> $O/dry_comm.err
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu < /dev/null > $O/kt.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o write -- python bench.py --steps 3 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
 D=$(dirname $(find $O -name "kt_kernel_stats.csv" | head -1))
 for f in fetch_counter_collection.csv write_counter_collection.csv; do s=$(find $O -name $f | head -1); [ -n "$s" ] && [ "$(dirname $s)" != "$D" ] && cp $s $D/; done
 python tools/summarize_pmc.py $D $O/kernels_pmc.md $O/pmc_traffic.json auto < /dev/null | head -40
+cp $O/pmc_traffic.json profiles/ 2>/dev/null  # (so that the line below quotes it: same sources, same box)
+timeout -k 5 600 python bench.py < /dev/null > $O/bench.json 2> $O/bench.err
+timeout -k 5 300 python bench.py --config mip < /dev/null > $O/bench_mip.json 2> $O/bench_mip.err
+timeout -k 5 120 python bench.py --dry-comm < /dev/null > $O/dry_comm.json 2> $O/dry_comm.err
+# the sharded path's own overhead against the resident single volume: same step through SlabVolume at world 1
+IVX_FORCE_SLAB=1 timeout -k 5 300 python bench.py --no-cpu < /dev/null > $O/force_slab.json 2> $O/force_slab.err
+IVX_FORCE_SLAB=1 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o slab_kt -- python bench.py --steps 5 --warmup 1 --no-cpu < /dev/null > $O/slab_kt.log 2>&1
+# configs[4]'s kernels, and the device cost of the cross-slab stitch where it has work: 8 loop-back slabs of configs[3]'s geometry
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o mip_kt -- python bench.py --config mip --steps 5 --warmup 1 --no-cpu < /dev/null > $O/mip_kt.log 2>&1
+timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stitch_kt -- python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k eight_slabs < /dev/null > $O/stitch_kt.log 2>&1
 for c in watershed watershed_sk; do
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${c}_kt -- python bench.py --config $c --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > $O/${c}_kt.log 2>&1
   timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o ${c}_fetch -- python bench.py --config $c --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
   timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o ${c}_write -- python bench.py --config $c --size 512 --steps 2 --warmup 1 --no-cpu < /dev/null > /dev/null 2>&1
   python tools/summarize_ws_pmc.py $c $(find $O -name "${c}_fetch_counter_collection.csv" | head -1) $(find $O -name "${c}_write_counter_collection.csv" | head -1) $O/pmc_traffic_$c.json $O/${c}_kernels_pmc.md < /dev/null | tail -12
 done
-cp $O/pmc_traffic_watershed.json $O/pmc_traffic_watershed_sk.json profiles/ 2>/dev/null  # (so that the two lines below quote them)
+# ... and the same two counters at configs[2]'s stated size (one flood per pass)
+for c in watershed watershed_sk; do
+  timeout -k 5 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o ${c}_1024_fetch -- python bench.py --config $c --steps 1 --warmup 0 --no-cpu < /dev/null > /dev/null 2>&1
+  timeout -k 5 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o ${c}_1024_write -- python bench.py --config $c --steps 1 --warmup 0 --no-cpu < /dev/null > /dev/null 2>&1
+  python tools/summarize_ws_pmc.py $c $(find $O -name "${c}_1024_fetch_counter_collection.csv" | head -1) $(find $O -name "${c}_1024_write_counter_collection.csv" | head -1) $O/pmc_traffic_${c}_1024.json $O/${c}_1024_kernels_pmc.md 1024 < /dev/null | tail -4
+done
+cp $O/pmc_traffic_watershed.json $O/pmc_traffic_watershed_sk.json $O/pmc_traffic_watershed_1024.json $O/pmc_traffic_watershed_sk_1024.json profiles/ 2>/dev/null  # (so that the lines below quote them)
 timeout -k 5 400 python bench.py --config watershed --size 512 < /dev/null > $O/bench_watershed_512.json 2> $O/bench_watershed_512.err
 timeout -k 5 400 python bench.py --config watershed_sk --size 512 < /dev/null > $O/bench_watershed_sk_512.json 2> $O/bench_watershed_sk_512.err
 timeout -k 5 400 python bench.py --config watershed < /dev/null > $O/bench_watershed_1024.json 2> $O/bench_watershed.err
