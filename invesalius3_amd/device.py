@@ -214,11 +214,14 @@ class DeviceVolume:
         self._tris = None
         self._verts = None
         self._faces = None
+        self._range_buf = None
+        self._range_valid = False
         self.sync()
 
     # -- plumbing -------------------------------------------------------------------------------------
     def _image_touched(self):
         self._mbits_range = None
+        self._range_valid = False
 
     def _mask_touched(self):
         self._mbits_valid = False
@@ -764,6 +767,30 @@ class DeviceVolume:
     def project(self, axis: int, op: int, out: DeviceBuffer):
         L.check(L.lib().ivx_dev_mip_reduce(L.I16, self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(axis),
                                            int(op), out.ptr, self.stream), "project")
+
+    def image_range(self) -> DeviceBuffer:
+        """float32[2] on the device: min and max of the resident image -- mida_internal's own pre-pass over the volume
+        (mips.rs:113-121).  The reference runs it inside every call; a resident volume keeps the result until the image's
+        bytes change (any access to `image` from outside the pipeline's kernels drops it, like the bit-plane notes), the way
+        `Slice` keeps the image's histogram (slice_.py:192-194; SURVEY 8d counts the cached range as allowed).
+        `forget_image_range()` drops it by hand."""
+        if getattr(self, "_range_buf", None) is None:
+            self._range_buf = DeviceBuffer(64)
+            self._range_valid = False
+        if not self._range_valid:
+            L.check(L.lib().ivx_dev_minmax_f32(L.I16, self.image.raw, c64(self.n), self._range_buf.ptr, self.stream), "minmax")
+            self._range_valid = True
+        return self._range_buf
+
+    def forget_image_range(self):
+        self._range_valid = False
+
+    def mida(self, axis: int, wl, ww, out: DeviceBuffer, status: DeviceBuffer):
+        """mida (mips.rs:102-168) of the resident image along `axis` into `out` (int16 image of the projection's shape); the
+        volume's range comes from `image_range()`.  `status` (int32, zeroed by the caller) receives IVX_EDOM where the
+        reference's NumCast would panic."""
+        L.check(L.lib().ivx_dev_mida(L.I16, self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(axis), ctypes.c_float(float(wl)),
+                                     ctypes.c_float(float(ww)), self.image_range().ptr, L.I16, out.ptr, status.ptr, self.stream), "mida")
 
 
 def c64(v):
