@@ -274,7 +274,7 @@ class DeviceVolume:
         for b in (self.image, self.mask, self.out_mask):
             b._on_touch = None  # freeing is not "somebody looked at the contents"
         for b in (self.image, self.mask, self.out_mask, self.cand, self.reached, self._mbits, self.flood_scratch,
-                  self._mc_scratch, self._tris, self._verts, self._faces, self._gate):
+                  self._mc_scratch, self._tris, self._verts, self._faces, self._gate, getattr(self, "_range_buf", None)):
             if b is not None:
                 b.close()
         if self.stream is not None:

@@ -140,3 +140,34 @@ def test_fused_contour_maxip_equals_the_materialised_contour_volume(ivxlib, orac
             d_a.close()
             d_b.close()
     assert int(d_st.download((1,), np.int32)[0]) == 0
+
+
+def test_resident_mida_keeps_the_image_range_until_the_image_changes(ivxlib, oracle):
+    """DeviceVolume.mida takes the volume's min / max from DeviceVolume.image_range(): computed once, kept while the image's
+    bytes are the pipeline's own, dropped by any outside access to `image` (upload, .ptr) and by forget_image_range()."""
+    from invesalius3_amd.device import DeviceBuffer, DeviceVolume
+    img = synth_volume((24, 40, 64), seed=58)
+    vol = DeviceVolume(img)
+    status = DeviceBuffer(64)
+    status.zero(vol.stream)
+    for round_ in range(2):
+        for axis in range(3):
+            shp = tuple(d for i, d in enumerate(img.shape) if i != axis)
+            out = DeviceBuffer(int(np.prod(shp)) * 2 + 64)
+            vol.mida(axis, 300, 900, out, status)
+            vol.sync()
+            r = np.zeros(shp, np.int16)
+            oracle.mida(img, axis, 300, 900, r)
+            assert np.array_equal(out.download(shp, np.int16), r), (round_, axis)
+            assert vol._range_valid
+            out.close()
+        if round_ == 0:
+            img = (img // 2 + 100).astype(np.int16)   # another range
+            vol.image.upload(img)
+            assert not vol._range_valid              # an upload from outside drops the note
+    mm = vol.image_range().download((2,), np.float32)
+    assert mm[0] == img.min() and mm[1] == img.max()
+    vol.forget_image_range()
+    assert not vol._range_valid
+    assert int(status.download((1,), np.int32)[0]) == 0
+    vol.close()
