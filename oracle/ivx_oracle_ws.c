@@ -115,6 +115,10 @@ static int ws_ift_impl(int idt, const void *input, const int64_t shape[3], int m
                     }
                     if (p->next || p->prev) {
                         ws_el *prev = p->prev, *next = p->next;
+                        /* the splice goes wrong exactly when p's recorded neighbours are not its neighbours in the list it
+                         * is being taken out of: a predecessor that does not point at p (ev[4]) or a successor that does not
+                         * point back at p (ev[5]) -- only possible after the defect's trigger left p in two lists at once */
+                        if (ev && flags) { if (prev && prev->next != p) ev[4]++; if (next && next->prev != p) ev[5]++; }
                         if (first[pcost] == p) first[pcost] = next;
                         if (last[pcost] == p) last[pcost] = prev;
                         if (prev) prev->next = next;
@@ -162,7 +166,7 @@ int orc_watershed_ift_events(int idt, const void *input, const int64_t shape[3],
 
 /* The same, plus WHERE: per-voxel event flags and per-level counters (tools/ift_defect_confinement.py). */
 int orc_watershed_ift_trace(int idt, const void *input, const int64_t shape[3], int mdt, const void *markers,
-                            const uint8_t *strct, void *output, int64_t ev[4], uint8_t *flags, int64_t *lvl) {
-    ev[0] = ev[1] = ev[2] = ev[3] = 0;
+                            const uint8_t *strct, void *output, int64_t ev[6], uint8_t *flags, int64_t *lvl) {
+    ev[0] = ev[1] = ev[2] = ev[3] = ev[4] = ev[5] = 0;
     return ws_ift_impl(idt, input, shape, mdt, markers, strct, output, ev, flags, lvl);
 }

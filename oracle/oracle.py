@@ -641,10 +641,11 @@ def watershed_ift_events(image, markers, strct):
 
 def watershed_ift_trace(image, markers, strct):
     """watershed_ift_events plus WHERE: per-voxel flags (1 popped late, 2 never popped, 4 trigger, 8 popped twice) and
-    per-level counters (pops, late pops, triggers), each of length 65536."""
+    per-level counters (pops, late pops, triggers), each of length 65536.  The event tuple has two more entries: unlinks
+    that spliced through a predecessor / a successor which did not link to the voxel (the only way the defect does harm)."""
     image, markers, s3, shp = _ws_args(image, markers, strct)
     out = np.empty_like(markers)
-    ev = (ctypes.c_int64 * 4)()
+    ev = (ctypes.c_int64 * 6)()
     flags = np.zeros(image.shape, np.uint8)
     lvl = np.zeros((3, 65536), np.int64)
     _check(lib().orc_watershed_ift_trace(0 if image.dtype == np.uint8 else 3, _p(image), _i64(shp),

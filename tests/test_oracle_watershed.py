@@ -147,3 +147,34 @@ def test_cost_map_is_the_minimax_arc_cost(oracle):
     line = np.array([[0, 0, 0], [1, 1, 1], [0, 0, 0]], np.uint8)
     lab, cost = oracle.watershed_ift_clean(a, m, line, want_cost=True)
     assert list(cost.ravel()) == [0, 6, 6, 6, 12, 12] and (lab == 1).all()
+
+
+def test_trace_says_where_the_defect_acts_and_labels_never_differ_without_a_late_or_lost_pop(oracle):
+    """`watershed_ift_trace` (round 4) marks the voxels scipy's queue pops late / never / twice and counts the unlinks that
+    splice through a wrong neighbour.  On random volumes: the traced flood IS orc_watershed_ift; its labels leave the
+    defect-free statement only in runs with a late or lost pop."""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    s6, s26 = ndimage.generate_binary_structure(3, 1), ndimage.generate_binary_structure(3, 3)
+    seen_diff = seen_late = 0
+    for _ in range(400):
+        shape = tuple(int(v) for v in rng.integers(3, 12, 3))
+        img = rng.integers(0, int(rng.choice([4, 16, 64, 255])), shape).astype(np.uint8)
+        mk = np.zeros(shape, np.int8)
+        for _ in range(int(rng.integers(2, 6))):
+            mk[tuple(int(rng.integers(0, s)) for s in shape)] = int(rng.integers(1, 3))
+        st = s6 if rng.integers(2) else s26
+        out, ev, flags, lvl = oracle.watershed_ift_trace(img, mk, st)
+        assert np.array_equal(out, ndimage.watershed_ift(img, mk, st))
+        assert ev[:4] == oracle.watershed_ift_events(img, mk, st)[1]
+        assert (int(((flags & 1) != 0).sum()), int(((flags & 2) != 0).sum())) == (ev[1], ev[3])
+        assert 0 <= int(((flags & 4) != 0).sum()) <= ev[0]  # (a voxel can trigger more than once)
+        assert int(lvl[1].sum()) == ev[1] and int(lvl[2].sum()) == ev[0] and int(lvl[0].sum()) >= int((out != 0).sum()) - ev[3]
+        clean = oracle.watershed_ift_clean(img, mk, st)
+        diff = out != clean
+        if diff.any():
+            seen_diff += 1
+            assert ev[1] + ev[3] > 0  # (how FAR the difference reaches from those voxels depends on the image: whole plateaus here,
+            #                           at most five steps on the bench's noise volume -- profiles/r04_ift_defect_confinement.json)
+        seen_late += (ev[1] + ev[3]) > 0
+    assert seen_late > 50 and seen_diff > 5
