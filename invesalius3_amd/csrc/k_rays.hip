@@ -155,19 +155,35 @@ __global__ __launch_bounds__(256) void k_rays_strided(const T *__restrict__ vol,
     T cur[B], nxt[B];
 #pragma unroll
     for (int k = 0; k < B; k++) cur[k] = (k < g.len) ? p[k * g.sl] : (T)0;
-    for (int64_t l0 = 0; l0 < g.len; l0 += B) {
+    int64_t l0 = 0;
+    // whole blocks with a whole block behind them: no per-sample bounds tests, the next block's samples come off one running
+    // pointer (the 64-bit index arithmetic and compares were ~10 of the ~55 vector instructions a sample cost)
+    const T *q = p + (int64_t)B * g.sl;
+    for (; l0 + 2 * B <= g.len; l0 += B) {
 #pragma unroll
-        for (int k = 0; k < B; k++) nxt[k] = (l0 + B + k < g.len) ? p[(l0 + B + k) * g.sl] : (T)0;
-#pragma unroll
-        for (int k = 0; k < B; k++)
-        {
-            const bool active = !done && l0 + k < g.len;
-            done |= MODE == 0 ? lr.step(cur[k], active) : mr.step((float)cur[k], active);
+        for (int k = 0; k < B; k++) {
+            nxt[k] = *q;
+            q += g.sl;
         }
+#pragma unroll
+        for (int k = 0; k < B; k++) done |= MODE == 0 ? lr.step(cur[k], !done) : mr.step((float)cur[k], !done);
         if (__all(done)) break; // the whole wave's rays have terminated
 #pragma unroll
         for (int k = 0; k < B; k++) cur[k] = nxt[k];
     }
+    if (!__all(done))
+        for (; l0 < g.len; l0 += B) { // the last one or two blocks: guarded
+#pragma unroll
+            for (int k = 0; k < B; k++) nxt[k] = (l0 + B + k < g.len) ? p[(l0 + B + k) * g.sl] : (T)0;
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const bool active = !done && l0 + k < g.len;
+                done |= MODE == 0 ? lr.step(cur[k], active) : mr.step((float)cur[k], active);
+            }
+            if (__all(done)) break;
+#pragma unroll
+            for (int k = 0; k < B; k++) cur[k] = nxt[k];
+        }
     if (state_out) { // more slabs follow: hand the ray over instead of finishing it
         double *so = state_out + pix * 5;
         if (MODE == 0) {
@@ -238,8 +254,18 @@ __global__ __launch_bounds__(256) void k_rays_rows(const T *__restrict__ vol, in
         __builtin_amdgcn_wave_barrier();
         const T *mine = reinterpret_cast<const T *>(tile + lane * PITCH);
         const int n = (int)((len - c0) < CH ? (len - c0) : CH);
-#pragma unroll 8
-        for (int e = 0; e < n; e++) done |= MODE == 0 ? lr.step(mine[e], !done) : mr.step((float)mine[e], !done);
+        // eight bytes of the lane's row per LDS read (the pitch keeps every row 8-byte aligned), then the samples one by one
+        constexpr int PER = 8 / (int)sizeof(T);
+        int e = 0;
+#pragma unroll 2
+        for (; e + PER <= n; e += PER) {
+            const unsigned long long w = *reinterpret_cast<const unsigned long long *>(mine + e);
+            T v[PER];
+            memcpy(v, &w, 8);
+#pragma unroll
+            for (int u = 0; u < PER; u++) done |= MODE == 0 ? lr.step(v[u], !done) : mr.step((float)v[u], !done);
+        }
+        for (; e < n; e++) done |= MODE == 0 ? lr.step(mine[e], !done) : mr.step((float)mine[e], !done);
         __builtin_amdgcn_wave_barrier();
         if (__all(done)) break;
     }
