@@ -478,7 +478,9 @@ def run_grow_mc(args, job):
         got = {"region_voxels": reached, "triangles": ntri, "mask_crc32": mask_crc}
         ok = got == orc_out and ntri_dl == ntri
         res["parity"] = {"ok": bool(ok), "checked": "region voxels, triangle count, CRC-32 of the whole uint8 mask vs the CPU oracle "
-                         "on the same volume (oracle pinned upstream for threshold / flood fill; marching-cubes table unpinned vs VTK)",
+                         "on the same volume (oracle pinned upstream for threshold / flood fill; marching cubes: the reference's vtkContourFilter "
+                         "delegates to vtkSynchronizedTemplates3D for image data -- own templates, point-merged output -- so only the vertex "
+                         "set and closedness are pinned, the case table is the builder's own)",
                          "gpu": got, "oracle": orc_out}
         if not ok:
             print(json.dumps(res), flush=True)

@@ -633,6 +633,15 @@ int ivx_watershed_sk(int idtype /* IVX_U8 | IVX_U16 */, const void *input, const
 int ivx_do_watershed(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mdtype, const void *markers,
                      const uint8_t strct[27], int algorithm, const int gradient_size[3] /* NULL for algorithm 0 */,
                      int use_ww_wl, double window, double level, uint8_t *out_u8, int64_t stats[16]);
+/* The same, as the Python hook calls it: `markers` in the caller's own integer dtype (IVX_U8 / I8 / I16 / U16 / I32 / I64, dense or a
+ * sub-box view: byte strides) and cast on the device to `mdtype` (IVX_I16 | IVX_I8 -- watershed_process.py:39,45,52,57 do
+ * `markers.astype("int16" | "int8")` on the host, two's-complement truncation like numpy); the uint8 labels are written through
+ * `out_strides` straight into the caller's array -- the memmap of `tfile` (watershed_process.py:21,58) -- so the reference's
+ * `mask[:] = tmp_mask` second pass over the volume does not exist. */
+int ivx_do_watershed_into(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mk_src_dtype, const void *markers,
+                          const int64_t mk_strides[3], int mdtype, const uint8_t strct[27], int algorithm,
+                          const int gradient_size[3] /* NULL for algorithm 0 */, int use_ww_wl, double window, double level,
+                          uint8_t *out_u8, const int64_t out_strides[3], int64_t stats[16]);
 
 /* ------------------------------------------------------------------------------------------------
  * confidence-connected region growing support (do_rg_confidence, invesalius/data/styles.py:3220-3251):

@@ -270,7 +270,11 @@ int copy_h2d(void *dst_dev, const void *src, size_t n) {
 }
 int copy_d2h(void *dst, const void *src_dev, size_t n) {
     if (!n) return IVX_OK;
-    if (n >= STAGE_MIN && stage_lanes() > 0 && mostly_untouched(dst, n) && !host_is_pinned(dst))
+    // IVX_D2H_LANES (read per call: A/B runs flip it inside one process): 1 = every pageable destination through the lanes,
+    // 0 = never, unset = where the destination's pages are mostly not resident yet
+    const char *force = getenv("IVX_D2H_LANES");
+    const bool lanes_ok = n >= STAGE_MIN && stage_lanes() > 0 && !(force && force[0] == '0');
+    if (lanes_ok && ((force && force[0] == '1') || mostly_untouched(dst, n)) && !host_is_pinned(dst))
         return staged_copy(const_cast<void *>(src_dev), dst, n, false);
     IVX_HIP(hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));
     return IVX_OK;

@@ -1,7 +1,9 @@
 // k_mc.hip -- marching cubes over a (virtually) padded + Y-flipped piece: the geometry of
 // create_surface_piece (invesalius/data/surface_process.py:52-68,100-186; converters.py:34-101), whose
-// contouring step in the reference is vtkContourFilter (VTK 9.3, third party).  Case table: the generated
-// include/ivx_mc_tables.h shared with the CPU oracle (oracle/ivx_oracle.c orc_marching_cubes).
+// contouring step in the reference is vtkContourFilter (VTK 9.3, third party; on vtkImageData it delegates to
+// vtkSynchronizedTemplates3D: own templates table, point-merged output in its own order).  Case table here: the generated
+// include/ivx_mc_tables.h shared with the CPU oracle (oracle/ivx_oracle.c orc_marching_cubes) -- the vertex set and the
+// closedness of the surface are pinned (table-independent), per-cell triangulation and triangle order vs VTK are not.
 //
 // MI355X design (memory-bound, no MFMA):
 //   1. k_mc_bits     one streaming pass over the voxels (2 B/voxel int16, 1 B/voxel uint8; one aligned 16-B load

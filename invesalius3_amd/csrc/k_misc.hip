@@ -349,6 +349,41 @@ __global__ __launch_bounds__(256) void k_or_eq(uint8_t *__restrict__ dst, const 
         if (src[i] == (uint8_t)value) dst[i] = 1;
 }
 
+// markers.astype("int16" | "int8") (watershed_process.py:39,45,52,57) on the device: the caller's integer array goes up in its
+// own dtype and is narrowed / widened here like numpy does it (two's complement truncation), 4 voxels per lane
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void k_cast_markers(const S *__restrict__ src, D *__restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (i + q < n) dst[i + q] = (D)src[i + q];
+    }
+}
+template <typename D> static int cast_markers_to(int sdt, const void *src, D *dst, int64_t n, hipStream_t st) {
+    const dim3 gr(grid_for(n, 4)), bl(256);
+    switch (sdt) {
+    case IVX_U8: hipLaunchKernelGGL((k_cast_markers<uint8_t, D>), gr, bl, 0, st, (const uint8_t *)src, dst, n); break;
+    case IVX_I8: hipLaunchKernelGGL((k_cast_markers<int8_t, D>), gr, bl, 0, st, (const int8_t *)src, dst, n); break;
+    case IVX_I16: hipLaunchKernelGGL((k_cast_markers<int16_t, D>), gr, bl, 0, st, (const int16_t *)src, dst, n); break;
+    case IVX_U16: hipLaunchKernelGGL((k_cast_markers<uint16_t, D>), gr, bl, 0, st, (const uint16_t *)src, dst, n); break;
+    case IVX_I32: hipLaunchKernelGGL((k_cast_markers<int32_t, D>), gr, bl, 0, st, (const int32_t *)src, dst, n); break;
+    case IVX_I64: hipLaunchKernelGGL((k_cast_markers<int64_t, D>), gr, bl, 0, st, (const int64_t *)src, dst, n); break;
+    default: ivx::set_error("do_watershed: markers of dtype code %d cannot be cast on the device", sdt); return IVX_EINVAL;
+    }
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+static inline size_t marker_size(int dt) {
+    switch (dt) {
+    case IVX_U8: case IVX_I8: return 1;
+    case IVX_I16: case IVX_U16: return 2;
+    case IVX_I32: return 4;
+    case IVX_I64: return 8;
+    default: return 0;
+    }
+}
+
 } // namespace
 
 extern "C" int ivx_dev_fill_holes(uint8_t *mask, const uint32_t *labels, int64_t n, uint32_t nlabels, uint32_t max_size,
@@ -513,15 +548,21 @@ extern "C" int ivx_watershed_prepare(const int16_t *img, const int64_t shape[3],
 
 // do_watershed in one host call: the image and the markers go up once, the uint8 labels come back once; the cost /
 // gradient image and the labels in the markers' width never cross PCIe (watershed_process.py:19-60 moves them through
-// host memory between its numpy / scipy / scikit-image steps).
-extern "C" int ivx_do_watershed(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mdtype, const void *markers,
-                                const uint8_t strct[27], int algorithm, const int gradient_size[3], int use_ww_wl, double window,
-                                double level, uint8_t *out_u8, int64_t stats[16]) {
+// host memory between its numpy / scipy / scikit-image steps).  The markers travel in the CALLER's dtype (any integer
+// width, dense or a sub-box view) and are cast to `mdtype` on the device -- the host-side `markers.astype(...)` of the
+// reference is a 134 M-element pass on one core at 512^3 --, and the labels land straight in the caller's array (the memmap
+// behind `tfile`: its untouched pages are faulted in by the lane threads of copy_d2h, not by one numpy assignment).
+extern "C" int ivx_do_watershed_into(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mk_src_dtype,
+                                     const void *markers, const int64_t mk_strides[3], int mdtype, const uint8_t strct[27], int algorithm,
+                                     const int gradient_size[3], int use_ww_wl, double window, double level, uint8_t *out_u8,
+                                     const int64_t out_strides[3], int64_t stats[16]) {
     ivx::HostCallGuard host_guard__;
     using namespace ivx;
     IVX_REQUIRE(algorithm == 0 || algorithm == 1, IVX_EINVAL, "do_watershed: algorithm must be 0 (Watershed IFT) or 1 (Watershed)");
-    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "do_watershed: markers must be int16 or int8");
+    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "do_watershed: markers must be cast to int16 or int8");
     IVX_REQUIRE(algorithm == 0 || gradient_size, IVX_EINVAL, "do_watershed: the Watershed branch needs the gradient size");
+    const size_t ssz = marker_size(mk_src_dtype);
+    IVX_REQUIRE(ssz != 0, IVX_EINVAL, "do_watershed: markers must be an integer array (dtype code %d)", mk_src_dtype);
     const int64_t n = shape[0] * shape[1] * shape[2];
     if (n == 0) return IVX_OK;
     const size_t msz = mdtype == IVX_I16 ? 2 : 1;
@@ -532,7 +573,16 @@ extern "C" int ivx_do_watershed(const int16_t *img, const int64_t shape[3], cons
     if ((rc = ws_get(WS_AUX2, (size_t)n * msz, &d_mk))) return rc;
     if ((rc = ws_get(WS_OUT, (size_t)n, &d_out))) return rc;
     if ((rc = upload_strided(d_img, img, shape, strides, 2, WS_IN))) return rc;
-    IVX_HIP(hipMemcpy(d_mk, markers, (size_t)n * msz, hipMemcpyHostToDevice));
+    if (mk_src_dtype == mdtype) {
+        if ((rc = upload_strided(d_mk, markers, shape, mk_strides, msz, WS_AUX2))) return rc;
+    } else {
+        void *d_raw;
+        if ((rc = ws_get(WS_AUX3, (size_t)n * ssz, &d_raw))) return rc;
+        if ((rc = upload_strided(d_raw, markers, shape, mk_strides, ssz, WS_AUX3))) return rc;
+        rc = mdtype == IVX_I16 ? cast_markers_to<int16_t>(mk_src_dtype, d_raw, (int16_t *)d_mk, n, nullptr)
+                               : cast_markers_to<int8_t>(mk_src_dtype, d_raw, (int8_t *)d_mk, n, nullptr);
+        if (rc) return rc;
+    }
     if (use_ww_wl) {
         if ((rc = ivx_dev_lut_u16((const int16_t *)d_img, n, window, level, 0, (uint16_t *)d_a, nullptr))) return rc;
     } else {
@@ -556,8 +606,18 @@ extern "C" int ivx_do_watershed(const int16_t *img, const int64_t shape[3], cons
     }
     if (rc != IVX_OK) return rc;
     IVX_HIP(hipDeviceSynchronize());
-    IVX_HIP(hipMemcpy(out_u8, d_out, (size_t)n, hipMemcpyDeviceToHost));
-    return IVX_OK;
+    return download_strided(out_u8, shape, out_strides, d_out, 1, WS_OUT);
+}
+
+extern "C" int ivx_do_watershed(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mdtype, const void *markers,
+                                const uint8_t strct[27], int algorithm, const int gradient_size[3], int use_ww_wl, double window,
+                                double level, uint8_t *out_u8, int64_t stats[16]) {
+    IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "do_watershed: markers must be int16 or int8");
+    const int64_t msz = mdtype == IVX_I16 ? 2 : 1;
+    const int64_t mst[3] = {shape[1] * shape[2] * msz, shape[2] * msz, msz};
+    const int64_t ost[3] = {shape[1] * shape[2], shape[2], 1};
+    return ivx_do_watershed_into(img, shape, strides, mdtype, markers, mst, mdtype, strct, algorithm, gradient_size, use_ww_wl, window, level,
+                                 out_u8, ost, stats);
 }
 
 extern "C" int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mst[3], const uint8_t *tmp,

@@ -153,43 +153,93 @@ def watershed(image: np.ndarray, markers: np.ndarray, connectivity=None, want_co
     return res[0] if len(res) == 1 else res
 
 
+class IftDeviationWarning(UserWarning):
+    """``do_watershed(..., algorithm="Watershed IFT")`` ran.  The reference's flood for that branch is
+    ``scipy.ndimage.watershed_ift`` (watershed_process.py:44-46,54-57), whose C source has a linked-list defect
+    (``ni_measure.c``: ``if (p->next || p->prev)`` misses the only element of a bucket) that pops some voxels late or
+    never.  This package computes the DEFECT-FREE statement of that algorithm (oracle/ivx_oracle_wsz.c), so on realistic
+    volumes a small share of the labels differs from the reference's: 87 372 of 2^27 voxels on bench.py's 512^3 volume,
+    206 606 of 2^30 at 1024^3 (small fixtures such as the reference's own 5^3 test are identical).
+    Emitted once per process, after the labels are written and ``q`` is signalled."""
+
+
+_IFT_REFERENCE = "scipy.ndimage.watershed_ift"
+_IFT_NOTE = ("defect-free statement of scipy's NI_WatershedIFT; live scipy deviates from its own algorithm through a linked-list "
+             "defect in ni_measure.c, so labels can differ from the reference's on realistic volumes (87 372 / 2^27 voxels on "
+             "bench.py's 512^3 volume, 206 606 / 2^30 at 1024^3; DESIGN.md section 6)")
+_ift_warned = False
+
+_MK_CODES = {np.dtype(np.uint8): L.U8, np.dtype(np.int8): L.I8, np.dtype(np.int16): L.I16, np.dtype(np.uint16): L.U16,
+             np.dtype(np.int32): L.I32, np.dtype(np.int64): L.I64, np.dtype(np.bool_): L.U8}
+
+
+def _box_view(a: np.ndarray) -> bool:
+    """contiguous rows and non-negative pitches: what the strided host <-> device staging moves without a host-side pass"""
+    isz = a.itemsize
+    return a.strides[2] == isz and a.strides[1] >= a.shape[2] * isz and a.strides[0] >= a.strides[1] * a.shape[1]
+
+
 def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_ww_wl, wl, ww, q=None):
     """Same signature and side effects as watershed_process.do_watershed (:19-60): writes the uint8 label volume to
-    the memmap `tfile` and signals ``q.put(1)``.  Cost image and flood run on the GPU.  With ``algorithm ==
-    "Watershed"`` this is the raster-tie variant of scikit-image's flood (see `watershed`): the number of adjacent tied
-    markers of different labels is kept in ``do_watershed.last_stats`` and a `MarkerTieWarning` says so when it is not 0."""
+    the memmap `tfile` and signals ``q.put(1)``.  Cost image and flood run on the GPU; the markers go up in the caller's
+    dtype and are cast (``astype("int16" | "int8")``, :39,45,52,57) on the device, the labels are downloaded straight into
+    the memmap's pages (no ``tmp_mask``, no second host pass).  ``do_watershed.last_stats`` describes the run:
+
+    * ``algorithm == "Watershed"``: the raster-tie variant of scikit-image's flood (see `watershed`) -- the number of
+      adjacent tied markers of different labels, and a `MarkerTieWarning` when it is not 0;
+    * ``algorithm == "Watershed IFT"``: ``{"reference": "scipy.ndimage.watershed_ift", "exact": False, "note": ...}`` and,
+      once per process, an `IftDeviationWarning` -- the labels are those of scipy's documented algorithm, not of its
+      defective linked list.
+
+    Either warning comes after ``q.put(1)``."""
+    global _ift_warned
     mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")
     image = np.asarray(image)
     if image.dtype != np.int16 or image.ndim not in (2, 3):
         raise TypeError("image must be a 2-D or 3-D int16 array")
     sk = algorithm == "Watershed"
     # watershed_process.py:39,45,52,57: int16 markers, except for the IFT flood of the min-shifted image (int8)
-    mk = np.ascontiguousarray(np.asarray(markers).astype("int16" if (sk or use_ww_wl) else "int8"))
+    mdt = np.dtype("int16" if (sk or use_ww_wl) else "int8")
+    mk = np.asarray(markers)
     if mk.shape != image.shape:
         raise RuntimeError("input and markers must have equal shape")
     img3 = image if image.ndim == 3 else image[np.newaxis]
+    mk3 = mk if mk.ndim == 3 else mk[np.newaxis]
+    if mk3.dtype not in _MK_CODES or not _box_view(mk3):  # floats, exotic views: the host cast the reference does
+        mk3 = np.ascontiguousarray(mk3.astype(mdt))
     gs = None
     if sk:  # int -> the same size on every axis (scipy semantics); tuple -> per axis
         sz = tuple(int(v) for v in mg_size) if np.ndim(mg_size) else (int(mg_size),) * image.ndim
         if len(sz) != image.ndim:
             raise RuntimeError("size must have one entry per image axis")
         gs = (ctypes.c_int * 3)(*((1,) * (3 - len(sz)) + sz))
-    tmp_mask = np.empty(img3.shape, np.uint8)
+    # `mask[:] = tmp_mask` (:58): the labels land in the memmap itself when it has the image's shape (it always does in the
+    # reference's callers, styles.py:2102-2134); a broadcasting assignment keeps numpy's semantics through a temporary
+    direct = mask.size == img3.size and tuple(d for d in mask.shape if d != 1) == tuple(d for d in img3.shape if d != 1)
+    dst = mask.reshape(img3.shape) if direct else np.empty(img3.shape, np.uint8)
     stats = (ctypes.c_int64 * 16)()
-    # one call: image and markers up, uint8 labels back (the cost / gradient image never leaves the device)
-    L.check(L.lib().ivx_do_watershed(L.ptr(img3), L.i64(img3.shape), L.i64(img3.strides), L.I16 if mk.dtype == np.int16 else L.I8,
-                                     L.ptr(mk), L.ptr(_strct27(bstruct, image.ndim)), int(sk), gs, int(bool(use_ww_wl)),
-                                     ctypes.c_double(float(ww)), ctypes.c_double(float(wl)), L.ptr(tmp_mask), stats), "do_watershed")
-    do_watershed.last_stats = {"algorithm": algorithm, "tied_markers_of_different_labels": int(stats[6]) if sk else 0}
-    tmp_mask = tmp_mask.reshape(image.shape)
-    mask[:] = tmp_mask
+    L.check(L.lib().ivx_do_watershed_into(L.ptr(img3), L.i64(img3.shape), L.i64(img3.strides), _MK_CODES[mk3.dtype], L.ptr(mk3),
+                                          L.i64(mk3.strides), L.I16 if mdt == np.int16 else L.I8, L.ptr(_strct27(bstruct, image.ndim)),
+                                          int(sk), gs, int(bool(use_ww_wl)), ctypes.c_double(float(ww)), ctypes.c_double(float(wl)),
+                                          L.ptr(dst), L.i64(dst.strides), stats), "do_watershed")
+    if sk:
+        do_watershed.last_stats = {"algorithm": algorithm, "reference": "skimage.segmentation.watershed",
+                                   "tied_markers_of_different_labels": int(stats[6]), "exact": int(stats[6]) == 0}
+    else:
+        do_watershed.last_stats = {"algorithm": algorithm, "reference": _IFT_REFERENCE, "exact": False, "note": _IFT_NOTE,
+                                   "tied_markers_of_different_labels": 0}
+    if not direct:
+        mask[:] = dst.reshape(image.shape)
     mask.flush()
     if q is not None:
         q.put(1)
-    # the warning comes LAST: with warnings promoted to errors (-W error) the labels are written and the caller waiting on
+    # the warnings come LAST: with warnings promoted to errors (-W error) the labels are written and the caller waiting on
     # `q` (styles.py:2116-2134) has its signal before anything can raise
     if sk:
         _warn_ties(int(stats[6]), "do_watershed")
+    elif not _ift_warned:
+        _ift_warned = True
+        warnings.warn("do_watershed(algorithm='Watershed IFT'): " + _IFT_NOTE, IftDeviationWarning, stacklevel=2)
 
 
 do_watershed.last_stats = None

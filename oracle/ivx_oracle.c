@@ -14,9 +14,18 @@
  *     (tests/test_segmentation_tools.py:17-134) -> tests/test_oracle_golden.py
  *   - MIDA / LMIP / contour-MIP: the reference has no tests -> restatement
  *     cross-checked by hand-worked rays ("parity unpinned" upstream)
- *   - marching cubes: reference = vtkContourFilter (VTK 9.3, not vendored) ->
- *     "parity unpinned" for triangle topology; vertex positions follow the
- *     documented linear interpolation on grid edges.
+ *   - marching cubes: reference = vtkContourFilter (VTK 9.3, not vendored),
+ *     which for vtkImageData input (what surface_process.py:172-186 feeds it)
+ *     delegates to vtkSynchronizedTemplates3D: its own templates table, one
+ *     pass that emits a POINT-MERGED polydata (shared points, its own
+ *     traversal order) with point normals / scalars by the filter's defaults
+ *     -- not the Lorensen case table and not a triangle soup.  This file's
+ *     case table is the builder's own (tools/gen_mc_tables.py), so triangle
+ *     topology and order are "parity unpinned" vs VTK; what IS pinned is the
+ *     vertex SET (grid-edge crossings by the documented linear interpolation,
+ *     table-independent, checked analytically) and closedness.  Comparisons
+ *     with the classic (Lorensen) table in tests/test_mc_crosscheck.py place
+ *     the home-made table in a known family; they say nothing about VTK.
  *   - watershed_ift: pinned against the live scipy.ndimage.watershed_ift.
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off, see oracle/Makefile)

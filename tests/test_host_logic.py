@@ -236,3 +236,72 @@ def test_bench_launcher_gives_every_rank_the_same_nonce_and_the_rendezvous_compl
     code2 = code.replace("timeout_s=20.0", "timeout_s=0.5")
     p = subprocess.run([sys.executable, "-c", code2], env=other, capture_output=True)
     assert p.returncode != 0 and b"no RCCL id of this launch" in p.stderr
+
+
+def test_do_watershed_says_where_it_leaves_the_reference_and_only_after_the_queue_is_signalled(tmp_path, monkeypatch):
+    """the IFT branch of do_watershed computes the defect-free statement of scipy's flood, which differs
+    from live scipy (the reference, watershed_process.py:44-46,54-57) on realistic volumes.  The hook must SAY so where the
+    user is: `last_stats` carries reference / exact / note, an `IftDeviationWarning` is raised once per process, and -- like
+    the scikit-image branch's `MarkerTieWarning` -- only after the labels are in the memmap, flushed, and `q` has its
+    signal (with -W error the caller waiting on q, styles.py:2116-2134, must not hang).  The device call is a stand-in that
+    writes known labels; everything else is the shipped host code."""
+    import ctypes
+    import warnings
+
+    import numpy as np
+    import pytest
+    from invesalius3_amd import watershed_process as wp
+
+    shape = (3, 4, 5)
+    calls = []
+
+    class Lib:
+        def ivx_do_watershed_into(self, img, ishape, istr, mk_code, mk, mk_str, mdt, strct, alg, gs, uw, ww, wl, out, ostr, stats):
+            calls.append((mk_code, mdt, alg, list(ostr)))
+            n = int(np.prod(shape))
+            ctypes.memmove(out.value, (np.arange(n) % 3).astype(np.uint8).ctypes.data, n)
+            stats[6] = 2 if alg == 1 else 0
+            return 0
+
+    monkeypatch.setattr(wp.L, "lib", lambda: Lib())
+    monkeypatch.setattr(wp, "_ift_warned", False)
+    tfile = str(tmp_path / "m.dat")
+    np.zeros(shape, np.uint8).tofile(tfile)
+    img = np.zeros(shape, np.int16)
+    mk = np.zeros(shape, np.int16)
+    st = np.ones((3, 3, 3), bool)
+    events = []
+
+    class Q:
+        def put(self, v):
+            # the labels must already be on disk when the signal goes out
+            events.append(("put", v, bytes(np.fromfile(tfile, np.uint8)[:4])))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # -W error: the warning becomes an exception ...
+        with pytest.raises(wp.IftDeviationWarning):
+            wp.do_watershed(img, mk, tfile, shape, st, "Watershed IFT", (3, 3, 3), True, 300, 400, Q())
+    assert events == [("put", 1, bytes([0, 1, 2, 0]))]  # ... and it came after the write and the signal
+    ls = wp.do_watershed.last_stats
+    assert ls["algorithm"] == "Watershed IFT" and ls["reference"] == "scipy.ndimage.watershed_ift" and ls["exact"] is False
+    assert "87 372" in ls["note"] and "206 606" in ls["note"]
+    # int16 markers with ww/wl: passed in their own dtype, cast to int16 on the device; labels straight into the memmap (dense strides)
+    assert calls[-1] == (wp.L.I16, wp.L.I16, 0, [20, 5, 1])
+    # once per process: the second call is silent, still describes itself
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        wp.do_watershed(img, mk.astype(np.int32), tfile, shape, st, "Watershed IFT", (3, 3, 3), False, 0, 0, Q())
+    assert calls[-1][:3] == (wp.L.I32, wp.L.I8, 0) and len(events) == 2  # min-shift IFT branch: int8 (watershed_process.py:57)
+    assert wp.do_watershed.last_stats["exact"] is False
+    # the scikit-image branch keeps its own warning, same placement
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with pytest.raises(wp.MarkerTieWarning):
+            wp.do_watershed(img, mk, tfile, shape, st, "Watershed", (3, 3, 3), True, 300, 400, Q())
+    assert len(events) == 3 and wp.do_watershed.last_stats["tied_markers_of_different_labels"] == 2
+    assert wp.do_watershed.last_stats["reference"] == "skimage.segmentation.watershed" and wp.do_watershed.last_stats["exact"] is False
+    # float markers (not castable on the device) take the reference's host cast
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wp.do_watershed(img, mk.astype(np.float64), tfile, shape, st, "Watershed", (3, 3, 3), True, 300, 400, None)
+    assert calls[-1][:2] == (wp.L.I16, wp.L.I16)

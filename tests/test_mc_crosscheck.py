@@ -1,6 +1,9 @@
 """The generated marching-cubes table (tools/gen_mc_tables.py) against scikit-image's two published tables on the vectors
-of tests/golden/make_golden_mc.py.  This pins nothing to the reference (it contours with VTK, which exists nowhere in this
-container); it shows where the home-made table stands: vertex for vertex on the same grid-edge crossings as both, and
+of tests/golden/make_golden_mc.py.  This pins nothing to the reference: it contours with VTK 9.3's vtkContourFilter
+(surface_process.py:172-186), which for vtkImageData delegates to vtkSynchronizedTemplates3D -- its own templates table and a
+point-merged polydata in its own traversal order, neither the Lorensen table nor a soup -- and VTK exists nowhere in this
+container.  What these tests pin is therefore the VERTEX SET (table-independent: the analytic edge crossings) and
+closedness only; the comparison with the classic table merely shows where the home-made table stands: vertex for vertex on the same grid-edge crossings as both, and
 topologically the classic (Lorensen) table -- same vertex, edge and face counts, same Euler characteristic, closed -- on
 smooth fields and on binary noise alike; Lewiner's table joins ambiguous cells differently (more faces, other genus)."""
 import os
