@@ -10,6 +10,15 @@ A "step" is one pass of the hot path over the resident volume:
     2. threshold image -> mask (255/0)         (slice_.py:1240-1247)
     3. floodfill_threshold(image, seed, lo, hi, 1, 26-conn, out_mask); mask[out_mask==1] = 254   (styles.py:3200-3214)
     4. marching cubes of the mask at iso 127 (from_binary), whole volume   (surface_process.py:100-186)
+Which line answers which BASELINE.json config:
+    configs[1] (the metric's)  the default line (512^3; `roofline.per_stage_frac` per stage) + `other_configs.grow_mc_1024` (the same step
+                               past the 256 MiB Infinity Cache, volume made in HBM) + `other_configs.region_grow_generic_512` (a click
+                               whose thresholds are not the mask's: the candidate pass is paid); N > 1: weak scaling on the line,
+                               `strong_scaling` beside it (`--scaling strong`: ONE 512^3 volume split into N slabs)
+    configs[2] (1024^3)        `other_configs.watershed_ift_1024` / `watershed_gui_default_1024` (and `_512`); full lines: `--config watershed[_sk]`
+    configs[3] (2048^3 / 8)    `other_configs.sharded2048_on_one_gpu`; `--config sharded2048 --gpus 8` on a node
+    configs[4] (MIP sweep)     `other_configs.mip_sweep_512`; full line `--config mip`
+    configs[0] (Cranium, CPU)  tests/test_gpu_cranium.py (phantom of the sample's geometry); not a bench line
 The volume is uploaded once before the timed region (inputs resident in HBM).  N > 1: weak scaling, every rank
 owns one 512^3 Z-slab of a (512*N) x 512 x 512 volume; slab boundaries exchange one reached-bit plane per
 region-growing round (ncclSend/Recv + a 4-byte all-reduce, one enqueue-only call) and the image's halo slice once.
@@ -78,8 +87,8 @@ def _synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
     out = np.empty(shape, np.int16)
     nrng = np.random.default_rng(seed + 1 + z_offset)
     step = 32
-    for z0 in range(0, dz, step):
-        z1 = min(dz, z0 + step)
+
+    def work(z0, z1, noise):
         f = np.zeros((z1 - z0, dy, dx), np.float32)
         for b in range(6):
             gz = sum(np.exp(-((zz[z0:z1] - cz[b] - sh) ** 2) / (2 * sg[b] ** 2)) for sh in shifts)
@@ -87,9 +96,27 @@ def _synth_v512(shape=(512, 512, 512), seed=SEED, z_offset=0, z_total=None):
             gx = np.exp(-((xx - cx[b]) ** 2) / (2 * sg[b] ** 2))
             f += 1800.0 * gz[:, None, None] * gy[None, :, None] * gx[None, None, :]
         f += 150.0 * np.sin(6.0 * xx)[None, None, :] * np.cos(5.0 * zz[z0:z1])[:, None, None] * np.cos(4.0 * yy)[None, :, None]
-        f += nrng.standard_normal(f.shape, dtype=np.float32) * 25.0
+        noise *= 25.0
+        f += noise
         np.clip(f - 1000.0, -1024, 3071, out=f)
         out[z0:z1] = f.astype(np.int16)
+
+    # The noise comes from ONE generator in slab order (that fixes the volume's bits); everything else of a 32-slice slab
+    # is independent of the other slabs and runs on a few threads (numpy drops the GIL): 1024^3 in ~25 s instead of minutes,
+    # bit-identical to the one-thread loop (tests/golden/ws{512,1024}_full.npz are keyed by this volume's CRC-32).
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(8, (os.cpu_count() or 2) - 1))
+    with ThreadPoolExecutor(nthreads) as ex:
+        pending = []
+        for z0 in range(0, dz, step):
+            z1 = min(dz, z0 + step)
+            noise = nrng.standard_normal((z1 - z0, dy, dx), dtype=np.float32)
+            pending.append(ex.submit(work, z0, z1, noise))
+            del noise
+            while len(pending) > nthreads + 1:  # bounded: at most a few slabs of float32 in flight
+                pending.pop(0).result()
+        for f_ in pending:
+            f_.result()
     return out
 
 
@@ -323,14 +350,47 @@ def run_grow_mc(args, job):
 
     rank, world = job.rank, job.world
     n = args.size or 512
-    shape = (n, n, n)
-    img = synth_v512(shape, z_offset=rank * n, z_total=world * n)
-    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
-    seed = (int(x), int(y), int(z) + rank * n)  # global (x, y, z): every rank seeds the brightest voxel of its slab
+    strong = getattr(args, "scaling", "weak") == "strong"
+    hbm = bool(getattr(args, "hbm_synth", False))  # the volume is made in HBM (k_synth) and fetched for the oracle: 1024^3 without minutes of numpy
+    vol = None
+    if strong:
+        # configs[1]'s ONE n^3 volume split into `world` Z-slabs of n / world slices (8 GPUs: 64 slices = 4 flood-tile layers each);
+        # one seed, the whole volume's brightest voxel; at one GPU this is the default line, bit for bit
+        if n % world:
+            raise SystemExit("bench.py --scaling strong: %d slices do not split over %d ranks" % (n, world))
+        nz = n // world
+        full = synth_v512((n, n, n))
+        z, y, x = np.unravel_index(int(np.argmax(full)), full.shape)
+        seed = (int(x), int(y), int(z))
+        img = full[rank * nz:(rank + 1) * nz]
+    elif hbm:
+        if world != 1:
+            raise SystemExit("bench.py: the HBM-synthesised volume is a one-GPU configuration")
+        import ctypes
+
+        from invesalius3_amd.device import c64
+        rng = np.random.default_rng(SEED)
+        blobs = np.stack([rng.uniform(0.15, 0.85, 6), rng.uniform(0.15, 0.85, 6), rng.uniform(0.15, 0.85, 6),
+                          rng.uniform(0.12, 0.28, 6)], axis=1).astype(np.float32)  # (cz, cy, cx, sigma) x 6, as synth_v512 draws them
+        vol = DeviceVolume(None, shape=(n, n, n))
+        L.check(L.lib().ivx_dev_synth_volume(vol.image.raw, c64(n), c64(n), c64(n), c64(0), c64(n), ctypes.c_uint32(SEED), L.ptr(blobs),
+                                             vol.stream), "synth_volume")
+        vol._image_touched()
+        vol.sync()
+        img = vol.image.download((n, n, n), np.int16)
+        z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+        seed = (int(x), int(y), int(z))
+    else:
+        img = synth_v512((n, n, n), z_offset=rank * n, z_total=world * n)
+        z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+        seed = (int(x), int(y), int(z) + rank * n)  # global (x, y, z): every rank seeds the brightest voxel of its slab
+    shape = tuple(img.shape)
     strct = generate_binary_structure(3, 3)
     force_slab = os.environ.get("IVX_FORCE_SLAB") == "1"  # exercise the sharded path at world 1
     t_up = time.perf_counter()
-    if world > 1 or force_slab:
+    if vol is not None:
+        pass
+    elif world > 1 or force_slab:
         from invesalius3_amd.parallel import SlabVolume
 
         vol = SlabVolume(img, rank, world, comm=job.comm, device=job.local_rank)
@@ -395,7 +455,9 @@ def run_grow_mc(args, job):
     copy_gbs = copy_bandwidth(vol, nvox) if rank == 0 else None
     # one step the way a caller without a resident volume pays for it: host -> HBM, the step, mask + triangles -> host
     e2e_ms = e2e_first_ms = None
-    if world == 1 and not force_slab:
+    e2e = world == 1 and not force_slab and not hbm
+    mask_crc = ntri_dl = None
+    if e2e:
         for k in range(2):  # the first pass also pays the process's first pageable copies (page locking set-up, lane buffers)
             t = time.perf_counter()
             vol.image.upload(img)
@@ -410,7 +472,7 @@ def run_grow_mc(args, job):
     # ... and the same with the caller's arrays in page-locked host memory (invesalius3_amd._lib.pinned_empty): the DMA
     # engines then reach them directly instead of through the runtime's bounce buffers
     e2e_pinned_ms = None
-    if world == 1 and not force_slab:
+    if e2e:
         p_img = L.pinned_empty(img.shape, np.int16)
         p_img[:] = img
         p_mask = L.pinned_empty(img.shape, np.uint8)
@@ -427,6 +489,8 @@ def run_grow_mc(args, job):
         del p_img, p_mask, p_tris, m2, t2
     dt = job.max(dt)
     ntri_all, reached_all = job.sum(ntri), job.sum(reached)
+    if world == 1 and not force_slab and not e2e:  # (the HBM-made volume: the parity gate's mask CRC without the end-to-end passes)
+        mask_crc, ntri_dl = zlib.crc32(vol.download_mask()), ntri
     if rank != 0:
         return None
     ms_per_step = dt / args.steps * 1e3
@@ -436,16 +500,18 @@ def run_grow_mc(args, job):
     stage_time = {"threshold": stage_ms.get("threshold", 0.0), "region_grow": stage_ms.get("region_grow", 0.0),
                   "marching_cubes": mc_ms}
     dom = max(stage_time, key=lambda k: stage_time[k])
-    traffic = pmc_traffic("grow_mc", dom) if n == 512 and world == 1 else None
+    traffic = pmc_traffic("grow_mc", dom) if n == 512 and world == 1 and not hbm else None
     res = {
         "metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
         "value": round(world * nvox / (dt / args.steps) / 1e6, 2),
         "unit": "Mvoxel/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i16", "data": "synthetic",
-        "config": {"workload": "configs[1]: %dx%dx%d int16 per GPU, threshold(226..3071) + 26-neighbour region-grow + marching-cubes(mask@127)" % shape,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "i16", "data": "synthetic (made in HBM by k_synth)" if hbm else "synthetic",
+        "config": {"workload": "configs[1]: %dx%dx%d int16 per GPU, threshold(226..3071) + 26-neighbour region-grow + marching-cubes(mask@127)" % shape
+                               + (" -- ONE %d^3 volume split over the GPUs (strong scaling; no multi-GPU box has run this yet: the curve is "
+                                  "the driver's to measure)" % n if strong else ""),
                    "global_voxels": world * nvox, "parallelism": "z-slab x%d" % world,
                    "collectives": "RCCL via libivx ivx_comm_* (no PyTorch)" if world > 1 else "none",
                    "overlap": "marching-cubes count+scan+list on a second stream under region growing" if overlap else "none"},
@@ -473,7 +539,7 @@ def run_grow_mc(args, job):
         "device": L.device_name(),
     }
     if args.cpu and world == 1 and not force_slab:
-        rec, orc_out = cpu_grow_mc(img, seed)
+        rec, orc_out = cpu_grow_mc(np.ascontiguousarray(img), seed)
         res["cpu_baseline"] = rec
         got = {"region_voxels": reached, "triangles": ntri, "mask_crc32": mask_crc}
         ok = got == orc_out and ntri_dl == ntri
@@ -485,6 +551,76 @@ def run_grow_mc(args, job):
         if not ok:
             print(json.dumps(res), flush=True)
             raise SystemExit("bench.py: GPU result differs from the CPU oracle: %s vs %s" % (got, orc_out))
+    else:
+        res["cpu_baseline"] = None
+    return res
+
+
+def run_grow_generic(args, job):
+    """configs[1]'s region growing when the click's thresholds are NOT the mask's: the headline step
+    floods with the thresholds the mask was made with, so the threshold pass's bit plane IS the candidate plane
+    (DeviceVolume._candidate_plane); any other click pays its own pass over the volume for the candidates
+    (k_flood_candidates16).  Step = out_mask zeros + threshold(226..3071) + floodfill_threshold(image, seed, 300, 3071) + mask[out] = 254
+    on the 512^3 volume; the flood stage is timed with HIP events inside the timed steps."""
+    import zlib
+
+    from scipy.ndimage import generate_binary_structure
+
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceVolume
+
+    n = args.size or 512
+    img = synth_v512((n, n, n))
+    z, y, x = np.unravel_index(int(np.argmax(img)), img.shape)
+    seed = (int(x), int(y), int(z))
+    strct = generate_binary_structure(3, 3)
+    T0, T1 = 300, BONE[1]
+    vol = DeviceVolume(img, device=job.local_rank)
+    nvox = img.size
+
+    def step():
+        vol.zero_out_mask()
+        vol.threshold(BONE[0], BONE[1], preserve=False)
+        with vol.timer.span("region_grow"):
+            return vol.region_grow([seed], T0, T1, strct, fill=1, select_value=254)
+
+    for _ in range(args.warmup):
+        step()
+    vol.sync()
+    vol.timer.collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rounds = step()
+    vol.sync()
+    dt = time.perf_counter() - t0
+    grow_ms = float(np.mean(vol.timer.collect()["region_grow"]))
+    reached = vol.reached_count()
+    out = vol.download_out_mask()
+    vol.close()
+    res = {"metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU",
+           "value": round(nvox / (grow_ms * 1e-3) / 1e6, 2), "unit": "Mvoxel/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16",
+           "data": "synthetic",
+           "config": {"workload": "configs[1]'s region growing with thresholds that differ from the mask's: %d^3 int16, mask = threshold(226..3071), "
+                                  "26-neighbour flood of image in [%d, %d] from the brightest voxel (candidate pass k_flood_candidates16 + flood + "
+                                  "apply); `value` and `frac` are the flood stage's, `ms` the whole step's" % (n, T0, T1)},
+           "stage_ms": {"region_grow": round(grow_ms, 4)}, "region_voxels": reached, "region_grow_rounds": rounds,
+           "roofline": roofline("region_grow (generic thresholds)", 3.0 * nvox, grow_ms, None, None), "device": L.device_name()}
+    if args.cpu:
+        from oracle import oracle as orc
+        orc.build()
+        ref = np.zeros(img.shape, np.uint8)
+        t = time.perf_counter()
+        orc.floodfill_threshold(img, [seed], T0, T1, 1, strct, ref)
+        ts = time.perf_counter() - t
+        ok = zlib.crc32(out) == zlib.crc32(ref) and reached == int(ref.sum())
+        res["cpu_baseline"] = {"value": round(nvox / ts / 1e6, 2), "unit": "Mvoxel/s", "cores": 1, "kind": "port",
+                               "sample": "the serial flood of floodfill.rs:96-166 restated in C on the whole volume, %.2f s" % ts}
+        res["parity"] = {"ok": bool(ok), "checked": "CRC-32 of the whole out_mask and the region's voxel count vs the CPU oracle (pinned by the "
+                                                    "reference's golden vectors)"}
+        if not ok:
+            print(json.dumps(res), flush=True)
+            raise SystemExit("bench.py: generic region growing differs from the CPU oracle")
     else:
         res["cpu_baseline"] = None
     return res
@@ -1102,19 +1238,26 @@ def other_configs(args, job, runners):
     their numbers and parity -- {name: {ms, frac, parity_ok, differs_from_reference, ...}}.  Full lines: `--config <name>`."""
     import contextlib
     import copy
-    plan = (("watershed_ift_512", "watershed", 512, 2, 1), ("watershed_gui_default_512", "watershed_sk", 512, 2, 1),
-            ("mip_sweep_512", "mip", None, 10, 2), ("sharded2048_on_one_gpu", "sharded2048", None, 3, 1))
+    plan = (("watershed_ift_512", "watershed", 512, 2, 1, False), ("watershed_gui_default_512", "watershed_sk", 512, 2, 1, False),
+            ("mip_sweep_512", "mip", None, 10, 2, False), ("sharded2048_on_one_gpu", "sharded2048", None, 3, 1, False),
+            # past the 256 MiB Infinity Cache, and configs[2] at its stated size (VERDICT r4 item 3)
+            ("region_grow_generic_512", "grow_generic", 512, 10, 2, False), ("grow_mc_1024", "grow_mc", 1024, 5, 2, True),
+            ("watershed_ift_1024", "watershed", 1024, 2, 1, False), ("watershed_gui_default_1024", "watershed_sk", 1024, 2, 1, False))
+    skip = set(filter(None, os.environ.get("IVX_BENCH_SKIP", "").split(",")))  # (names to leave out: short smoke runs)
     out = {}
-    for name, cfg, size, steps, warmup in plan:
+    for name, cfg, size, steps, warmup, hbm in plan:
+        if name in skip:
+            continue
         a = copy.copy(args)
-        a.config, a.size, a.steps, a.warmup, a.ws_raw, a.bounded = cfg, size, steps, warmup, False, True
+        a.config, a.size, a.steps, a.warmup, a.ws_raw, a.bounded, a.hbm_synth, a.scaling = cfg, size, steps, warmup, False, True, hbm, "weak"
         t = time.perf_counter()
         try:
             with contextlib.redirect_stdout(sys.stderr):  # (a failing gate prints its own record: keep stdout to ONE line)
                 r = runners[cfg](a, job)
             par = r.get("parity") or {}
             out[name] = {"workload": r["config"]["workload"], "ms": r["ms_per_step"], "steps": steps, "mvoxel_per_s": r["value"],
-                         "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"], "stage_ms": r.get("stage_ms"),
+                         "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"],
+                         "per_stage_frac": r["roofline"].get("per_stage_frac"), "stage_ms": r.get("stage_ms"),
                          "parity_ok": par.get("ok"), "differs_from_reference": r.get("differs_from_reference", 0 if par.get("ok") else None),
                          "parity_compared": par.get("compared") or par.get("checked"),
                          "cpu_baseline": {k: (r.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
@@ -1131,9 +1274,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("grow_mc", "watershed", "watershed_sk", "mip", "sharded2048"), default="grow_mc",
+    ap.add_argument("--config", choices=("grow_mc", "grow_generic", "watershed", "watershed_sk", "mip", "sharded2048"), default="grow_mc",
                     help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2] (IFT branch), watershed_sk = configs[2] with the GUI's default scikit-image branch; sharded2048 = "
                          "configs[3] (strong scaling: the whole volume split over --gpus); mip = configs[4]")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="grow_mc with --gpus N: weak = every GPU owns its own 512^3 slab of a (512 N) x 512 x 512 volume (default); strong = "
+                         "configs[1]'s ONE 512^3 volume split into N slabs of 512 / N slices")
+    ap.add_argument("--hbm-synth", action="store_true", help="grow_mc, one GPU: make the volume in HBM (k_synth) instead of with numpy "
+                    "(--size 1024 in seconds); the CPU oracle then runs on the downloaded volume")
     ap.add_argument("--size", type=int, default=None, help="edge of the volume (defaults: 512 / 1024 / 512 per GPU; 2048 in total for sharded2048)")
     ap.add_argument("--ws-raw", action="store_true", help="watershed_sk: the image - image.min() branch instead of the GUI's default window/level")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false", help="skip the CPU baseline + full-size parity check")
@@ -1149,7 +1297,7 @@ def main():
     args = ap.parse_args()
     if args.cpu_slices == 0:
         args.cpu = False
-    dflt = {"grow_mc": (20, 3), "watershed": (3, 1), "watershed_sk": (2, 1), "mip": (20, 3), "sharded2048": (5, 2)}[args.config]
+    dflt = {"grow_mc": (20, 3), "grow_generic": (20, 3), "watershed": (3, 1), "watershed_sk": (2, 1), "mip": (20, 3), "sharded2048": (5, 2)}[args.config]
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
 
@@ -1163,11 +1311,28 @@ def main():
     if args.dry_comm:
         return dry_comm(world)
     job = Ranks()
-    runners = {"grow_mc": run_grow_mc, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048}
+    runners = {"grow_mc": run_grow_mc, "grow_generic": run_grow_generic, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048}
     res = runners[args.config](args, job)
     if res is not None and args.config == "grow_mc" and args.others and args.cpu and world == 1 and args.size is None \
-            and os.environ.get("IVX_FORCE_SLAB") != "1":
+            and not args.hbm_synth and os.environ.get("IVX_FORCE_SLAB") != "1":
         res["other_configs"] = other_configs(args, job, runners)
+    if args.config == "grow_mc" and world > 1 and args.scaling == "weak" and args.size is None and not args.hbm_synth \
+            and os.environ.get("IVX_BENCH_NO_STRONG") != "1":
+        # The metric reads "512^3 ... 1/2/4/8 GPU": the first multi-GPU run yields BOTH curves -- the line's own numbers are weak
+        # scaling (512^3 per GPU), `strong_scaling` is configs[1]'s one 512^3 volume split over the same ranks, same steps,
+        # same keys.  Every rank takes part (the slabs exchange planes); a failure is recorded, the weak line still goes out.
+        import copy
+        a = copy.copy(args)
+        a.scaling, a.cpu = "strong", False
+        try:
+            r2 = run_grow_mc(a, job)
+            if res is not None and r2 is not None:
+                res["strong_scaling"] = {k: r2.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "stage_ms",
+                                                                "comm_ms_per_step", "triangles", "region_voxels", "region_grow_rounds",
+                                                                "timed_region_s", "config")}
+        except Exception as e:  # noqa: BLE001
+            if res is not None:
+                res["strong_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if res is not None:
         print(json.dumps(res), flush=True)
     if job.comm is not None:

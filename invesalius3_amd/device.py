@@ -773,7 +773,8 @@ class DeviceVolume:
         (mips.rs:113-121).  The reference runs it inside every call; a resident volume keeps the result until the image's
         bytes change (any access to `image` from outside the pipeline's kernels drops it, like the bit-plane notes), the way
         `Slice` keeps the image's histogram (slice_.py:192-194; SURVEY 8d counts the cached range as allowed).
-        `forget_image_range()` drops it by hand."""
+        `forget_image_range()` drops it by hand -- and every writer inside this package that goes to `image.raw` /
+        `image.raw_at()` directly (past the tracked accessor) must call it."""
         if getattr(self, "_range_buf", None) is None:
             self._range_buf = DeviceBuffer(64)
             self._range_valid = False
@@ -788,9 +789,10 @@ class DeviceVolume:
     def mida(self, axis: int, wl, ww, out: DeviceBuffer, status: DeviceBuffer):
         """mida (mips.rs:102-168) of the resident image along `axis` into `out` (int16 image of the projection's shape); the
         volume's range comes from `image_range()`.  `status` (int32, zeroed by the caller) receives IVX_EDOM where the
-        reference's NumCast would panic."""
-        L.check(L.lib().ivx_dev_mida(L.I16, self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(axis), ctypes.c_float(float(wl)),
-                                     ctypes.c_float(float(ww)), self.image_range().ptr, L.I16, out.ptr, status.ptr, self.stream), "mida")
+        reference's NumCast would panic.  Window level / width are truncated like the reference's wrapper does
+        (invesalius_rs/__init__.py:91-95: ``_native.mida(image, axis, int(wl), int(ww), out)``)."""
+        L.check(L.lib().ivx_dev_mida(L.I16, self.image.raw, c64(self.dz), c64(self.dy), c64(self.dx), int(axis), ctypes.c_float(float(int(wl))),
+                                     ctypes.c_float(float(int(ww))), self.image_range().ptr, L.I16, out.ptr, status.ptr, self.stream), "mida")
 
 
 def c64(v):

@@ -194,6 +194,15 @@ def _make_slab_volume():
             self._votes = DeviceBuffer(64)  # int32 [0] vote travelling with the planes, [1] words my last OR gained
             self._cand = self.cand
 
+        # the single-volume forms would take min / max and the projection over THIS rank's slices, halo included: per-rank
+        # normalisation, silently different from the whole volume's.  The sharded forms are rays_global / project_global.
+        def image_range(self):
+            raise RuntimeError("SlabVolume.image_range: a slab does not know the whole volume's range; use rays_global "
+                               "(it all-reduces min / max over the ranks' interior slices)")
+
+        def mida(self, *a, **k):
+            raise RuntimeError("SlabVolume.mida: use rays_global('mida', axis, wl, ww) -- the range and, along Z, the rays span ranks")
+
         def close(self):
             for b in getattr(self, "_recv", []) + [getattr(self, "_votes", None)]:
                 if b is not None:

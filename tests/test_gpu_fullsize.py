@@ -72,6 +72,51 @@ def test_v512_bench_step_equals_oracle_bit_for_bit(ivxlib, v512, v512_oracle, mo
     vol.close()
 
 
+def test_v512_strong_scaling_split_eight_slabs_of_64_slices_equals_the_single_volume(ivxlib, v512, v512_oracle):
+    """`bench.py --gpus 8 --scaling strong`: configs[1]'s ONE 512^3 volume as 8 Z-slabs of 64 slices (4 flood-tile layers each), one
+    seed that lies in one slab only; 8 loop-back ranks on this GPU through the real sharded HIP path (image halo, plane exchange
+    + vote per round, per-rank marching-cubes piece).  Concatenated masks, out_masks and the triangle soup == the oracle's
+    whole-volume bits -- the same arrays the default line's parity gate checks."""
+    from _ptr_comm import LoopbackWorld
+    from invesalius3_amd.parallel import SlabVolume
+
+    img, seed = v512
+    mask0, out0, soup0 = v512_oracle
+    world, nz = 8, 64
+    lw = LoopbackWorld(world)
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            vol = SlabVolume(img[rank * nz:(rank + 1) * nz], rank, world, comm=lw.comm(rank))
+            for _ in range(2):  # bench.py's step, twice
+                vol.zero_out_mask()
+                vol.threshold(BONE[0], BONE[1], preserve=False)
+                vol.region_grow([seed], BONE[0], BONE[1], S26, fill=1, select_value=254)
+                ntri = vol.marching_cubes(from_binary=True)
+            lay = vol.lay
+            res[rank] = dict(ntri=ntri, count=vol.reached_count(), tris=vol.marching_cubes(from_binary=True, download=True),
+                             mask=vol.download_mask()[lay.first_interior:lay.last_interior + 1],
+                             out=vol.download_out_mask()[lay.first_interior:lay.last_interior + 1])
+            vol.close()
+        except Exception:  # pragma: no cover
+            import traceback
+            errs.append((rank, traceback.format_exc()))
+            lw.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    assert not errs, errs
+    assert sum(res[r]["count"] for r in range(world)) == int(out0.sum()) == 19797285
+    assert np.array_equal(np.concatenate([res[r]["mask"] for r in range(world)]), mask0), "mask"
+    assert np.array_equal(np.concatenate([res[r]["out"] for r in range(world)]), out0), "out_mask"
+    cat = np.concatenate([res[r]["tris"] for r in range(world)])
+    assert sum(res[r]["ntri"] for r in range(world)) == len(cat) == len(soup0) == 6323604
+    # (as a multiset: the ranks' pieces are cut at other slices than the oracle's 20-slice pieces, so the order differs)
+    assert np.array_equal(_tri_hash(cat), _tri_hash(soup0)), "triangle soup"
+
+
 def test_512_rays_exact_against_oracle(ivxlib, oracle, v512):
     """MIDA / LMIP / fast contour MIP on V512, every axis, every pixel (replaces the range-bound property test)"""
     from invesalius3_amd import invesalius_rs as mips
