@@ -79,6 +79,13 @@ def main():
         lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed", (3, 3, 3), True, 300, 400, None), reps=2)
     res["do_watershed (Watershed IFT, ww/wl, 6 neighbours)"] = timeit(
         lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed IFT", (3, 3, 3), True, 300, 400, None), reps=2)
+    # ... and the download into the memmap through the page-locked lanes (every chunk's page faults on its own thread) or as one
+    # hipMemcpy (IVX_D2H_LANES is read per call; unset = lanes where the destination's pages are mostly not resident)
+    for mode in ("1", "0"):
+        os.environ["IVX_D2H_LANES"] = mode
+        res["do_watershed (Watershed IFT, ww/wl) IVX_D2H_LANES=%s" % mode] = timeit(
+            lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed IFT", (3, 3, 3), True, 300, 400, None), reps=2)
+    os.environ.pop("IVX_D2H_LANES")
     os.remove(tfile)
     print(json.dumps({"size": "512^3", "triangles": int(len(tri[0])),
                       "results": {k: {"s": round(v, 4), "Mvoxel/s": round(nvox / v / 1e6, 1)} for k, v in res.items()}}, indent=1))
