@@ -211,6 +211,18 @@ int ivx_dev_mc_emit(const ivx_mc_params *p, const void *a, const void *scratch, 
  * triangle costs three bit look-ups instead of six byte gathers; same arithmetic on the same numbers, same soup. */
 int ivx_dev_mc_emit_levels(const ivx_mc_params *p, const void *scratch, const uint64_t *sel_bits, double v_out, double v_in,
                            double v_sel, float *tris, int64_t max_tris, void *stream);
+/* The whole surface in ONE launch (k_mc_fused): cell words -> active cells -> triangle counts -> output offsets by a decoupled
+ * look-back across the workgroups -> triangles, without per-word counts, a scan launch or a triangle list.  One iso-value
+ * (from_binary surfaces: surface_process.py:172-186 with the mask at iso 127; two-iso "Default" pieces keep count + emit).
+ * inside_bits: the plane "value >= iso[0]" in source coordinates if the caller holds it, else NULL (derived from `a`).  Writes at
+ * most max_tris triangles -- same soup, same order, same bits as ivx_dev_mc_count + ivx_dev_mc_emit (measured SLOWER than those at
+ * 512^3, equal at 1024^3: an opt-in, IVX_MC_ONE_LAUNCH=1, see csrc/k_mc.hip); ivx_dev_mc_total then
+ * returns the count (if it exceeds max_tris, call again with a larger buffer).  The *_levels form reads no voxel: the mask's
+ * bytes are v_out outside inside_bits, v_sel where sel_bits has a bit, v_in elsewhere inside (see ivx_dev_mc_emit_levels). */
+int ivx_dev_mc_surface(const ivx_mc_params *p, const void *a, const uint64_t *inside_bits /* may be NULL */, void *scratch,
+                       float *tris, int64_t max_tris, void *stream);
+int ivx_dev_mc_surface_levels(const ivx_mc_params *p, const uint64_t *inside_bits, const uint64_t *sel_bits, double v_out, double v_in,
+                              double v_sel, void *scratch, float *tris, int64_t max_tris, void *stream);
 /* the list pass of ivx_dev_mc_emit on its own (it needs the counts, not the voxels): queue it early, on the stream the
  * emit will use; the emit that follows with max_tris <= this max_tris skips its own list pass */
 int ivx_dev_mc_list(const ivx_mc_params *p, const void *scratch, int64_t max_tris, void *stream);

@@ -511,6 +511,71 @@ static inline McLevels make_levels(const uint64_t *sel, double iso, double v_out
         }
     return lv;
 }
+// The nine floats of ONE triangle: cell (k, j, i) of the padded grid, case `idx`, triangle `rel` of the case.  s_tri = the
+// triangle table (rows of 15), s_e0 / s_e1 / s_ec = the per-edge constants (see k_mc_emit).  Shared by the list-driven emit
+// and the single-pass surface kernel: same arithmetic, same bits.
+template <typename T, bool LEVELS>
+__device__ __forceinline__ void mc_triangle(const T *__restrict__ a, const Geom &g, const McLevels &lv, double iso,
+                                            const uint8_t *s_tri, const int *s_e0, const int *s_e1, const int *s_ec, int32_t k,
+                                            int32_t j, int32_t i, int idx, int rel, float *o) {
+    const int32_t ka = k - (int32_t)g.pb, ja = ((int32_t)g.NY - 1 - j) - (int32_t)g.pxy; // source row of corner (dy=0, dz=0)
+    const int32_t ia = i - (int32_t)g.pxy;
+    const bool fast = ka >= 0 && ka + 1 < (int32_t)g.nz && ja - 1 >= 0 && ja < (int32_t)g.ny && ia >= 0 &&
+                      ia + 1 < (int32_t)g.nx;
+    double s0[3], s1[3];
+    int ec[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) ec[v] = s_tri[idx * 15 + 3 * rel + v];
+    double ttl[3];
+    if (LEVELS) {
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            const int c = s_ec[ec[v]];
+            const int ax = c & 3, bx = (c >> 2) & 1, by = (c >> 3) & 1, bz = (c >> 4) & 1;
+            const int lo = bx + 2 * by + 4 * bz; // corner numbers of the edge's ends in the case index
+            const bool in0 = (idx >> lo) & 1, in1 = (idx >> (lo + (1 << ax))) & 1; // exactly one of them is inside
+            // the inside end is a source voxel (padding is never inside a from_binary piece): its bit of `sel`
+            const int32_t kk = k + bz + (in1 && ax == 2), jj = j + by + (in1 && ax == 1), ii = i + bx + (in1 && ax == 0);
+            const int64_t sk = kk - (int32_t)g.pb, sj = ((int32_t)g.NY - 1 - jj) - (int32_t)g.pxy, si = ii - (int32_t)g.pxy;
+            const uint64_t wsel = lv.sel[(sk * g.ny + sj) * g.ws + (si >> 6)];
+            ttl[v] = lv.tt[(in0 ? 2 : 0) + (int)((wsel >> (si & 63)) & 1ull)];
+            ec[v] = c;
+        }
+    } else if (fast) { // interior cell: one base pointer, six byte/short gathers at table offsets, issued back to back
+        const T *cell = a + ((int64_t)ka * g.ny + ja) * g.nx + ia;
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            s0[v] = (double)cell[s_e0[ec[v]]];
+            s1[v] = (double)cell[s_e1[ec[v]]];
+        }
+#pragma unroll
+        for (int v = 0; v < 3; v++) ec[v] = s_ec[ec[v]];
+    } else {
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            const int c = s_ec[ec[v]];
+            const int ax = c & 3, bx = (c >> 2) & 1, by = (c >> 3) & 1, bz = (c >> 4) & 1;
+            s0[v] = mc_at(a, g, k + bz, j + by, i + bx);
+            s1[v] = mc_at(a, g, k + bz + (ax == 2), j + by + (ax == 1), i + bx + (ax == 0));
+            ec[v] = c;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        const int ax = ec[v] & 3, bx = (ec[v] >> 2) & 1, by = (ec[v] >> 3) & 1, bz = (ec[v] >> 4) & 1;
+        const double tt = LEVELS ? ttl[v] : (iso - s0[v]) / (s1[v] - s0[v]);
+        double p0 = (double)(i + bx - (int32_t)g.pxy);
+        double p1 = (double)(j + by - (int32_t)g.yoff);
+        double p2 = (double)(k + bz + g.zoff);
+        if (ax == 0) p0 += tt;
+        else if (ax == 1) p1 += tt;
+        else p2 += tt;
+        o[3 * v + 0] = (float)(g.sx * p0);
+        o[3 * v + 1] = (float)(g.sy * p1);
+        o[3 * v + 2] = (float)(g.sz * p2);
+    }
+}
+
 template <typename T, bool LEVELS>
 __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g, double iso0, double iso1,
                                                  const uint64_t *__restrict__ split_dev,
@@ -551,64 +616,7 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
         const int b = (int)(d >> 11) & 63, idx = (int)(d >> 3) & 255, rel = (int)d & 7;
         const uint32_t w = (uint32_t)(d >> 17) & 0x7fffu;
         const int32_t k = (int32_t)(d >> 48), j = (int32_t)((d >> 32) & 0xffffull);
-        const int32_t i = (int32_t)w * 64 + b;
-        const int32_t ka = k - (int32_t)g.pb, ja = ((int32_t)g.NY - 1 - j) - (int32_t)g.pxy; // source row of corner (dy=0, dz=0)
-        const int32_t ia = i - (int32_t)g.pxy;
-        const bool fast = ka >= 0 && ka + 1 < (int32_t)g.nz && ja - 1 >= 0 && ja < (int32_t)g.ny && ia >= 0 &&
-                          ia + 1 < (int32_t)g.nx;
-        float *o = s_out + tid * 9;
-        double s0[3], s1[3];
-        int ec[3];
-#pragma unroll
-        for (int v = 0; v < 3; v++) ec[v] = s_tri[idx * 15 + 3 * rel + v];
-        double ttl[3];
-        if (LEVELS) {
-#pragma unroll
-            for (int v = 0; v < 3; v++) {
-                const int c = s_ec[ec[v]];
-                const int ax = c & 3, bx = (c >> 2) & 1, by = (c >> 3) & 1, bz = (c >> 4) & 1;
-                const int lo = bx + 2 * by + 4 * bz; // corner numbers of the edge's ends in the case index
-                const bool in0 = (idx >> lo) & 1, in1 = (idx >> (lo + (1 << ax))) & 1; // exactly one of them is inside
-                // the inside end is a source voxel (padding is never inside a from_binary piece): its bit of `sel`
-                const int32_t kk = k + bz + (in1 && ax == 2), jj = j + by + (in1 && ax == 1), ii = i + bx + (in1 && ax == 0);
-                const int64_t sk = kk - (int32_t)g.pb, sj = ((int32_t)g.NY - 1 - jj) - (int32_t)g.pxy, si = ii - (int32_t)g.pxy;
-                const uint64_t wsel = lv.sel[(sk * g.ny + sj) * g.ws + (si >> 6)];
-                ttl[v] = lv.tt[(in0 ? 2 : 0) + (int)((wsel >> (si & 63)) & 1ull)];
-                ec[v] = c;
-            }
-        } else if (fast) { // interior cell: one base pointer, six byte/short gathers at table offsets, issued back to back
-            const T *cell = a + ((int64_t)ka * g.ny + ja) * g.nx + ia;
-#pragma unroll
-            for (int v = 0; v < 3; v++) {
-                s0[v] = (double)cell[s_e0[ec[v]]];
-                s1[v] = (double)cell[s_e1[ec[v]]];
-            }
-#pragma unroll
-            for (int v = 0; v < 3; v++) ec[v] = s_ec[ec[v]];
-        } else {
-#pragma unroll
-            for (int v = 0; v < 3; v++) {
-                const int c = s_ec[ec[v]];
-                const int ax = c & 3, bx = (c >> 2) & 1, by = (c >> 3) & 1, bz = (c >> 4) & 1;
-                s0[v] = mc_at(a, g, k + bz, j + by, i + bx);
-                s1[v] = mc_at(a, g, k + bz + (ax == 2), j + by + (ax == 1), i + bx + (ax == 0));
-                ec[v] = c;
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < 3; v++) {
-            const int ax = ec[v] & 3, bx = (ec[v] >> 2) & 1, by = (ec[v] >> 3) & 1, bz = (ec[v] >> 4) & 1;
-            const double tt = LEVELS ? ttl[v] : (iso - s0[v]) / (s1[v] - s0[v]);
-            double p0 = (double)(i + bx - (int32_t)g.pxy);
-            double p1 = (double)(j + by - (int32_t)g.yoff);
-            double p2 = (double)(k + bz + g.zoff);
-            if (ax == 0) p0 += tt;
-            else if (ax == 1) p1 += tt;
-            else p2 += tt;
-            o[3 * v + 0] = (float)(g.sx * p0);
-            o[3 * v + 1] = (float)(g.sy * p1);
-            o[3 * v + 2] = (float)(g.sz * p2);
-        }
+        mc_triangle<T, LEVELS>(a, g, lv, iso, s_tri, s_e0, s_e1, s_ec, k, j, (int32_t)w * 64 + b, idx, rel, s_out + tid * 9);
     }
     __syncthreads();
     const uint32_t nt_chunk = ntris - T0 < 256 ? (uint32_t)(ntris - T0) : 256u;
@@ -624,6 +632,230 @@ __global__ __launch_bounds__(256) void k_mc_emit(const T *__restrict__ a, Geom g
         if (tid < 64) __builtin_nontemporal_store(s4[tid + 512], &d4[tid + 512]);
     } else {
         for (uint32_t f = tid; f < nt_chunk * 9; f += 256) dst[f] = s_out[f];
+    }
+}
+
+// ---- 5. the surface in ONE launch: count, offsets and emit without per-word counts, scan launch or triangle list ------------
+// (VERDICT r4 item 5 / DESIGN section 9.4.)  The four-launch path walks the cell words twice (k_mc_count, k_mc_list), writes a
+// 54 MB descriptor list and reads it straight back; its passes are bound by the life time of 9 259 short workgroups each.  Here
+// a workgroup owns 256 cell words from the corner loads to the last store:
+//   (a) corner words -> active-cell masks, active words packed to the first lanes (as k_mc_count does);
+//   (b) those lanes walk their cells once for the word's triangle count -> block sum;
+//   (c) the block's place in the output by a decoupled look-back over one status word per workgroup (flag | value, one
+//       agent-scope store / load each: wave 0 inspects 64 predecessors per step; workgroups are dispatched in index order, so a
+//       predecessor is always running or done) -- output order stays the oracle's (cell raster order);
+//   (d) the lanes walk their cells again and write one 32-bit descriptor per triangle into an LDS window (slot | cell | case |
+//       triangle-in-case; windows of MCF_WIN descriptors, one window for all but the densest blocks);
+//   (e) one lane per triangle of the window, 256 at a time: the same arithmetic as k_mc_emit (mc_triangle), nine floats staged
+//       in LDS at the output's own 16-byte phase, so the chunk leaves as aligned non-temporal 16-byte stores although a block's
+//       first triangle starts anywhere (head / tail dwords go out one by one).
+// The last workgroup leaves the total where k_mc_scan would (boff[nblocks]) for ivx_dev_mc_total.  One iso-value.
+// MEASURED (round 5, profiles/r05/r05_mc_one_launch.md): same soup bit for bit, but 239 us against the 158 us of the four launches
+// at 512^3 (1024^3: 1.29 vs 1.26 ms).  Decomposed by leaving parts out: phases (a)-(d) 74 us, the look-back 12 us, stores 21 us,
+// and phase (e)'s arithmetic 130 us -- the per-chunk emit is a ~6 us latency chain (plane gathers, LDS, fp64) that the list-driven
+// k_mc_emit hides behind 24 700 independent one-chunk workgroups, while here a workgroup's chunks queue up behind each other and
+// behind its own barriers.  Kept as an opt-in (IVX_MC_ONE_LAUNCH=1; tests run both paths), not the default.
+constexpr int MCF_WIN = 1024;
+constexpr uint64_t MCF_VAL = (1ull << 40) - 1ull;
+__device__ __forceinline__ void mcf_publish(unsigned long long *st, uint64_t flag, uint64_t v) {
+    __hip_atomic_store(st, (unsigned long long)((flag << 40) | v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T, bool LEVELS>
+__global__ __launch_bounds__(256) void k_mc_fused(const uint64_t *__restrict__ bits, const T *__restrict__ a, Geom g, size_t nwords,
+                                                  uint64_t pbits, double iso, unsigned long long *state /* zeroed, one per workgroup */,
+                                                  uint64_t *__restrict__ total_out, uint64_t cap, float *__restrict__ tris, McLevels lv) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tri[256 * 15];
+    // 19 KB of LDS per workgroup = eight workgroups per CU (at 34 KB and four per CU the kernel took 269 us against the 158 us of
+    // the four launches it replaces: a workgroup's phases are a chain of barriers and round trips that only other workgroups
+    // hide).  The hand-over table of phase (a) -- per active word the four even corner words + the active mask -- is dead once
+    // its lanes hold it in registers, so it shares its bytes with the staging buffer and the descriptor window of (d) / (e).
+    constexpr int OUT_BYTES = (256 * 9 + 4) * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[OUT_BYTES + MCF_WIN * 4];
+    static_assert(OUT_BYTES % 16 == 0 && OUT_BYTES + MCF_WIN * 4 >= 256 * 5 * 8, "LDS overlay");
+    float *s_out = (float *)s_raw;
+    uint32_t *s_desc = (uint32_t *)(s_raw + OUT_BYTES);
+    uint64_t(*s_c)[5] = (uint64_t(*)[5])s_raw;
+    __shared__ uint8_t s_ntri[256];
+    __shared__ uint8_t s_hi[256];    // bit 63 of the four odd corner words (cell 63's far corners)
+    __shared__ uint16_t s_k[256], s_j[256], s_w[256];
+    __shared__ uint32_t s_wcnt[4], s_part[4];
+    __shared__ unsigned long long s_excl;
+    __shared__ int s_e0[12], s_e1[12], s_ec[12];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t bid = blockIdx.x;
+    s_ntri[tid] = MC_NTRI[tid];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q * 256 + tid < 960) ((uint32_t *)s_tri)[q * 256 + tid] = ((const uint32_t *)&MC_TRI[0][0])[q * 256 + tid];
+    const int plane32 = (int)(g.ny * g.nx), nx32 = (int)g.nx;
+    if (tid < 12) {
+        int ax, bx, by, bz;
+        edge_decode(tid, ax, bx, by, bz);
+        const int o0 = bz * plane32 - by * nx32 + bx;
+        s_e0[tid] = o0;
+        s_e1[tid] = o0 + (ax == 2 ? plane32 : (ax == 1 ? -nx32 : 1));
+        s_ec[tid] = ax | (bx << 2) | (by << 3) | (bz << 4);
+    }
+    // (a) corners, active words packed
+    const size_t wid = (size_t)bid * 256 + tid;
+    uint64_t act = 0;
+    Corner8 r;
+    uint32_t k = 0, j = 0, w = 0;
+    if (wid < nwords) {
+        const uint32_t row = (uint32_t)wid / (uint32_t)g.WC;
+        w = (uint32_t)wid - row * (uint32_t)g.WC;
+        k = row / (uint32_t)(g.NY - 1);
+        j = row - k * (uint32_t)(g.NY - 1);
+        r = load_corners(bits, g, (int64_t)k, (int64_t)j, (int64_t)w, pbits);
+        act = r.active;
+    }
+    const unsigned long long am = __ballot(act != 0);
+    if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(am);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int q = 0; q < wv; q++) before += s_wcnt[q];
+    const uint32_t nact = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (act) {
+        const uint32_t slot = before + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+        uint32_t hi = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            s_c[slot][q] = r.c[2 * q];
+            hi |= (uint32_t)(r.c[2 * q + 1] >> 63) << q;
+        }
+        s_c[slot][4] = act;
+        s_hi[slot] = (uint8_t)hi;
+        s_k[slot] = (uint16_t)k;
+        s_j[slot] = (uint16_t)j;
+        s_w[slot] = (uint16_t)w;
+    }
+    __syncthreads();
+    // (b) triangle count of my word (lanes < nact own one active word each)
+    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, mine = 0;
+    uint32_t hi = 0, n = 0;
+    const auto case_at = [&](int b) -> int {
+        if (b != 63)
+            return (int)((c0 >> b) & 3ull) | ((int)((c1 >> b) & 3ull) << 2) | ((int)((c2 >> b) & 3ull) << 4) | ((int)((c3 >> b) & 3ull) << 6);
+        return (int)(c0 >> 63) | ((int)(hi & 1u) << 1) | ((int)(c1 >> 63) << 2) | ((int)(hi >> 1 & 1u) << 3) | ((int)(c2 >> 63) << 4) |
+               ((int)(hi >> 2 & 1u) << 5) | ((int)(c3 >> 63) << 6) | ((int)(hi >> 3 & 1u) << 7);
+    };
+    if ((uint32_t)tid < nact) {
+        c0 = s_c[tid][0]; c1 = s_c[tid][1]; c2 = s_c[tid][2]; c3 = s_c[tid][3];
+        mine = s_c[tid][4];
+        hi = s_hi[tid];
+        uint64_t a2 = mine;
+        while (a2) {
+            const int b = __builtin_ctzll(a2);
+            a2 &= a2 - 1;
+            n += s_ntri[case_at(b)];
+        }
+    }
+    uint32_t inc = n; // inclusive scan of the slots' counts inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_part[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int q = 0; q < wv; q++) wbase += s_part[q];
+    const uint32_t S = s_part[0] + s_part[1] + s_part[2] + s_part[3]; // the block's triangles
+    const uint32_t mypos = wbase + inc - n; // first triangle of my word, relative to the block
+    // (c) where the block's triangles go: decoupled look-back, by the LAST wave (it rarely owns active words) while the other
+    // waves already write the first window's descriptors, which are block-relative and need no offset
+    if (wv == 3) {
+        if (lane == 0) mcf_publish(&state[bid], bid == 0 ? 2ull : 1ull, (uint64_t)S);
+        uint64_t excl = 0;
+        if (bid > 0) {
+            int64_t look = (int64_t)bid - 1;
+            while (true) {
+                const int64_t idx = look - lane;
+                uint64_t v = 2ull << 40; // before block 0: an inclusive prefix of 0
+                if (idx >= 0) {
+                    v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 40) == 0) { // (back off: two thousand resident workgroups poll the same few lines)
+                        __builtin_amdgcn_s_sleep(16);
+                        v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                const unsigned long long pm = __ballot((v >> 40) == 2ull);
+                const int stop = pm ? __builtin_ctzll(pm) : 64; // nearest predecessor whose inclusive prefix is known
+                uint64_t contrib = lane <= stop ? (v & MCF_VAL) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
+                excl += contrib;
+                if (pm) break;
+                look -= 64;
+            }
+            if (lane == 0) mcf_publish(&state[bid], 2ull, excl + S);
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            if (bid == gridDim.x - 1) *total_out = excl + S;
+        }
+    }
+    const bool vec_ok = ((uintptr_t)tris & 15) == 0;
+    uint64_t E = 0;
+    // (d) + (e), window by window
+    for (uint32_t base = 0; base < S; base += MCF_WIN) {
+        const uint32_t wend = base + MCF_WIN < S ? base + MCF_WIN : S;
+        if ((uint32_t)tid < nact && mypos < wend && mypos + n > base) {
+            uint64_t a2 = mine;
+            uint32_t pos = mypos;
+            while (a2 && pos < wend) {
+                const int b = __builtin_ctzll(a2);
+                a2 &= a2 - 1;
+                const int idx = case_at(b);
+                const uint32_t nt = s_ntri[idx];
+                if (pos + nt > base) {
+                    const uint32_t d0 = ((uint32_t)tid << 17) | ((uint32_t)b << 11) | ((uint32_t)idx << 3);
+#pragma unroll
+                    for (uint32_t t = 0; t < MC_MAX_TRI; t++)
+                        if (t < nt && pos + t >= base && pos + t < wend) s_desc[pos + t - base] = d0 | t;
+                }
+                pos += nt;
+            }
+        }
+        __syncthreads();
+        if (base == 0) {
+            E = s_excl;
+            if (E >= cap) return; // (uniform) nothing of this block fits the caller's buffer; the total still reports the need
+        }
+        for (uint32_t cb = base; cb < wend; cb += 256) {
+            const uint64_t G = E + cb; // global index of the chunk's first triangle
+            if (G >= cap) break;       // (uniform)
+            uint32_t ntc = wend - cb < 256 ? wend - cb : 256u;
+            if (G + ntc > cap) ntc = (uint32_t)(cap - G);
+            const uint32_t ph = (uint32_t)((G * 9ull) & 3ull); // the chunk's first float inside its 16-byte line
+            if ((uint32_t)tid < ntc) {
+                const uint32_t d = s_desc[cb - base + tid];
+                const uint32_t slot = d >> 17;
+                const int b = (int)(d >> 11) & 63, idx = (int)(d >> 3) & 255, rel = (int)d & 7;
+                mc_triangle<T, LEVELS>(a, g, lv, iso, s_tri, s_e0, s_e1, s_ec, (int32_t)s_k[slot], (int32_t)s_j[slot],
+                                       (int32_t)s_w[slot] * 64 + b, idx, rel, s_out + ph + tid * 9);
+            }
+            __syncthreads();
+            const uint32_t nf = ntc * 9;
+            float *dst = tris + G * 9ull - ph; // 16-byte aligned when tris is
+            if (vec_ok) {
+                typedef float float4_t __attribute__((ext_vector_type(4)));
+                const uint32_t nvec = (ph + nf + 3) / 4;
+                for (uint32_t v = tid; v < nvec; v += 256) {
+                    const uint32_t f0 = v * 4;
+                    if (f0 >= ph && f0 + 4 <= ph + nf) {
+                        __builtin_nontemporal_store(((const float4_t *)s_out)[v], &((float4_t *)dst)[v]);
+                    } else {
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; q++)
+                            if (f0 + q >= ph && f0 + q < ph + nf) dst[f0 + q] = s_out[f0 + q];
+                    }
+                }
+            } else {
+                for (uint32_t f = tid; f < nf; f += 256) dst[ph + f] = s_out[ph + f];
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1268,6 +1500,88 @@ extern "C" int ivx_dev_mc_emit_levels(const ivx_mc_params *p, const void *scratc
     return run_emit<uint8_t>(p, g, s, nullptr, (const char *)scratch, tris, max_tris, ivx::S(stream), &lv);
 }
 
+// The surface in one launch (k_mc_fused): no per-word counts, no scan launch, no triangle list.  One iso-value.  `inside_bits`
+// = the plane "value >= iso[0]" in source coordinates when the caller holds it (a resident pipeline's threshold pass), else
+// NULL: it is derived from `a` into the scratch first.  At most max_tris triangles are written; ivx_dev_mc_total (same params,
+// scratch, stream) then returns how many there ARE -- a caller whose buffer was too small calls again with a larger one.  The
+// soup is the one ivx_dev_mc_count + ivx_dev_mc_emit produce, bit for bit and in the same order.  The per-word counts in the
+// scratch are NOT produced: the indexed-mesh calls still need their ivx_dev_mc_count first.
+template <typename T>
+static int run_fused(const ivx_mc_params *p, const Geom &g, const Scratch &s, const void *a, const uint64_t *bits, char *scratch,
+                     float *tris, int64_t max_tris, hipStream_t st, const McLevels *lv) {
+    uint64_t *boff = (uint64_t *)(scratch + s.off_boff);
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        g_list_built.erase(scratch); // whatever list was built from this scratch's old counts is void
+    }
+    IVX_HIP(hipMemsetAsync(boff, 0, (s.nblocks + 1) * 8, st)); // the look-back's status words + the total
+    if (lv)
+        hipLaunchKernelGGL((k_mc_fused<T, true>), dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, (const T *)a, g, s.nwords, pad_bits(p, 0),
+                           p->iso[0], (unsigned long long *)boff, boff + s.nblocks, (uint64_t)(max_tris > 0 ? max_tris : 0), tris, *lv);
+    else
+        hipLaunchKernelGGL((k_mc_fused<T, false>), dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, (const T *)a, g, s.nwords, pad_bits(p, 0),
+                           p->iso[0], (unsigned long long *)boff, boff + s.nblocks, (uint64_t)(max_tris > 0 ? max_tris : 0), tris,
+                           McLevels{nullptr, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0, 0.0}});
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
+extern "C" int ivx_dev_mc_surface(const ivx_mc_params *p, const void *a, const uint64_t *inside_bits, void *scratch_, float *tris,
+                                  int64_t max_tris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    IVX_REQUIRE(p->niso == 1, IVX_EINVAL, "mc_surface: one iso-value only (two-iso pieces take ivx_dev_mc_count + ivx_dev_mc_emit)");
+    IVX_REQUIRE(a && scratch_ && (tris || max_tris <= 0), IVX_EINVAL, "mc_surface: null buffer");
+    const Scratch s = make_scratch(g, p->niso);
+    if (s.nwords == 0) return IVX_OK;
+    IVX_REQUIRE(s.nblocks < 0x7fffffffull && s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for one launch");
+    char *scratch = (char *)scratch_;
+    hipStream_t st = ivx::S(stream);
+    const uint64_t *bits = inside_bits;
+    if (!bits) {
+        switch (p->dtype) {
+        case IVX_U8: rc = run_bits<uint8_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+        case IVX_I16: rc = run_bits<int16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+        default: rc = run_bits<uint16_t>(p, g, s, a, (uint8_t *)(scratch + s.off_bits), p->iso[0], p->iso[1], st); break;
+        }
+        if (rc) return rc;
+        bits = (const uint64_t *)(scratch + s.off_bits);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        if (inside_bits) g_ext_bits[scratch_] = inside_bits;
+        else g_ext_bits.erase(scratch_);
+    }
+    switch (p->dtype) {
+    case IVX_U8: return run_fused<uint8_t>(p, g, s, a, bits, scratch, tris, max_tris, st, nullptr);
+    case IVX_I16: return run_fused<int16_t>(p, g, s, a, bits, scratch, tris, max_tris, st, nullptr);
+    default: return run_fused<uint16_t>(p, g, s, a, bits, scratch, tris, max_tris, st, nullptr);
+    }
+}
+
+// ... for a uint8 mask whose bytes are KNOWN through two planes (see ivx_dev_mc_emit_levels): v_out outside `inside_bits`, v_sel
+// where `sel_bits` has a bit, v_in elsewhere inside.  No voxel is read.
+extern "C" int ivx_dev_mc_surface_levels(const ivx_mc_params *p, const uint64_t *inside_bits, const uint64_t *sel_bits, double v_out,
+                                         double v_in, double v_sel, void *scratch_, float *tris, int64_t max_tris, void *stream) {
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    IVX_REQUIRE(p->dtype == IVX_U8 && p->niso == 1 && inside_bits && sel_bits && scratch_, IVX_EINVAL,
+                "mc_surface_levels: uint8 mask, one iso-value, both planes");
+    IVX_REQUIRE(v_out < p->iso[0] && v_in >= p->iso[0] && v_sel >= p->iso[0] && (double)p->pad_value == v_out, IVX_EINVAL,
+                "mc_surface_levels: v_out must lie below the iso-value and equal the padding value, v_in and v_sel at or above it");
+    const Scratch s = make_scratch(g, p->niso);
+    if (s.nwords == 0) return IVX_OK;
+    IVX_REQUIRE(s.nblocks < 0x7fffffffull && s.nwords < 0xffffffffull, IVX_EINVAL, "mc: piece too large for one launch");
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        g_ext_bits[scratch_] = inside_bits;
+    }
+    const McLevels lv = make_levels(sel_bits, p->iso[0], v_out, v_in, v_sel);
+    return run_fused<uint8_t>(p, g, s, nullptr, inside_bits, (char *)scratch_, tris, max_tris, ivx::S(stream), &lv);
+}
+
 // The list pass of ivx_dev_mc_emit on its own: it needs the counts only, not the voxels, so a pipeline can queue it (on
 // the stream the emit will use: the list lives in that stream's workspace) before the values the emit interpolates are
 // final.  The emit that follows with max_tris <= this max_tris skips its own list pass.
@@ -1305,14 +1619,27 @@ extern "C" int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const i
     if ((rc = ws_get(WS_AUX0, sb, &d_scr))) return rc;
     if ((rc = upload_strided(d_a, a, shape, strides, isz, WS_IN))) return rc;
     int64_t cnt = 0;
-    if ((rc = ivx_dev_mc_count(p, d_a, d_scr, &cnt, nullptr))) return rc;
+    // one iso-value (from_binary pieces): the single-launch surface, first with no room at all -- a pure count --, then with the
+    // buffer the count asks for (the inside plane of the first pass is still in the scratch) -- opt-in, IVX_MC_ONE_LAUNCH=1:
+    // measured slower than count + list + emit at 512^3 (see k_mc_fused).
+    const char *e = getenv("IVX_MC_ONE_LAUNCH");
+    const bool one = p->niso == 1 && e && e[0] == '1';
+    if (one) {
+        if ((rc = ivx_dev_mc_surface(p, d_a, nullptr, d_scr, nullptr, 0, nullptr))) return rc;
+        if ((rc = ivx_dev_mc_total(p, d_scr, &cnt, nullptr))) return rc;
+    } else if ((rc = ivx_dev_mc_count(p, d_a, d_scr, &cnt, nullptr)))
+        return rc;
     *ntris = cnt;
     if (!tris || cnt == 0) return IVX_OK;
     IVX_REQUIRE(max_tris >= cnt, IVX_ERANGE, "mc: output buffer holds %lld triangles, %lld needed", (long long)max_tris,
                 (long long)cnt);
     void *d_tris;
     if ((rc = ws_get(WS_OUT, (size_t)cnt * 36, &d_tris))) return rc;
-    if ((rc = ivx_dev_mc_emit(p, d_a, d_scr, (float *)d_tris, cnt, nullptr))) return rc;
+    if (one) {
+        const Scratch s = make_scratch(g, p->niso);
+        if ((rc = ivx_dev_mc_surface(p, d_a, (const uint64_t *)((const char *)d_scr + s.off_bits), d_scr, (float *)d_tris, cnt, nullptr))) return rc;
+    } else if ((rc = ivx_dev_mc_emit(p, d_a, d_scr, (float *)d_tris, cnt, nullptr)))
+        return rc;
     IVX_HIP(hipMemcpy(tris, d_tris, (size_t)cnt * 36, hipMemcpyDeviceToHost));
     return IVX_OK;
 }

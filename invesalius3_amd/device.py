@@ -521,6 +521,21 @@ class DeviceVolume:
         else:
             L.check(lib.ivx_dev_mc_emit(ctypes.byref(p), src, self._mc_scratch.ptr, self._tris.ptr, c64(cap), stream), "mc_emit")
 
+    def _surface_one_launch(self, p, src, plane, z0, cap, stream):
+        """count + offsets + emit of a one-iso piece in ONE kernel (ivx_dev_mc_surface / _levels: no per-word counts, no scan
+        launch, no triangle list); `ivx_dev_mc_total` reads the count afterwards.  Same predicate as `_emit` for the levels form."""
+        lib, lv = L.lib(), self._mask_levels
+        if (plane is not None and lv is not None and self._fuse and os.environ.get("IVX_MC_LEVELS", "1") != "0"
+                and float(p.pad_value) == 0.0 and lv[0] > 127 and (lv[1] is None or lv[1] > 127)):
+            if lv[1] is None:
+                sel, v_sel = plane, float(lv[0])
+            else:
+                sel, v_sel = self.reached.at(z0 * self.dy * ((self.dx + 63) // 64) * 8), float(lv[1])
+            L.check(lib.ivx_dev_mc_surface_levels(ctypes.byref(p), plane, sel, ctypes.c_double(0.0), ctypes.c_double(float(lv[0])),
+                                                  ctypes.c_double(v_sel), self._mc_scratch.ptr, self._tris.ptr, c64(cap), stream), "mc_surface")
+        else:
+            L.check(lib.ivx_dev_mc_surface(ctypes.byref(p), src, plane, self._mc_scratch.ptr, self._tris.ptr, c64(cap), stream), "mc_surface")
+
     def _second_stream(self):
         if self._stream2 is None:
             s = ctypes.c_void_p()
@@ -618,7 +633,20 @@ class DeviceVolume:
                 # the surface outgrew the buffer: take the ordinary path below (it re-counts and re-emits)
         src, plane = self._mc_setup(p, z0)
         n = ctypes.c_int64(0)
-        if self._tris is not None:
+        if self._tris is not None and p.niso == 1 and os.environ.get("IVX_MC_ONE_LAUNCH", "0") == "1":
+            # opt-in (measured slower at 512^3, equal at 1024^3: csrc/k_mc.hip, k_mc_fused): the whole surface in ONE launch
+            # (count, output offsets by a look-back across the workgroups, emit); the count is read afterwards and only a
+            # surface that outgrew the buffer is emitted again
+            cap = self._tris.nbytes // 36
+            with self.timer.span("mc_emit"):
+                self._surface_one_launch(p, src, plane, z0, cap, self.stream)
+            L.check(lib.ivx_dev_mc_total(ctypes.byref(p), self._mc_scratch.ptr, ctypes.byref(n), self.stream), "mc_total")
+            nt = n.value
+            if nt > cap:
+                self._tris.close()
+                self._tris = DeviceBuffer(int(nt * 36 * 1.25) + 4096)
+                self._surface_one_launch(p, src, plane, z0, nt, self.stream)
+        elif self._tris is not None:
             # steady state: the triangle buffer of the previous call gives a capacity, so count, list and emit are queued
             # back to back and the count is read afterwards (no host round trip between the two halves)
             cap = self._tris.nbytes // 36

@@ -151,3 +151,49 @@ def test_indexed_mesh_is_the_merged_soup(ivxlib, oracle, case):
     assert faces.min() == 0 and faces.max() == len(verts) - 1
     vol, area = sp.mass_properties(verts[faces])
     assert area > 0
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16])
+def test_single_launch_surface_equals_count_list_emit_and_the_oracle(ivxlib, oracle, monkeypatch, dtype):
+    """ivx_dev_mc_surface (k_mc_fused: count, look-back offsets and emit in one launch) against the four-launch path and the
+    oracle, soup for soup: dense binary noise (thousands of triangles per workgroup -> several LDS windows, every output
+    phase of the 16-byte stores), padded and unpadded pieces, rows that are not whole words, many workgroups (look-back
+    across more than 64 predecessors)."""
+    from invesalius3_amd import surface_process as sp
+    rng = np.random.default_rng(11)
+    for shape, pads, dens in [((12, 40, 200), (True, True, True), 0.5), ((5, 33, 130), (False, False, False), 0.5),
+                              ((20, 64, 64), (True, False, True), 0.3), ((70, 96, 129), (True, True, True), 0.08),
+                              ((3, 2, 2), (True, True, True), 0.5), ((40, 128, 192), (True, True, False), 0.5)]:
+        if dtype == np.uint8:
+            a = np.where(rng.random(shape) < dens, rng.integers(128, 256, shape), rng.integers(0, 127, shape)).astype(np.uint8)
+            iso, padv = 127.0, 0.0
+        else:
+            a = np.where(rng.random(shape) < dens, rng.integers(300, 2000, shape), rng.integers(-1000, 299, shape)).astype(np.int16)
+            iso, padv = 299.5, float(np.iinfo(np.int16).min)
+        args = ((0.5, 0.75, 2.0), [iso], 7, *pads, padv, int(pads[0] and pads[1]))
+        monkeypatch.setenv("IVX_MC_ONE_LAUNCH", "1")
+        new = sp.marching_cubes(a, *args)
+        monkeypatch.setenv("IVX_MC_ONE_LAUNCH", "0")
+        old = sp.marching_cubes(a, *args)
+        monkeypatch.delenv("IVX_MC_ONE_LAUNCH")
+        assert len(new) > 0
+        _cmp(new, old)
+        _cmp(new, oracle.marching_cubes(a, *args))
+
+
+def test_single_launch_surface_that_outgrows_its_buffer(ivxlib, oracle, monkeypatch):
+    """A resident volume's triangle buffer comes from the previous call: a surface that outgrew it is written up to the
+    capacity (nothing past it), the count says so, and the second launch into a larger buffer gives the whole soup."""
+    from invesalius3_amd.device import DeviceVolume
+    monkeypatch.setenv("IVX_MC_ONE_LAUNCH", "1")  # (opt-in path: measured slower than count + list + emit at 512^3)
+    rng = np.random.default_rng(12)
+    img = rng.integers(-1000, 1000, (40, 64, 128)).astype(np.int16)
+    vol = DeviceVolume(img)
+    for lo in (990, 0, 600, -500):  # sparse -> dense (outgrows) -> sparser (fits) -> densest
+        vol.threshold(lo, 3071)
+        got = vol.marching_cubes(from_binary=True, download=True)
+        mask = np.zeros(tuple(s + 1 for s in img.shape), np.uint8)
+        oracle.set_mask_threshold_volume(mask, img, (lo, 3071))
+        want = oracle.create_surface_piece(None, mask, slice(0, img.shape[0]), (1.0, 1.0, 1.0), 0, 0, True)
+        _cmp(got, want)
+    vol.close()
