@@ -995,6 +995,10 @@ def run_mip(args, job):
     status = DeviceBuffer(64)
     status.zero(vol.stream)
     WL, WW = 300.0, 300.0  # get_image_slice hands the window LEVEL in for level and width alike (slice_.py:898-900, quirk Q1)
+    # fast_countour_mip's exponent is the GUI's border size (constants.py:814: PROJECTION_BORDER_SIZE = 1.0): the sweep times that
+    # default (base ** 1 is the identity in glibc's powf, checked exhaustively); any other exponent goes through the restated glibc
+    # powf on the device (csrc/glibc_powf.h) -- timed apart as `contour_mip_axis0_exponent_2`, same parity gate
+    FCM_N, FCM_N2 = 1.0, 2.0
 
     def step():
         # MaxIP (int16-exact) + MIDA (f32, the reference's operation order) along each of the three axes,
@@ -1016,7 +1020,7 @@ def run_mip(args, job):
                 L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[("mida", axis)].ptr, vol.stream))
         with vol.timer.span("contour_mip_axis0"):
             # fast_countour_mip(tmip 0) = max fold of the contour volume (mips.rs:237-247): folded as it is computed, no temp
-            L.check(lib.ivx_dev_fcm_maxip(L.I16, vol.image.raw, c64(n), c64(n), c64(n), ctypes.c_float(2.0), 0, proj.ptr, status.ptr,
+            L.check(lib.ivx_dev_fcm_maxip(L.I16, vol.image.raw, c64(n), c64(n), c64(n), ctypes.c_float(FCM_N), 0, proj.ptr, status.ptr,
                                           vol.stream), "fcm_maxip")
         with vol.timer.span("viewport"):
             L.check(lib.ivx_dev_replicate_i16(proj.ptr, c64(n), c64(n), f, view[("contour", 0)].ptr, vol.stream))
@@ -1036,6 +1040,15 @@ def run_mip(args, job):
     dt = job.max(time.perf_counter() - t0)
     raw = vol.timer.collect()
     spans = {k: float(np.mean(v)) * (7 if k == "viewport" else 1) for k, v in raw.items()}  # ("viewport": seven per step)
+    # the contour MIP with an exponent that is not 1 (outside the sweep: four passes, the last one kept for the parity gate)
+    proj2 = DeviceBuffer(n * n * 2 + 64)
+    for _ in range(4):
+        with vol.timer.span("fcm_n2"):
+            L.check(lib.ivx_dev_fcm_maxip(L.I16, vol.image.raw, c64(n), c64(n), c64(n), ctypes.c_float(FCM_N2), 0, proj2.ptr, status.ptr,
+                                          vol.stream), "fcm_maxip")
+    vol.sync()
+    fcm_n2_ms = float(np.min(vol.timer.collect()["fcm_n2"]))
+    got_n2 = proj2.download((n, n), np.int16)
     copy_gbs = copy_bandwidth(vol, nvox) if job.rank == 0 else None
     up = lambda a2: np.repeat(np.repeat(a2, f, axis=0), f, axis=1)
     got = {k: view[k].download((n * f, n * f), np.int16) for k in view}
@@ -1060,6 +1073,9 @@ def run_mip(args, job):
                                "is not installed here and is not the comparator" % (n, n * f, n * f, f, f),
                    "parallelism": "replicas x%d" % job.world},
         "stage_ms": {k: round(v, 4) for k, v in spans.items()},
+        "contour_mip_axis0_exponent_2": {"ms": round(fcm_n2_ms, 4), "frac": round(2.0 * nvox / (fcm_n2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "powf": "glibc's algorithm restated on the device, %s build (ivx_powf_variant: what this host's "
+                                                 "libm runs)" % ("FMA" if lib.ivx_powf_variant() else "plain")},
         "roofline": roofline("3-axis MaxIP + MIDA sweep, contour MIP, viewports", sweep_bytes, sum(spans.values()), None, copy_gbs,
                              {"slowest": worst, "projection_ms": round(proj_ms, 4),
                               "per_kernel_frac": {k: round(per_kernel_bytes[k.split("_")[0]] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -1082,10 +1098,12 @@ def run_mip(args, job):
             ref_mida.append(o)
         t2 = time.perf_counter()
         ref_fcm = np.zeros(shape[1:], np.int16)
-        orc.fast_countour_mip(img, 2.0, 0, int(WL), int(WW), 0, ref_fcm)
+        orc.fast_countour_mip(img, FCM_N, 0, int(WL), int(WW), 0, ref_fcm)
         t3 = time.perf_counter()
+        ref_fcm2 = np.zeros(shape[1:], np.int16)
+        orc.fast_countour_mip(img, FCM_N2, 0, int(WL), int(WW), 0, ref_fcm2)
         ok_rays = all(np.array_equal(got[("mida", a)], up(ref_mida[a])) for a in range(3)) and \
-            np.array_equal(got[("contour", 0)], up(ref_fcm))
+            np.array_equal(got[("contour", 0)], up(ref_fcm)) and np.array_equal(got_n2, ref_fcm2)
         res["cpu_baseline"] = {"value": round(7 * nvox / (t3 - t) / 1e6, 2), "unit": "Mvoxel/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": "the whole volume: numpy .max(axis) x3 %.2fs (one thread: that IS the reference, slice_.py:885-889) + "
                                          "C MIDA x3 %.2fs + C contour MIP %.2fs with OpenMP over the rays on %d cores (rayon in the "
@@ -1095,8 +1113,8 @@ def run_mip(args, job):
         res["cpu_baseline"] = None
     res["parity"] = {"ok": bool(ok_max and ok_rays is not False),
                      "checked": "MaxIP viewports == numpy max(axis) repeated %dx%d bit for bit%s" % (
-                         f, f, "; MIDA x3 and contour-MIP viewports == the C restatement of mips.rs bit for bit (unpinned upstream: "
-                               "no Rust toolchain, no reference test)" if ok_rays is not None else " (--no-cpu: MIDA / contour not compared)")}
+                         f, f, "; MIDA x3 and contour-MIP viewports (exponents 1 and 2: the host libm's powf) == the C restatement of mips.rs "
+                               "bit for bit (unpinned upstream: no Rust toolchain, no reference test)" if ok_rays is not None else " (--no-cpu: MIDA / contour not compared)")}
     if not res["parity"]["ok"]:
         print(json.dumps(res), flush=True)
         raise SystemExit("bench.py: viewport differs from the reference")

@@ -147,6 +147,13 @@ int ivx_dev_lmip(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx,
 int ivx_dev_rays_z_slab(int kind, int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, double p0, double p1,
                         const float *minmax2, const double *state_in, double *state_out, int out_dtype, void *out,
                         int *status, void *stream);
+/* The contour volume of fast_countour_mip (calc_fcm_intensity, invesalius_rs/src/mips.rs:197-213).  `base^n` is Rust's f32::powf =
+ * the platform libm's powf: reproduced bit for bit for glibc (csrc/glibc_powf.h restates its algorithm and tables; checked
+ * against libm on 1.5e9 inputs) in the build this machine's glibc selects -- ivx_powf_variant(): 1 = the FMA build x86-64 glibc
+ * runs on CPUs with FMA + AVX2, 0 = the plain build (override: IVX_POWF_VARIANT=fma|plain). */
+int ivx_powf_variant(void);
+/* out[i] = powf(x[i], y[i]) as the contour MIP computes it (device float arrays; variant 1 / 0 as above, -1 = this machine's) */
+int ivx_dev_powf(const float *x, const float *y, float *out, int64_t n, int variant, void *stream);
 int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
                        void *tmp /* same dtype/shape */, int *status, void *stream);
 /* fast_countour_mip_internal with tmip == 0 (invesalius_rs/src/mips.rs:237-247: tmp = contour volume, out = fold_axis max):

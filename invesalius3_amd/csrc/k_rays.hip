@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include "ivx_internal.h"
+#include "glibc_powf.h"
 
 namespace {
 
@@ -343,9 +344,31 @@ template <> __device__ __forceinline__ float fd_sub<int16_t>(int16_t a, int16_t 
 template <> __device__ __forceinline__ float fd_sub<uint8_t>(uint8_t a, uint8_t b) { return (float)(uint8_t)(a - b); }
 template <> __device__ __forceinline__ float fd_sub<double>(double a, double b) { return (float)(a - b); }
 
+// base^n as the reference computes it: Rust's f32::powf = the platform libm's powf (mips.rs:211).  pmode 1: n == 1 -- glibc's
+// powf(x, 1) IS x for every float in [-1, 1] (checked exhaustively against libm, both signs); pmode 2 / 3: glibc's algorithm
+// restated (glibc_powf.h), the build with fused multiply-adds that x86-64 glibc selects on CPUs with FMA + AVX2 / the plain
+// build -- the host passes the one this machine's libm runs (ivx_powf_variant).  n == 2 is NOT base * base: glibc's powf is
+// not correctly rounded and differs from the product in the last bit for 0.07 % of the bases in [2^-24, 1].
+struct PowTabs { // glibc's two powf tables (512 bytes), copied to LDS once per workgroup: two dynamic look-ups per voxel
+    double lt[32];
+    unsigned long long et[32];
+};
+__device__ __forceinline__ void fcm_pow_setup(PowTabs *t) { // (every thread of the workgroup, before any early return)
+    if (threadIdx.x < 32) glibc_powf::copy_table_entry((int)threadIdx.x, t->lt, (uint64_t *)t->et);
+    __syncthreads();
+}
+__device__ __forceinline__ float fcm_pow(float base, float n, int pmode, const PowTabs *t) {
+    if (pmode == 1) return base;
+    return pmode == 2 ? glibc_powf::powf_glibc<true>(base, n, t->lt, (const uint64_t *)t->et)
+                      : glibc_powf::powf_glibc<false>(base, n, t->lt, (const uint64_t *)t->et);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_fcm_volume(const T *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
-                                                    float n, int axis, T *__restrict__ tmp, int *__restrict__ status) {
+                                                    float n, int pmode, int axis, T *__restrict__ tmp, int *__restrict__ status) {
+    __shared__ PowTabs s_pt;
+    fcm_pow_setup(&s_pt);
+    const PowTabs *pt = &s_pt;
     const int64_t total = sz * sy * sx;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -362,9 +385,7 @@ __global__ __launch_bounds__(256) void k_fcm_volume(const T *__restrict__ img, i
         if (gm != 0.0f) {
             const float d = axis == 0 ? g2 : axis == 1 ? g1 : axis == 2 ? g0 : 0.0f; // dir = unit axis
             const float base = 1.0f - fabsf(d / gm);
-            // f32 powf: evaluated in double and rounded once (== the correctly rounded f32 result except in
-            // astronomically rare double-rounding cases); n == 1 is exact by definition
-            const float sf = n == 1.0f ? base : (float)pow((double)base, (double)n);
+            const float sf = fcm_pow(base, n, pmode, pt);
             v = gm * sf;
         }
         T o = (T)0;
@@ -378,8 +399,11 @@ __global__ __launch_bounds__(256) void k_fcm_volume(const T *__restrict__ img, i
 // instead of 7 two-byte loads and a two-byte store per voxel
 typedef short rshort8_t __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void k_fcm_volume_i16x8(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
-                                                          float n, int axis, int16_t *__restrict__ tmp,
+                                                          float n, int pmode, int axis, int16_t *__restrict__ tmp,
                                                           int *__restrict__ status) {
+    __shared__ PowTabs s_pt;
+    fcm_pow_setup(&s_pt);
+    const PowTabs *pt = &s_pt;
     const int64_t cpr = sx / 8, total = sz * sy * cpr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -407,7 +431,7 @@ __global__ __launch_bounds__(256) void k_fcm_volume_i16x8(const int16_t *__restr
             if (gm != 0.0f) {
                 const float d = axis == 0 ? g2 : axis == 1 ? g1 : axis == 2 ? g0 : 0.0f;
                 const float base = 1.0f - fabsf(d / gm);
-                const float sf = n == 1.0f ? base : (float)pow((double)base, (double)n);
+                const float sf = fcm_pow(base, n, pmode, pt);
                 v = gm * sf;
             }
             int16_t ov = 0;
@@ -429,7 +453,7 @@ __global__ __launch_bounds__(256) void k_fcm_volume_i16x8(const int16_t *__restr
 //               (neighbour lanes' centre chunks: L1 / L2 hits) and the two 2-byte x-neighbours across the chunk edge.
 //   AXIS 2:     a wave per row: each lane folds its chunks' 8 values, then a shuffle tree.
 __device__ __forceinline__ float fcm_value(int16_t xm, int16_t xp, int16_t ym, int16_t yp, int16_t zm, int16_t zp, float n,
-                                           int axis, int pmode) {
+                                           int axis, int pmode, const PowTabs *pt) {
     const float g0 = fd_sub<int16_t>(xp, xm) / (2.0f * 1.0f);
     const float g1 = fd_sub<int16_t>(yp, ym) / (2.0f * 1.0f);
     const float g2 = fd_sub<int16_t>(zp, zm) / (2.0f * 1.0f);
@@ -438,9 +462,7 @@ __device__ __forceinline__ float fcm_value(int16_t xm, int16_t xp, int16_t ym, i
     if (gm != 0.0f) {
         const float d = axis == 0 ? g2 : axis == 1 ? g1 : g0;
         const float base = 1.0f - fabsf(d / gm);
-        // powf: n == 1 is the identity; n == 2 is ONE correctly rounded f32 product (the double product of two floats is
-        // exact, so this is what rounding pow's exact result once gives); anything else in double, rounded once
-        const float sf = pmode == 1 ? base : pmode == 2 ? base * base : (float)pow((double)base, (double)n);
+        const float sf = fcm_pow(base, n, pmode, pt);
         v = gm * sf;
     }
     return v;
@@ -450,6 +472,9 @@ template <int AXIS>
 __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
                                                       float n, int pmode, int64_t seg, float *__restrict__ partial,
                                                       int *__restrict__ status) {
+    __shared__ PowTabs s_pt;
+    fcm_pow_setup(&s_pt);
+    const PowTabs *pt = &s_pt;
     // output pixel row r = y (AXIS 0) or z (AXIS 1); the ray runs along l = z (AXIS 0) or y (AXIS 1)
     const int64_t cpr = sx / 8;
     const int64_t nr = AXIS == 0 ? sy : sz, len = AXIS == 0 ? sz : sy;
@@ -479,8 +504,8 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int16_t xm = e == 0 ? left : (int16_t)cur[e - 1], xp = e == 7 ? right : (int16_t)cur[e + 1];
-            const float v = AXIS == 0 ? fcm_value(xm, xp, (int16_t)am[e], (int16_t)ap[e], (int16_t)prev[e], (int16_t)next[e], n, 0, pmode)
-                                      : fcm_value(xm, xp, (int16_t)prev[e], (int16_t)next[e], (int16_t)am[e], (int16_t)ap[e], n, 1, pmode);
+            const float v = AXIS == 0 ? fcm_value(xm, xp, (int16_t)am[e], (int16_t)ap[e], (int16_t)prev[e], (int16_t)next[e], n, 0, pmode, pt)
+                                      : fcm_value(xm, xp, (int16_t)prev[e], (int16_t)next[e], (int16_t)am[e], (int16_t)ap[e], n, 1, pmode, pt);
             bad |= !(v > -32769.0f && v < 32768.0f);
             acc[e] = v > acc[e] ? v : acc[e];
         }
@@ -495,6 +520,9 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
 
 __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx, float n,
                                                       int pmode, int16_t *__restrict__ out, int *__restrict__ status) {
+    __shared__ PowTabs s_pt;
+    fcm_pow_setup(&s_pt);
+    const PowTabs *pt = &s_pt;
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= sz * sy) return;
@@ -515,7 +543,7 @@ __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict_
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int16_t xm = e == 0 ? left : (int16_t)c[e - 1], xp = e == 7 ? right : (int16_t)c[e + 1];
-            const float v = fcm_value(xm, xp, (int16_t)ym[e], (int16_t)yp[e], (int16_t)zm[e], (int16_t)zp[e], n, 2, pmode);
+            const float v = fcm_value(xm, xp, (int16_t)ym[e], (int16_t)yp[e], (int16_t)zm[e], (int16_t)zp[e], n, 2, pmode, pt);
             bad |= !(v > -32769.0f && v < 32768.0f);
             acc = v > acc ? v : acc;
         }
@@ -642,6 +670,41 @@ extern "C" int ivx_dev_rays_z_slab(int kind, int dtype, const void *vol, int64_t
     return IVX_EINVAL;
 }
 
+// Which build of glibc's powf this machine's libm runs (sysdeps/x86_64/fpu/multiarch/e_powf.c: `__powf_fma` when the CPU has
+// FMA and AVX2, the plain one otherwise; other architectures build the plain source with their own contraction rules -- on
+// those, and under another libm, IVX_POWF_VARIANT=fma|plain says which).  The two differ in the last bit of ~3 results in 10^9.
+extern "C" int ivx_powf_variant(void) {
+    static const int v = []() {
+        const char *e = getenv("IVX_POWF_VARIANT");
+        if (e) return strcmp(e, "fma") == 0 ? 1 : 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        __builtin_cpu_init();
+        return (__builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2")) ? 1 : 0;
+#else
+        return 0;
+#endif
+    }();
+    return v;
+}
+static int fcm_pmode(float n) { return n == 1.0f ? 1 : (ivx_powf_variant() ? 2 : 3); }
+
+// the power function of the contour MIP on its own (parity probe: tests compare it with the host libm's powf bit for bit)
+__global__ __launch_bounds__(256) void k_powf_probe(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out,
+                                                    int64_t n, int fma_build) {
+    __shared__ PowTabs s_pt;
+    fcm_pow_setup(&s_pt);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = fcm_pow(x[i], y[i], fma_build ? 2 : 3, &s_pt);
+}
+extern "C" int ivx_dev_powf(const float *x, const float *y, float *out, int64_t n, int variant /* -1: this machine's */, void *stream) {
+    IVX_REQUIRE(n >= 0 && (n == 0 || (x && y && out)), IVX_EINVAL, "powf: bad arguments");
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_powf_probe, dim3((unsigned)ivx::cdiv(n, 256)), dim3(256), 0, ivx::S(stream), x, y, out, n,
+                       variant < 0 ? ivx_powf_variant() : (variant ? 1 : 0));
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
 extern "C" int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
                                   void *tmp, int *status, void *stream) {
     hipStream_t st = ivx::S(stream);
@@ -649,17 +712,18 @@ extern "C" int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_
     if (!total) return IVX_OK;
     const int64_t blocks = ivx::cdiv(total, 256);
     const int grid = (int)(blocks < 65536 ? blocks : 65536);
+    const int pmode = fcm_pmode(n);
     if (dtype == IVX_I16 && dx % 8 == 0 && (((uintptr_t)vol | (uintptr_t)tmp) & 15) == 0) {
         const int64_t b8 = ivx::cdiv(total / 8, 256);
         hipLaunchKernelGGL(k_fcm_volume_i16x8, dim3((unsigned)(b8 < 65536 ? b8 : 65536)), dim3(256), 0, st, (const int16_t *)vol,
-                           dz, dy, dx, n, axis, (int16_t *)tmp, status);
+                           dz, dy, dx, n, pmode, axis, (int16_t *)tmp, status);
         IVX_LAUNCH_CHECK();
         return IVX_OK;
     }
     switch (dtype) {
-    case IVX_I16: hipLaunchKernelGGL(k_fcm_volume<int16_t>, dim3(grid), dim3(256), 0, st, (const int16_t *)vol, dz, dy, dx, n, axis, (int16_t *)tmp, status); break;
-    case IVX_U8: hipLaunchKernelGGL(k_fcm_volume<uint8_t>, dim3(grid), dim3(256), 0, st, (const uint8_t *)vol, dz, dy, dx, n, axis, (uint8_t *)tmp, status); break;
-    case IVX_F64: hipLaunchKernelGGL(k_fcm_volume<double>, dim3(grid), dim3(256), 0, st, (const double *)vol, dz, dy, dx, n, axis, (double *)tmp, status); break;
+    case IVX_I16: hipLaunchKernelGGL(k_fcm_volume<int16_t>, dim3(grid), dim3(256), 0, st, (const int16_t *)vol, dz, dy, dx, n, pmode, axis, (int16_t *)tmp, status); break;
+    case IVX_U8: hipLaunchKernelGGL(k_fcm_volume<uint8_t>, dim3(grid), dim3(256), 0, st, (const uint8_t *)vol, dz, dy, dx, n, pmode, axis, (uint8_t *)tmp, status); break;
+    case IVX_F64: hipLaunchKernelGGL(k_fcm_volume<double>, dim3(grid), dim3(256), 0, st, (const double *)vol, dz, dy, dx, n, pmode, axis, (double *)tmp, status); break;
     default: ivx::set_error("fcm: unsupported dtype %d", dtype); return IVX_EINVAL;
     }
     IVX_LAUNCH_CHECK();
@@ -678,7 +742,7 @@ extern "C" int ivx_dev_fcm_maxip(int dtype, const void *vol, int64_t dz, int64_t
     static const bool fused_ok = []() { const char *e = getenv("IVX_FCM_FUSED"); return !(e && e[0] == '0'); }();
     int rc;
     if (fused_ok && dtype == IVX_I16 && dx % 8 == 0 && (((uintptr_t)vol) & 15) == 0) {
-        const int pmode = n == 1.0f ? 1 : n == 2.0f ? 2 : 0;
+        const int pmode = fcm_pmode(n);
         const int16_t *img = (const int16_t *)vol;
         if (axis == 2) {
             hipLaunchKernelGGL(k_fcm_max_rows, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,

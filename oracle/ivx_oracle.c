@@ -383,6 +383,12 @@ static float fcm_intensity(int dt, const char *img, const int64_t shape[3], cons
 }
 
 /* the FCM volume alone (tmp in fast_countour_mip_internal :237-242), dtype T */
+/* libm's powf over arrays: what Rust's f32::powf (mips.rs:211) calls on this machine.  The contour MIP's GPU kernels
+ * restate glibc's algorithm (invesalius3_amd/csrc/glibc_powf.h); tests compare the two bit for bit through this. */
+void orc_powf_array(const float *x, const float *y, float *out, int64_t n) {
+    for (int64_t i = 0; i < n; i++) out[i] = powf(x[i], y[i]);
+}
+
 int orc_fcm_volume(int dt, const void *img_, const int64_t shape[3], const int64_t s[3], float n, int axis,
                    void *tmp_) {
     const char *img = (const char *)img_;

@@ -246,6 +246,15 @@ def fcm_volume(image, n, axis):
     return tmp
 
 
+def powf_array(x, y):
+    """libm's powf elementwise (float32 in, float32 out): Rust's f32::powf on this machine (mips.rs:211)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    out = np.empty(x.shape, np.float32)
+    lib().orc_powf_array(_p(x), _p(y), _p(out), ctypes.c_int64(x.size))
+    return out
+
+
 def fast_countour_mip(image, n, axis, wl, ww, tmip, out):
     """fast_countour_mip_internal mips.rs:215-279."""
     _check(lib().orc_fast_countour_mip(DT[image.dtype], _p(image), _i64(image.shape), _i64(image.strides),

@@ -147,3 +147,25 @@ def test_contour_volume_and_its_three_projections_second_restatement(oracle, n):
             oracle.fast_countour_mip(img, n, axis, 300, 1500, tmip, got)
             want = tmp.max(axis) if tmip == 0 else lmip_py(tmp, axis, 700, 3033) if tmip == 1 else mida_py(tmp, axis, 300, 1500)
             assert np.array_equal(got, want), (axis, tmip)
+
+
+def test_the_restated_glibc_powf_is_this_machines_libm_powf_bit_for_bit(tmp_path):
+    """invesalius3_amd/csrc/glibc_powf.h (the power function of the contour MIP's kernels: glibc's algorithm and tables
+    restated, in the plain and the FMA build) compiled for the HOST and run against libm's powf -- Rust's f32::powf
+    (mips.rs:211) on this machine -- on 2 * 10^7 inputs: the contour MIP's own domain, arbitrary bit patterns (NaN, inf,
+    subnormal), negative bases, the overflow / underflow range.  tools/check_powf.c exits 0 iff the build that glibc's
+    selector picks on this CPU (FMA + AVX2 -> the FMA build) agrees on every input."""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        import pytest
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "check_powf")
+    subprocess.run([cxx, "-O2", "-ffp-contract=off", "-o", exe, "-x", "c++", os.path.join(root, "tools", "check_powf.c"), "-lm"], check=True)
+    r = subprocess.run([exe, "20"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "differs from libm" in r.stdout
