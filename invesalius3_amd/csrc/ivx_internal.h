@@ -54,7 +54,7 @@ static inline size_t dtype_size(int dt) {
 }
 
 // Cached device workspaces for the host-level entry points (grow-only, freed by ivx_release_workspace).
-enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_CCL0, WS_CCL1, WS_MCLIST, WS_MCV, WS_MCST, WS_MESH, WS_MESH2, WS_HOLES, WS_LUT, WS_WSIFT, WS_WSSK, WS_WSA, WS_COUNT };
+enum { WS_IN = 0, WS_OUT, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_SMALL, WS_CCL0, WS_CCL1, WS_MCLIST, WS_MCV, WS_MCST, WS_MESH, WS_MESH2, WS_HOLES, WS_LUT, WS_WSIFT, WS_WSSK, WS_WSA, WS_WSLINK, WS_COUNT };
 int ws_get(int slot, size_t nbytes, void **dptr);
 // Same, but private to `stream`: the device-level entry points keep their internal scratch (MC triangle list, MIP
 // partials, union-find tables, ...) per stream, so several resident volumes can run concurrently from different

@@ -12,6 +12,7 @@
 // All are HBM streaming passes (bytes per voxel in DESIGN.md section 3); no LDS tiling is needed except for the
 // gradient, whose 27 taps are served by L1/L2 (each row is re-read by its y/z neighbours while still cached).
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 #include "ivx_internal.h"
@@ -558,6 +559,17 @@ extern "C" int ivx_do_watershed_into(const int16_t *img, const int64_t shape[3],
                                      const int64_t out_strides[3], int64_t stats[16]) {
     ivx::HostCallGuard host_guard__;
     using namespace ivx;
+    // IVX_HOST_TIMING=1: where the call's wall time goes (stderr; every mark waits for the device)
+    const bool timing = getenv("IVX_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        const auto t = now();
+        fprintf(stderr, "ivx do_watershed: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     IVX_REQUIRE(algorithm == 0 || algorithm == 1, IVX_EINVAL, "do_watershed: algorithm must be 0 (Watershed IFT) or 1 (Watershed)");
     IVX_REQUIRE(mdtype == IVX_I16 || mdtype == IVX_I8, IVX_EINVAL, "do_watershed: markers must be cast to int16 or int8");
     IVX_REQUIRE(algorithm == 0 || gradient_size, IVX_EINVAL, "do_watershed: the Watershed branch needs the gradient size");
@@ -572,7 +584,9 @@ extern "C" int ivx_do_watershed_into(const int16_t *img, const int64_t shape[3],
     if ((rc = ws_get(WS_AUX0, (size_t)n * 2, &d_a))) return rc;
     if ((rc = ws_get(WS_AUX2, (size_t)n * msz, &d_mk))) return rc;
     if ((rc = ws_get(WS_OUT, (size_t)n, &d_out))) return rc;
+    mark("workspaces");
     if ((rc = upload_strided(d_img, img, shape, strides, 2, WS_IN))) return rc;
+    mark("image up");
     if (mk_src_dtype == mdtype) {
         if ((rc = upload_strided(d_mk, markers, shape, mk_strides, msz, WS_AUX2))) return rc;
     } else {
@@ -583,6 +597,7 @@ extern "C" int ivx_do_watershed_into(const int16_t *img, const int64_t shape[3],
                                : cast_markers_to<int8_t>(mk_src_dtype, d_raw, (int8_t *)d_mk, n, nullptr);
         if (rc) return rc;
     }
+    mark("markers up (+ cast)");
     if (use_ww_wl) {
         if ((rc = ivx_dev_lut_u16((const int16_t *)d_img, n, window, level, 0, (uint16_t *)d_a, nullptr))) return rc;
     } else {
@@ -606,7 +621,10 @@ extern "C" int ivx_do_watershed_into(const int16_t *img, const int64_t shape[3],
     }
     if (rc != IVX_OK) return rc;
     IVX_HIP(hipDeviceSynchronize());
-    return download_strided(out_u8, shape, out_strides, d_out, 1, WS_OUT);
+    mark("cost image + flood");
+    rc = download_strided(out_u8, shape, out_strides, d_out, 1, WS_OUT);
+    mark("labels down");
+    return rc;
 }
 
 extern "C" int ivx_do_watershed(const int16_t *img, const int64_t shape[3], const int64_t strides[3], int mdtype, const void *markers,

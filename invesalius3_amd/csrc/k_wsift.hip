@@ -89,12 +89,54 @@ __device__ __forceinline__ uint32_t ws_tau_of(const uint32_t *__restrict__ comp,
     return __hip_atomic_load(&tau[cv == ENTRY ? (uint32_t)v : cv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// mark the wave's keys in the used-key bitmap: one atomic per distinct key of the wave, and none for keys already marked (the
+// leader looks right before it would set the bit).  (Round 5, measured: every lane testing its own bit up front -- all loads in
+// flight together -- and fire-and-forget atomics for the unmarked keys made the level chain SLOWER, 11.3 -> 13.2 ms at 512^3:
+// when a level starts, a thousand workgroups see the same few hundred bits unset at once and all of them send their atomics;
+// the late look inside the loop is what keeps the same-address traffic down.)
+__device__ __forceinline__ void ws_mark_used(uint32_t *used, bool has, uint32_t K) {
+    unsigned long long todo = __ballot(has);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lk = __shfl(K, leader, 64);
+        const unsigned long long same = __ballot(has && K == lk);
+        if (lane == leader) {
+            const uint32_t bit = 1u << (lk & 31);
+            if (!(__hip_atomic_load(&used[lk >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&used[lk >> 5], bit);
+        }
+        todo &= ~same;
+    }
+}
+
+// ... per WORKGROUP when the stamps issued so far fit an LDS bitmap (2^18 of them; a 512^3 flood issues ~10^5): the lanes set
+// their keys' bits with LDS atomics, then every lane flushes a few words -- its loads of the global words in flight together,
+// an atomic only where bits are still missing.  The per-wave loop above pays one dependent agent-scope load per DISTINCT key
+// of the wave, serially (rocprofv3, round 5: k_ws_keys 55 us per level with three gathers per entry, 61 us with one -- the
+// gathers were never the cost).
+constexpr uint32_t USED_LDS_WORDS = 8192;
+__device__ __forceinline__ void ws_mark_used_block(uint32_t *used, uint32_t *s_used, uint32_t nw, bool has, uint32_t K) {
+    if (has) atomicOr(&s_used[K >> 5], 1u << (K & 31));
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nw; i += 256) {
+        const uint32_t m = s_used[i];
+        if (m && (m & ~__hip_atomic_load(&used[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicOr(&used[i], m);
+    }
+}
+
 // key of every entry of level c: the earliest time stamp among its admissible parents (the set bits of pmask); mark the
 // key as used
 template <int CONN>
 __global__ __launch_bounds__(256) void k_ws_keys(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ comp,
                                                  const uint32_t *tau, const uint32_t *__restrict__ elist, uint32_t *__restrict__ key,
-                                                 uint32_t *used, uint32_t start, uint32_t count) {
+                                                 uint32_t *used, uint32_t start, uint32_t count, const WsState *st) {
+    __shared__ uint32_t s_used[USED_LDS_WORDS];
+    const uint32_t nw = (st->base + 31) >> 5; // (stamps issued before this level: every key is one of them)
+    const bool lds = nw <= USED_LDS_WORDS;
+    if (lds) {
+        for (uint32_t w = threadIdx.x; w < nw; w += 256) s_used[w] = 0u;
+        __syncthreads();
+    }
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < count;
     uint32_t K = NONE;
@@ -109,19 +151,8 @@ __global__ __launch_bounds__(256) void k_ws_keys(WsGeom g, const uint32_t *__res
         }
         key[start + i] = K;
     }
-    // one atomic per distinct key of the wave, and none for keys already marked
-    unsigned long long todo = __ballot(act && K != NONE);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t lk = __shfl(K, leader, 64);
-        const unsigned long long same = __ballot(act && K == lk);
-        if (lane == leader) {
-            const uint32_t bit = 1u << (lk & 31);
-            if (!(__hip_atomic_load(&used[lk >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&used[lk >> 5], bit);
-        }
-        todo &= ~same;
-    }
+    if (lds) ws_mark_used_block(used, s_used, nw, act && K != NONE, K);
+    else ws_mark_used(used, act && K != NONE, K);
 }
 
 // ONE workgroup: the used keys in ascending order, split into classes where the label changes; class j (ascending) gets
@@ -238,6 +269,156 @@ __global__ __launch_bounds__(256) void k_ws_claim(WsGeom g, const uint32_t *__re
         if (r == ENTRY) continue;
         if (__hip_atomic_load(&tau[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > t) atomicMin(&tau[r], t);
     }
+}
+
+// ---- links resolved once, in raster order (round 5) --------------------------------------------------------------------------
+// The per-level kernels above chase, for every entry of a level, pmask[p] -> comp[q] -> tau[q or root] (keys) and zmask[p] ->
+// comp[q] -> tau[root] (claim): three dependent gathers into 0.5 GB tables at places that have nothing to do with each other
+// inside a level's list (PMC: 9.7 + 7.3 GB per 512^3 flood, ~300 B per entry).  But WHICH words of tau an entry reads and
+// writes is fixed once the zones are flattened: the scatter pass that puts the entries into their levels' lists walks the
+// volume in raster order, where p's masks are a streaming read and comp[p +- 1 / w / hw] sit on lines its neighbours in the
+// wave just touched, and leaves next to elist[slot]
+// one 32-byte record per entry in place of elist[slot]: the voxel, the (up to two distinct) words of tau that hold its parents'
+// stamps, and the (up to three distinct) zone roots it hands its own stamp to; an entry with more of either gets LINK_MORE in
+// the last slot and takes the old walk over its mask.  A level's keys / claim then cost one coalesced read of the records and
+// ONE gather / atomic each into tau.  (Separate link arrays -- six scattered 4 / 8-byte stores per entry -- cost the scatter
+// +1.6 ms at 512^3, +11 ms at 1024^3; one record is two stores into one 32-byte sector.)
+constexpr uint32_t LINK_MORE = 0xFFFFFFFEu;
+
+template <int CONN, typename MT>
+__global__ __launch_bounds__(256) void k_ws_bucket_links(WsGeom g, const uint16_t *__restrict__ C, const uint32_t *__restrict__ comp,
+                                                         const MT *__restrict__ mk, const uint32_t *__restrict__ pmask,
+                                                         const uint32_t *__restrict__ zmask, uint32_t *__restrict__ cursor,
+                                                         uint32_t *__restrict__ rec) {
+    __shared__ uint32_t sh[BK_LB];
+    for (int i = threadIdx.x; i < BK_LB; i += 256) sh[i] = 0;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
+    for (int pass = 0; pass < 2; pass++) { // (the counting / placing scheme of k_ws_bucket<PRED, true>)
+        for (int j = 0; j < BK_CH; j++) {
+            const int64_t p = b0 + (int64_t)j * 256 + threadIdx.x;
+            const bool e = p < g.n && comp[p] == ENTRY && mk[p] == 0;
+            if (!e) continue;
+            const uint32_t c = C[p];
+            uint32_t off;
+            if (c < BK_LB) {
+                off = atomicAdd(&sh[c], 1u);
+                if (pass == 0) continue;
+            } else {
+                if (pass == 0) continue;
+                off = atomicAdd(&cursor[c], 1u);
+            }
+            uint32_t pl[2] = {NONE, NONE}, zl[3] = {NONE, NONE, NONE};
+            int np = 0, nzl = 0;
+            uint32_t pm = pmask[p];
+            while (pm) {
+                const int k = __ffs(pm) - 1;
+                pm &= pm - 1;
+                const int64_t q = p + (k / 9 - 1) * g.hw + ((k / 3) % 3 - 1) * g.w + (k % 3 - 1);
+                const uint32_t cv = comp[q];
+                const uint32_t loc = cv == ENTRY ? (uint32_t)q : cv;
+                if (loc == pl[0] || loc == pl[1]) continue;
+                if (np < 2) pl[np] = loc;
+                np++;
+            }
+            if (np > 2) pl[1] = LINK_MORE;
+            uint32_t zm = zmask[p];
+            while (zm) {
+                const int k = __ffs(zm) - 1;
+                zm &= zm - 1;
+                const int64_t q = p + (k / 9 - 1) * g.hw + ((k / 3) % 3 - 1) * g.w + (k % 3 - 1);
+                const uint32_t r = comp[q];
+                if (r == ENTRY || r == zl[0] || r == zl[1] || r == zl[2]) continue;
+                if (nzl < 3) zl[nzl] = r;
+                nzl++;
+            }
+            if (nzl > 3) zl[2] = LINK_MORE;
+            // ONE 32-byte record per entry (two 16-byte stores into one sector): { p, parent 0, parent 1, zone 0 | zone 1, zone 2, -, - }
+            uint4 *r4 = reinterpret_cast<uint4 *>(rec + 8 * (size_t)off);
+            r4[0] = make_uint4((uint32_t)p, pl[0], pl[1], zl[0]);
+            r4[1] = make_uint4(zl[1], zl[2], 0u, 0u);
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int i = threadIdx.x; i < BK_LB; i += 256) {
+                const uint32_t v = sh[i];
+                if (v) sh[i] = atomicAdd(&cursor[i], v);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int CONN>
+__global__ __launch_bounds__(256) void k_ws_keys_links(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ comp,
+                                                       const uint32_t *tau, const uint32_t *__restrict__ rec, uint32_t *__restrict__ key,
+                                                       uint32_t *used, uint32_t start, uint32_t count, const WsState *st) {
+    __shared__ uint32_t s_used[USED_LDS_WORDS];
+    const uint32_t nw = (st->base + 31) >> 5; // (stamps issued before this level: every key is one of them)
+    const bool lds = nw <= USED_LDS_WORDS;
+    if (lds) {
+        for (uint32_t w = threadIdx.x; w < nw; w += 256) s_used[w] = 0u;
+        __syncthreads();
+    }
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < count;
+    uint32_t K = NONE;
+    if (act) {
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(rec + 8 * (size_t)(start + i));
+        const uint2 l = make_uint2(r0.y, r0.z);
+        if (l.y == LINK_MORE) { // more than two distinct parents: the walk over the mask
+            const int64_t p = r0.x;
+            uint32_t pm = pmask[p];
+            while (pm) {
+                const int k = __ffs(pm) - 1;
+                pm &= pm - 1;
+                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                K = min(K, ws_tau_of(comp, tau, p + dz * g.hw + dy * g.w + dx));
+            }
+        } else { // both gathers in flight together
+            const uint32_t t0 = l.x != NONE ? __hip_atomic_load(&tau[l.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;
+            const uint32_t t1 = l.y != NONE ? __hip_atomic_load(&tau[l.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;
+            K = min(t0, t1);
+        }
+        key[start + i] = K;
+    }
+    if (lds) ws_mark_used_block(used, s_used, nw, act && K != NONE, K);
+    else ws_mark_used(used, act && K != NONE, K);
+}
+
+template <int CONN>
+__global__ __launch_bounds__(256) void k_ws_claim_links(WsGeom g, const uint32_t *__restrict__ zmask, const uint32_t *__restrict__ comp,
+                                                        uint32_t *tau, const uint32_t *__restrict__ rec, const uint32_t *__restrict__ key,
+                                                        const uint32_t *__restrict__ remap, uint32_t start, uint32_t count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t K = key[start + i];
+    if (K == NONE) return;
+    const uint4 r0 = *reinterpret_cast<const uint4 *>(rec + 8 * (size_t)(start + i));
+    const uint2 r1 = *reinterpret_cast<const uint2 *>(rec + 8 * (size_t)(start + i) + 4);
+    const int64_t p = r0.x;
+    const uint32_t z0 = r0.w, z1 = r1.x, z2 = r1.y;
+    const uint32_t t = remap[K];
+    tau[p] = t;
+    if (z2 == LINK_MORE) { // more than three distinct zones: the walk over the mask
+        uint32_t zm = zmask[p];
+        while (zm) {
+            const int k = __ffs(zm) - 1;
+            zm &= zm - 1;
+            const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+            const uint32_t r = comp[p + dz * g.hw + dy * g.w + dx];
+            if (r == ENTRY) continue;
+            if (__hip_atomic_load(&tau[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > t) atomicMin(&tau[r], t);
+        }
+        return;
+    }
+    const uint32_t zz[3] = {z0, z1, z2};
+    uint32_t cur[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) cur[q] = zz[q] != NONE ? __hip_atomic_load(&tau[zz[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        if (zz[q] != NONE && cur[q] > t) atomicMin(&tau[zz[q]], t);
 }
 
 template <typename MT>
@@ -398,11 +579,29 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     }
     hipLaunchKernelGGL((k_ws_marker_list<MT>), dim3((unsigned)nblk), dim3(256), 0, st, g, mk, b.bcount, b.elist, b.key, b.lab);
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_ws_bucket<WsEntryPred<MT>, true>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g.n, b.C, WsEntryPred<MT>{b.comp, mk}, b.cursor, b.elist);
-    IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ws_fill32, dim3(2048), dim3(256), 0, st, b.tau, g.n, NONE);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipStreamSynchronize(st)); // hist is on the host now
+    // the entries' links next to the list (IVX_WS_LINKS=0: the per-level kernels chase the masks themselves; same labels)
+    uint32_t *rec = nullptr;
+    {
+        const char *el = getenv("IVX_WS_LINKS");
+        if (!(el && el[0] == '0')) {
+            uint64_t total_entries = 0;
+            for (uint32_t c = 0; c < 65536; c++) total_entries += hist[c];
+            void *lm = nullptr;
+            IVX_REQUIRE(ws_get_s(WS_WSLINK, st, (size_t)total_entries * 32 + 256, &lm) == IVX_OK, IVX_ENOMEM,
+                        "watershed_ift: %zu bytes for the entries' link records", (size_t)total_entries * 32 + 256);
+            rec = (uint32_t *)lm;
+        }
+    }
+    if (rec) {
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_bucket_links<CC, MT>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g, b.C, b.comp,
+                                                  mk, b.pmask, b.zmask, b.cursor, rec));
+    } else {
+        hipLaunchKernelGGL((k_ws_bucket<WsEntryPred<MT>, true>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g.n, b.C, WsEntryPred<MT>{b.comp, mk}, b.cursor, b.elist);
+    }
+    IVX_LAUNCH_CHECK();
 
     tm.mark(st);
     // ---- 4. the level chain --------------------------------------------------------------------------------
@@ -417,15 +616,26 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         if (!cnt) continue;
         nlevels++;
         const unsigned gb = (unsigned)cdiv(cnt, 256);
+        const bool links = rec != nullptr && c > 0; // (level 0 = the markers: listed by k_ws_marker_list, no links)
         if (c > 0) {
-            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_keys<CC>, dim3(gb), dim3(256), 0, st, g, b.pmask, b.comp, b.tau, b.elist, b.key,
-                                                      b.used, start, cnt));
+            if (links) {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_keys_links<CC>, dim3(gb), dim3(256), 0, st, g, b.pmask, b.comp, b.tau, rec, b.key, b.used, start,
+                                                          cnt, b.st));
+            } else {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_keys<CC>, dim3(gb), dim3(256), 0, st, g, b.pmask, b.comp, b.tau, b.elist, b.key,
+                                                          b.used, start, cnt, b.st));
+            }
             IVX_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(k_ws_rank, dim3(1), dim3(1024), 0, st, b.st, b.used, b.remap, b.lab, cap);
         IVX_LAUNCH_CHECK();
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_claim<CC>, dim3(gb), dim3(256), 0, st, g, b.zmask, b.comp, b.tau, b.elist, b.key,
-                                                  b.remap, start, cnt));
+        if (links) {
+            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_claim_links<CC>, dim3(gb), dim3(256), 0, st, g, b.zmask, b.comp, b.tau, rec, b.key, b.remap, start,
+                                                      cnt));
+        } else {
+            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_ws_claim<CC>, dim3(gb), dim3(256), 0, st, g, b.zmask, b.comp, b.tau, b.elist, b.key,
+                                                      b.remap, start, cnt));
+        }
         IVX_LAUNCH_CHECK();
         start += cnt;
     }

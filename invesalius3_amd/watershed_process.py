@@ -193,6 +193,16 @@ def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_
 
     Either warning comes after ``q.put(1)``."""
     global _ift_warned
+    import os
+    import time
+    t_host = [time.perf_counter()] if os.environ.get("IVX_HOST_TIMING") else None
+
+    def _mark(what):
+        if t_host is not None:
+            t = time.perf_counter()
+            import sys
+            print("py  do_watershed: %-28s %8.2f ms" % (what, (t - t_host[0]) * 1e3), file=sys.stderr)
+            t_host[0] = t
     mask = np.memmap(tfile, shape=shape, dtype="uint8", mode="r+")
     image = np.asarray(image)
     if image.dtype != np.int16 or image.ndim not in (2, 3):
@@ -218,6 +228,7 @@ def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_
     direct = mask.size == img3.size and tuple(d for d in mask.shape if d != 1) == tuple(d for d in img3.shape if d != 1)
     dst = mask.reshape(img3.shape) if direct else np.empty(img3.shape, np.uint8)
     stats = (ctypes.c_int64 * 16)()
+    _mark("memmap + argument checks")
     L.check(L.lib().ivx_do_watershed_into(L.ptr(img3), L.i64(img3.shape), L.i64(img3.strides), _MK_CODES[mk3.dtype], L.ptr(mk3),
                                           L.i64(mk3.strides), L.I16 if mdt == np.int16 else L.I8, L.ptr(_strct27(bstruct, image.ndim)),
                                           int(sk), gs, int(bool(use_ww_wl)), ctypes.c_double(float(ww)), ctypes.c_double(float(wl)),
@@ -228,9 +239,11 @@ def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_
     else:
         do_watershed.last_stats = {"algorithm": algorithm, "reference": _IFT_REFERENCE, "exact": False, "note": _IFT_NOTE,
                                    "tied_markers_of_different_labels": 0}
+    _mark("ivx_do_watershed_into")
     if not direct:
         mask[:] = dst.reshape(image.shape)
     mask.flush()
+    _mark("flush (msync)")
     if q is not None:
         q.put(1)
     # the warnings come LAST: with warnings promoted to errors (-W error) the labels are written and the caller waiting on
