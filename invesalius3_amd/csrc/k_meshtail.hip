@@ -137,6 +137,18 @@ __global__ __launch_bounds__(256) void k_rim_next(const int32_t *__restrict__ fa
     lab[i] = i;
     dead[i] = nx == NONE ? 1u : 0u;
 }
+// `next` must be injective for the walk below: with duplicated directed edges (non-manifold input) the edge hash keeps one of
+// them and two rim edges can end up with the same successor -- a tail hanging into a cycle.  Its leader would walk into the
+// cycle and overwrite the real leader's ranks.  Every rim edge with an in-degree other than one is declared dead
+// before the pointer jumping, which spreads "dead" to everything that reaches it: such rims are left open, like open chains.
+__global__ __launch_bounds__(256) void k_rim_indegree(uint32_t nb, const uint32_t *__restrict__ next, uint32_t *__restrict__ indeg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb && next[i] != NONE) atomicAdd(&indeg[next[i]], 1u);
+}
+__global__ __launch_bounds__(256) void k_rim_kill(uint32_t nb, const uint32_t *__restrict__ indeg, uint32_t *__restrict__ dead) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb && indeg[i] != 1u) dead[i] = 1u;
+}
 // one round of pointer jumping (reads generation g, writes generation g + 1)
 __global__ __launch_bounds__(256) void k_rim_jump(uint32_t nb, const uint32_t *__restrict__ nx0, const uint32_t *__restrict__ lab0,
                                                   const uint32_t *__restrict__ dead0, uint32_t *__restrict__ nx1, uint32_t *__restrict__ lab1,
@@ -337,16 +349,26 @@ __global__ __launch_bounds__(256) void k_fan_scatter(const int32_t *__restrict__
     const uint32_t s = atomicAdd(&cursor[v], 1u);
     seg[(size_t)off[v] + s] = ((unsigned long long)label << 32) | (uint32_t)c;
 }
-// one lane per vertex: sort its segment (fan-major, corner ascending inside a fan) and count the fans beyond the first
+// one lane per vertex: sort its segment (fan-major, corner ascending inside a fan) and count the fans beyond the first.  A vertex
+// has a handful of corners -- except the centroid of a filled hole, which has as many as its rim has edges (thousands, with hole
+// size 300), in the arbitrary order k_fan_scatter's atomics left them: an insertion sort in one lane is ~n^2 / 4 dependent
+// global moves there.  Segments beyond FAN_LANE_MAX corners are only listed here and sorted by a workgroup each
+// (k_fan_sort_big).
+constexpr uint32_t FAN_LANE_MAX = 48;
 __global__ __launch_bounds__(256) void k_fan_sort(int64_t nv, const uint32_t *__restrict__ off, unsigned long long *__restrict__ seg,
-                                                  uint32_t *__restrict__ extra) {
+                                                  uint32_t *__restrict__ extra, uint32_t *__restrict__ big, uint32_t *__restrict__ nbig) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v > nv) return;
     if (v == nv) { extra[v] = 0u; return; }
     const uint32_t s0 = off[v], s1 = off[v + 1];
     unsigned long long *p = seg + s0;
     const uint32_t n = s1 - s0;
-    for (uint32_t i = 1; i < n; i++) { // insertion sort: a vertex has a handful of corners (a hole's centroid has its rim's)
+    if (n > FAN_LANE_MAX) {
+        big[atomicAdd(nbig, 1u)] = (uint32_t)v;
+        extra[v] = 0u; // (k_fan_sort_big writes the count)
+        return;
+    }
+    for (uint32_t i = 1; i < n; i++) {
         const unsigned long long x = p[i];
         uint32_t j = i;
         while (j > 0 && p[j - 1] > x) { p[j] = p[j - 1]; j--; }
@@ -356,6 +378,45 @@ __global__ __launch_bounds__(256) void k_fan_sort(int64_t nv, const uint32_t *__
     for (uint32_t i = 0; i < n; i++)
         if (i == 0 || (p[i] >> 32) != (p[i - 1] >> 32)) fans++;
     extra[v] = fans > 1u ? fans - 1u : 0u;
+}
+// one workgroup per listed vertex: bitonic network over the segment in global memory, all comparators ascending (the first step
+// of every merge pairs i with i ^ (k - 1), the others i with i ^ j), so the virtual +inf padding up to the next power of two is
+// never touched; then the fans are counted
+__global__ __launch_bounds__(256) void k_fan_sort_big(const uint32_t *__restrict__ off, unsigned long long *seg, uint32_t *__restrict__ extra,
+                                                      const uint32_t *__restrict__ big, const uint32_t *__restrict__ nbig) {
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t count = *nbig;
+    for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
+        const uint32_t v = big[b], s0 = off[v], n = off[v + 1] - s0;
+        unsigned long long *p = seg + s0;
+        uint32_t P = 1;
+        while (P < n) P <<= 1;
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t flip = j == (k >> 1) ? k - 1u : j;
+                for (uint32_t i = threadIdx.x; i < P; i += 256) {
+                    const uint32_t l = i ^ flip;
+                    if (l > i && l < n) {
+                        const unsigned long long a = p[i], c = p[l];
+                        if (a > c) { p[i] = c; p[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        uint32_t fans = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            if (i == 0 || (p[i] >> 32) != (p[i - 1] >> 32)) fans++;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fans += __shfl_xor(fans, o, 64);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = fans;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t f = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            extra[v] = f > 1u ? f - 1u : 0u;
+        }
+        __syncthreads();
+    }
 }
 // one lane per vertex: ids of its fans' points, the faces' corners, the copied points and every point's normal
 __global__ __launch_bounds__(256) void k_fan_emit(const float *__restrict__ verts, int64_t nv, const uint32_t *__restrict__ off,
@@ -510,6 +571,11 @@ extern "C" int ivx_mesh_fill_holes(const float *verts, int64_t nverts, const int
         IVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_rim_next, dim3(grid_for(nb)), dim3(256), 0, st, d_f, d_rim, nb, h, d_flag, d_next, d_lab[0], d_dead[0]);
         IVX_LAUNCH_CHECK();
+        IVX_HIP(hipMemsetAsync(d_rank, 0, (size_t)nb * 4, st)); // (d_rank doubles as the in-degree table until the walk writes it)
+        hipLaunchKernelGGL(k_rim_indegree, dim3(grid_for(nb)), dim3(256), 0, st, nb, d_next, d_rank);
+        IVX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_rim_kill, dim3(grid_for(nb)), dim3(256), 0, st, nb, d_rank, d_dead[0]);
+        IVX_LAUNCH_CHECK();
         IVX_HIP(hipMemcpyAsync(d_nx[0], d_next, (size_t)nb * 4, hipMemcpyDeviceToDevice, st));
         int g = 0;
         for (uint64_t reach = 1; reach < (uint64_t)nb * 2; reach <<= 1, g ^= 1) { // after r rounds an edge has seen 2^r successors
@@ -532,6 +598,7 @@ extern "C" int ivx_mesh_fill_holes(const float *verts, int64_t nverts, const int
         if (!new_verts || !new_faces || nholes == 0) return IVX_OK;
         IVX_REQUIRE(want_v >= (int64_t)nholes && want_t >= (int64_t)ncap, IVX_EINVAL,
                     "mesh_fill_holes: room for %lld points / %lld triangles, %u / %u needed", (long long)want_v, (long long)want_t, nholes, ncap);
+        IVX_HIP(hipMemsetAsync(d_nf, 0, (size_t)ncap * 12, st)); // (no row of the caller's array is ever left as it was found)
         hipLaunchKernelGGL(k_rim_emit, dim3(grid_for(nb)), dim3(256), 0, st, d_f, d_rim, nb, d_rank, d_loop, d_info, d_lflag, d_lcount, nverts, d_nv,
                            d_nf);
         IVX_LAUNCH_CHECK();
@@ -570,6 +637,7 @@ extern "C" int ivx_mesh_point_normals(const float *verts, int64_t nverts, const 
     EdgeHash h{nullptr, nullptr, hmask};
     uint32_t *d_parent = nullptr, *d_first = nullptr, *d_deg = nullptr, *d_cursor = nullptr, *d_extra = nullptr, *d_bsum = nullptr, *d_tot = nullptr;
     unsigned long long *d_seg = nullptr;
+    uint32_t *d_big = nullptr, *d_nbig = nullptr;
     for (int pass = 0; pass < 2; pass++) {
         ar.used = 0;
         d_f = (int32_t *)ar.take((size_t)ne * 4);
@@ -587,6 +655,8 @@ extern "C" int ivx_mesh_point_normals(const float *verts, int64_t nverts, const 
         d_cursor = (uint32_t *)ar.take((size_t)nverts * 4 + 16);
         d_extra = (uint32_t *)ar.take(((size_t)nverts + 1) * 4);
         d_seg = (unsigned long long *)ar.take((size_t)ne * 8);
+        d_big = (uint32_t *)ar.take(((size_t)ne / FAN_LANE_MAX + 2) * 4); // vertices with more than FAN_LANE_MAX corners + their count
+        d_nbig = (uint32_t *)ar.take(256);
         d_bsum = (uint32_t *)ar.take(((size_t)scan_u32_blocks(nverts + 1) + 2) * 4);
         d_tot = (uint32_t *)ar.take(256);
         if (pass == 0) {
@@ -623,7 +693,11 @@ extern "C" int ivx_mesh_point_normals(const float *verts, int64_t nverts, const 
     if ((rc = scan_u32_exclusive(d_deg, nverts + 1, d_bsum, d_tot, st))) return rc; // d_deg is now the segment offsets
     hipLaunchKernelGGL(k_fan_scatter, dim3(grid_for(ne)), dim3(256), 0, st, d_of, ne, d_parent, d_first, splitting, d_deg, d_cursor, d_seg);
     IVX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_fan_sort, dim3(grid_for(nverts + 1)), dim3(256), 0, st, nverts, d_deg, d_seg, d_extra);
+    IVX_HIP(hipMemsetAsync(d_nbig, 0, 4, st));
+    hipLaunchKernelGGL(k_fan_sort, dim3(grid_for(nverts + 1)), dim3(256), 0, st, nverts, d_deg, d_seg, d_extra, d_big, d_nbig);
+    IVX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fan_sort_big, dim3((unsigned)std::min<int64_t>(ne / FAN_LANE_MAX + 1, 1024)), dim3(256), 0, st, d_deg, d_seg, d_extra, d_big,
+                       d_nbig);
     IVX_LAUNCH_CHECK();
     if ((rc = scan_u32_exclusive(d_extra, nverts + 1, d_bsum, d_tot, st))) return rc;
     uint32_t nextra = 0;

@@ -554,7 +554,11 @@ template <int CONN>
 __global__ __launch_bounds__(256) void k_ws_union(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= g.n) return;
-    if (__hip_atomic_load(&comp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) return;
+    // Whether a voxel is a member at all (comp != ENTRY) was settled by the launches before this one and never changes here: those
+    // tests are ordinary loads that the L2 may serve (a neighbour's line was fetched by the lanes next door); only the parent
+    // pointers that other workgroups rewrite meanwhile are read at agent scope (ws_find).
+    const uint32_t *member = comp;
+    if (member[p] == ENTRY) return;
     uint32_t zm = zmask[p] >> 14; // forward neighbours only (k = 14 .. 26)
     if ((threadIdx.x & 63) != 63) zm &= ~1u; // +x inside a wave: done by k_ws_runs
     while (zm) {
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256) void k_ws_union(WsGeom g, const uint32_t *__re
         zm &= zm - 1;
         const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
         const int64_t q = p + dz * g.hw + dy * g.w + dx;
-        if (__hip_atomic_load(&comp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ENTRY) continue;
+        if (member[q] == ENTRY) continue;
         ws_unite(comp, (uint32_t)p, (uint32_t)q);
     }
 }

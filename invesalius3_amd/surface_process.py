@@ -294,16 +294,19 @@ def fill_holes(verts, faces, hole_size=300.0):
     plain Python (tests/_mesh_tail_ref.py).  Returns (verts, faces, number of holes filled)."""
     v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
     f = np.ascontiguousarray(np.asarray(faces, np.int32).reshape(-1, 3))
-    nv, nt = ctypes.c_int64(0), ctypes.c_int64(0)
-    lib = L.lib()
-    L.check(lib.ivx_mesh_fill_holes(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), ctypes.c_double(float(hole_size)),
-                                    None, None, ctypes.byref(nv), ctypes.byref(nt)), "mesh_fill_holes")
+    if not len(f):
+        return v, f, 0
+    # ONE call (the size-query-then-fill protocol ran the whole pipeline -- upload, edge hash, rim walk, scans -- twice): room for
+    # the worst case, one new point per three rim edges and one cap triangle per rim edge, of which every edge of the mesh could be
+    # one; np.empty pages that are never written cost nothing
+    cap_v, cap_t = len(f), 3 * len(f)
+    new_v, new_f = np.empty((cap_v, 3), np.float32), np.empty((cap_t, 3), np.int32)
+    nv, nt = ctypes.c_int64(cap_v), ctypes.c_int64(cap_t)
+    L.check(L.lib().ivx_mesh_fill_holes(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), ctypes.c_double(float(hole_size)),
+                                        L.ptr(new_v), L.ptr(new_f), ctypes.byref(nv), ctypes.byref(nt)), "mesh_fill_holes")
     if nv.value == 0:
         return v, f, 0
-    new_v, new_f = np.empty((nv.value, 3), np.float32), np.empty((nt.value, 3), np.int32)
-    L.check(lib.ivx_mesh_fill_holes(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), ctypes.c_double(float(hole_size)),
-                                    L.ptr(new_v), L.ptr(new_f), ctypes.byref(nv), ctypes.byref(nt)), "mesh_fill_holes")
-    return np.concatenate([v, new_v]), np.concatenate([f, new_f]), int(nv.value)
+    return np.concatenate([v, new_v[:nv.value]]), np.concatenate([f, new_f[:nt.value]]), int(nv.value)
 
 
 def point_normals(verts, faces, feature_angle=80.0, splitting=True, auto_orient=True):
@@ -322,13 +325,14 @@ def point_normals(verts, faces, feature_angle=80.0, splitting=True, auto_orient=
         return v, f, np.zeros((len(v), 3), np.float32), np.zeros((0, 3), np.float32)
     lib = L.lib()
     cosang = ctypes.c_double(float(np.cos(np.deg2rad(feature_angle))))
-    n = ctypes.c_int64(0)
+    # ONE call with room for the worst case (every corner its own point): pages of np.empty that are never written cost nothing
+    cap = len(v) + 3 * len(f)
+    n = ctypes.c_int64(cap)
     args = (L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), cosang, int(bool(splitting)), int(bool(auto_orient)))
-    L.check(lib.ivx_mesh_point_normals(*args, None, None, None, None, ctypes.byref(n)), "mesh_point_normals")
-    out_v, out_f = np.empty((n.value, 3), np.float32), np.empty((len(f), 3), np.int32)
-    pn, cn = np.empty((n.value, 3), np.float32), np.empty((len(f), 3), np.float32)
+    out_v, out_f = np.empty((cap, 3), np.float32), np.empty((len(f), 3), np.int32)
+    pn, cn = np.empty((cap, 3), np.float32), np.empty((len(f), 3), np.float32)
     L.check(lib.ivx_mesh_point_normals(*args, L.ptr(out_v), L.ptr(out_f), L.ptr(pn), L.ptr(cn), ctypes.byref(n)), "mesh_point_normals")
-    return out_v, out_f, pn, cn
+    return out_v[:n.value], out_f, pn[:n.value], cn
 
 
 def join_process_surface(filenames, algorithm, smooth_iterations, smooth_relaxation_factor, decimate_reduction, keep_largest,

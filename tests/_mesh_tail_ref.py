@@ -7,6 +7,8 @@ convention, so that the kernels can be compared array for array:
 * a rim (boundary) edge has no opposite edge; the successor of rim edge (a -> v) of face F is found by turning about v: F's
   next edge (v -> x), the face across it, that face's next edge, ... until an edge leaving v has no face across it (at most 64
   faces, else the chain ends) -- at a pinch point every fan of faces continues its own rim;
+* a rim edge that is the successor of two rim edges (duplicated directed edges of non-manifold input: a chain hanging into a
+  cycle) spoils every rim that reaches it -- such rims stay open, like chains that do not close;
 * rims that close are ordered by their smallest edge and walked from it; a rim of >= 3 edges whose bounding sphere (half the
   diagonal of its bounding box) has a radius <= hole_size gets ONE new point, the mean of its points (float64, summed in
   walking order), and the triangles (b, a, centre) of its edges a -> b;
@@ -47,6 +49,9 @@ def rim_loops(faces):
             cur = first.get((int(x), int(v)))
             if cur is None:
                 break
+    indeg = {}
+    for j in nxt.values():
+        indeg[j] = indeg.get(j, 0) + 1
     loops, seen = [], set()
     for i in rim.tolist():  # ascending: the first unseen edge of a closed rim is its smallest
         if i in seen:
@@ -56,7 +61,7 @@ def rim_loops(faces):
             seen.add(j)
             path.append(j)
             j = nxt.get(j)
-        if j == i:
+        if j == i and all(indeg.get(k, 0) == 1 for k in path):  # a rim another chain hangs into is left open
             loops.append(path)
     return loops
 
