@@ -553,20 +553,28 @@ __device__ __forceinline__ void ws_unite(uint32_t *comp, uint32_t a, uint32_t b)
 template <int CONN>
 __global__ __launch_bounds__(256) void k_ws_union(WsGeom g, const uint32_t *__restrict__ zmask, uint32_t *comp) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= g.n) return;
+    const int lane = threadIdx.x & 63;
     // Whether a voxel is a member at all (comp != ENTRY) was settled by the launches before this one and never changes here: those
-    // tests are ordinary loads that the L2 may serve (a neighbour's line was fetched by the lanes next door); only the parent
-    // pointers that other workgroups rewrite meanwhile are read at agent scope (ws_find).
+    // tests are ordinary loads that the L2 may serve; only the parent pointers that other workgroups rewrite meanwhile are read at
+    // agent scope (ws_find).
     const uint32_t *member = comp;
-    if (member[p] == ENTRY) return;
-    uint32_t zm = zmask[p] >> 14; // forward neighbours only (k = 14 .. 26)
-    if ((threadIdx.x & 63) != 63) zm &= ~1u; // +x inside a wave: done by k_ws_runs
+    const bool mine = p < g.n && member[p] != ENTRY;
+    const uint32_t zmp = mine ? zmask[p] : 0u;
+    // A +y / +z link p -> q is implied by its left neighbour's when p-1 ~ p and q-1 ~ q are links themselves and p-1 -> q-1 is the
+    // same kind of link: the sets are the same with or without it (round 5: inside a plateau only the first voxel of a row segment
+    // hooks across, the others skip two finds and an atomic each).  The left neighbour's mask comes by shuffle, so lane 0 never skips.
+    const uint32_t zleft = __shfl_up(zmp, 1, 64);
+    const bool left_ok = lane > 0 && (zmp >> 12 & 1u) && __shfl_up((int)mine, 1, 64);
+    if (!mine) return;
+    uint32_t zm = zmp >> 14; // forward neighbours only (k = 14 .. 26)
+    if (lane != 63) zm &= ~1u; // +x inside a wave: done by k_ws_runs
     while (zm) {
         const int k = 14 + __ffs(zm) - 1;
         zm &= zm - 1;
         const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
         const int64_t q = p + dz * g.hw + dy * g.w + dx;
         if (member[q] == ENTRY) continue;
+        if ((k == 16 || k == 22) && left_ok && (zleft >> k & 1u) && (zmask[q] >> 12 & 1u) && member[q - 1] != ENTRY) continue;
         ws_unite(comp, (uint32_t)p, (uint32_t)q);
     }
 }
