@@ -14,6 +14,7 @@ cp $O/watershed_1024_kernels_pmc.md $P/${R}_wsift_1024_kernels_pmc.md 2>/dev/nul
 cp $O/watershed_kt_kernel_stats.csv $P/${R}_wsift_512_kernel_stats.csv; cp $O/watershed_kernels_pmc.md $P/${R}_wsift_512_kernels_pmc.md
 cp $O/watershed_sk_kt_kernel_stats.csv $P/${R}_wssk_512_kernel_stats.csv; cp $O/watershed_sk_kernels_pmc.md $P/${R}_wssk_512_kernels_pmc.md
 for f in bench_watershed_512 bench_watershed_sk_512 bench_watershed_1024 bench_watershed_sk_1024 bench_sharded2048_1gpu; do cp $O/$f.json $P/${R}_$f.json; done
+for f in bench_strong_1gpu bench_host_512 bench_mc_one_launch bench_watershed_512_nolinks; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/gpu_tests.txt ] && cp $O/gpu_tests.txt $P/${R}_gpu_tests.txt
 [ -f $O/force_slab.json ] && cp $O/force_slab.json $P/${R}_force_slab.json
 for k in slab_kt mip_kt stitch_kt; do f=$(find $O -name "${k}_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_${k}_kernel_stats.csv; done

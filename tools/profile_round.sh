@@ -18,7 +18,12 @@ D=$(dirname $(find $O -name "kt_kernel_stats.csv" | head -1))
 for f in fetch_counter_collection.csv write_counter_collection.csv; do s=$(find $O -name $f | head -1); [ -n "$s" ] && [ "$(dirname $s)" != "$D" ] && cp $s $D/; done
 python tools/summarize_pmc.py $D $O/kernels_pmc.md $O/pmc_traffic.json auto < /dev/null | head -40
 cp $O/pmc_traffic.json profiles/ 2>/dev/null  # (so that the line below quotes it: same sources, same box)
-timeout -k 5 600 python bench.py < /dev/null > $O/bench.json 2> $O/bench.err
+timeout -k 5 900 python bench.py < /dev/null > $O/bench.json 2> $O/bench.err
+timeout -k 5 300 python bench.py --scaling strong --no-others --no-cpu < /dev/null > $O/bench_strong_1gpu.json 2> $O/bench_strong_1gpu.err
+timeout -k 5 600 python tools/bench_host.py < /dev/null > $O/bench_host_512.json 2> $O/bench_host_512.err
+# the opt-in paths kept for A/B: marching cubes in one launch, the IFT level chain without link records
+IVX_MC_ONE_LAUNCH=1 timeout -k 5 300 python bench.py --no-others --no-cpu < /dev/null > $O/bench_mc_one_launch.json 2> /dev/null
+IVX_WS_LINKS=0 timeout -k 5 300 python bench.py --config watershed --size 512 --no-cpu < /dev/null > $O/bench_watershed_512_nolinks.json 2> /dev/null
 timeout -k 5 300 python bench.py --config mip < /dev/null > $O/bench_mip.json 2> $O/bench_mip.err
 timeout -k 5 120 python bench.py --dry-comm < /dev/null > $O/dry_comm.json 2> $O/dry_comm.err
 # the sharded path's own overhead against the resident single volume: same step through SlabVolume at world 1
@@ -48,7 +53,7 @@ timeout -k 5 600 python bench.py --config sharded2048 < /dev/null > $O/bench_sha
 find $O -name "*_kernel_trace.csv" -size +8M -delete
 find $O -name "*_counter_collection.csv" -size +8M -delete
 cat $O/gpu_tests.txt 2>/dev/null
-for f in bench bench_mip bench_watershed_512 bench_watershed_sk_512 bench_watershed_1024 bench_watershed_sk_1024 bench_sharded2048_1gpu; do
+for f in bench bench_strong_1gpu bench_mc_one_launch bench_mip bench_watershed_512 bench_watershed_512_nolinks bench_watershed_sk_512 bench_watershed_1024 bench_watershed_sk_1024 bench_sharded2048_1gpu; do
 python - $O/$f.json $f <<'PY'
 import json,sys
 try:
