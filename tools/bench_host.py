@@ -75,20 +75,36 @@ def main():
     os.close(fd)
     np.memmap(tfile, shape=img.shape, dtype="uint8", mode="w+").flush()
     s6 = generate_binary_structure(3, 1)
-    res["do_watershed (Watershed, ww/wl, 6 neighbours)"] = timeit(
-        lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed", (3, 3, 3), True, 300, 400, None), reps=2)
-    res["do_watershed (Watershed IFT, ww/wl, 6 neighbours)"] = timeit(
-        lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed IFT", (3, 3, 3), True, 300, 400, None), reps=2)
+    import warnings
+    warnings.simplefilter("ignore")
+    flush = {}
+
+    def dows(alg):
+        # wall time of the whole hook and, inside it, of the reference's own `mask.flush()` (msync of 134 MB to the file system)
+        best = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            wp.do_watershed(img, mk, tfile, img.shape, s6, alg, (3, 3, 3), True, 300, 400, None)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, wp.do_watershed.last_flush_ms)
+        return best
+    for alg, name in (("Watershed", "do_watershed (Watershed, ww/wl, 6 neighbours)"), ("Watershed IFT", "do_watershed (Watershed IFT, ww/wl, 6 neighbours)")):
+        t, fl = dows(alg)
+        res[name] = t
+        flush[name] = fl
     # ... and the download into the memmap through the page-locked lanes (every chunk's page faults on its own thread) or as one
     # hipMemcpy (IVX_D2H_LANES is read per call; unset = lanes where the destination's pages are mostly not resident)
     for mode in ("1", "0"):
         os.environ["IVX_D2H_LANES"] = mode
-        res["do_watershed (Watershed IFT, ww/wl) IVX_D2H_LANES=%s" % mode] = timeit(
-            lambda: wp.do_watershed(img, mk, tfile, img.shape, s6, "Watershed IFT", (3, 3, 3), True, 300, 400, None), reps=2)
+        t, fl = dows("Watershed IFT")
+        res["do_watershed (Watershed IFT, ww/wl) IVX_D2H_LANES=%s" % mode] = t
+        flush["do_watershed (Watershed IFT, ww/wl) IVX_D2H_LANES=%s" % mode] = fl
     os.environ.pop("IVX_D2H_LANES")
     os.remove(tfile)
     print(json.dumps({"size": "512^3", "triangles": int(len(tri[0])),
-                      "results": {k: {"s": round(v, 4), "Mvoxel/s": round(nvox / v / 1e6, 1)} for k, v in res.items()}}, indent=1))
+                      "results": {k: dict({"s": round(v, 4), "Mvoxel/s": round(nvox / v / 1e6, 1)},
+                                          **({"of_which_msync_s": round(flush[k] / 1e3, 4)} if k in flush else {})) for k, v in res.items()}}, indent=1))
 
 
 if __name__ == "__main__":
