@@ -30,8 +30,11 @@
 //   2. k_sk_classify   generation-0 flags, drained voxels (I < C) and their same-level drained neighbours; union-find
 //                      (k_ws_runs / k_ws_union / k_ws_flatten) makes every drained basin one set whose time stamp lives at
 //                      its root; k_ws_bucket: generation 0 and the drained voxels, each bucketed by level;
-//   3. per non-empty level, ascending: k_sk_keys (marker: raster index; other: smallest T among lower-C neighbours)
-//      -> radix sort -> k_sk_assign (T, run labels, first frontier) -> k_sk_round until the level is exhausted.  A
+//   3. per non-empty level, ascending: k_sk_gen0 -- ONE launch: keys (marker: raster index; other: smallest T among
+//      lower-C neighbours) -> sorted (every workgroup sorts a chunk in LDS, then ranks its keys against every other
+//      chunk behind one device-wide barrier) -> T, run labels, first frontier -- then k_sk_round until the level is
+//      exhausted (levels of more than 2^20 generation-0 voxels: k_sk_keys -> k_sk_sort_chunks -> k_sk_merge_pass x log2
+//      -> k_sk_assign).  A
 //      generation is at most two launches: A -- the frontier stamps its unstamped neighbours of value c with the next
 //      generation and offers its own stamp to the basins it touches (atomicMin at the root); B -- only if a basin was
 //      stamped: the level's drained voxels whose basin carries this generation's stamp hand it, one generation later, to
@@ -47,7 +50,6 @@
 #include <vector>
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ivx_internal.h"
 #include "scan_u32.h"
@@ -115,7 +117,7 @@ constexpr uint8_t KIND_GEN0 = 1, KIND_DRAINED = 2;
 template <int CONN, typename MT>
 __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
                                                      const MT *__restrict__ mk, uint8_t *__restrict__ kind, uint32_t *__restrict__ comp,
-                                                     uint32_t *__restrict__ zmask, uint32_t *__restrict__ pmask) {
+                                                     uint32_t *__restrict__ zmask, uint32_t *__restrict__ pmask, uint32_t *mbits) {
     __shared__ uint32_t s[NCELL];
     int z0, y0, x0;
     tile_origin(g, blockIdx.x, z0, y0, x0);
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *_
             pm |= ((qv >> 16) == c && (qv & 0xFFFFu) == c) ? 1u << k : 0u;
         }
         if (c == CINF) zm = pm = 0; // never reached: takes part in nothing
-        kind[p] = (mk[p] != 0 || (c != CINF && iv == c && lower)) ? KIND_GEN0 : drained ? KIND_DRAINED : 0;
+        const bool marker = mk[p] != 0;
+        kind[p] = (marker || (c != CINF && iv == c && lower)) ? KIND_GEN0 : drained ? KIND_DRAINED : 0;
+        // which levels hold markers (one bit per level; the host launches the tied-marker check for those only)
+        if (marker && c != CINF && !((__hip_atomic_load(&mbits[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (c & 31u)) & 1u))
+            atomicOr(&mbits[c >> 5], 1u << (c & 31u));
         comp[p] = drained ? (uint32_t)p : ENTRY;
         zmask[p] = zm; // (the union-find only follows it from drained voxels)
         pmask[p] = pm;
@@ -207,6 +213,467 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
     tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + i);
     front[i] = p;
     if (m && i > 0 && (int)mk[val[i - 1]] != m) atomicAdd(&st->mixed, 1u); // markers sort first: val[i-1] is one too
+}
+
+// ---- generation 0 of a level in ONE launch (k_sk_gen0): keys -> sorted -> stamps.
+// A level's generation 0 is ~5 x 10^4 (512^3) to ~5 x 10^5 (1024^3) voxels, once per level, 170 levels per flood, every one
+// on the flood's critical path.  As k_sk_keys + a library radix sort (one block sort + ~6 merge launches at this size) +
+// k_sk_assign that was 10 dependent launches at the dispatch floor, ~80 us per level.  Here every workgroup computes the keys
+// of one chunk, sorts (key, voxel) pairs in LDS (bitonic), publishes the sorted KEYS, and -- behind one device-wide barrier --
+// ranks its own keys against every other chunk staged through LDS: position = own index + sum over the other chunks of the
+// keys below (ties: the chunk with the lower index first), which is the position in the sorted whole.  Both lists are sorted,
+// so a lane's consecutive keys continue where the previous one stopped (a gallop of ~2 probes instead of a 12-probe search).
+// The order among equal keys is (chunk, voxel): it never matters -- equal keys carry one label (see TIME above) -- but it is
+// a function of the level's list alone.  All workgroups must be resident (one per compute unit, 2^20 voxels at most; above:
+// the launches of sk_sort_big below); a lost barrier ends the launch with ctl->fail = 1, never a hang.
+constexpr int G0_T = 1024;
+struct SkG0Ctl {
+    uint32_t arrive[2]; // the two barriers of a launch
+    uint32_t nmark;     // markers among the level's generation 0
+    uint32_t exits;     // workgroups that have left: the last one clears the words above for the next launch
+    uint32_t fail;      // a barrier timed out (sticky for the flood)
+    uint32_t ticks[8];  // workgroup 0's time per phase, summed over the flood's launches (wall_clock64 ticks of 10 ns; IVX_WS_TRACE prints them)
+    uint32_t pad[19];
+};
+static_assert(sizeof(SkG0Ctl) == 128, "one line");
+
+__device__ __forceinline__ bool sk_pair_less(unsigned long long ka, uint32_t va, unsigned long long kb, uint32_t vb) {
+    return ka < kb || (ka == kb && va < vb);
+}
+
+// bitonic sort of n2 (a power of two) (key, voxel) pairs in LDS by all threads of the workgroup
+__device__ __forceinline__ void sk_bitonic(unsigned long long *s_key, uint32_t *s_val, uint32_t n2) {
+    for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1)
+        for (uint32_t j = k2 >> 1, lj = 31u - __clz(k2 >> 1); j > 0; j >>= 1, lj--) { // (shifts: j is not a compile-time constant)
+            for (uint32_t t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+                const uint32_t lo = ((t >> lj) << (lj + 1)) | (t & (j - 1u)), hi = lo + j;
+                const bool up = ((lo & k2) == 0);
+                const unsigned long long ka = s_key[lo], kb = s_key[hi];
+                const uint32_t va = s_val[lo], vb = s_val[hi];
+                if (sk_pair_less(kb, vb, ka, va) == up) {
+                    s_key[lo] = kb; s_key[hi] = ka;
+                    s_val[lo] = vb; s_val[hi] = va;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// key of a generation-0 voxel (see k_sk_keys)
+template <int CONN, typename MT>
+__device__ __forceinline__ unsigned long long sk_key_of(const WsGeom &g, const uint16_t *__restrict__ C, const MT *__restrict__ mk,
+                                                        const uint16_t *__restrict__ I, const uint32_t *__restrict__ comp,
+                                                        const unsigned long long *tau, uint32_t p, uint32_t c, bool *marker) {
+    *marker = mk[p] != 0;
+    if (*marker) return p;
+    unsigned long long K = TINF;
+    const int64_t z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        if (!has_off<CONN>(g.smask, k)) continue;
+        const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const int64_t Z = z + dz, Y = y + dy, X = x + dx;
+        if ((uint64_t)X >= (uint64_t)g.w || (uint64_t)Y >= (uint64_t)g.h || (uint64_t)Z >= (uint64_t)g.d) continue;
+        const int64_t q = (int64_t)p + dz * g.hw + dy * g.w + dx;
+        const uint32_t qc = C[q];
+        if (qc < c) K = min(K, ld64(&tau[(uint32_t)I[q] < qc ? comp[q] : (uint32_t)q]));
+    }
+    return K;
+}
+
+constexpr uint32_t G0_SPIN_LIMIT = 1u << 21;
+
+// device-wide barrier of a launch whose workgroups are all resident.  What a workgroup published before it (agent-scope,
+// write-through stores) has been acknowledged when it arrives; what it reads after it, it reads with agent-scope loads.
+__device__ __forceinline__ bool sk_g0_barrier(uint32_t *word, uint32_t nwg, uint32_t *fail, uint32_t *s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ok = 1;
+        __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg; spins++) {
+            if (spins > G0_SPIN_LIMIT) {
+                __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        *s_flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *s_flag != 0;
+    __syncthreads(); // (the flag word is reused by the next barrier)
+    return ok;
+}
+
+// number of staged keys that sort before K (le: or equal to it), continuing from `from` keys already known to (gallop + bisection)
+__device__ __forceinline__ uint32_t sk_count_from(const unsigned long long *sb, uint32_t ch, uint32_t from, unsigned long long K, bool le) {
+    uint32_t lo = from, step = 1;
+    while (lo + step <= ch) {
+        const unsigned long long x = sb[lo + step - 1];
+        if (!(le ? x <= K : x < K)) break;
+        lo += step;
+        step <<= 1;
+    }
+    for (step >>= 1; step; step >>= 1)
+        if (lo + step <= ch) {
+            const unsigned long long x = sb[lo + step - 1];
+            if (le ? x <= K : x < K) lo += step;
+        }
+    return lo;
+}
+
+// the same count by bisection over the whole chunk (ch a power of two): a lane's first key
+__device__ __forceinline__ uint32_t sk_count_bisect(const unsigned long long *sb, uint32_t ch, unsigned long long K, bool le) {
+    uint32_t lo = 0;
+    for (uint32_t step = ch >> 1; step; step >>= 1) {
+        const unsigned long long x = sb[lo + step - 1];
+        if (le ? x <= K : x < K) lo += step;
+    }
+    const unsigned long long x = sb[lo];
+    return lo + ((le ? x <= K : x < K) ? 1u : 0u);
+}
+
+template <int CONN, typename MT, int IPT>
+__global__ __launch_bounds__(G0_T) void k_sk_gen0(WsGeom g, const uint16_t *__restrict__ C, const MT *__restrict__ mk,
+                                                  const uint16_t *__restrict__ I, const uint32_t *__restrict__ comp, unsigned long long *tau,
+                                                  const uint32_t *__restrict__ elist, unsigned long long *ckey, int32_t *runlabel,
+                                                  uint32_t *front, uint32_t cnt, uint32_t ch, uint32_t c, uint32_t roff, uint32_t gbase,
+                                                  uint32_t seq, SkState *st, SkG0Ctl *ctl) {
+    constexpr int CAP = G0_T * IPT;
+    __shared__ unsigned long long s_key[CAP];
+    __shared__ uint32_t s_val[CAP];
+    __shared__ unsigned long long s_b[2][CAP];
+    __shared__ uint32_t s_flag, s_nm;
+    const uint32_t tid = threadIdx.x, chunk = blockIdx.x, nwg = gridDim.x;
+    const uint32_t base = chunk * ch, nown = min(ch, cnt - base);
+    // gbase 0: the level follows another one of the same chain on the device (nobody writes gnext during this launch)
+    if (gbase == 0) gbase = __hip_atomic_load(&st->gnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (chunk == 0 && tid == 0) { // the level's frontier loop starts from list 0, phase A (as k_sk_assign)
+        st->done = 0; st->gen = gbase; st->n_in = cnt;
+        st->phase = 0; st->in_sel = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->ctl = sk_ctl(seq, 0, 0, cnt);
+        st->pctl = sk_pctl(0, 0, 0, 0, cnt);
+    }
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+    unsigned long long tk = chunk == 0 && tid == 0 ? wall_clock64() : 0ull;
+    auto tick = [&](int slot) {
+        if (chunk == 0 && tid == 0) {
+            const unsigned long long now = wall_clock64();
+            atomicAdd(&ctl->ticks[slot], (uint32_t)(now - tk));
+            tk = now;
+        }
+    };
+    // ---- keys of this chunk, sorted in LDS
+    uint32_t n2 = 1;
+    while (n2 < nown) n2 <<= 1;
+    uint32_t nm = 0;
+    for (uint32_t i = tid; i < n2; i += G0_T) {
+        unsigned long long K = TINF;
+        uint32_t p = 0xFFFFFFFFu;
+        if (i < nown) {
+            p = elist[base + i];
+            bool marker;
+            K = sk_key_of<CONN, MT>(g, C, mk, I, comp, tau, p, c, &marker);
+            nm += marker;
+        }
+        s_key[i] = K;
+        s_val[i] = p;
+    }
+    if (nm) atomicAdd(&s_nm, nm);
+    __syncthreads();
+    if (tid == 0 && s_nm && nwg > 1) __hip_atomic_fetch_add(&ctl->nmark, s_nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tick(0);
+    sk_bitonic(s_key, s_val, n2);
+    tick(1);
+    uint32_t pos[IPT]; // position of this lane's pairs (sorted positions IPT * tid + k) in the sorted whole
+#pragma unroll
+    for (int k = 0; k < IPT; k++) pos[k] = IPT * tid + k;
+    if (nwg > 1) {
+        for (uint32_t i = tid; i < nown; i += G0_T) __hip_atomic_store(&ckey[base + i], s_key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!sk_g0_barrier(&ctl->arrive[0], nwg, &ctl->fail, &s_flag)) return;
+        tick(2);
+        // ---- rank against every other chunk (starting behind the own one: the chunks' readers spread over the chip)
+        unsigned long long pre[IPT];
+        auto fetch = [&](uint32_t oc) {
+            const uint32_t ob = oc * ch, on = min(ch, cnt - ob);
+#pragma unroll
+            for (int e = 0; e < IPT; e++) {
+                const uint32_t i = tid + e * G0_T;
+                pre[e] = i < on ? __hip_atomic_load(&ckey[ob + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : TINF;
+            }
+        };
+        unsigned long long own[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) own[k] = IPT * tid + k < nown ? s_key[IPT * tid + k] : TINF;
+        uint32_t oc = chunk + 1 == nwg ? 0 : chunk + 1;
+        fetch(oc);
+        int cur = 0;
+        for (uint32_t s = 0; s + 1 < nwg; s++) {
+            unsigned long long *sb = s_b[cur];
+#pragma unroll
+            for (int e = 0; e < IPT; e++)
+                if (tid + e * G0_T < ch) sb[tid + e * G0_T] = pre[e];
+            __syncthreads();
+            const uint32_t this_oc = oc, on = min(ch, cnt - this_oc * ch);
+            oc = oc + 1 == nwg ? 0 : oc + 1;
+            if (s + 2 < nwg) fetch(oc); // in flight during the search
+            const bool le = this_oc < chunk;
+            uint32_t from = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                if (IPT * tid + k >= nown) break;
+                from = k == 0 ? sk_count_bisect(sb, ch, own[k], le) : sk_count_from(sb, ch, from, own[k], le);
+                pos[k] += min(from, on);
+            }
+            cur ^= 1;
+        }
+        tick(3);
+    }
+    // ---- stamps (G = gbase, R = roff + position), the runs' labels, the first frontier
+    const uint32_t nmark = nwg > 1 ? __hip_atomic_load(&ctl->nmark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_nm;
+    const bool check = nmark >= 2;
+    uint32_t mixed = 0;
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        const uint32_t q = IPT * tid + k;
+        if (q >= nown) break;
+        const uint32_t p = s_val[q];
+        const unsigned long long K = s_key[q];
+        const int m = (int)mk[p];
+        // a run's label: its marker's, or the label of the run its parent belongs to (an earlier level: final)
+        const int32_t l = m ? (int32_t)m : (K == TINF ? 0 : runlabel[(uint32_t)(K & 0xFFFFFFFFull)]);
+        runlabel[roff + pos[k]] = l;
+        tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + pos[k]);
+        if (check && nwg > 1) __hip_atomic_store(&front[pos[k]], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else front[pos[k]] = p;
+        // markers sort first, in raster order: adjacent tied markers of different labels (one chunk: the neighbour is at hand)
+        if (check && nwg == 1 && m && q > 0 && (int)mk[s_val[q - 1]] != m) mixed++;
+    }
+    if (check && nwg > 1) {
+        if (!sk_g0_barrier(&ctl->arrive[1], nwg, &ctl->fail, &s_flag)) return;
+        for (uint32_t r = 1 + chunk * G0_T + tid; r < nmark; r += nwg * G0_T) {
+            const uint32_t p0 = __hip_atomic_load(&front[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t p1 = __hip_atomic_load(&front[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mixed += mk[p0] != mk[p1];
+        }
+    }
+    if (mixed) atomicAdd(&st->mixed, mixed);
+    __syncthreads();
+    tick(4);
+    if (tid == 0 && nwg > 1) { // the last workgroup out clears the barrier words for the next launch
+        if (__hip_atomic_fetch_add(&ctl->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+            ctl->arrive[0] = 0; ctl->arrive[1] = 0; ctl->nmark = 0; ctl->exits = 0;
+        }
+    }
+}
+
+// ---- levels of more than 2^20 generation-0 voxels (more chunks than workgroups that are resident at once): the same chunk
+// sort, then merge passes as launches (merge path: every lane finds where its 8 outputs start in the two runs)
+// 2048 pairs, 256 lanes, eight pairs per lane in registers: a trip through LDS serves up to three compare-exchange steps (the
+// lane fetches the eight pairs whose indices differ in the three bits those steps pair up), 24 trips instead of 66 steps
+// with a barrier each (the plain network, sk_bitonic, is LDS-throughput bound: 30 us per chunk).  One spare slot per eight
+// keeps the strided trips at two-way bank conflicts.
+__device__ __forceinline__ uint32_t sc_phys(uint32_t i) { return i + (i >> 3); }
+
+template <int SC_T> // lanes: sorts up to 8 * SC_T pairs (chunks of 512 / 1024 / 2048)
+__global__ __launch_bounds__(SC_T) void k_sk_sort_chunks(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
+                                                         unsigned long long *__restrict__ okey, uint32_t *__restrict__ oval, uint32_t cnt, uint32_t ch) {
+    constexpr int SC_N = 8 * SC_T, SC_LOG = SC_T == 256 ? 11 : SC_T == 128 ? 10 : 9;
+    static_assert(SC_T == 64 || SC_T == 128 || SC_T == 256, "512, 1024 or 2048 pairs");
+    __shared__ unsigned long long s_key[SC_N + SC_N / 8];
+    __shared__ uint32_t s_val[SC_N + SC_N / 8];
+    const uint32_t base = blockIdx.x * ch, nown = min(ch, cnt - base), tid = threadIdx.x;
+    unsigned long long k[8];
+    uint32_t v[8], idx[8];
+    auto cex = [&](int a, int b, uint32_t k2) { // compare-exchange of registers a < b (indices idx[a] < idx[b]) at merge size k2
+        const bool up = (idx[a] & k2) == 0;
+        if (sk_pair_less(k[b], v[b], k[a], v[a]) == up) {
+            const unsigned long long tk = k[a]; k[a] = k[b]; k[b] = tk;
+            const uint32_t tv = v[a]; v[a] = v[b]; v[b] = tv;
+        }
+    };
+    // the first trip starts from global memory: pairs 8 * tid .. 8 * tid + 7, merge sizes 2, 4, 8 entirely in registers
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        idx[e] = 8 * tid + e;
+        k[e] = idx[e] < nown ? key[base + idx[e]] : TINF;
+        v[e] = idx[e] < nown ? val[base + idx[e]] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int m = 1; m <= 3; m++)
+#pragma unroll
+        for (int bit = m - 1; bit >= 0; bit--)
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (!((e >> bit) & 1)) cex(e, e | (1 << bit), 1u << m);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        s_key[sc_phys(idx[e])] = k[e];
+        s_val[sc_phys(idx[e])] = v[e];
+    }
+    __syncthreads();
+    for (int m = 4; m <= SC_LOG; m++) {
+        const uint32_t k2 = 1u << m;
+        for (int top = m - 1; top >= 0; top -= 3) {
+            const int B = top < 2 ? 2 : top, s0 = B - 2; // the trip's pairs differ in index bits s0 .. s0 + 2
+            const uint32_t low = tid & ((1u << s0) - 1u), high = tid >> s0, b0 = (high << (B + 1)) | low;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                idx[e] = b0 | ((uint32_t)e << s0);
+                k[e] = s_key[sc_phys(idx[e])];
+                v[e] = s_val[sc_phys(idx[e])];
+            }
+            const int lo_bit = top - 2 < 0 ? 0 : top - 2;
+            for (int bit = top; bit >= lo_bit; bit--) {
+                const int eb = bit - s0; // (uniform)
+                if (eb == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cex(e, e | 4, k2);
+                } else if (eb == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        if (!(e & 2)) cex(e, e | 2, k2);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) cex(e, e | 1, k2);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                s_key[sc_phys(idx[e])] = k[e];
+                s_val[sc_phys(idx[e])] = v[e];
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < nown; i += SC_T) {
+        okey[base + i] = s_key[sc_phys(i)];
+        oval[base + i] = s_val[sc_phys(i)];
+    }
+}
+
+// ---- the default for a level's generation 0 (up to 128 chunks): keys (k_sk_keys) -> sorted chunks (k_sk_sort_chunks) -> every
+// key's position in the sorted whole = its position in its chunk + the keys below it in every other chunk (k_sk_rank_pairs:
+// one workgroup per (chunk, share of the other chunks), the other chunk staged in LDS, a lane's consecutive keys galloping on
+// from the previous one's count) -> stamps by position (k_sk_assign_ranked).  Four launches that use the whole chip instead of
+// a block sort + ~6 merge passes at the dispatch floor; equal keys are ordered (chunk, voxel), which never matters (TIME).
+template <int RP_E> // keys per lane (256 lanes: chunks of up to 256 * RP_E keys)
+__global__ __launch_bounds__(256) void k_sk_rank_pairs(const unsigned long long *__restrict__ key, uint32_t *__restrict__ part, uint32_t cnt, uint32_t ch) {
+    __shared__ unsigned long long sb[256 * RP_E + 1];
+    const uint32_t a = blockIdx.x, nch = gridDim.x, base = a * ch, nown = min(ch, cnt - base), tid = threadIdx.x;
+    // a lane's keys are 256 apart (a wave's lanes hold neighbouring keys: their probes fall into neighbouring slots), its eight
+    // bisections run in lockstep, branch-free: twelve rounds of eight independent LDS reads
+    unsigned long long own[RP_E];
+    uint32_t acc[RP_E];
+#pragma unroll
+    for (int k = 0; k < RP_E; k++) {
+        own[k] = tid + 256 * k < nown ? key[base + tid + 256 * k] : TINF;
+        acc[k] = 0;
+    }
+    for (uint32_t b = blockIdx.y; b < nch; b += gridDim.y) {
+        if (b == a) continue; // (uniform)
+        const uint32_t ob = b * ch, on = min(ch, cnt - ob);
+        __syncthreads(); // (the previous chunk has been searched)
+        for (uint32_t i = tid; i <= ch; i += 256) sb[i] = i < on ? key[ob + i] : TINF;
+        __syncthreads();
+        const bool le = b < a;
+        uint32_t lo[RP_E];
+#pragma unroll
+        for (int k = 0; k < RP_E; k++) lo[k] = 0;
+        for (uint32_t step = ch >> 1; step; step >>= 1) {
+#pragma unroll
+            for (int k = 0; k < RP_E; k++) {
+                const unsigned long long x = sb[lo[k] + step - 1];
+                lo[k] += (le ? x <= own[k] : x < own[k]) ? step : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RP_E; k++) {
+            const unsigned long long x = sb[lo[k]];
+            lo[k] += (le ? x <= own[k] : x < own[k]) ? 1u : 0u;
+            acc[k] += min(lo[k], on);
+        }
+    }
+    // this share's counts, one plane per share (summed by k_sk_assign_ranked: a million device-scope atomics per level were
+    // the slow part of this kernel, 40 us)
+    uint32_t *mine = part + (size_t)blockIdx.y * cnt + base;
+#pragma unroll
+    for (int k = 0; k < RP_E; k++)
+        if (tid + 256 * k < nown) mine[tid + 256 * k] = acc[k];
+}
+
+// sorted chunks + positions -> time stamps (G = gbase, R = roff + position), the runs' labels, the first frontier
+template <typename MT>
+__global__ __launch_bounds__(256) void k_sk_assign_ranked(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
+                                                          const uint32_t *__restrict__ part, uint32_t shares, uint32_t ch, const MT *__restrict__ mk,
+                                                          unsigned long long *tau, int32_t *runlabel, uint32_t *__restrict__ front, uint32_t cnt,
+                                                          uint32_t roff, uint32_t gbase, uint32_t seq, SkState *st) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (gbase == 0) gbase = __hip_atomic_load(&st->gnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i == 0) {
+        st->done = 0; st->gen = gbase; st->n_in = cnt;
+        st->phase = 0; st->in_sel = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->ctl = sk_ctl(seq, 0, 0, cnt);
+        st->pctl = sk_pctl(0, 0, 0, 0, cnt);
+    }
+    if (i >= cnt) return;
+    const uint32_t p = val[i];
+    uint32_t pos = i & (ch - 1u); // position inside its chunk + the keys below it in the other chunks (one plane per share)
+    for (uint32_t sh = 0; sh < shares; sh++) pos += part[(size_t)sh * cnt + i];
+    const unsigned long long K = key[i];
+    const int m = (int)mk[p];
+    const int32_t l = m ? (int32_t)m : (K == TINF ? 0 : runlabel[(uint32_t)(K & 0xFFFFFFFFull)]);
+    runlabel[roff + pos] = l;
+    tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + pos);
+    front[pos] = p;
+}
+
+// adjacent tied markers of different labels (markers sort first, in raster order); launched for the levels that hold markers
+template <typename MT>
+__global__ __launch_bounds__(256) void k_sk_mixed(const uint32_t *__restrict__ front, const MT *__restrict__ mk, uint32_t cnt, SkState *st) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 || i >= cnt) return;
+    const int m = (int)mk[front[i]];
+    if (m && (int)mk[front[i - 1]] != m) atomicAdd(&st->mixed, 1u);
+}
+
+constexpr uint32_t MP_E = 8; // outputs per lane
+__global__ __launch_bounds__(256) void k_sk_merge_pass(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
+                                                       unsigned long long *__restrict__ okey, uint32_t *__restrict__ oval, uint32_t cnt, uint32_t run) {
+    const uint64_t o0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * MP_E;
+    if (o0 >= cnt) return;
+    const uint64_t pairb = o0 / (2ull * run) * (2ull * run);
+    const uint32_t a0 = (uint32_t)pairb, na = cnt - pairb < run ? (uint32_t)(cnt - pairb) : run;
+    const uint32_t b0 = a0 + na, nb = cnt - (pairb + na) < run ? (uint32_t)(cnt - (pairb + na)) : run;
+    const uint32_t d = (uint32_t)(o0 - pairb);
+    // i = pairs of this diagonal's prefix that come from run A (ties: A first)
+    uint32_t lo = d > nb ? d - nb : 0, hi = min(d, na);
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1, j = d - 1 - mid;
+        if (!sk_pair_less(key[b0 + j], val[b0 + j], key[a0 + mid], val[a0 + mid])) lo = mid + 1;
+        else hi = mid;
+    }
+    uint32_t i = lo, j = d - lo;
+    const uint32_t nout = na + nb - d < MP_E ? na + nb - d : MP_E;
+    unsigned long long ka = i < na ? key[a0 + i] : TINF, kb = j < nb ? key[b0 + j] : TINF;
+    uint32_t va = i < na ? val[a0 + i] : 0xFFFFFFFFu, vb = j < nb ? val[b0 + j] : 0xFFFFFFFFu;
+    for (uint32_t e = 0; e < nout; e++) {
+        const bool take_b = i >= na || (j < nb && sk_pair_less(kb, vb, ka, va));
+        if (take_b) {
+            okey[o0 + e] = kb; oval[o0 + e] = vb;
+            j++;
+            if (j < nb) { kb = key[b0 + j]; vb = val[b0 + j]; }
+        } else {
+            okey[o0 + e] = ka; oval[o0 + e] = va;
+            i++;
+            if (i < na) { ka = key[a0 + i]; va = val[a0 + i]; }
+        }
+    }
 }
 
 // Appends to the next-generation list are staged per wave in LDS and handed to the global list with ONE atomic per wave
@@ -847,11 +1314,11 @@ struct SkBufs {
     uint16_t *C;
     uint8_t *kind, *dirty, *pending;
     unsigned long long *tau, *key_a, *key_b;
-    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *lhist, *bcount, *bsum, *tlist, *total;
+    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *lhist, *mbits, *rank, *bcount, *bsum, *tlist, *total;
     int32_t *runlabel;
     WsState *wst;
     SkState *st;
-    void *cub;
+    SkG0Ctl *g0ctl;
     size_t bytes;
 };
 
@@ -874,6 +1341,7 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->dhist = (uint32_t *)take(65536 * 4);
     b->dcursor = (uint32_t *)take(65536 * 4);
     b->lhist = (uint32_t *)take(65536 * 4);
+    b->mbits = (uint32_t *)take(2048 * 4);
     b->bcount = (uint32_t *)take((size_t)(nblk + 1) * 4);
     b->bsum = (uint32_t *)take((size_t)(std::max<int64_t>(cdiv(nblk, 4096), 16) + 2) * 4);
     b->tlist = (uint32_t *)take((size_t)g.ntiles * 4);
@@ -881,12 +1349,13 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->pending = (uint8_t *)take((size_t)g.ntiles);
     b->wst = (WsState *)take(sizeof(WsState));
     b->st = (SkState *)take(sizeof(SkState));
+    b->g0ctl = (SkG0Ctl *)take(sizeof(SkG0Ctl));
     b->total = (uint32_t *)take(256);
     b->bytes = o;
 }
 
 // the part sized once generation 0 has been counted (slot WS_WSSK)
-static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, size_t cub_bytes, char *base, SkBufs *b) {
+static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, bool big, char *base, SkBufs *b) {
     size_t o = 0;
     auto take = [&](size_t n) { char *p = base ? base + o : nullptr; o += al(n); return p; };
     b->runlabel = (int32_t *)take((size_t)(ngen0 + 1) * 4);
@@ -894,7 +1363,8 @@ static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, size_t cub_bytes, char
     b->key_b = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
     b->val_a = (uint32_t *)take((size_t)maxcnt * 4 + 8);
     b->val_b = (uint32_t *)take((size_t)maxcnt * 4 + 8);
-    b->cub = take(cub_bytes + 256);
+    b->rank = (uint32_t *)take((size_t)std::min<uint64_t>((uint64_t)maxcnt * 128u, 1024u * 2048u) * 4 + 8); // the share planes of k_sk_rank_pairs
+    (void)big;
     return o;
 }
 
@@ -916,6 +1386,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     // ---- 1. costs ------------------------------------------------------------------------------------------
     IVX_HIP(hipMemsetAsync(b.wst, 0, sizeof(WsState), st));
     IVX_HIP(hipMemsetAsync(b.st, 0, sizeof(SkState), st));
+    IVX_HIP(hipMemsetAsync(b.g0ctl, 0, sizeof(SkG0Ctl), st));
     IVX_HIP(hipMemsetAsync(b.dirty, 0, (size_t)g.ntiles, st));
     hipLaunchKernelGGL((k_ws_init<MT, true>), dim3((unsigned)nblk), dim3(256), 0, st, g, mk, I, b.C, b.dirty, b.bcount, b.wst);
     IVX_LAUNCH_CHECK();
@@ -963,8 +1434,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
 
     tm.mark(st);
     // ---- 2. generation 0 and the drained basins, bucketed by level ------------------------------------------
+    IVX_HIP(hipMemsetAsync(b.mbits, 0, 2048 * 4, st));
     WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind, b.comp,
-                                              b.zmask, b.pmask));
+                                              b.zmask, b.pmask, b.mbits));
     IVX_LAUNCH_CHECK();
     {
         const int rc = ws_zone_union(g, conn, b.zmask, b.comp, st);
@@ -991,6 +1463,8 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     hipLaunchKernelGGL((k_ws_bucket<SkLevelPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkLevelPred{}, b.lhist, b.elist);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipMemcpyAsync(lhist.data(), b.lhist, 65536 * 4, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> mbits(2048); // levels that hold markers
+    IVX_HIP(hipMemcpyAsync(mbits.data(), b.mbits, 2048 * 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(k_sk_fill64, dim3(2048), dim3(256), 0, st, b.tau, g.n, TINF);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipStreamSynchronize(st)); // the histograms are on the host now
@@ -1001,15 +1475,38 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         maxcnt = std::max(maxcnt, hist[c]);
     }
     IVX_REQUIRE(ngen0 < 0xFFFFFFF0ull, IVX_EINVAL, "watershed: more than 2^32 queue entries");
-    size_t cub_bytes = 0;
-    // (rocPRIM, ROCm's own primitives library, called directly: the sizing call of its radix sort)
-    IVX_HIP(rocprim::radix_sort_pairs(nullptr, cub_bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                      (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)maxcnt, 0u, 64u, st));
+    int ncu = 0;
+    {
+        int dev = 0;
+        IVX_HIP(hipGetDevice(&dev));
+        IVX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    // A level's generation 0 is keyed, sorted and stamped by our own kernels -- no library on this path:
+    //   up to 128 chunks of 2048 voxels (the default): k_sk_keys -> k_sk_sort_chunks -> k_sk_rank_pairs -> k_sk_assign_ranked;
+    //   more: k_sk_keys -> k_sk_sort_chunks -> k_sk_merge_pass x log2(chunks) -> k_sk_assign;
+    //   IVX_SK_SORT=fused: everything in ONE launch with a device-wide barrier (k_sk_gen0; measured slower: DESIGN.md section 8),
+    //   IVX_SK_SORT=merge: every level through the merge passes (tests, A/B);
+    //   IVX_SK_CHUNK = n (a power of two up to 2048): the chunk length (tests: many chunks on small volumes).
+    const char *ech = getenv("IVX_SK_CHUNK"), *eso2 = getenv("IVX_SK_SORT");
+    uint32_t ch_env = ech ? (uint32_t)atoi(ech) : 0u;
+    if (ch_env < 2 || ch_env > 2048 || (ch_env & (ch_env - 1))) ch_env = 0;
+    const bool sort_merge = eso2 && eso2[0] == 'm', sort_fused = eso2 && eso2[0] == 'f';
+    const uint32_t g0_wgs = (uint32_t)std::max(ncu, 8);
+    const uint32_t chb = ch_env ? ch_env : 1024u;
+    const int64_t PAIR_CHUNKS = 128 * (2048 / chb), PAIR_WGS = 1024 * (2048 / chb); // (shares * chunks <= PAIR_WGS: the share planes hold at most PAIR_WGS * 2048 counts)
+    auto g0_chunk = [&](uint32_t cnt) -> uint32_t { // chunk length of the one-launch path, 0: not for this level
+        if (!sort_fused) return 0u;
+        if (ch_env) return cdiv((int64_t)cnt, ch_env) <= (int64_t)g0_wgs ? ch_env : 0u;
+        if (cdiv((int64_t)cnt, 2048) <= (int64_t)g0_wgs) return 2048u;
+        if (cdiv((int64_t)cnt, 4096) <= (int64_t)g0_wgs) return 4096u;
+        return 0u;
+    };
+    const bool any_big = true;
     {
         void *mem2 = nullptr;
-        const size_t need = sk_layout2(ngen0, maxcnt, cub_bytes, nullptr, &b);
+        const size_t need = sk_layout2(ngen0, maxcnt, any_big, nullptr, &b);
         IVX_REQUIRE(ws_get_s(WS_WSSK, st, need, &mem2) == IVX_OK, IVX_ENOMEM, "watershed: %zu bytes of scratch", need);
-        sk_layout2(ngen0, maxcnt, cub_bytes, (char *)mem2, &b);
+        sk_layout2(ngen0, maxcnt, any_big, (char *)mem2, &b);
     }
 
     tm.mark(st);
@@ -1028,14 +1525,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     // generation travels on the device (SkState::gnext); `gknown` says whether the host's gbase is current.
     const char *penv = getenv("IVX_SK_PERSIST");
     const bool persist = !(penv && penv[0] == '0');
-    int ncu = 0;
-    {
-        int dev = 0;
-        IVX_HIP(hipGetDevice(&dev));
-        IVX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
     bool gknown = true;
-    uint64_t gbound = 1; // gbase <= gbound always (a generation stamps at least one voxel): sizes the sort's key width
     auto sync_gbase = [&]() -> int { // the chain's last level has finished: fetch the generation counter
         if (gknown) return IVX_OK;
         uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
@@ -1061,7 +1551,6 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             dstart += ndl;
             continue;
         }
-        gbound += (uint64_t)lhist[c] + 1u;
         if (is_small(c)) { // a run of consecutive small levels: one launch
             {
                 const int rc = sync_gbase();
@@ -1098,29 +1587,65 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
         uint32_t lvl_batches = 0;
         const unsigned gb = (unsigned)cdiv(cnt, 256);
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau, b.elist + start, b.key_a,
-                                                  b.val_a, cnt, c));
-        IVX_LAUNCH_CHECK();
-        const unsigned long long *ks = b.key_a;
-        const uint32_t *vs = b.val_a;
         const bool tile_level = ndl == 0 && tile_min && lhist[c] >= tile_min;
         if (tile_level || !persist || trace) {
             const int rc = sync_gbase();
             if (rc != IVX_OK) return rc;
         }
-        if (cnt > 1) {
-            int end_bit = 33; // keys are below (gbase << 32): the bits that can differ
-            const uint64_t gtop = gknown ? (uint64_t)gbase : std::min<uint64_t>(gbound, 0x7FFFFFF0u);
-            while (end_bit < 64 && (gtop >> (end_bit - 32))) end_bit++;
-            size_t tb = cub_bytes + 256;
-            IVX_HIP(rocprim::radix_sort_pairs(b.cub, tb, (const unsigned long long *)b.key_a, b.key_b, (const uint32_t *)b.val_a, b.val_b,
-                                              (size_t)cnt, 0u, (unsigned int)end_bit, st));
-            ks = b.key_b;
-            vs = b.val_b;
+        const uint32_t g0_gbase = gknown ? gbase : 0u, g0_seq = persist && !tile_level ? 0u : seq;
+        if (const uint32_t chl = g0_chunk(cnt)) { // keys -> sorted -> stamps, run labels, first frontier: one launch
+            const unsigned nch = (unsigned)cdiv((int64_t)cnt, chl);
+            if (chl <= 2048) {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_gen0<CC, MT, 2>), dim3(nch), dim3(G0_T), 0, st, g, b.C, mk, I, b.comp, b.tau,
+                                                          b.elist + start, b.key_a, b.runlabel, b.lists[0], cnt, chl, c, roff, g0_gbase, g0_seq,
+                                                          b.st, b.g0ctl));
+            } else {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_gen0<CC, MT, 4>), dim3(nch), dim3(G0_T), 0, st, g, b.C, mk, I, b.comp, b.tau,
+                                                          b.elist + start, b.key_a, b.runlabel, b.lists[0], cnt, chl, c, roff, g0_gbase, g0_seq,
+                                                          b.st, b.g0ctl));
+            }
+            IVX_LAUNCH_CHECK();
+        } else {
+            WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau, b.elist + start,
+                                                      b.key_a, b.val_a, cnt, c));
+            IVX_LAUNCH_CHECK();
+            const int64_t nch = cdiv((int64_t)cnt, chb);
+            const bool pairs = !sort_merge && nch <= PAIR_CHUNKS;
+            unsigned long long *ka = b.key_a, *kb = b.key_b;
+            uint32_t *va = b.val_a, *vb = b.val_b;
+            if (chb <= 512) hipLaunchKernelGGL(k_sk_sort_chunks<64>, dim3((unsigned)nch), dim3(64), 0, st, ka, va, kb, vb, cnt, chb);
+            else if (chb <= 1024) hipLaunchKernelGGL(k_sk_sort_chunks<128>, dim3((unsigned)nch), dim3(128), 0, st, ka, va, kb, vb, cnt, chb);
+            else hipLaunchKernelGGL(k_sk_sort_chunks<256>, dim3((unsigned)nch), dim3(256), 0, st, ka, va, kb, vb, cnt, chb);
+            IVX_LAUNCH_CHECK();
+            std::swap(ka, kb);
+            std::swap(va, vb);
+            if (pairs) {
+                unsigned shares = 0;
+                if (nch > 1) { // (chunk, share of the other chunks): about a thousand workgroups
+                    shares = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nch - 1, PAIR_WGS / nch));
+                    if (chb <= 512) hipLaunchKernelGGL(k_sk_rank_pairs<2>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
+                    else if (chb <= 1024) hipLaunchKernelGGL(k_sk_rank_pairs<4>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
+                    else hipLaunchKernelGGL(k_sk_rank_pairs<8>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
+                    IVX_LAUNCH_CHECK();
+                }
+                hipLaunchKernelGGL(k_sk_assign_ranked<MT>, dim3(gb), dim3(256), 0, st, ka, va, b.rank, shares, chb, mk, b.tau, b.runlabel, b.lists[0],
+                                   cnt, roff, g0_gbase, g0_seq, b.st);
+                IVX_LAUNCH_CHECK();
+                if ((mbits[c >> 5] >> (c & 31u)) & 1u) {
+                    hipLaunchKernelGGL(k_sk_mixed<MT>, dim3(gb), dim3(256), 0, st, b.lists[0], mk, cnt, b.st);
+                    IVX_LAUNCH_CHECK();
+                }
+            } else { // too many chunks to rank pairwise: merge passes
+                for (uint64_t run = chb; run < cnt; run *= 2) {
+                    hipLaunchKernelGGL(k_sk_merge_pass, dim3((unsigned)cdiv((int64_t)cnt, 256 * MP_E)), dim3(256), 0, st, ka, va, kb, vb, cnt, (uint32_t)run);
+                    IVX_LAUNCH_CHECK();
+                    std::swap(ka, kb);
+                    std::swap(va, vb);
+                }
+                hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ka, va, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, g0_gbase, g0_seq, b.st);
+                IVX_LAUNCH_CHECK();
+            }
         }
-        hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ks, vs, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, gknown ? gbase : 0u,
-                           persist && !tile_level ? 0u : seq, b.st);
-        IVX_LAUNCH_CHECK();
         if (tile_level) {
             hipLaunchKernelGGL(k_sk_mark_tiles, dim3(gb), dim3(256), 0, st, g, b.lists[0], cnt, b.dirty);
             IVX_LAUNCH_CHECK();
@@ -1218,8 +1743,14 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_LAUNCH_CHECK();
     tm.mark(st);
     SkState hs;
+    SkG0Ctl hg;
     IVX_HIP(hipMemcpyAsync(&hs, b.st, sizeof(hs), hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipMemcpyAsync(&hg, b.g0ctl, sizeof(hg), hipMemcpyDeviceToHost, st));
     IVX_HIP(hipStreamSynchronize(st));
+    IVX_REQUIRE(!hg.fail, IVX_EHIP, "watershed: a generation-0 launch lost its device-wide barrier (workgroups not resident)");
+    if (trace)
+        fprintf(stderr, "sk generation-0 launches, workgroup 0: keys %.0f us, chunk sort %.0f, barrier %.0f, ranks %.0f, stamps %.0f (sums over the flood)\n",
+                hg.ticks[0] * 0.01, hg.ticks[1] * 0.01, hg.ticks[2] * 0.01, hg.ticks[3] * 0.01, hg.ticks[4] * 0.01);
     if (stats) {
         stats[0] = rounds; stats[1] = visits; stats[2] = nlevels; stats[3] = gbase; stats[4] = M; stats[5] = (int64_t)ngen0;
         stats[6] = hs.mixed; stats[7] = hs.rounds;

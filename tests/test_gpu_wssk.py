@@ -250,3 +250,40 @@ def test_cost_levels_on_the_region_growing_engine(ivxlib, oracle, monkeypatch, c
         monkeypatch.setenv("IVX_SK_LEVELS", levels)
         assert np.array_equal(cost, rcost), (conn, frac, levels, trial, int((cost != rcost).sum()))
         assert np.array_equal(got, ref) and np.array_equal(got, oracle.watershed_sk(grad, mk, st, 1)), (conn, frac, levels, trial)
+
+
+@pytest.mark.parametrize("env", [{}, {"IVX_SK_CHUNK": "64"}, {"IVX_SK_CHUNK": "512"}, {"IVX_SK_SORT": "merge"},
+                                 {"IVX_SK_SORT": "merge", "IVX_SK_CHUNK": "32"}, {"IVX_SK_SORT": "fused"},
+                                 {"IVX_SK_SORT": "fused", "IVX_SK_CHUNK": "64"}])
+def test_generation0_sorts(ivxlib, oracle, monkeypatch, env):
+    """A level's generation 0 -- keys, sort, stamps -- on the library-free paths: chunk sort in LDS + pairwise ranks (the
+    default), chunk sort + merge passes (levels of more than 64 chunks), and everything in one launch behind a device-wide
+    barrier (opt-in); every level forced off the one-workgroup path and chunks short enough that a small volume has
+    dozens of them: labels == the serial flood, generations and the tied-marker count == the default path's."""
+    import warnings
+
+    from invesalius3_amd import watershed_process as wp
+    rng = np.random.default_rng(23)
+    cases = [_rand_case(rng, k) for k in range(40)]
+    for conn, use_ww_wl in ((1, True), (3, False)):
+        img, am = _ct_like((40, 112, 128), 5)
+        grad = wp.cost_image(img, use_ww_wl, 300, 400, (3, 3, 3))
+        mk = np.zeros(img.shape, np.int16)
+        mk[max(am[0] - 2, 0):am[0] + 3, am[1] - 4:am[1] + 5, am[2] - 4:am[2] + 5] = 1
+        mk[:4, :8, :8] = 2
+        mk[-4:, -8:, -8:] = 2
+        mk[20, 50:60, 60:64] = 3   # a brush stroke across a flat region: tied markers next to label 1 / 2 further on
+        mk[20, 60:62, 60:64] = 1
+        cases.append((grad, mk, ndimage.generate_binary_structure(3, conn)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = [wp.watershed(i, m, s, want_stats=True) for i, m, s in cases]
+        monkeypatch.setenv("IVX_SK_SMALL", "0")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for n, (i, m, s) in enumerate(cases):
+            got, stats = wp.watershed(i, m, s, want_stats=True)
+            assert np.array_equal(got, oracle.watershed_sk(i, m, s, 1)), (env, n, i.shape)
+            assert np.array_equal(got, base[n][0]), (env, n)
+            for key in ("generations", "tied_markers_of_different_labels", "levels", "generation0"):
+                assert stats[key] == base[n][1][key], (env, n, key, stats[key], base[n][1][key])
