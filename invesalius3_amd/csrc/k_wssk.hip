@@ -84,7 +84,8 @@ struct SkState {
     // the resident launch (k_sk_level) polls its control word from every workgroup: a line of its own, away from the counters
     // the working workgroups add to
     unsigned long long pctl;
-    uint32_t pad2[30];
+    uint32_t ticks[16]; // IVX_WS_TRACE: workgroup 0's time per part of a round, summed over the flood (wall_clock64 ticks of 10 ns)
+    uint32_t pad2[14];
 };
 static_assert(sizeof(SkState) == 256 && offsetof(SkState, pctl) == 128, "ctl is 8-byte aligned, pctl starts a 128-byte line");
 
@@ -642,37 +643,76 @@ __global__ __launch_bounds__(256) void k_sk_mixed(const uint32_t *__restrict__ f
     if (m && (int)mk[front[i - 1]] != m) atomicAdd(&st->mixed, 1u);
 }
 
-constexpr uint32_t MP_E = 8; // outputs per lane
+// One merge pass: runs of `run` pairs -> runs of 2 * run.  A workgroup produces MP_TILE consecutive outputs: two waves find,
+// each with a 64-way search (64 probes per dependent round trip instead of one), where the tile's first and last diagonal cut
+// the two runs (merge path; ties: run A first -- (key, voxel) pairs are unique anyway); the two input stretches go to LDS, every
+// lane finds its own 8 outputs' cut there and merges them serially.
+constexpr uint32_t MP_E = 8, MP_TILE = 256 * MP_E; // outputs per lane / per workgroup
+
+// pairs of diagonal d's prefix that come from run A, by the wave: a0 / b0 the runs' starts, na / nb their lengths
+__device__ __forceinline__ uint32_t mp_cut_wave(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val, uint32_t a0,
+                                                uint32_t na, uint32_t b0, uint32_t nb, uint32_t d) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lo = d > nb ? d - nb : 0u, hi = min(d, na);
+    while (lo < hi) { // (uniform)
+        const uint32_t span = hi - lo, step = (span + 63u) / 64u, mid = lo + lane * step;
+        bool p = false; // "A[mid] belongs to the prefix": true for a prefix of the lanes
+        if (mid < hi) {
+            const uint32_t j = d - 1u - mid;
+            p = !sk_pair_less(key[b0 + j], val[b0 + j], key[a0 + mid], val[a0 + mid]);
+        }
+        const uint32_t t = (uint32_t)__popcll(__ballot(p));
+        const uint32_t nlo = t ? lo + (t - 1u) * step + 1u : lo;
+        const uint32_t mt = lo + t * step; // the first probe that failed (if any)
+        hi = (t < 64u && mt < hi) ? mt : hi;
+        lo = nlo;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_sk_merge_pass(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
-                                                       unsigned long long *__restrict__ okey, uint32_t *__restrict__ oval, uint32_t cnt, uint32_t run) {
-    const uint64_t o0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * MP_E;
-    if (o0 >= cnt) return;
+                                                       unsigned long long *__restrict__ okey, uint32_t *__restrict__ oval, uint32_t cnt, uint32_t run,
+                                                       uint32_t tile) {
+    __shared__ unsigned long long s_k[MP_TILE];
+    __shared__ uint32_t s_v[MP_TILE];
+    __shared__ uint32_t s_cut[2];
+    // tile = min(MP_TILE, 2 * run), both powers of two: a tile never straddles two pairs of runs
+    const uint64_t o0 = (uint64_t)blockIdx.x * tile;
     const uint64_t pairb = o0 / (2ull * run) * (2ull * run);
     const uint32_t a0 = (uint32_t)pairb, na = cnt - pairb < run ? (uint32_t)(cnt - pairb) : run;
     const uint32_t b0 = a0 + na, nb = cnt - (pairb + na) < run ? (uint32_t)(cnt - (pairb + na)) : run;
-    const uint32_t d = (uint32_t)(o0 - pairb);
-    // i = pairs of this diagonal's prefix that come from run A (ties: A first)
-    uint32_t lo = d > nb ? d - nb : 0, hi = min(d, na);
+    const uint32_t d0 = (uint32_t)(o0 - pairb), d1 = min(d0 + tile, na + nb), tid = threadIdx.x;
+    if (tid < 128) { // waves 0 and 1
+        const uint32_t c = mp_cut_wave(key, val, a0, na, b0, nb, tid < 64 ? d0 : d1);
+        if ((tid & 63u) == 0) s_cut[tid >> 6] = c;
+    }
+    __syncthreads();
+    const uint32_t i0 = s_cut[0], i1 = s_cut[1], j0 = d0 - i0, j1 = d1 - i1, la = i1 - i0, lb = j1 - j0; // la + lb == d1 - d0
+    for (uint32_t x = tid; x < la + lb; x += 256) {
+        const uint32_t src = x < la ? a0 + i0 + x : b0 + j0 + (x - la);
+        s_k[x] = key[src];
+        s_v[x] = val[src];
+    }
+    __syncthreads();
+    // this lane's outputs: local diagonal dl = 8 * tid of the two staged stretches [0, la) and [la, la + lb)
+    const uint32_t dl = tid * MP_E;
+    if (dl >= la + lb) return;
+    uint32_t lo = dl > lb ? dl - lb : 0u, hi = min(dl, la);
     while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1, j = d - 1 - mid;
-        if (!sk_pair_less(key[b0 + j], val[b0 + j], key[a0 + mid], val[a0 + mid])) lo = mid + 1;
+        const uint32_t mid = (lo + hi) >> 1, j = dl - 1u - mid;
+        if (!sk_pair_less(s_k[la + j], s_v[la + j], s_k[mid], s_v[mid])) lo = mid + 1u;
         else hi = mid;
     }
-    uint32_t i = lo, j = d - lo;
-    const uint32_t nout = na + nb - d < MP_E ? na + nb - d : MP_E;
-    unsigned long long ka = i < na ? key[a0 + i] : TINF, kb = j < nb ? key[b0 + j] : TINF;
-    uint32_t va = i < na ? val[a0 + i] : 0xFFFFFFFFu, vb = j < nb ? val[b0 + j] : 0xFFFFFFFFu;
+    uint32_t i = lo, j = dl - lo;
+    const uint32_t nout = min(MP_E, la + lb - dl);
+    const uint64_t ob = pairb + d0 + dl;
     for (uint32_t e = 0; e < nout; e++) {
-        const bool take_b = i >= na || (j < nb && sk_pair_less(kb, vb, ka, va));
-        if (take_b) {
-            okey[o0 + e] = kb; oval[o0 + e] = vb;
-            j++;
-            if (j < nb) { kb = key[b0 + j]; vb = val[b0 + j]; }
-        } else {
-            okey[o0 + e] = ka; oval[o0 + e] = va;
-            i++;
-            if (i < na) { ka = key[a0 + i]; va = val[a0 + i]; }
-        }
+        const bool take_b = i >= la || (j < lb && sk_pair_less(s_k[la + j], s_v[la + j], s_k[i], s_v[i]));
+        const uint32_t src = take_b ? la + j : i;
+        okey[ob + e] = s_k[src];
+        oval[ob + e] = s_v[src];
+        i += !take_b;
+        j += take_b;
     }
 }
 
@@ -850,7 +890,13 @@ __device__ __forceinline__ void sk_offer_plateau_wide(const WsGeom &g, unsigned 
     }
 }
 
-constexpr uint32_t SK_SOLO_MAX = 1024; // list entries up to which ONE workgroup takes the round without a hand-over
+#ifndef SK_POLL_SLEEP
+#define SK_POLL_SLEEP 16 // (x 64 cycles between two polls of the control word)
+#endif
+#ifndef SK_TICKS
+#define SK_TICKS 0 // 1: workgroup 0 times the parts of its rounds (build with -DSK_TICKS=1; tools/build_variant.py)
+#endif
+constexpr uint32_t SK_SOLO_MAX = 256; // list entries up to which ONE workgroup takes the round without a hand-over (one pass)
 
 // one round's share of a workgroup: list entries wg * 256 + k * nactive * 256 (the whole workgroup is here)
 template <int CONN>
@@ -864,6 +910,14 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
     const uint32_t stride = nactive * 256;
     if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
     __syncthreads();
+    const bool tr = SK_TICKS && wg == 0 && threadIdx.x == 0;
+    unsigned long long tk = tr ? wall_clock64() : 0ull;
+#define SK_TICK(slot)                                                          \
+    if (tr) {                                                                  \
+        const unsigned long long now_ = wall_clock64();                        \
+        atomicAdd(&st->ticks[(slot) + (phase ? 6 : 0)], (uint32_t)(now_ - tk)); \
+        tk = now_;                                                             \
+    }
     uint32_t stamped = 0;
     for (uint32_t i0 = wg * 256; i0 < n_in; i0 += stride) {
         const uint32_t i = i0 + threadIdx.x;
@@ -872,6 +926,7 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
         if (phase == 0) {
             const uint32_t pm = act ? pmask[v] : 0u, zm = (ndl && act) ? zmask[v] : 0u;
             const unsigned long long t = act ? ld64(&tau[v]) : TINF;
+            if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(0) }
             uint32_t root[27]; // the basins this voxel touches: all their roots in flight, then all their stamps
 #pragma unroll
             for (int k = 0; k < 27; k++) {
@@ -881,6 +936,7 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
                 if ((zm >> k) & 1u) root[k] = comp[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)];
             }
             sk_offer_plateau_wide<CONN>(g, tau, pm, v, t + GEN1, sg, next, st);
+            if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(1) }
             uint32_t last = ENTRY;
 #pragma unroll
             for (int k = 0; k < 27; k++) {
@@ -889,18 +945,24 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
                 last = root[k];
                 stamped += atomicMin(&tau[root[k]], t) == TINF;
             }
+            if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(2) }
         } else {
             unsigned long long tb = TINF;
             if (act) tb = ld64(&tau[comp[v]]);
             act = act && (uint32_t)(tb >> 32) == gen;
+            if (SK_TICKS && tr) { SK_TICK(0) }
             sk_offer_plateau_wide<CONN>(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
+            if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(1) }
         }
         stage_flush(sg, next, &st->n_next);
+        if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(3) }
     }
     if (stamped) atomicAdd(&st->n_stamped, stamped);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0); // this wave's stores and atomics have been acknowledged
     __syncthreads();
+    SK_TICK(4)
+#undef SK_TICK
 }
 
 // SOLO: most rounds of a level are tiny -- on the 512^3 bench 670 of the 990 frontier rounds have at most 1 024 voxels, and
@@ -926,6 +988,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
     for (;;) {
         if (threadIdx.x == 0) {
             unsigned long long c;
+            const unsigned long long tp0 = SK_TICKS && blockIdx.x == 0 ? wall_clock64() : 0ull;
             for (uint32_t spins = 0;; spins++) {
                 c = __hip_atomic_load(&st->pctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t sq = (uint32_t)(c >> 54);
@@ -936,8 +999,9 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
                     __hip_atomic_store(&st->pctl, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the others leave too)
                     break;
                 }
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(SK_POLL_SLEEP);
             }
+            if (SK_TICKS && blockIdx.x == 0) atomicAdd(&st->ticks[12], (uint32_t)(wall_clock64() - tp0)); // waiting for the round's word
             s_ctl = c;
         }
         __syncthreads();
@@ -952,8 +1016,13 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
         const uint32_t nactive = min((uint32_t)gridDim.x, (n_in + per_wg - 1u) / per_wg);
         if (blockIdx.x < nactive) {
             sk_level_round<CONN>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, blockIdx.x, nactive);
+            const unsigned long long tt0 = SK_TICKS && blockIdx.x == 0 && threadIdx.x == 0 ? wall_clock64() : 0ull;
             if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1u) == nactive - 1;
             __syncthreads();
+            if (SK_TICKS && blockIdx.x == 0 && threadIdx.x == 0) {
+                atomicAdd(&st->ticks[13], (uint32_t)(wall_clock64() - tt0)); // the ticket
+                atomicAdd(&st->ticks[14], 1u);                                // rounds workgroup 0 took part in
+            }
             if (s_last) { // (the whole workgroup)
                 if (threadIdx.x == 0) st32(&st->ticket, 0u);
                 for (;;) {
@@ -1355,6 +1424,7 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
 }
 
 // the part sized once generation 0 has been counted (slot WS_WSSK)
+constexpr uint64_t PLANE_CAP = 4u << 20; // counts in all share planes of one level (16 MB)
 static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, bool big, char *base, SkBufs *b) {
     size_t o = 0;
     auto take = [&](size_t n) { char *p = base ? base + o : nullptr; o += al(n); return p; };
@@ -1363,7 +1433,7 @@ static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, bool big, char *base, 
     b->key_b = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
     b->val_a = (uint32_t *)take((size_t)maxcnt * 4 + 8);
     b->val_b = (uint32_t *)take((size_t)maxcnt * 4 + 8);
-    b->rank = (uint32_t *)take((size_t)std::min<uint64_t>((uint64_t)maxcnt * 128u, 1024u * 2048u) * 4 + 8); // the share planes of k_sk_rank_pairs
+    b->rank = (uint32_t *)take((size_t)std::min<uint64_t>((uint64_t)maxcnt * 512u, PLANE_CAP) * 4 + 8); // the share planes of k_sk_rank_pairs
     (void)big;
     return o;
 }
@@ -1492,8 +1562,12 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     if (ch_env < 2 || ch_env > 2048 || (ch_env & (ch_env - 1))) ch_env = 0;
     const bool sort_merge = eso2 && eso2[0] == 'm', sort_fused = eso2 && eso2[0] == 'f';
     const uint32_t g0_wgs = (uint32_t)std::max(ncu, 8);
-    const uint32_t chb = ch_env ? ch_env : 1024u;
-    const int64_t PAIR_CHUNKS = 128 * (2048 / chb), PAIR_WGS = 1024 * (2048 / chb); // (shares * chunks <= PAIR_WGS: the share planes hold at most PAIR_WGS * 2048 counts)
+    // chunks of 1024 voxels (the chunk sort is bound by one compute unit's instruction rate: 15 us for 1024 pairs, 31 for 2048)
+    // until the pairwise ranks outweigh that -- their work grows with voxels x chunks; IVX_SK_CHUNK_SWITCH, _PAIR_CHUNKS, _PAIR_WGS: A/B
+    const char *e_sw = getenv("IVX_SK_CHUNK_SWITCH"), *e_pc = getenv("IVX_SK_PAIR_CHUNKS"), *e_pw = getenv("IVX_SK_PAIR_WGS");
+    const uint32_t ch_switch = e_sw ? (uint32_t)atoll(e_sw) : (1u << 17);
+    const int64_t PAIR_CHUNKS = e_pc ? atoll(e_pc) : 128, PAIR_WGS = e_pw ? std::max<int64_t>(atoll(e_pw), 1) : 2048;
+    auto chunk_len = [&](uint32_t cnt) -> uint32_t { return ch_env ? ch_env : cnt <= ch_switch ? 1024u : 2048u; };
     auto g0_chunk = [&](uint32_t cnt) -> uint32_t { // chunk length of the one-launch path, 0: not for this level
         if (!sort_fused) return 0u;
         if (ch_env) return cdiv((int64_t)cnt, ch_env) <= (int64_t)g0_wgs ? ch_env : 0u;
@@ -1514,7 +1588,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     int64_t nlevels = 0, ntile_rounds = 0, nsmall_runs = 0;
     const bool trace = getenv("IVX_WS_TRACE") != nullptr;
     const char *epb = getenv("IVX_SK_PER_WG"); // list entries per working workgroup (A/B measurements)
-    const uint32_t per_wg = epb && atoi(epb) >= 256 ? (uint32_t)atoi(epb) : 1024u;
+    const uint32_t per_wg = epb && atoi(epb) >= 32 ? (uint32_t)atoi(epb) : 256u; // (round 6: 1024 -> 256 = one pass per workgroup, 49.8 -> 44.7 ms of level chain at 512^3)
     const char *eso = getenv("IVX_SK_SOLO"); // most list entries one workgroup takes alone inside a resident launch (0: never; A/B)
     const uint32_t solo_max = eso ? (uint32_t)atoi(eso) : SK_SOLO_MAX;
     const char *erc = getenv("IVX_SK_RES_PER_CU");
@@ -1609,8 +1683,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau, b.elist + start,
                                                       b.key_a, b.val_a, cnt, c));
             IVX_LAUNCH_CHECK();
+            const uint32_t chb = chunk_len(cnt);
             const int64_t nch = cdiv((int64_t)cnt, chb);
-            const bool pairs = !sort_merge && nch <= PAIR_CHUNKS;
+            const bool pairs = !sort_merge && (nch <= PAIR_CHUNKS || ch_env);
             unsigned long long *ka = b.key_a, *kb = b.key_b;
             uint32_t *va = b.val_a, *vb = b.val_b;
             if (chb <= 512) hipLaunchKernelGGL(k_sk_sort_chunks<64>, dim3((unsigned)nch), dim3(64), 0, st, ka, va, kb, vb, cnt, chb);
@@ -1622,7 +1697,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             if (pairs) {
                 unsigned shares = 0;
                 if (nch > 1) { // (chunk, share of the other chunks): about a thousand workgroups
-                    shares = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nch - 1, PAIR_WGS / nch));
+                    shares = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nch - 1, PAIR_WGS / nch), (int64_t)(PLANE_CAP / cnt)));
                     if (chb <= 512) hipLaunchKernelGGL(k_sk_rank_pairs<2>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
                     else if (chb <= 1024) hipLaunchKernelGGL(k_sk_rank_pairs<4>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
                     else hipLaunchKernelGGL(k_sk_rank_pairs<8>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
@@ -1637,7 +1712,8 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
                 }
             } else { // too many chunks to rank pairwise: merge passes
                 for (uint64_t run = chb; run < cnt; run *= 2) {
-                    hipLaunchKernelGGL(k_sk_merge_pass, dim3((unsigned)cdiv((int64_t)cnt, 256 * MP_E)), dim3(256), 0, st, ka, va, kb, vb, cnt, (uint32_t)run);
+                    const uint32_t tile = (uint32_t)std::min<uint64_t>(MP_TILE, 2 * run);
+                    hipLaunchKernelGGL(k_sk_merge_pass, dim3((unsigned)cdiv((int64_t)cnt, tile)), dim3(256), 0, st, ka, va, kb, vb, cnt, (uint32_t)run, tile);
                     IVX_LAUNCH_CHECK();
                     std::swap(ka, kb);
                     std::swap(va, vb);
@@ -1748,6 +1824,10 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_HIP(hipMemcpyAsync(&hg, b.g0ctl, sizeof(hg), hipMemcpyDeviceToHost, st));
     IVX_HIP(hipStreamSynchronize(st));
     IVX_REQUIRE(!hg.fail, IVX_EHIP, "watershed: a generation-0 launch lost its device-wide barrier (workgroups not resident)");
+    if (trace && SK_TICKS)
+        fprintf(stderr, "sk rounds, workgroup 0 (%u rounds): A: loads %.0f us, plateau offers %.0f, basin offers %.0f, flush %.0f, drain %.0f | B: loads %.0f, offers %.0f, flush %.0f, drain %.0f | word wait %.0f, ticket %.0f\n",
+                hs.ticks[14], hs.ticks[0] * 0.01, hs.ticks[1] * 0.01, hs.ticks[2] * 0.01, hs.ticks[3] * 0.01, hs.ticks[4] * 0.01, hs.ticks[6] * 0.01,
+                hs.ticks[7] * 0.01, hs.ticks[9] * 0.01, hs.ticks[10] * 0.01, hs.ticks[12] * 0.01, hs.ticks[13] * 0.01);
     if (trace)
         fprintf(stderr, "sk generation-0 launches, workgroup 0: keys %.0f us, chunk sort %.0f, barrier %.0f, ranks %.0f, stamps %.0f (sums over the flood)\n",
                 hg.ticks[0] * 0.01, hg.ticks[1] * 0.01, hg.ticks[2] * 0.01, hg.ticks[3] * 0.01, hg.ticks[4] * 0.01);
