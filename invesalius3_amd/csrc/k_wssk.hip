@@ -111,14 +111,15 @@ struct SkKindPred {
     uint8_t which;
     __device__ bool operator()(int64_t p) const { return kind[p] == which; }
 };
-constexpr uint8_t KIND_GEN0 = 1, KIND_DRAINED = 2;
+constexpr uint8_t KIND_GEN0 = 1, KIND_DRAINED = 2, KIND_GEN0_LATE = 3; // (late: see k_sk_classify)
 
 // per voxel: generation 0 (markers, and voxels that sit AT their cost, I == C, next to a voxel of lower cost), or drained
 // (I < C: part of a basin that is flooded the moment it is reached) with the mask of its drained neighbours of equal cost
 template <int CONN, typename MT>
 __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
                                                      const MT *__restrict__ mk, uint8_t *__restrict__ kind, uint32_t *__restrict__ comp,
-                                                     uint32_t *__restrict__ zmask, uint32_t *__restrict__ pmask, uint32_t *mbits) {
+                                                     uint32_t *__restrict__ zmask, uint32_t *__restrict__ pmask, uint32_t *mbits,
+                                                     const uint16_t *__restrict__ prevl) {
     __shared__ uint32_t s[NCELL];
     int z0, y0, x0;
     tile_origin(g, blockIdx.x, z0, y0, x0);
@@ -133,20 +134,25 @@ __global__ __launch_bounds__(256) void k_sk_classify(WsGeom g, const uint16_t *_
         const uint32_t c = cell >> 16, iv = cell & 0xFFFFu;
         const int64_t p = (int64_t)(z0 + zz) * g.hw + (int64_t)(y0 + ly) * g.w + (x0 + lx);
         const bool drained = c != CINF && iv < c; // (never a marker: those sit at their own value)
-        bool lower = false;
+        uint32_t minlow = CINF; // smallest cost among the neighbours of lower cost
         uint32_t zm = 0, pm = 0; // neighbours of the same level: drained ones (zm), those at the level's value (pm)
 #pragma unroll
         for (int k = 0; k < 27; k++) {
             if (!has_off<CONN>(g.smask, k)) continue;
             const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
             const uint32_t qv = s[ci + (dz * BY + dy) * BX + dx]; // cells outside the volume carry CINF
-            lower |= (qv >> 16) < c;
+            if ((qv >> 16) < c) minlow = min(minlow, qv >> 16);
             zm |= ((qv >> 16) == c && (qv & 0xFFFFu) < c) ? 1u << k : 0u;
             pm |= ((qv >> 16) == c && (qv & 0xFFFFu) == c) ? 1u << k : 0u;
         }
         if (c == CINF) zm = pm = 0; // never reached: takes part in nothing
-        const bool marker = mk[p] != 0;
-        kind[p] = (marker || (c != CINF && iv == c && lower)) ? KIND_GEN0 : drained ? KIND_DRAINED : 0;
+        const bool marker = mk[p] != 0, lower = minlow != CINF;
+        // LATE: every neighbour of lower cost sits in the level right below (prevl[c]: the next lower level that has voxels), so
+        // the key -- the smallest time stamp among them -- is known only when that level has been flooded.  Everybody else's
+        // key is final one level earlier: their keys and sort run beside the level below (sk_run), and they all sort before
+        // the late ones (a stamp of the level below is later than every earlier stamp).
+        const bool late = !marker && lower && minlow == (uint32_t)prevl[c];
+        kind[p] = (marker || (c != CINF && iv == c && lower)) ? (late ? KIND_GEN0_LATE : KIND_GEN0) : drained ? KIND_DRAINED : 0;
         // which levels hold markers (one bit per level; the host launches the tied-marker check for those only)
         if (marker && c != CINF && !((__hip_atomic_load(&mbits[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (c & 31u)) & 1u))
             atomicOr(&mbits[c >> 5], 1u << (c & 31u));
@@ -166,6 +172,8 @@ __global__ __launch_bounds__(256) void k_sk_keys(WsGeom g, const uint16_t *__res
                                                  const uint16_t *__restrict__ I, const uint32_t *__restrict__ comp,
                                                  const unsigned long long *tau, const uint32_t *__restrict__ elist,
                                                  unsigned long long *__restrict__ key, uint32_t *__restrict__ val, uint32_t cnt, uint32_t c) {
+    // c: neighbours of cost below c count.  (The level itself -- or, for the voxels whose key is final one level earlier, the
+    // level below: its stamps are being written while this runs and would lose against every earlier one anyway.)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= cnt) return;
     const uint32_t p = elist[i];
@@ -216,6 +224,136 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
     if (m && i > 0 && (int)mk[val[i - 1]] != m) atomicAdd(&st->mixed, 1u); // markers sort first: val[i-1] is one too
 }
 
+__device__ __forceinline__ bool sk_pair_less(unsigned long long ka, uint32_t va, unsigned long long kb, uint32_t vb) {
+    return ka < kb || (ka == kb && va < vb);
+}
+
+// prevl[c] = the largest level below c that holds voxels (CINF: none), from the voxels-per-level histogram; one workgroup
+__global__ __launch_bounds__(1024) void k_sk_prevlevel(const uint32_t *__restrict__ lhist, uint16_t *__restrict__ prevl) {
+    __shared__ int s_last[1024];
+    const int t = threadIdx.x; // levels 64 t .. 64 t + 63
+    int last = -1;
+    for (int q = 0; q < 64; q++)
+        if (lhist[64 * t + q]) last = 64 * t + q;
+    s_last[t] = last;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // running maximum
+        const int v = t >= off ? s_last[t - off] : -1;
+        __syncthreads();
+        s_last[t] = max(s_last[t], v);
+        __syncthreads();
+    }
+    int run = t ? s_last[t - 1] : -1;
+    for (int q = 0; q < 64; q++) {
+        prevl[64 * t + q] = run < 0 ? (uint16_t)CINF : (uint16_t)run;
+        if (lhist[64 * t + q]) run = 64 * t + q;
+    }
+}
+
+// generation 0 bucketed by (level, late): bucket 2 c holds the voxels of level c whose key is final one level early (markers
+// among them), bucket 2 c + 1 the late ones -- a level's list is one stretch, early part first.  (k_ws_bucket's scheme.)
+constexpr int BK2_LB = 8192;
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_sk_bucket2(int64_t n, const uint16_t *__restrict__ C, const uint8_t *__restrict__ kind,
+                                                    uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist) {
+    __shared__ uint32_t sh[BK2_LB];
+    for (int i = threadIdx.x; i < BK2_LB; i += 256) sh[i] = 0;
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
+    for (int pass = 0; pass < (SCATTER ? 2 : 1); pass++) {
+        for (int j = 0; j < BK_CH; j++) {
+            const int64_t p = b0 + (int64_t)j * 256 + threadIdx.x;
+            const uint8_t kd = p < n ? kind[p] : (uint8_t)0;
+            if (kd != KIND_GEN0 && kd != KIND_GEN0_LATE) continue;
+            const uint32_t bk = 2u * C[p] + (kd == KIND_GEN0_LATE ? 1u : 0u);
+            if (bk < (uint32_t)BK2_LB) {
+                const uint32_t off = atomicAdd(&sh[bk], 1u);
+                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
+            } else if (!SCATTER || pass == 1) {
+                const uint32_t off = atomicAdd(&hist_or_cursor[bk], 1u);
+                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int i = threadIdx.x; i < BK2_LB; i += 256) {
+                const uint32_t v = sh[i];
+                if (v) {
+                    const uint32_t base = atomicAdd(&hist_or_cursor[i], v);
+                    if (SCATTER) sh[i] = base;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// sorted chunks + share planes -> one sorted list (the early part's sort runs beside the level below, on its own stream)
+__global__ __launch_bounds__(256) void k_sk_scatter_sorted(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
+                                                           const uint32_t *__restrict__ part, uint32_t shares, uint32_t ch,
+                                                           unsigned long long *__restrict__ okey, uint32_t *__restrict__ oval, uint32_t cnt) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    uint32_t pos = i & (ch - 1u);
+    for (uint32_t sh = 0; sh < shares; sh++) pos += part[(size_t)sh * cnt + i];
+    okey[pos] = key[i];
+    oval[pos] = val[i];
+}
+
+// A level's stamps when its generation 0 comes in two parts: the early part already sorted (position = index), the late part
+// (keys from k_sk_keys, a few thousand at most) ranked here by brute force -- every late workgroup stages ALL late pairs in
+// LDS, sixteen lanes share one pair's count (a sixteenth of the list each, eight probes in flight) -- and placed behind the early part.
+constexpr uint32_t LATE_MAX = 12000, LATE_SPLIT = 16, LATE_PER_WG = 256 / LATE_SPLIT;
+template <typename MT>
+__global__ __launch_bounds__(256) void k_sk_split_assign(const unsigned long long *__restrict__ ekey, const uint32_t *__restrict__ evl, uint32_t cnt_e,
+                                                         const unsigned long long *__restrict__ lkey, const uint32_t *__restrict__ lvl, uint32_t cnt_l,
+                                                         const MT *__restrict__ mk, unsigned long long *tau, int32_t *runlabel,
+                                                         uint32_t *__restrict__ front, uint32_t roff, uint32_t gbase, uint32_t seq, SkState *st) {
+    extern __shared__ unsigned long long s_dyn[]; // cnt_l keys, then cnt_l voxels
+    const uint32_t nwe = (cnt_e + 255u) / 256u, tid = threadIdx.x;
+    if (gbase == 0) gbase = __hip_atomic_load(&st->gnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && tid == 0) {
+        const uint32_t cnt = cnt_e + cnt_l;
+        st->done = 0; st->gen = gbase; st->n_in = cnt;
+        st->phase = 0; st->in_sel = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->ctl = sk_ctl(seq, 0, 0, cnt);
+        st->pctl = sk_pctl(0, 0, 0, 0, cnt);
+    }
+    uint32_t p, pos;
+    unsigned long long K;
+    if (blockIdx.x < nwe) {
+        const uint32_t i = blockIdx.x * 256 + tid;
+        if (i >= cnt_e) return;
+        p = evl[i]; K = ekey[i]; pos = i;
+    } else {
+        unsigned long long *s_k = s_dyn;
+        uint32_t *s_v = (uint32_t *)(s_dyn + cnt_l);
+        for (uint32_t i = tid; i < cnt_l; i += 256) {
+            s_k[i] = lkey[i];
+            s_v[i] = lvl[i];
+        }
+        __syncthreads();
+        const uint32_t j = (blockIdx.x - nwe) * LATE_PER_WG + tid / LATE_SPLIT, part = tid % LATE_SPLIT;
+        const bool act = j < cnt_l;
+        K = act ? s_k[j] : TINF;
+        p = act ? s_v[j] : 0xFFFFFFFFu;
+        const uint32_t per = (cnt_l + LATE_SPLIT - 1u) / LATE_SPLIT, i0 = part * per, i1 = min(cnt_l, i0 + per);
+        uint32_t below = 0;
+#pragma unroll 8
+        for (uint32_t i = i0; i < i1; i++) below += sk_pair_less(s_k[i], s_v[i], K, p) ? 1u : 0u;
+#pragma unroll
+        for (int o = 1; o < (int)LATE_SPLIT; o <<= 1) below += __shfl_xor(below, o, 64);
+        if (!act || part != 0) return;
+        pos = cnt_e + below;
+    }
+    const int m = (int)mk[p];
+    const int32_t l = m ? (int32_t)m : (K == TINF ? 0 : runlabel[(uint32_t)(K & 0xFFFFFFFFull)]);
+    runlabel[roff + pos] = l;
+    tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + pos);
+    front[pos] = p;
+}
+
 // ---- generation 0 of a level in ONE launch (k_sk_gen0): keys -> sorted -> stamps.
 // A level's generation 0 is ~5 x 10^4 (512^3) to ~5 x 10^5 (1024^3) voxels, once per level, 170 levels per flood, every one
 // on the flood's critical path.  As k_sk_keys + a library radix sort (one block sort + ~6 merge launches at this size) +
@@ -237,10 +375,6 @@ struct SkG0Ctl {
     uint32_t pad[19];
 };
 static_assert(sizeof(SkG0Ctl) == 128, "one line");
-
-__device__ __forceinline__ bool sk_pair_less(unsigned long long ka, uint32_t va, unsigned long long kb, uint32_t vb) {
-    return ka < kb || (ka == kb && va < vb);
-}
 
 // bitonic sort of n2 (a power of two) (key, voxel) pairs in LDS by all threads of the workgroup
 __device__ __forceinline__ void sk_bitonic(unsigned long long *s_key, uint32_t *s_val, uint32_t n2) {
@@ -1245,10 +1379,10 @@ __global__ __launch_bounds__(1024) void k_sk_levels_small(WsGeom g, SkSmallArgs 
     const uint32_t tid = threadIdx.x;
     if (tid == 0) s_mixed = 0;
     for (uint32_t c = c_lo; c <= c_hi; c++) {
-        const uint32_t cnt = a.hist[c];
+        const uint32_t cnt = a.hist[2 * c] + a.hist[2 * c + 1]; // (early + late part: one stretch of the list)
         if (!cnt) continue; // (uniform)
         const uint32_t ndl = a.dhist[c];
-        const uint32_t *el = a.elist + (a.cursor[c] - cnt), *dl = a.dlist + (a.dcursor[c] - ndl);
+        const uint32_t *el = a.elist + (a.cursor[2 * c + 1] - cnt), *dl = a.dlist + (a.dcursor[c] - ndl);
         // keys
         uint32_t n2 = 1;
         while (n2 < cnt) n2 <<= 1;
@@ -1379,11 +1513,17 @@ __global__ void k_sk_fill64(unsigned long long *p, int64_t n, unsigned long long
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+constexpr uint64_t PLANE_CAP = 4u << 20; // counts in all share planes of one level (16 MB)
+struct SkSortBufs { // working set of one generation-0 sort
+    unsigned long long *key_a, *key_b;
+    uint32_t *val_a, *val_b, *rank;
+};
 struct SkBufs {
-    uint16_t *C;
+    uint16_t *C, *prevl;
     uint8_t *kind, *dirty, *pending;
-    unsigned long long *tau, *key_a, *key_b;
-    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *val_a, *val_b, *hist, *cursor, *dhist, *dcursor, *lhist, *mbits, *rank, *bcount, *bsum, *tlist, *total;
+    unsigned long long *tau, *ekey[2];
+    SkSortBufs sort[2];
+    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *eval[2], *hist, *cursor, *dhist, *dcursor, *lhist, *mbits, *bcount, *bsum, *tlist, *total;
     int32_t *runlabel;
     WsState *wst;
     SkState *st;
@@ -1405,14 +1545,15 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->dlist = (uint32_t *)take((size_t)g.n * 4);
     b->elist = (uint32_t *)take((size_t)g.n * 4);
     for (int i = 0; i < 2; i++) b->lists[i] = (uint32_t *)take((size_t)g.n * 4);
-    b->hist = (uint32_t *)take(65536 * 4);
-    b->cursor = (uint32_t *)take(65536 * 4);
+    b->hist = (uint32_t *)take(131072 * 4); // (level, late) buckets
+    b->cursor = (uint32_t *)take(131072 * 4);
+    b->prevl = (uint16_t *)take(65536 * 2);
     b->dhist = (uint32_t *)take(65536 * 4);
     b->dcursor = (uint32_t *)take(65536 * 4);
     b->lhist = (uint32_t *)take(65536 * 4);
     b->mbits = (uint32_t *)take(2048 * 4);
     b->bcount = (uint32_t *)take((size_t)(nblk + 1) * 4);
-    b->bsum = (uint32_t *)take((size_t)(std::max<int64_t>(cdiv(nblk, 4096), 16) + 2) * 4);
+    b->bsum = (uint32_t *)take((size_t)(std::max<int64_t>(cdiv(nblk, 4096), 64) + 2) * 4);
     b->tlist = (uint32_t *)take((size_t)g.ntiles * 4);
     b->dirty = (uint8_t *)take((size_t)g.ntiles);
     b->pending = (uint8_t *)take((size_t)g.ntiles);
@@ -1424,17 +1565,22 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
 }
 
 // the part sized once generation 0 has been counted (slot WS_WSSK)
-constexpr uint64_t PLANE_CAP = 4u << 20; // counts in all share planes of one level (16 MB)
-static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, bool big, char *base, SkBufs *b) {
+static size_t sk_layout2(uint64_t ngen0, uint32_t maxcnt, bool split, char *base, SkBufs *b) {
     size_t o = 0;
     auto take = [&](size_t n) { char *p = base ? base + o : nullptr; o += al(n); return p; };
     b->runlabel = (int32_t *)take((size_t)(ngen0 + 1) * 4);
-    b->key_a = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
-    b->key_b = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
-    b->val_a = (uint32_t *)take((size_t)maxcnt * 4 + 8);
-    b->val_b = (uint32_t *)take((size_t)maxcnt * 4 + 8);
-    b->rank = (uint32_t *)take((size_t)std::min<uint64_t>((uint64_t)maxcnt * 512u, PLANE_CAP) * 4 + 8); // the share planes of k_sk_rank_pairs
-    (void)big;
+    for (int w = 0; w < (split ? 2 : 1); w++) { // [0]: the level chain's own stream; [1]: the early parts, sorted beside the level below
+        SkSortBufs &sb = b->sort[w];
+        sb.key_a = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
+        sb.key_b = (unsigned long long *)take((size_t)maxcnt * 8 + 8);
+        sb.val_a = (uint32_t *)take((size_t)maxcnt * 4 + 8);
+        sb.val_b = (uint32_t *)take((size_t)maxcnt * 4 + 8);
+        sb.rank = (uint32_t *)take((size_t)std::min<uint64_t>((uint64_t)maxcnt * 512u, PLANE_CAP) * 4 + 8); // the share planes of k_sk_rank_pairs
+    }
+    for (int w = 0; w < 2; w++) { // two levels' sorted early parts (one being made while the other is read)
+        b->ekey[w] = (unsigned long long *)take(split ? (size_t)maxcnt * 8 + 8 : 8);
+        b->eval[w] = (uint32_t *)take(split ? (size_t)maxcnt * 4 + 8 : 8);
+    }
     return o;
 }
 
@@ -1504,40 +1650,56 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
 
     tm.mark(st);
     // ---- 2. generation 0 and the drained basins, bucketed by level ------------------------------------------
-    IVX_HIP(hipMemsetAsync(b.mbits, 0, 2048 * 4, st));
-    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind, b.comp,
-                                              b.zmask, b.pmask, b.mbits));
-    IVX_LAUNCH_CHECK();
-    {
-        const int rc = ws_zone_union(g, conn, b.zmask, b.comp, st);
-        if (rc != IVX_OK) return rc;
-    }
-    IVX_HIP(hipMemsetAsync(b.hist, 0, 65536 * 4, st));
-    IVX_HIP(hipMemsetAsync(b.dhist, 0, 65536 * 4, st));
     const unsigned gbk = (unsigned)cdiv(g.n, 256 * BK_CH);
-    std::vector<uint32_t> hist(65536), dhist(65536);
-    for (int which = 0; which < 2; which++) { // generation 0 -> elist, drained voxels -> dlist
-        const SkKindPred pred{b.kind, which ? KIND_DRAINED : KIND_GEN0};
-        uint32_t *h = which ? b.dhist : b.hist, *cur = which ? b.dcursor : b.cursor, *lst = which ? b.dlist : b.elist;
-        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, h, lst);
-        IVX_LAUNCH_CHECK();
-        IVX_HIP(hipMemcpyAsync((which ? dhist : hist).data(), h, 65536 * 4, hipMemcpyDeviceToHost, st));
-        IVX_HIP(hipMemcpyAsync(cur, h, 65536 * 4, hipMemcpyDeviceToDevice, st));
-        const int rc = scan_u32_exclusive(cur, 65536, b.bsum, b.total, st);
-        if (rc != IVX_OK) return rc;
-        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, true>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, cur, lst);
-        IVX_LAUNCH_CHECK();
-    }
     std::vector<uint32_t> lhist(65536); // voxels per level (a level that holds much of the volume is relaxed tile-wise)
     IVX_HIP(hipMemsetAsync(b.lhist, 0, 65536 * 4, st));
     hipLaunchKernelGGL((k_ws_bucket<SkLevelPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkLevelPred{}, b.lhist, b.elist);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipMemcpyAsync(lhist.data(), b.lhist, 65536 * 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_sk_prevlevel, dim3(1), dim3(1024), 0, st, b.lhist, b.prevl);
+    IVX_LAUNCH_CHECK();
+    IVX_HIP(hipMemsetAsync(b.mbits, 0, 2048 * 4, st));
+    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_classify<CC, MT>), dim3((unsigned)g.ntiles), dim3(256), 0, st, g, I, b.C, mk, b.kind, b.comp,
+                                              b.zmask, b.pmask, b.mbits, b.prevl));
+    IVX_LAUNCH_CHECK();
+    {
+        const int rc = ws_zone_union(g, conn, b.zmask, b.comp, st);
+        if (rc != IVX_OK) return rc;
+    }
+    IVX_HIP(hipMemsetAsync(b.hist, 0, 131072 * 4, st));
+    IVX_HIP(hipMemsetAsync(b.dhist, 0, 65536 * 4, st));
+    std::vector<uint32_t> hist2(131072), dhist(65536);
+    { // generation 0 -> elist, a level's early part then its late part (bucket 2 c, 2 c + 1)
+        hipLaunchKernelGGL(k_sk_bucket2<false>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.hist, b.elist);
+        IVX_LAUNCH_CHECK();
+        IVX_HIP(hipMemcpyAsync(hist2.data(), b.hist, 131072 * 4, hipMemcpyDeviceToHost, st));
+        IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, 131072 * 4, hipMemcpyDeviceToDevice, st));
+        const int rc = scan_u32_exclusive(b.cursor, 131072, b.bsum, b.total, st);
+        if (rc != IVX_OK) return rc;
+        hipLaunchKernelGGL(k_sk_bucket2<true>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.cursor, b.elist);
+        IVX_LAUNCH_CHECK();
+    }
+    { // drained voxels -> dlist
+        const SkKindPred pred{b.kind, KIND_DRAINED};
+        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, b.dhist, b.dlist);
+        IVX_LAUNCH_CHECK();
+        IVX_HIP(hipMemcpyAsync(dhist.data(), b.dhist, 65536 * 4, hipMemcpyDeviceToHost, st));
+        IVX_HIP(hipMemcpyAsync(b.dcursor, b.dhist, 65536 * 4, hipMemcpyDeviceToDevice, st));
+        const int rc = scan_u32_exclusive(b.dcursor, 65536, b.bsum, b.total, st);
+        if (rc != IVX_OK) return rc;
+        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, true>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, b.dcursor, b.dlist);
+        IVX_LAUNCH_CHECK();
+    }
     std::vector<uint32_t> mbits(2048); // levels that hold markers
     IVX_HIP(hipMemcpyAsync(mbits.data(), b.mbits, 2048 * 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(k_sk_fill64, dim3(2048), dim3(256), 0, st, b.tau, g.n, TINF);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipStreamSynchronize(st)); // the histograms are on the host now
+    std::vector<uint32_t> hist(65536), hist_l(65536); // generation 0 per level: all of it, its late part
+    for (uint32_t c = 0; c < 65536; c++) {
+        hist[c] = hist2[2 * c] + hist2[2 * c + 1];
+        hist_l[c] = hist2[2 * c + 1];
+    }
     uint64_t ngen0 = 0;
     uint32_t maxcnt = 0;
     for (uint32_t c = 0; c < 65535; c++) { // (65535 = never reached: no generation 0 there)
@@ -1575,13 +1737,68 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         if (cdiv((int64_t)cnt, 4096) <= (int64_t)g0_wgs) return 4096u;
         return 0u;
     };
-    const bool any_big = true;
+    // The early / late split (k_sk_classify): a level's early part is keyed and sorted on a second stream while the level
+    // below is being flooded; behind that level only the late part is keyed (k_sk_keys) and everything stamped in one launch
+    // (k_sk_split_assign).  IVX_SK_SPLIT=0: every level's generation 0 as one list on the chain's own stream (A/B, tests).
+    const char *esp = getenv("IVX_SK_SPLIT");
+    const char *penv0 = getenv("IVX_SK_PERSIST");
+    const bool split_on = !(esp && esp[0] == '0') && !sort_fused && !(penv0 && penv0[0] == '0');
     {
         void *mem2 = nullptr;
-        const size_t need = sk_layout2(ngen0, maxcnt, any_big, nullptr, &b);
+        const size_t need = sk_layout2(ngen0, maxcnt, split_on, nullptr, &b);
         IVX_REQUIRE(ws_get_s(WS_WSSK, st, need, &mem2) == IVX_OK, IVX_ENOMEM, "watershed: %zu bytes of scratch", need);
-        sk_layout2(ngen0, maxcnt, any_big, (char *)mem2, &b);
+        sk_layout2(ngen0, maxcnt, split_on, (char *)mem2, &b);
     }
+    // keys -> sorted chunks -> (pairwise ranks | merge passes) of one list on one stream; what comes back is read as
+    // "position of entry i = (i & (ch - 1)) + sum over the share planes" (merge passes: no planes, ch covers the whole list)
+    struct SortOut {
+        const unsigned long long *key;
+        const uint32_t *val, *part;
+        unsigned shares;
+        uint32_t ch;
+    };
+    auto sort_list = [&](hipStream_t s, SkSortBufs &w, const uint32_t *el, uint32_t cnt, uint32_t climit, SortOut *out) -> int {
+        const unsigned gb = (unsigned)cdiv(cnt, 256);
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, s, g, b.C, mk, I, b.comp, b.tau, el, w.key_a, w.val_a, cnt, climit));
+        IVX_LAUNCH_CHECK();
+        const uint32_t chb = chunk_len(cnt);
+        const int64_t nch = cdiv((int64_t)cnt, chb);
+        const bool pairs = !sort_merge && (nch <= PAIR_CHUNKS || ch_env);
+        unsigned long long *ka = w.key_a, *kb = w.key_b;
+        uint32_t *va = w.val_a, *vb = w.val_b;
+        if (chb <= 512) hipLaunchKernelGGL(k_sk_sort_chunks<64>, dim3((unsigned)nch), dim3(64), 0, s, ka, va, kb, vb, cnt, chb);
+        else if (chb <= 1024) hipLaunchKernelGGL(k_sk_sort_chunks<128>, dim3((unsigned)nch), dim3(128), 0, s, ka, va, kb, vb, cnt, chb);
+        else hipLaunchKernelGGL(k_sk_sort_chunks<256>, dim3((unsigned)nch), dim3(256), 0, s, ka, va, kb, vb, cnt, chb);
+        IVX_LAUNCH_CHECK();
+        std::swap(ka, kb);
+        std::swap(va, vb);
+        out->part = w.rank;
+        if (pairs) {
+            unsigned shares = 0;
+            if (nch > 1) { // (chunk, share of the other chunks): a thousand or two workgroups
+                shares = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nch - 1, PAIR_WGS / nch), (int64_t)(PLANE_CAP / cnt)));
+                if (chb <= 512) hipLaunchKernelGGL(k_sk_rank_pairs<2>, dim3((unsigned)nch, shares), dim3(256), 0, s, ka, w.rank, cnt, chb);
+                else if (chb <= 1024) hipLaunchKernelGGL(k_sk_rank_pairs<4>, dim3((unsigned)nch, shares), dim3(256), 0, s, ka, w.rank, cnt, chb);
+                else hipLaunchKernelGGL(k_sk_rank_pairs<8>, dim3((unsigned)nch, shares), dim3(256), 0, s, ka, w.rank, cnt, chb);
+                IVX_LAUNCH_CHECK();
+            }
+            out->shares = shares;
+            out->ch = chb;
+        } else { // too many chunks to rank pairwise: merge passes
+            for (uint64_t run = chb; run < cnt; run *= 2) {
+                const uint32_t tile = (uint32_t)std::min<uint64_t>(MP_TILE, 2 * run);
+                hipLaunchKernelGGL(k_sk_merge_pass, dim3((unsigned)cdiv((int64_t)cnt, tile)), dim3(256), 0, s, ka, va, kb, vb, cnt, (uint32_t)run, tile);
+                IVX_LAUNCH_CHECK();
+                std::swap(ka, kb);
+                std::swap(va, vb);
+            }
+            out->shares = 0;
+            out->ch = 0x80000000u; // (a power of two above every list: position = index)
+        }
+        out->key = ka;
+        out->val = va;
+        return IVX_OK;
+    };
 
     tm.mark(st);
     // ---- 3. the level chain ----------------------------------------------------------------------------------
@@ -1619,6 +1836,56 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     auto is_small = [&](uint32_t c) { return small_on && hist[c] <= (uint32_t)SMALL_GEN0 && lhist[c] <= SMALL_TOTAL; };
     SkSmallArgs sa{b.C, I, b.comp, b.pmask, b.zmask, b.elist, b.dlist, b.hist, b.cursor, b.dhist, b.dcursor, b.tau, b.runlabel,
                    b.lists[0], b.lists[1], b.st};
+    static const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
+    const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
+    auto is_tile_level = [&](uint32_t c) { return dhist[c] == 0 && tile_min && lhist[c] >= tile_min; };
+    // ---- the second stream (the early parts' sorts) and the events that order it against the chain
+    struct SkSide {
+        hipStream_t stream = nullptr;
+        hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr}, early[2] = {nullptr, nullptr};
+    };
+    static thread_local SkSide side;
+    if (split_on && !side.stream) {
+        IVX_HIP(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
+        for (auto &e : side.done) IVX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : side.early) IVX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    static thread_local bool attr_set[2] = {false, false};
+    if (split_on && !attr_set[sizeof(MT) == 2]) { // (one instantiation per marker type)
+        IVX_HIP(hipFuncSetAttribute((const void *)k_sk_split_assign<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LATE_MAX * 12)));
+        attr_set[sizeof(MT) == 2] = true;
+    }
+    uint32_t ndone = 0;           // events recorded on the chain's stream so far (a ring of four)
+    uint32_t early_of = 0xFFFFFFFFu, early_cnt = 0; // the level whose early part is (being) sorted on the side stream, in set early_set
+    int early_set = 0, next_set = 0;
+    int64_t nsplit = 0;
+    // the early part of the level that follows c, if that level is a candidate: called before c's own work is queued
+    auto queue_early_after = [&](uint32_t c) -> int {
+        if (!split_on) return IVX_OK;
+        uint32_t cn = c + 1;
+        while (cn < 65535 && !hist[cn]) cn++;
+        if (cn >= 65535) return IVX_OK;
+        const uint32_t ce = hist[cn] - hist_l[cn];
+        if (is_small(cn) || is_tile_level(cn) || hist_l[cn] > LATE_MAX || ce == 0) return IVX_OK;
+        uint32_t sn = start + hist[c]; // where level cn's stretch of the list begins (levels between c and cn are empty)
+        // levels below c are final -- and c's own generation 0 (the chain's critical stretch) has the chip to itself: the side
+        // stream starts when c's flood does
+        IVX_HIP(hipEventRecord(side.done[ndone % 4], st));
+        ndone++;
+        IVX_HIP(hipStreamWaitEvent(side.stream, side.done[(ndone - 1) % 4], 0));
+        SortOut so;
+        const int rc = sort_list(side.stream, b.sort[1], b.elist + sn, ce, c, &so); // (neighbours below c count: c itself is being flooded)
+        if (rc != IVX_OK) return rc;
+        hipLaunchKernelGGL(k_sk_scatter_sorted, dim3((unsigned)cdiv(ce, 256)), dim3(256), 0, side.stream, so.key, so.val, so.part, so.shares, so.ch,
+                           b.ekey[next_set], b.eval[next_set], ce);
+        IVX_LAUNCH_CHECK();
+        IVX_HIP(hipEventRecord(side.early[next_set], side.stream));
+        early_of = cn;
+        early_cnt = ce;
+        early_set = next_set;
+        next_set ^= 1;
+        return IVX_OK;
+    };
     for (uint32_t c = 0; c < 65535; c++) {
         const uint32_t cnt = hist[c], ndl = dhist[c];
         if (!cnt) { // (no voxel of the level at all: a level's drained voxels hang off its generation 0)
@@ -1657,11 +1924,12 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         }
         nlevels++;
         const auto lvl_t0 = std::chrono::steady_clock::now();
-        static const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
-        const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
         uint32_t lvl_batches = 0;
         const unsigned gb = (unsigned)cdiv(cnt, 256);
-        const bool tile_level = ndl == 0 && tile_min && lhist[c] >= tile_min;
+        const bool tile_level = is_tile_level(c);
+        const bool split_here = early_of == c; // this level's early part is on its way (queued when the level below started)
+        const uint32_t my_early_cnt = early_cnt;
+        const int my_early_set = early_set;
         if (tile_level || !persist || trace) {
             const int rc = sync_gbase();
             if (rc != IVX_OK) return rc;
@@ -1671,56 +1939,46 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             const unsigned nch = (unsigned)cdiv((int64_t)cnt, chl);
             if (chl <= 2048) {
                 WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_gen0<CC, MT, 2>), dim3(nch), dim3(G0_T), 0, st, g, b.C, mk, I, b.comp, b.tau,
-                                                          b.elist + start, b.key_a, b.runlabel, b.lists[0], cnt, chl, c, roff, g0_gbase, g0_seq,
+                                                          b.elist + start, b.sort[0].key_a, b.runlabel, b.lists[0], cnt, chl, c, roff, g0_gbase, g0_seq,
                                                           b.st, b.g0ctl));
             } else {
                 WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_gen0<CC, MT, 4>), dim3(nch), dim3(G0_T), 0, st, g, b.C, mk, I, b.comp, b.tau,
-                                                          b.elist + start, b.key_a, b.runlabel, b.lists[0], cnt, chl, c, roff, g0_gbase, g0_seq,
+                                                          b.elist + start, b.sort[0].key_a, b.runlabel, b.lists[0], cnt, chl, c, roff, g0_gbase, g0_seq,
                                                           b.st, b.g0ctl));
             }
             IVX_LAUNCH_CHECK();
-        } else {
-            WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3(gb), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau, b.elist + start,
-                                                      b.key_a, b.val_a, cnt, c));
-            IVX_LAUNCH_CHECK();
-            const uint32_t chb = chunk_len(cnt);
-            const int64_t nch = cdiv((int64_t)cnt, chb);
-            const bool pairs = !sort_merge && (nch <= PAIR_CHUNKS || ch_env);
-            unsigned long long *ka = b.key_a, *kb = b.key_b;
-            uint32_t *va = b.val_a, *vb = b.val_b;
-            if (chb <= 512) hipLaunchKernelGGL(k_sk_sort_chunks<64>, dim3((unsigned)nch), dim3(64), 0, st, ka, va, kb, vb, cnt, chb);
-            else if (chb <= 1024) hipLaunchKernelGGL(k_sk_sort_chunks<128>, dim3((unsigned)nch), dim3(128), 0, st, ka, va, kb, vb, cnt, chb);
-            else hipLaunchKernelGGL(k_sk_sort_chunks<256>, dim3((unsigned)nch), dim3(256), 0, st, ka, va, kb, vb, cnt, chb);
-            IVX_LAUNCH_CHECK();
-            std::swap(ka, kb);
-            std::swap(va, vb);
-            if (pairs) {
-                unsigned shares = 0;
-                if (nch > 1) { // (chunk, share of the other chunks): about a thousand workgroups
-                    shares = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nch - 1, PAIR_WGS / nch), (int64_t)(PLANE_CAP / cnt)));
-                    if (chb <= 512) hipLaunchKernelGGL(k_sk_rank_pairs<2>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
-                    else if (chb <= 1024) hipLaunchKernelGGL(k_sk_rank_pairs<4>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
-                    else hipLaunchKernelGGL(k_sk_rank_pairs<8>, dim3((unsigned)nch, shares), dim3(256), 0, st, ka, b.rank, cnt, chb);
-                    IVX_LAUNCH_CHECK();
-                }
-                hipLaunchKernelGGL(k_sk_assign_ranked<MT>, dim3(gb), dim3(256), 0, st, ka, va, b.rank, shares, chb, mk, b.tau, b.runlabel, b.lists[0],
-                                   cnt, roff, g0_gbase, g0_seq, b.st);
-                IVX_LAUNCH_CHECK();
-                if ((mbits[c >> 5] >> (c & 31u)) & 1u) {
-                    hipLaunchKernelGGL(k_sk_mixed<MT>, dim3(gb), dim3(256), 0, st, b.lists[0], mk, cnt, b.st);
-                    IVX_LAUNCH_CHECK();
-                }
-            } else { // too many chunks to rank pairwise: merge passes
-                for (uint64_t run = chb; run < cnt; run *= 2) {
-                    const uint32_t tile = (uint32_t)std::min<uint64_t>(MP_TILE, 2 * run);
-                    hipLaunchKernelGGL(k_sk_merge_pass, dim3((unsigned)cdiv((int64_t)cnt, tile)), dim3(256), 0, st, ka, va, kb, vb, cnt, (uint32_t)run, tile);
-                    IVX_LAUNCH_CHECK();
-                    std::swap(ka, kb);
-                    std::swap(va, vb);
-                }
-                hipLaunchKernelGGL(k_sk_assign<MT>, dim3(gb), dim3(256), 0, st, ka, va, mk, b.tau, b.runlabel, b.lists[0], cnt, roff, g0_gbase, g0_seq, b.st);
+        } else if (split_here) { // the early part is sorted already: late keys, then every stamp in one launch
+            const uint32_t ce = my_early_cnt, cl = cnt - ce;
+            nsplit++;
+            if (cl) {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3((unsigned)cdiv(cl, 256)), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau,
+                                                          b.elist + start + ce, b.sort[0].key_a, b.sort[0].val_a, cl, c));
                 IVX_LAUNCH_CHECK();
             }
+            IVX_HIP(hipStreamWaitEvent(st, side.early[my_early_set], 0));
+            const unsigned nwg = (unsigned)(cdiv(ce, 256) + cdiv(cl, LATE_PER_WG));
+            hipLaunchKernelGGL(k_sk_split_assign<MT>, dim3(nwg), dim3(256), (size_t)cl * 12, st, b.ekey[my_early_set], b.eval[my_early_set], ce,
+                               b.sort[0].key_a, b.sort[0].val_a, cl, mk, b.tau, b.runlabel, b.lists[0], roff, g0_gbase, g0_seq, b.st);
+            IVX_LAUNCH_CHECK();
+            if ((mbits[c >> 5] >> (c & 31u)) & 1u) {
+                hipLaunchKernelGGL(k_sk_mixed<MT>, dim3(gb), dim3(256), 0, st, b.lists[0], mk, cnt, b.st);
+                IVX_LAUNCH_CHECK();
+            }
+        } else {
+            SortOut so;
+            const int rc = sort_list(st, b.sort[0], b.elist + start, cnt, c, &so);
+            if (rc != IVX_OK) return rc;
+            hipLaunchKernelGGL(k_sk_assign_ranked<MT>, dim3(gb), dim3(256), 0, st, so.key, so.val, so.part, so.shares, so.ch, mk, b.tau, b.runlabel,
+                               b.lists[0], cnt, roff, g0_gbase, g0_seq, b.st);
+            IVX_LAUNCH_CHECK();
+            if ((mbits[c >> 5] >> (c & 31u)) & 1u) {
+                hipLaunchKernelGGL(k_sk_mixed<MT>, dim3(gb), dim3(256), 0, st, b.lists[0], mk, cnt, b.st);
+                IVX_LAUNCH_CHECK();
+            }
+        }
+        {
+            const int rc = queue_early_after(c); // (this level's stamps are queued: the next level's early part may start beside its flood)
+            if (rc != IVX_OK) return rc;
         }
         if (tile_level) {
             hipLaunchKernelGGL(k_sk_mark_tiles, dim3(gb), dim3(256), 0, st, g, b.lists[0], cnt, b.dirty);
@@ -1824,6 +2082,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_HIP(hipMemcpyAsync(&hg, b.g0ctl, sizeof(hg), hipMemcpyDeviceToHost, st));
     IVX_HIP(hipStreamSynchronize(st));
     IVX_REQUIRE(!hg.fail, IVX_EHIP, "watershed: a generation-0 launch lost its device-wide barrier (workgroups not resident)");
+    if (trace) fprintf(stderr, "sk levels whose early part was sorted beside the level below: %lld of %lld\n", (long long)nsplit, (long long)nlevels);
     if (trace && SK_TICKS)
         fprintf(stderr, "sk rounds, workgroup 0 (%u rounds): A: loads %.0f us, plateau offers %.0f, basin offers %.0f, flush %.0f, drain %.0f | B: loads %.0f, offers %.0f, flush %.0f, drain %.0f | word wait %.0f, ticket %.0f\n",
                 hs.ticks[14], hs.ticks[0] * 0.01, hs.ticks[1] * 0.01, hs.ticks[2] * 0.01, hs.ticks[3] * 0.01, hs.ticks[4] * 0.01, hs.ticks[6] * 0.01,

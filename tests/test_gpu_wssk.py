@@ -254,12 +254,15 @@ def test_cost_levels_on_the_region_growing_engine(ivxlib, oracle, monkeypatch, c
 
 @pytest.mark.parametrize("env", [{}, {"IVX_SK_CHUNK": "64"}, {"IVX_SK_CHUNK": "512"}, {"IVX_SK_SORT": "merge"},
                                  {"IVX_SK_SORT": "merge", "IVX_SK_CHUNK": "32"}, {"IVX_SK_SORT": "fused"},
-                                 {"IVX_SK_SORT": "fused", "IVX_SK_CHUNK": "64"}])
+                                 {"IVX_SK_SORT": "fused", "IVX_SK_CHUNK": "64"}, {"IVX_SK_SPLIT": "0"},
+                                 {"IVX_SK_SPLIT": "0", "IVX_SK_CHUNK": "64"}])
 def test_generation0_sorts(ivxlib, oracle, monkeypatch, env):
     """A level's generation 0 -- keys, sort, stamps -- on the library-free paths: chunk sort in LDS + pairwise ranks (the
-    default), chunk sort + merge passes (levels of more than 64 chunks), and everything in one launch behind a device-wide
-    barrier (opt-in); every level forced off the one-workgroup path and chunks short enough that a small volume has
-    dozens of them: labels == the serial flood, generations and the tied-marker count == the default path's."""
+    default), chunk sort + merge passes (levels of more than 128 chunks), and everything in one launch behind a device-wide
+    barrier (opt-in); with the early part sorted on the side stream beside the level below and the late part ranked by
+    brute force (the default) and as one list (IVX_SK_SPLIT=0); every level forced off the one-workgroup path and chunks
+    short enough that a small volume has dozens of them: labels == the serial flood, generations and the tied-marker
+    count == the default path's."""
     import warnings
 
     from invesalius3_amd import watershed_process as wp
