@@ -746,19 +746,20 @@ template <typename MT>
 __global__ __launch_bounds__(256) void k_sk_assign_ranked(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
                                                           const uint32_t *__restrict__ part, uint32_t shares, uint32_t ch, const MT *__restrict__ mk,
                                                           unsigned long long *tau, int32_t *runlabel, uint32_t *__restrict__ front, uint32_t cnt,
-                                                          uint32_t roff, uint32_t gbase, uint32_t seq, SkState *st) {
+                                                          uint32_t pos_off, uint32_t total, uint32_t roff, uint32_t gbase, uint32_t seq, SkState *st) {
+    // (cnt entries of a level's `total`, placed from position pos_off on: a level's list may arrive in two sorted parts)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (gbase == 0) gbase = __hip_atomic_load(&st->gnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i == 0) {
-        st->done = 0; st->gen = gbase; st->n_in = cnt;
+    if (i == 0 && pos_off == 0) {
+        st->done = 0; st->gen = gbase; st->n_in = total;
         st->phase = 0; st->in_sel = 0;
         st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
-        st->ctl = sk_ctl(seq, 0, 0, cnt);
-        st->pctl = sk_pctl(0, 0, 0, 0, cnt);
+        st->ctl = sk_ctl(seq, 0, 0, total);
+        st->pctl = sk_pctl(0, 0, 0, 0, total);
     }
     if (i >= cnt) return;
     const uint32_t p = val[i];
-    uint32_t pos = i & (ch - 1u); // position inside its chunk + the keys below it in the other chunks (one plane per share)
+    uint32_t pos = pos_off + (i & (ch - 1u)); // position inside its chunk + the keys below it in the other chunks (one plane per share)
     for (uint32_t sh = 0; sh < shares; sh++) pos += part[(size_t)sh * cnt + i];
     const unsigned long long K = key[i];
     const int m = (int)mk[p];
@@ -1743,6 +1744,8 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const char *esp = getenv("IVX_SK_SPLIT");
     const char *penv0 = getenv("IVX_SK_PERSIST");
     const bool split_on = !(esp && esp[0] == '0') && !sort_fused && !(penv0 && penv0[0] == '0');
+    const char *elm = getenv("IVX_SK_LATE_MAX"); // longest late part ranked by brute force (tests: 0 = every late part through the sort)
+    const uint32_t late_max = elm ? std::min<uint32_t>((uint32_t)atoll(elm), LATE_MAX) : LATE_MAX;
     {
         void *mem2 = nullptr;
         const size_t need = sk_layout2(ngen0, maxcnt, split_on, nullptr, &b);
@@ -1866,7 +1869,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         while (cn < 65535 && !hist[cn]) cn++;
         if (cn >= 65535) return IVX_OK;
         const uint32_t ce = hist[cn] - hist_l[cn];
-        if (is_small(cn) || is_tile_level(cn) || hist_l[cn] > LATE_MAX || ce == 0) return IVX_OK;
+        if (is_small(cn) || is_tile_level(cn) || ce == 0 || hist_l[cn] > hist[cn] / 2) return IVX_OK; // (mostly late: nothing to gain)
         uint32_t sn = start + hist[c]; // where level cn's stretch of the list begins (levels between c and cn are empty)
         // levels below c are final -- and c's own generation 0 (the chain's critical stretch) has the chip to itself: the side
         // stream starts when c's flood does
@@ -1950,16 +1953,29 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         } else if (split_here) { // the early part is sorted already: late keys, then every stamp in one launch
             const uint32_t ce = my_early_cnt, cl = cnt - ce;
             nsplit++;
-            if (cl) {
-                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3((unsigned)cdiv(cl, 256)), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.tau,
-                                                          b.elist + start + ce, b.sort[0].key_a, b.sort[0].val_a, cl, c));
+            if (cl <= late_max) { // late keys, then every stamp in one launch (the late pairs ranked by brute force in LDS)
+                if (cl) {
+                    WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3((unsigned)cdiv(cl, 256)), dim3(256), 0, st, g, b.C, mk, I, b.comp,
+                                                              b.tau, b.elist + start + ce, b.sort[0].key_a, b.sort[0].val_a, cl, c));
+                    IVX_LAUNCH_CHECK();
+                }
+                IVX_HIP(hipStreamWaitEvent(st, side.early[my_early_set], 0));
+                const unsigned nwg = (unsigned)(cdiv(ce, 256) + cdiv(cl, LATE_PER_WG));
+                hipLaunchKernelGGL(k_sk_split_assign<MT>, dim3(nwg), dim3(256), (size_t)cl * 12, st, b.ekey[my_early_set], b.eval[my_early_set], ce,
+                                   b.sort[0].key_a, b.sort[0].val_a, cl, mk, b.tau, b.runlabel, b.lists[0], roff, g0_gbase, g0_seq, b.st);
+                IVX_LAUNCH_CHECK();
+            } else { // a late part too long for that (1024^3: 16 000 of a level's 360 000): sorted like any list, placed behind the early part
+                SortOut so;
+                const int rc = sort_list(st, b.sort[0], b.elist + start + ce, cl, c, &so);
+                if (rc != IVX_OK) return rc;
+                IVX_HIP(hipStreamWaitEvent(st, side.early[my_early_set], 0));
+                hipLaunchKernelGGL(k_sk_assign_ranked<MT>, dim3((unsigned)cdiv(ce, 256)), dim3(256), 0, st, b.ekey[my_early_set], b.eval[my_early_set],
+                                   (const uint32_t *)nullptr, 0u, 0x80000000u, mk, b.tau, b.runlabel, b.lists[0], ce, 0u, cnt, roff, g0_gbase, g0_seq, b.st);
+                IVX_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_sk_assign_ranked<MT>, dim3((unsigned)cdiv(cl, 256)), dim3(256), 0, st, so.key, so.val, so.part, so.shares, so.ch, mk,
+                                   b.tau, b.runlabel, b.lists[0], cl, ce, cnt, roff, g0_gbase, g0_seq, b.st);
                 IVX_LAUNCH_CHECK();
             }
-            IVX_HIP(hipStreamWaitEvent(st, side.early[my_early_set], 0));
-            const unsigned nwg = (unsigned)(cdiv(ce, 256) + cdiv(cl, LATE_PER_WG));
-            hipLaunchKernelGGL(k_sk_split_assign<MT>, dim3(nwg), dim3(256), (size_t)cl * 12, st, b.ekey[my_early_set], b.eval[my_early_set], ce,
-                               b.sort[0].key_a, b.sort[0].val_a, cl, mk, b.tau, b.runlabel, b.lists[0], roff, g0_gbase, g0_seq, b.st);
-            IVX_LAUNCH_CHECK();
             if ((mbits[c >> 5] >> (c & 31u)) & 1u) {
                 hipLaunchKernelGGL(k_sk_mixed<MT>, dim3(gb), dim3(256), 0, st, b.lists[0], mk, cnt, b.st);
                 IVX_LAUNCH_CHECK();
@@ -1969,7 +1985,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             const int rc = sort_list(st, b.sort[0], b.elist + start, cnt, c, &so);
             if (rc != IVX_OK) return rc;
             hipLaunchKernelGGL(k_sk_assign_ranked<MT>, dim3(gb), dim3(256), 0, st, so.key, so.val, so.part, so.shares, so.ch, mk, b.tau, b.runlabel,
-                               b.lists[0], cnt, roff, g0_gbase, g0_seq, b.st);
+                               b.lists[0], cnt, 0u, cnt, roff, g0_gbase, g0_seq, b.st);
             IVX_LAUNCH_CHECK();
             if ((mbits[c >> 5] >> (c & 31u)) & 1u) {
                 hipLaunchKernelGGL(k_sk_mixed<MT>, dim3(gb), dim3(256), 0, st, b.lists[0], mk, cnt, b.st);

@@ -255,7 +255,8 @@ def test_cost_levels_on_the_region_growing_engine(ivxlib, oracle, monkeypatch, c
 @pytest.mark.parametrize("env", [{}, {"IVX_SK_CHUNK": "64"}, {"IVX_SK_CHUNK": "512"}, {"IVX_SK_SORT": "merge"},
                                  {"IVX_SK_SORT": "merge", "IVX_SK_CHUNK": "32"}, {"IVX_SK_SORT": "fused"},
                                  {"IVX_SK_SORT": "fused", "IVX_SK_CHUNK": "64"}, {"IVX_SK_SPLIT": "0"},
-                                 {"IVX_SK_SPLIT": "0", "IVX_SK_CHUNK": "64"}])
+                                 {"IVX_SK_SPLIT": "0", "IVX_SK_CHUNK": "64"}, {"IVX_SK_LATE_MAX": "0"},
+                                 {"IVX_SK_LATE_MAX": "0", "IVX_SK_CHUNK": "32"}])
 def test_generation0_sorts(ivxlib, oracle, monkeypatch, env):
     """A level's generation 0 -- keys, sort, stamps -- on the library-free paths: chunk sort in LDS + pairwise ranks (the
     default), chunk sort + merge passes (levels of more than 128 chunks), and everything in one launch behind a device-wide
