@@ -2033,7 +2033,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             // (a large first frontier -- the levels of a 1024^3 volume hold 4 - 5 x 10^5 generation-0 voxels -- is served better by
             // twice the workgroups with half the entries each: 235 -> 224 ms at 1024^3; at 512^3, 5 x 10^4 voxels, it measured worse)
             const bool wide = !epb && !erc && cnt >= (1u << 17);
-            const uint32_t lvl_per_wg = wide ? 512u : per_wg;
+            const uint32_t lvl_per_wg = per_wg; // (round 6: one pass per workgroup here too -- 512 entries measured 136.7 ms of level chain at 1024^3, 256: 131.6)
             const int64_t lvl_res = wide ? 2 : res_per_cu;
             const unsigned nres = (unsigned)std::min<int64_t>(std::max<int64_t>(cdiv(2 * (int64_t)std::max(cnt, ndl), lvl_per_wg), 8), lvl_res * std::max(ncu, 8));
             WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_level<CC>, dim3(nres), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists,
