@@ -1122,6 +1122,131 @@ def run_mip(args, job):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# what join_process_surface does to the soup (surface_process.py:204-472), on the bench surface
+# ----------------------------------------------------------------------------------------------------------------
+def run_surface_tail(args, job):
+    """The stages behind marching cubes on configs[1]'s surface (6.3 M triangles at 512^3): indexed mesh (the point merge of
+    vtkAppendPolyData + vtkCleanPolyData, :229-268), keep-largest (:376-391), mass properties (:452-458), face normals, ten
+    context-aware smoothing steps (invesalius_rs/src/mesh.rs:27-395, call :313-317) -- device-resident, wall time around
+    queued calls on the volume's stream -- and the two host-level calls that close the pipeline, fill holes (:396-416) and
+    point normals (:420-435), arrays in / arrays out (PCIe inclusive, said so).  `ms_per_step` = the device-resident stages."""
+    import ctypes
+
+    from invesalius3_amd import _lib as L, surface_process as sp
+    from invesalius3_amd.device import DeviceBuffer, DeviceVolume
+
+    n = args.size or 512
+    nvox = n ** 3
+    img = synth_v512((n, n, n), seed=SEED + job.rank)
+    L.require_device()
+    vol = DeviceVolume(img, spacing=(0.5, 0.5, 0.5), device=job.local_rank)
+    vol.threshold(*BONE)
+    lib = L.lib()
+    c64 = ctypes.c_int64
+    reps = max(1, args.steps or 5)
+
+    def timed(fn, k=reps):
+        fn()
+        vol.sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            r = fn()
+        vol.sync()
+        return (time.perf_counter() - t0) * 1e3 / k, r
+
+    stage = {}
+    stage["soup"], ntri_soup = timed(vol.marching_cubes)
+    stage["indexed_mesh"], (nv, nt) = timed(vol.marching_cubes_indexed)
+    ov, of, mass = DeviceBuffer(nv * 12 + 16), DeviceBuffer(nt * 12 + 16), DeviceBuffer(64)
+    nrm = DeviceBuffer(nt * 24 + 16)
+    n1, n2, nr = c64(0), c64(0), c64(0)
+
+    def keep():
+        L.check(lib.ivx_dev_mesh_keep_largest(vol._verts.ptr, c64(nv), vol._faces.ptr, c64(nt), ov.ptr, c64(nv), of.ptr, c64(nt),
+                                              ctypes.byref(n1), ctypes.byref(n2), ctypes.byref(nr), vol.stream))
+        return n1.value, n2.value, nr.value
+
+    stage["keep_largest"], largest = timed(keep)
+
+    def massp():
+        L.check(lib.ivx_dev_mesh_mass_properties(vol._verts.ptr, vol._faces.ptr, c64(nt), mass.ptr, vol.stream))
+
+    stage["mass_properties"], _ = timed(massp)
+    vol.sync()
+    vol_area = [float(x) for x in mass.download((8,), np.float64)[:2]]
+
+    def normals():
+        L.check(lib.ivx_dev_mesh_face_normals(vol._verts.ptr, L.F32, vol._faces.ptr, c64(nt), nrm.ptr, vol.stream))
+
+    stage["face_normals"], _ = timed(normals)
+    work = DeviceBuffer(nv * 12 + 16)
+
+    def smooth(iters):
+        def run():
+            L.check(lib.ivx_memcpy_d2d(work.ptr, vol._verts.ptr, ctypes.c_size_t(nv * 12), vol.stream))
+            L.check(lib.ivx_dev_context_aware_smoothing(work.ptr, L.F32, c64(nv), vol._faces.ptr, c64(nt), nrm.ptr,
+                                                        ctypes.c_double(0.7), ctypes.c_double(3.0), ctypes.c_double(0.5),
+                                                        ctypes.c_int(iters), None, None, vol.stream))
+        return run
+
+    t0, _ = timed(smooth(0), 3)
+    t10, _ = timed(smooth(10), 3)
+    stage["smoothing_setup"] = t0
+    stage["smoothing_10_steps"] = t10 - t0
+    verts = vol._verts.download((nv, 3), np.float32)
+    faces = vol._faces.download((nt, 3), np.int32)
+    soup = vol.marching_cubes(download=True)
+    # host-level calls (arrays in, arrays out: upload + kernels + download), on the largest region like the reference's pipeline
+    kv, kf = ov.download((largest[0], 3), np.float32), of.download((largest[1], 3), np.int32)
+    t = time.perf_counter()
+    fv, ff, nholes = sp.fill_holes(kv, kf, 300.0)
+    t_fill = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    pv, pf, pn, cn = sp.point_normals(fv, ff, 80.0, True, True)
+    t_pn = (time.perf_counter() - t) * 1e3
+    # parity: what the indexed mesh must be (the soup, bit for bit) and what the numbers must add up to (float64 numpy)
+    ok_soup = None
+    if soup is not None:
+        ok_soup = bool(soup.shape[0] == nt and np.array_equal(verts[faces].reshape(-1, 9), soup.reshape(-1, 9)))
+    a, b, c = (verts[faces[:, k]].astype(np.float64) for k in range(3))
+    cr = np.cross(b - a, c - a)
+    area_np = 0.5 * np.sqrt((cr * cr).sum(1)).sum()
+    vol_np = abs((a * np.cross(b, c)).sum() / 6.0)
+    ok_mass = bool(abs(vol_area[0] - vol_np) <= 1e-9 * max(1.0, vol_np) and abs(vol_area[1] - area_np) <= 1e-9 * max(1.0, area_np))
+    unit = np.abs(np.sqrt((pn.astype(np.float64) ** 2).sum(1)) - 1.0).max() if len(pn) else 0.0
+    ok_tail = bool(len(pf) == len(ff) and unit < 1e-5)
+    V, F = float(nv), float(nt)
+    alg = {"soup": nvox * 1.0 + 36.0 * F, "indexed_mesh": nvox * 1.0 + 12.0 * V + 12.0 * F, "keep_largest": 2.0 * (12.0 * V + 12.0 * F),
+           "mass_properties": 12.0 * V + 12.0 * F, "face_normals": 12.0 * V + 36.0 * F, "smoothing_10_steps": 20.0 * (24.0 * V + 12.0 * F)}
+    frac = {k: round(alg[k] / (stage[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k in alg}
+    dev_ms = sum(stage[k] for k in ("indexed_mesh", "keep_largest", "mass_properties", "face_normals", "smoothing_setup", "smoothing_10_steps"))
+    res = {"metric": "Mvoxel/s segmentation + Mtriangles/s marching-cubes, 512^3 int16, 1/2/4/8 GPU", "value": round(nt / (dev_ms * 1e-3) / 1e6, 2), "unit": "Mtriangles/s", "n_gpus": 1, "steps": reps, "warmup": 1,
+           "ms_per_step": round(dev_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "SURVEY 8(f) on configs[1]'s surface (%d^3, %d triangles, %d points): indexed mesh, keep-largest, mass "
+                                  "properties, face normals, 10 context-aware smoothing steps (device-resident); fill holes + point "
+                                  "normals as host calls on the largest region" % (n, nt, nv), "parallelism": "single GPU"},
+           "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+           "host_call_ms": {"fill_holes": round(t_fill, 2), "point_normals": round(t_pn, 2),
+                            "note": "arrays in, arrays out: upload + kernels + download of %d triangles (PCIe inclusive)" % len(kf)},
+           "triangles": int(nt), "points": int(nv), "regions": int(largest[2]), "largest_region_triangles": int(largest[1]),
+           "holes_filled": int(nholes), "points_after_splitting": int(len(pv)), "volume_area": vol_area,
+           "roofline": roofline("indexed mesh (k_mc_count + k_mci_count + k_mci_vertices_levels + k_mci_faces)", alg["indexed_mesh"],
+                                stage["indexed_mesh"], None, None, {"per_stage_frac": frac, "algorithmic_bytes_per_stage": alg,
+                                "note": "mask 1 B/voxel + 12 B per point + 12 B per face written (SURVEY 8d's per-unit figures); every "
+                                        "stage's fraction of 8 TB/s from wall time around queued calls"}),
+           "cpu_baseline": None,
+           "parity": {"ok": bool(ok_mass and ok_tail and ok_soup is not False),
+                      "compared": "verts[faces] == the soup bit for bit, same order (%s); volume / area == float64 numpy on the "
+                                  "downloaded mesh to 1e-9 relative; point normals unit length, faces kept; VTK's own filters "
+                                  "(vtkCleanPolyData, vtkPolyDataConnectivityFilter, vtkFillHolesFilter, vtkPolyDataNormals) are "
+                                  "not installed: their outputs are unpinned, tests/test_mesh_tail.py pins the rules" % ok_soup}}
+    if not res["parity"]["ok"]:
+        print(json.dumps(res), flush=True)
+        raise SystemExit("bench.py: the surface tail's checks failed")
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # configs[3]: 2048^3 Z-sharded over the ranks (STRONG scaling), threshold + marching cubes + cross-slab stitch
 # ----------------------------------------------------------------------------------------------------------------
 def run_sharded2048(args, job):
@@ -1260,7 +1385,9 @@ def other_configs(args, job, runners):
             ("mip_sweep_512", "mip", None, 10, 2, False), ("sharded2048_on_one_gpu", "sharded2048", None, 3, 1, False),
             # past the 256 MiB Infinity Cache, and configs[2] at its stated size
             ("region_grow_generic_512", "grow_generic", 512, 10, 2, False), ("grow_mc_1024", "grow_mc", 1024, 5, 2, True),
-            ("watershed_ift_1024", "watershed", 1024, 2, 1, False), ("watershed_gui_default_1024", "watershed_sk", 1024, 2, 1, False))
+            ("watershed_ift_1024", "watershed", 1024, 2, 1, False), ("watershed_gui_default_1024", "watershed_sk", 1024, 2, 1, False),
+            # SURVEY 8(f)'s stages on the bench surface
+            ("surface_tail_512", "surface_tail", 512, 5, 1, False))
     skip = set(filter(None, os.environ.get("IVX_BENCH_SKIP", "").split(",")))  # (names to leave out: short smoke runs)
     out = {}
     for name, cfg, size, steps, warmup, hbm in plan:
@@ -1292,7 +1419,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=("grow_mc", "grow_generic", "watershed", "watershed_sk", "mip", "sharded2048"), default="grow_mc",
+    ap.add_argument("--config", choices=("grow_mc", "grow_generic", "watershed", "watershed_sk", "mip", "sharded2048", "surface_tail"), default="grow_mc",
                     help="grow_mc = BASELINE configs[1] (default, the metric's config); watershed = configs[2] (IFT branch), watershed_sk = configs[2] with the GUI's default scikit-image branch; sharded2048 = "
                          "configs[3] (strong scaling: the whole volume split over --gpus); mip = configs[4]")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -1315,7 +1442,7 @@ def main():
     args = ap.parse_args()
     if args.cpu_slices == 0:
         args.cpu = False
-    dflt = {"grow_mc": (20, 3), "grow_generic": (20, 3), "watershed": (3, 1), "watershed_sk": (2, 1), "mip": (20, 3), "sharded2048": (5, 2)}[args.config]
+    dflt = {"grow_mc": (20, 3), "grow_generic": (20, 3), "watershed": (3, 1), "watershed_sk": (2, 1), "mip": (20, 3), "sharded2048": (5, 2), "surface_tail": (5, 1)}[args.config]
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
 
@@ -1329,7 +1456,8 @@ def main():
     if args.dry_comm:
         return dry_comm(world)
     job = Ranks()
-    runners = {"grow_mc": run_grow_mc, "grow_generic": run_grow_generic, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048}
+    runners = {"grow_mc": run_grow_mc, "grow_generic": run_grow_generic, "watershed": run_watershed, "watershed_sk": run_watershed_sk, "mip": run_mip, "sharded2048": run_sharded2048,
+               "surface_tail": run_surface_tail}
     res = runners[args.config](args, job)
     if res is not None and args.config == "grow_mc" and args.others and args.cpu and world == 1 and args.size is None \
             and not args.hbm_synth and os.environ.get("IVX_FORCE_SLAB") != "1":

@@ -15,7 +15,7 @@
 //   2. k_mc_count    one lane per 64-cell word: four row words (+ the carry bit of the next word) give the
 //                    active-cell mask with a handful of 64-bit ops; only active cells look up the case table.
 //                    Per-word triangle counts (u16) + per-workgroup sums.
-//   3. k_mc_scan     exclusive scan of the per-workgroup sums (u64 offsets), single workgroup.
+//   3. k_mc_scan     exclusive scan of the per-workgroup sums (u64 offsets), one workgroup per 16 384 sums.
 //   4. k_mc_emit     one workgroup per 256 words.  Corner words + a block scan of the counts go to LDS; then the
 //                    workgroup walks its TRIANGLES 256 at a time, one lane per triangle (binary search of the
 //                    owning word in LDS, short walk over that word's active cells), so lanes stay busy however
@@ -378,13 +378,27 @@ __global__ __launch_bounds__(256) void k_mc_count(const uint64_t *__restrict__ b
 // 9 259 same-address agent-scope atomics of the ticket serialise at ~8 ns each: mc_count 44 -> 124 us.  Dropped.)
 __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ bsum, size_t n,
                                                   uint64_t *__restrict__ boff) {
+    // One workgroup per 16 384 sums (one at 512^3, five at 1024^3 -- where the single workgroup of rounds 1 - 5 took 68 us, 5 % of
+    // the stage).  No hand-over between workgroups: each first adds up everything in front of its chunk itself (a coalesced
+    // read of at most a few hundred KB out of the L2) and then scans its own chunk.
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
-    constexpr int PER = 16; // consecutive elements per lane: 16384 per pass (one pass for a 512^3 piece)
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
+    constexpr int PER = 16; // consecutive elements per lane
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (size_t base = 0; base < n; base += 1024 * PER) {
+    const size_t base = (size_t)blockIdx.x * (1024 * PER);
+    uint64_t pre = 0;
+    for (size_t i = threadIdx.x; i < base; i += 1024) pre += bsum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+    if (lane == 0) s_wave[wv] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t c = 0;
+        for (int q = 0; q < 16; q++) c += s_wave[q];
+        s_carry = c;
+    }
+    __syncthreads();
+    {
         const size_t i0 = base + (size_t)threadIdx.x * PER;
         uint32_t v[PER];
         uint64_t sum = 0;
@@ -399,6 +413,7 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
             const uint64_t t = __shfl_up(inc, o, 64);
             if (lane >= o) inc += t;
         }
+        __syncthreads(); // (s_wave is reused)
         if (lane == 63) s_wave[wv] = inc;
         __syncthreads();
         uint64_t off = s_carry + inc - sum;
@@ -408,11 +423,8 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
             if (i0 + q < n) boff[i0 + q] = off;
             off += v[q];
         }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = off;
-        __syncthreads();
+        if (threadIdx.x == 1023 && base + 1024 * PER >= n) boff[n] = off; // the last chunk's last lane holds the total
     }
-    if (threadIdx.x == 0) boff[n] = s_carry;
 }
 
 // ---- 4. emit: one lane per TRIANGLE ---------------------------------------------------------------
@@ -1368,7 +1380,7 @@ static int mc_queue_count(const ivx_mc_params *p, const Geom &g, const Scratch &
         IVX_LAUNCH_CHECK();
     }
     const size_t nb = s.nblocks * (size_t)p->niso;
-    hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, st, bsum, nb, boff);
+    hipLaunchKernelGGL(k_mc_scan, dim3((unsigned)std::max<size_t>(1, (nb + 16383) / 16384)), dim3(1024), 0, st, bsum, nb, boff);
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }

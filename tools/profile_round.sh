@@ -26,6 +26,11 @@ IVX_MC_ONE_LAUNCH=1 timeout -k 5 300 python bench.py --no-others --no-cpu < /dev
 IVX_WS_LINKS=0 timeout -k 5 300 python bench.py --config watershed --size 512 --no-cpu < /dev/null > $O/bench_watershed_512_nolinks.json 2> /dev/null
 timeout -k 5 300 python bench.py --config mip < /dev/null > $O/bench_mip.json 2> $O/bench_mip.err
 timeout -k 5 120 python bench.py --dry-comm < /dev/null > $O/dry_comm.json 2> $O/dry_comm.err
+# the stages behind marching cubes on the bench surface (bench line + kernel stats), the remaining edit / resample kernels
+timeout -k 5 300 python bench.py --config surface_tail < /dev/null > $O/bench_surface_tail.json 2> $O/bench_surface_tail.err
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o tail_kt -- python bench.py --config surface_tail --steps 3 < /dev/null > $O/tail_kt.log 2>&1
+timeout -k 5 300 python tools/bench_mesh.py < /dev/null > $O/bench_mesh_512.json 2> $O/bench_mesh_512.err
+timeout -k 5 300 python tools/bench_edit.py < /dev/null > $O/bench_edit_512.json 2> $O/bench_edit_512.err
 # the sharded path's own overhead against the resident single volume: same step through SlabVolume at world 1
 IVX_FORCE_SLAB=1 timeout -k 5 300 python bench.py --no-cpu < /dev/null > $O/force_slab.json 2> $O/force_slab.err
 IVX_FORCE_SLAB=1 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o slab_kt -- python bench.py --steps 5 --warmup 1 --no-cpu < /dev/null > $O/slab_kt.log 2>&1
@@ -53,7 +58,7 @@ timeout -k 5 600 python bench.py --config sharded2048 < /dev/null > $O/bench_sha
 find $O -name "*_kernel_trace.csv" -size +8M -delete
 find $O -name "*_counter_collection.csv" -size +8M -delete
 cat $O/gpu_tests.txt 2>/dev/null
-for f in bench bench_strong_1gpu bench_mc_one_launch bench_mip bench_watershed_512 bench_watershed_512_nolinks bench_watershed_sk_512 bench_watershed_1024 bench_watershed_sk_1024 bench_sharded2048_1gpu; do
+for f in bench bench_strong_1gpu bench_mc_one_launch bench_mip bench_surface_tail bench_watershed_512 bench_watershed_512_nolinks bench_watershed_sk_512 bench_watershed_1024 bench_watershed_sk_1024 bench_sharded2048_1gpu; do
 python - $O/$f.json $f <<'PY'
 import json,sys
 try:
