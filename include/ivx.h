@@ -72,6 +72,12 @@ int ivx_memset(void *dptr, int value, size_t nbytes, void *stream);
 int ivx_memcpy_h2d(void *dst, const void *src, size_t nbytes);
 int ivx_memcpy_d2h(void *dst, const void *src, size_t nbytes);
 int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
+/* the sharded flood's vote words (invesalius3_amd/parallel.py, slab_region_grow; no counterpart upstream -- the reference has no
+ * multi-GPU code): votes[0] = what ivx_comm_exchange_vote all-reduces, votes[1] = the words this rank's last OR gained.
+ * _set: both words by a one-thread kernel; _read: both words to the host through the pinned mailbox (no stream
+ * synchronisation), after which votes[0] <- votes[1] on the device -- staged for the next round's all-reduce */
+int ivx_dev_vote_set(int32_t *votes, int32_t v0, int32_t v1, void *stream);
+int ivx_dev_vote_read(int32_t *votes, int32_t out[2], void *stream);
 /* page-locked host memory (hipHostMalloc): arrays kept there cross PCIe at the link's rate instead of through the runtime's
  * bounce buffers; every host pointer of this header may point into it */
 int ivx_host_alloc(void **hptr, size_t nbytes);

@@ -487,6 +487,42 @@ int mailbox_publish(const void *dsrc, int ndwords, hipStream_t st, uint32_t *seq
     return IVX_OK;
 }
 
+// the sharded flood's vote (parallel.py, slab_region_grow): two device words { everybody's votes of the last round, my new count }.
+// Setting them and reading them used to be two memsets, a 4-byte device copy and a synchronising 8-byte download per round --
+// 16 us each as copy-engine calls; here: one-thread kernels and the mailbox (no stream synchronisation).
+__global__ void k_vote_set(int32_t *v, int32_t a, int32_t b) {
+    v[0] = a;
+    v[1] = b;
+}
+// publish both words, then stage the next round's vote (votes[0] <- my count: the next exchange all-reduces it in place)
+__global__ void k_vote_publish(int32_t *v, uint32_t *mb, uint32_t seq) {
+    if (threadIdx.x || blockIdx.x) return;
+    const int32_t a = v[0], b = v[1];
+    mb[0] = (uint32_t)a;
+    mb[1] = (uint32_t)b;
+    v[0] = b;
+    __threadfence_system();
+    __hip_atomic_store(&mb[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int vote_publish(int32_t *votes, hipStream_t st, uint32_t *seq_out) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_mb) {
+            void *p = nullptr;
+            IVX_HIP(hipHostMalloc(&p, 64 * 64 * 4, hipHostMallocMapped | hipHostMallocCoherent));
+            memset(p, 0, 64 * 64 * 4);
+            g_mb = (uint32_t *)p;
+        }
+        *seq_out = ++g_mb_seq;
+        if (*seq_out == 0) *seq_out = ++g_mb_seq;
+    }
+    uint32_t *slot = g_mb + (size_t)(*seq_out & 63u) * 64;
+    hipLaunchKernelGGL(k_vote_publish, dim3(1), dim3(64), 0, st, votes, slot, *seq_out);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
 int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords) {
     volatile uint32_t *slot = g_mb + (size_t)(seq & 63u) * 64;
     bool ok = false;
@@ -624,6 +660,23 @@ int ivx_host_free(void *hptr) {
 }
 int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream) {
     if (nbytes) IVX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, S(stream)));
+    return IVX_OK;
+}
+int ivx_dev_vote_set(int32_t *votes, int32_t v0, int32_t v1, void *stream) {
+    IVX_REQUIRE(votes, IVX_EINVAL, "ivx_dev_vote_set: null");
+    hipLaunchKernelGGL(ivx::k_vote_set, dim3(1), dim3(1), 0, S(stream), votes, v0, v1);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+int ivx_dev_vote_read(int32_t *votes, int32_t out[2], void *stream) {
+    IVX_REQUIRE(votes && out, IVX_EINVAL, "ivx_dev_vote_read: null");
+    uint32_t seq = 0, w[2] = {0, 0};
+    int rc = ivx::vote_publish(votes, S(stream), &seq);
+    if (rc != IVX_OK) return rc;
+    rc = ivx::mailbox_wait(seq, S(stream), w, 2);
+    if (rc != IVX_OK) return rc;
+    out[0] = (int32_t)w[0];
+    out[1] = (int32_t)w[1];
     return IVX_OK;
 }
 int ivx_stream_create(void **stream) {

@@ -226,12 +226,12 @@ def _make_slab_volume():
                     self._recv[1].ptr, nb, self._votes.ptr, self.stream)
 
         def _seed_votes(self):
-            """before round 1: "something happened" = the seeds"""
-            L.check(L.lib().ivx_memset(self._votes.ptr, 0, ctypes.c_size_t(8), self.stream))
-            L.check(L.lib().ivx_memset(self._votes.at(4), 1, ctypes.c_size_t(1), self.stream))  # votes[1] = 1
+            """before round 1: "something happened" = the seeds -- already staged for the first all-reduce"""
+            L.check(L.lib().ivx_dev_vote_set(self._votes.ptr, 1, 1, self.stream), "vote_set")
 
         def stage_vote(self):
-            L.check(L.lib().ivx_memcpy_d2d(self._votes.ptr, self._votes.at(4), ctypes.c_size_t(4), self.stream))
+            """(nothing to queue: read_votes leaves votes[0] <- votes[1] behind on the device, _seed_votes sets both words.
+            Rounds 1 - 5 queued a 4-byte device copy here and two memsets above: 16 us of copy engine each)"""
 
         def or_planes(self):
             pd = self._recv[0].ptr if self.lay.hb else None
@@ -241,9 +241,11 @@ def _make_slab_volume():
                                                         self._votes.at(4), self.stream), "flood_or_planes")
 
         def read_votes(self):
-            self.sync()
-            v = self._votes.download((2,), np.int32)
-            return int(v[0]), int(v[1])
+            """the round's only host read: both words through the pinned mailbox (no stream synchronisation, no copy-engine
+            call), the next round's vote staged by the same one-thread kernel"""
+            out = (ctypes.c_int32 * 2)()
+            L.check(L.lib().ivx_dev_vote_read(self._votes.ptr, out, self.stream), "vote_read")
+            return int(out[0]), int(out[1])
 
         # -- sharded operations ----------------------------------------------------------------------------------
         def region_grow(self, seeds_xyz_global, t0, t1, strct, fill: int = 1, select_value=254) -> int:
