@@ -363,6 +363,40 @@ __device__ __forceinline__ float fcm_pow(float base, float n, int pmode, const P
                       : glibc_powf::powf_glibc<false>(base, n, t->lt, (const uint64_t *)t->et);
 }
 
+// base^n in float32 on the transcendental unit, with a bound: the contour MaxIP's pixel is T(max over the ray of gm * base^n),
+// truncated to an integer, so a value known to (1 +- rel) decides the pixel unless an integer lies inside that interval -- and
+// only then is glibc's powf (two table look-ups and a dozen double-precision operations per voxel: the exponent-2 sweep was
+// ALU-bound at 0.09 of the roofline) worth its price.  v_log_f32 and v_exp_f32 are good to 1 ulp (CDNA ISA); with y = n * log2(base)
+// the result's relative error is below (|y| ln 2 + 2) * 2^-23, glibc's own result is within 1 ulp of the true power: the bound
+// returned, (|y| + 4) * 2^-21, keeps a factor of four in hand (tests/test_gpu_rays.py checks it on millions of inputs).
+// base in [0, 1] (1 - |d / gm|), n > 0.
+__device__ __forceinline__ float fcm_pow_fast(float base, float n, float *rel) {
+    *rel = 0.0f;
+    if (base <= 0.0f) return 0.0f; // powf(+0, n > 0) = +0
+    if (base >= 1.0f) return 1.0f; // powf(1, n) = 1
+    const float y = n * __builtin_amdgcn_logf(base); // (v_log_f32: log2)
+    if (!(y > -160.0f)) return 0.0f;                 // below 2^-160: nothing a 16-bit pixel can see (and no 0 * inf in the bound)
+    *rel = (fabsf(y) + 4.0f) * 4.76837158203125e-7f;
+    return __builtin_amdgcn_exp2f(y); // (v_exp_f32: 2^y; results below 2^-126 flush to zero -- covered: see the test)
+}
+
+// one voxel's contour value the exact way, from the volume (clamped neighbours): the few rays the fast fold cannot decide
+__device__ __forceinline__ float fcm_voxel_exact(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx, int64_t z, int64_t y,
+                                                 int64_t x, float n, int axis, int pmode, const PowTabs *pt) {
+    const int64_t px = x == 0 ? 0 : x - 1, fx = x == sx - 1 ? sx - 1 : x + 1;
+    const int64_t py = y == 0 ? 0 : y - 1, fy = y == sy - 1 ? sy - 1 : y + 1;
+    const int64_t pz = z == 0 ? 0 : z - 1, fz = z == sz - 1 ? sz - 1 : z + 1;
+    const int16_t *row = img + (z * sy + y) * sx;
+    const float g0 = fd_sub<int16_t>(row[fx], row[px]) / (2.0f * 1.0f);
+    const float g1 = fd_sub<int16_t>(img[(z * sy + fy) * sx + x], img[(z * sy + py) * sx + x]) / (2.0f * 1.0f);
+    const float g2 = fd_sub<int16_t>(img[(fz * sy + y) * sx + x], img[(pz * sy + y) * sx + x]) / (2.0f * 1.0f);
+    const float gm = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+    if (gm == 0.0f) return 0.0f;
+    const float d = axis == 0 ? g2 : axis == 1 ? g1 : g0;
+    const float base = 1.0f - fabsf(d / gm);
+    return gm * fcm_pow(base, n, pmode, pt);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_fcm_volume(const T *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
                                                     float n, int pmode, int axis, T *__restrict__ tmp, int *__restrict__ status) {
@@ -452,6 +486,25 @@ __global__ __launch_bounds__(256) void k_fcm_volume_i16x8(const int16_t *__restr
 //               next along the ray axis); per step it loads the next chunk, the two chunks of the OTHER in-slice axis
 //               (neighbour lanes' centre chunks: L1 / L2 hits) and the two 2-byte x-neighbours across the chunk edge.
 //   AXIS 2:     a wave per row: each lane folds its chunks' 8 values, then a shuffle tree.
+// the same value through fcm_pow_fast: lo <= the exact value <= hi
+__device__ __forceinline__ void fcm_value_fast(int16_t xm, int16_t xp, int16_t ym, int16_t yp, int16_t zm, int16_t zp, float n, int axis,
+                                               float *lo, float *hi) {
+    const float g0 = fd_sub<int16_t>(xp, xm) / (2.0f * 1.0f);
+    const float g1 = fd_sub<int16_t>(yp, ym) / (2.0f * 1.0f);
+    const float g2 = fd_sub<int16_t>(zp, zm) / (2.0f * 1.0f);
+    const float gm = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+    *lo = *hi = 0.0f;
+    if (gm != 0.0f) {
+        const float d = axis == 0 ? g2 : axis == 1 ? g1 : g0;
+        const float base = 1.0f - fabsf(d / gm);
+        float rel;
+        const float v = gm * fcm_pow_fast(base, n, &rel);
+        const float e = v * rel;
+        *lo = v - e;
+        *hi = v + e;
+    }
+}
+
 __device__ __forceinline__ float fcm_value(int16_t xm, int16_t xp, int16_t ym, int16_t yp, int16_t zm, int16_t zp, float n,
                                            int axis, int pmode, const PowTabs *pt) {
     const float g0 = fd_sub<int16_t>(xp, xm) / (2.0f * 1.0f);
@@ -468,12 +521,14 @@ __device__ __forceinline__ float fcm_value(int16_t xm, int16_t xp, int16_t ym, i
     return v;
 }
 
-template <int AXIS>
+// FAST: fcm_value_fast's bounds folded instead of the exact value -- two partial planes per segment (lower, upper; the upper ones
+// behind all the lower ones), decided or handed to k_fcm_fix by k_fcm_max_combine
+template <int AXIS, bool FAST>
 __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
                                                       float n, int pmode, int64_t seg, float *__restrict__ partial,
                                                       int *__restrict__ status) {
     __shared__ PowTabs s_pt;
-    fcm_pow_setup(&s_pt);
+    if (!FAST) fcm_pow_setup(&s_pt);
     const PowTabs *pt = &s_pt;
     // output pixel row r = y (AXIS 0) or z (AXIS 1); the ray runs along l = z (AXIS 0) or y (AXIS 1)
     const int64_t cpr = sx / 8;
@@ -489,9 +544,9 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
     const int16_t *colm = img + om * so + x0, *colp = img + op * so + x0;
     auto ld = [](const int16_t *p) { return *reinterpret_cast<const rshort8_t *>(p); };
     rshort8_t prev = ld(col + (l0 == 0 ? 0 : l0 - 1) * sl), cur = ld(col + l0 * sl);
-    float acc[8];
+    float acc[8], acc_hi[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) acc[e] = -INFINITY;
+    for (int e = 0; e < 8; e++) acc[e] = acc_hi[e] = -INFINITY;
     bool bad = false;
 #pragma unroll 2
     for (int64_t l = l0; l < l1; l++) {
@@ -504,10 +559,18 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int16_t xm = e == 0 ? left : (int16_t)cur[e - 1], xp = e == 7 ? right : (int16_t)cur[e + 1];
-            const float v = AXIS == 0 ? fcm_value(xm, xp, (int16_t)am[e], (int16_t)ap[e], (int16_t)prev[e], (int16_t)next[e], n, 0, pmode, pt)
-                                      : fcm_value(xm, xp, (int16_t)prev[e], (int16_t)next[e], (int16_t)am[e], (int16_t)ap[e], n, 1, pmode, pt);
-            bad |= !(v > -32769.0f && v < 32768.0f);
-            acc[e] = v > acc[e] ? v : acc[e];
+            if (FAST) {
+                float lo, hi;
+                if (AXIS == 0) fcm_value_fast(xm, xp, (int16_t)am[e], (int16_t)ap[e], (int16_t)prev[e], (int16_t)next[e], n, 0, &lo, &hi);
+                else fcm_value_fast(xm, xp, (int16_t)prev[e], (int16_t)next[e], (int16_t)am[e], (int16_t)ap[e], n, 1, &lo, &hi);
+                acc[e] = lo > acc[e] ? lo : acc[e];
+                acc_hi[e] = hi > acc_hi[e] ? hi : acc_hi[e];
+            } else {
+                const float v = AXIS == 0 ? fcm_value(xm, xp, (int16_t)am[e], (int16_t)ap[e], (int16_t)prev[e], (int16_t)next[e], n, 0, pmode, pt)
+                                          : fcm_value(xm, xp, (int16_t)prev[e], (int16_t)next[e], (int16_t)am[e], (int16_t)ap[e], n, 1, pmode, pt);
+                bad |= !(v > -32769.0f && v < 32768.0f);
+                acc[e] = v > acc[e] ? v : acc[e];
+            }
         }
         prev = cur;
         cur = next;
@@ -516,12 +579,19 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
     float *o = partial + ((int64_t)blockIdx.y * nr + r) * sx + x0;
     *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    if (FAST) {
+        float *oh = o + (int64_t)gridDim.y * nr * sx;
+        *reinterpret_cast<float4 *>(oh) = make_float4(acc_hi[0], acc_hi[1], acc_hi[2], acc_hi[3]);
+        *reinterpret_cast<float4 *>(oh + 4) = make_float4(acc_hi[4], acc_hi[5], acc_hi[6], acc_hi[7]);
+    }
 }
 
+template <bool FAST> // FAST: the bounds' two planes (partial: lower then upper, one segment) instead of the pixel
 __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx, float n,
-                                                      int pmode, int16_t *__restrict__ out, int *__restrict__ status) {
+                                                      int pmode, int16_t *__restrict__ out, float *__restrict__ partial,
+                                                      int *__restrict__ status) {
     __shared__ PowTabs s_pt;
-    fcm_pow_setup(&s_pt);
+    if (!FAST) fcm_pow_setup(&s_pt);
     const PowTabs *pt = &s_pt;
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -532,7 +602,7 @@ __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict_
     const int16_t *row = img + (z * sy + y) * sx;
     const int16_t *rym = img + (z * sy + py) * sx, *ryp = img + (z * sy + fy) * sx;
     const int16_t *rzm = img + (pz * sy + y) * sx, *rzp = img + (fz * sy + y) * sx;
-    float acc = -INFINITY;
+    float acc = -INFINITY, acc_hi = -INFINITY;
     bool bad = false;
     for (int64_t x0 = (int64_t)lane * 8; x0 < sx; x0 += 512) {
         const rshort8_t c = *reinterpret_cast<const rshort8_t *>(row + x0);
@@ -543,18 +613,36 @@ __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict_
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int16_t xm = e == 0 ? left : (int16_t)c[e - 1], xp = e == 7 ? right : (int16_t)c[e + 1];
-            const float v = fcm_value(xm, xp, (int16_t)ym[e], (int16_t)yp[e], (int16_t)zm[e], (int16_t)zp[e], n, 2, pmode, pt);
-            bad |= !(v > -32769.0f && v < 32768.0f);
-            acc = v > acc ? v : acc;
+            if (FAST) {
+                float lo, hi;
+                fcm_value_fast(xm, xp, (int16_t)ym[e], (int16_t)yp[e], (int16_t)zm[e], (int16_t)zp[e], n, 2, &lo, &hi);
+                acc = lo > acc ? lo : acc;
+                acc_hi = hi > acc_hi ? hi : acc_hi;
+            } else {
+                const float v = fcm_value(xm, xp, (int16_t)ym[e], (int16_t)yp[e], (int16_t)zm[e], (int16_t)zp[e], n, 2, pmode, pt);
+                bad |= !(v > -32769.0f && v < 32768.0f);
+                acc = v > acc ? v : acc;
+            }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float b = __shfl_xor(acc, o, 64);
         acc = b > acc ? b : acc;
+        if (FAST) {
+            const float bh = __shfl_xor(acc_hi, o, 64);
+            acc_hi = bh > acc_hi ? bh : acc_hi;
+        }
     }
     if (bad) atomicMin(status, IVX_EDOM);
-    if (lane == 0) out[ray] = (int16_t)acc; // (sx >= 8 here, so acc is a real value; out of range only with `bad` set)
+    if (lane == 0) {
+        if (FAST) {
+            partial[ray] = acc;
+            partial[sz * sy + ray] = acc_hi;
+        } else {
+            out[ray] = (int16_t)acc; // (sx >= 8 here, so acc is a real value; out of range only with `bad` set)
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fcm_max_combine(const float *__restrict__ partial, int64_t npix, int split,
@@ -567,6 +655,56 @@ __global__ __launch_bounds__(256) void k_fcm_max_combine(const float *__restrict
         acc = b > acc ? b : acc;
     }
     out[i] = (int16_t)acc;
+}
+
+// FAST fold: partial = `split` planes of lower bounds, then `split` planes of upper bounds.  A pixel whose bounds truncate to the
+// same integer is decided; the others (an integer inside the interval: a few in a thousand) go on a list for k_fcm_fix.
+__global__ __launch_bounds__(256) void k_fcm_max_decide(const float *__restrict__ partial, int64_t npix, int split, int16_t *__restrict__ out,
+                                                        uint32_t *__restrict__ list, uint32_t *nlist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float lo = partial[i], hi = partial[(int64_t)split * npix + i];
+    for (int s = 1; s < split; s++) {
+        const float a = partial[(int64_t)s * npix + i], b = partial[(int64_t)(split + s) * npix + i];
+        lo = a > lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    // (values are >= 0; anything near the top of int16 goes to the exact fold, which also owns the out-of-range report)
+    if (hi < 32766.0f && (int32_t)lo == (int32_t)hi) {
+        out[i] = (int16_t)lo;
+    } else {
+        out[i] = 0;
+        list[atomicAdd(nlist, 1u)] = (uint32_t)i;
+    }
+}
+
+// the undecided pixels, exactly: one wave per pixel, lanes along the ray, glibc's powf for every voxel of it
+__global__ __launch_bounds__(256) void k_fcm_fix(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx, float n, int axis,
+                                                 int pmode, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist,
+                                                 int16_t *__restrict__ out, int *__restrict__ status) {
+    __shared__ PowTabs s_pt;
+    fcm_pow_setup(&s_pt);
+    const int lane = threadIdx.x & 63;
+    const uint32_t nl = *nlist, nwaves = gridDim.x * 4u;
+    const int64_t len = axis == 0 ? sz : axis == 1 ? sy : sx, nc = axis == 2 ? sy : sx;
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nl; w += nwaves) {
+        const int64_t i = list[w], r = i / nc, c = i - r * nc; // pixel (r, c): axis 0 -> (y, x), 1 -> (z, x), 2 -> (z, y)
+        float acc = -INFINITY;
+        bool bad = false;
+        for (int64_t l = lane; l < len; l += 64) {
+            const int64_t z = axis == 0 ? l : r, y = axis == 0 ? r : axis == 1 ? l : c, x = axis == 2 ? l : c;
+            const float v = fcm_voxel_exact(img, sz, sy, sx, z, y, x, n, axis, pmode, &s_pt);
+            bad |= !(v > -32769.0f && v < 32768.0f);
+            acc = v > acc ? v : acc;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float b = __shfl_xor(acc, o, 64);
+            acc = b > acc ? b : acc;
+        }
+        if (bad) atomicMin(status, IVX_EDOM);
+        if (lane == 0) out[i] = (int16_t)acc;
+    }
 }
 
 template <typename T, typename U, int MODE>
@@ -694,13 +832,22 @@ __global__ __launch_bounds__(256) void k_powf_probe(const float *__restrict__ x,
     __shared__ PowTabs s_pt;
     fcm_pow_setup(&s_pt);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = fcm_pow(x[i], y[i], fma_build ? 2 : 3, &s_pt);
+    if (i >= n) return;
+    if (fma_build >= 2) { // 2: the fast power, 3: its error bound (relative)
+        float rel;
+        const float v = fcm_pow_fast(x[i], y[i], &rel);
+        out[i] = fma_build == 2 ? v : rel;
+    } else {
+        out[i] = fcm_pow(x[i], y[i], fma_build ? 2 : 3, &s_pt);
+    }
 }
-extern "C" int ivx_dev_powf(const float *x, const float *y, float *out, int64_t n, int variant /* -1: this machine's */, void *stream) {
+extern "C" int ivx_dev_powf(const float *x, const float *y, float *out, int64_t n,
+                            int variant /* -1: this machine's glibc build, 0 plain, 1 fma; 2: the fast power of the contour MaxIP, 3: its relative bound */,
+                            void *stream) {
     IVX_REQUIRE(n >= 0 && (n == 0 || (x && y && out)), IVX_EINVAL, "powf: bad arguments");
     if (n == 0) return IVX_OK;
     hipLaunchKernelGGL(k_powf_probe, dim3((unsigned)ivx::cdiv(n, 256)), dim3(256), 0, ivx::S(stream), x, y, out, n,
-                       variant < 0 ? ivx_powf_variant() : (variant ? 1 : 0));
+                       variant < 0 ? ivx_powf_variant() : variant >= 2 ? variant : (variant ? 1 : 0));
     IVX_LAUNCH_CHECK();
     return IVX_OK;
 }
@@ -744,11 +891,35 @@ extern "C" int ivx_dev_fcm_maxip(int dtype, const void *vol, int64_t dz, int64_t
     if (fused_ok && dtype == IVX_I16 && dx % 8 == 0 && (((uintptr_t)vol) & 15) == 0) {
         const int pmode = fcm_pmode(n);
         const int16_t *img = (const int16_t *)vol;
-        if (axis == 2) {
-            hipLaunchKernelGGL(k_fcm_max_rows, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,
-                               (int16_t *)out, status);
+        // exponents other than 1: the fold on bounds from the transcendental unit, glibc's powf only for the pixels the bounds leave
+        // open (IVX_FCM_FAST=0: glibc's powf for every voxel, as in round 5 -- A/B, tests)
+        static const bool fast_ok = []() { const char *e = getenv("IVX_FCM_FAST"); return !(e && e[0] == '0'); }();
+        const bool fast = fast_ok && pmode != 1 && n > 0.0f && n <= 64.0f;
+        auto decide_and_fix = [&](float *part, int64_t npix, int split, uint32_t *list, uint32_t *nlist) -> int {
+            hipLaunchKernelGGL(k_fcm_max_decide, dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st, (const float *)part, npix, split,
+                               (int16_t *)out, list, nlist);
+            IVX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_fcm_fix, dim3(1024), dim3(256), 0, st, img, dz, dy, dx, n, axis, pmode, (const uint32_t *)list,
+                               (const uint32_t *)nlist, (int16_t *)out, status);
             IVX_LAUNCH_CHECK();
             return IVX_OK;
+        };
+        if (axis == 2) {
+            if (!fast) {
+                hipLaunchKernelGGL(k_fcm_max_rows<false>, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,
+                                   (int16_t *)out, (float *)nullptr, status);
+                IVX_LAUNCH_CHECK();
+                return IVX_OK;
+            }
+            const int64_t npix = dz * dy;
+            void *part;
+            if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * 12 + 256, &part))) return rc;
+            uint32_t *list = (uint32_t *)((float *)part + 2 * npix), *nlist = list + npix;
+            IVX_HIP(hipMemsetAsync(nlist, 0, 4, st));
+            hipLaunchKernelGGL(k_fcm_max_rows<true>, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,
+                               (int16_t *)out, (float *)part, status);
+            IVX_LAUNCH_CHECK();
+            return decide_and_fix((float *)part, npix, 1, list, nlist);
         }
         const int64_t nr = axis == 0 ? dy : dz, len = axis == 0 ? dz : dy, npix = nr * dx;
         const int64_t nblk = ivx::cdiv(nr * (dx / 8), 256);
@@ -759,12 +930,25 @@ extern "C" int ivx_dev_fcm_maxip(int dtype, const void *vol, int64_t dz, int64_t
         const int64_t seg = ivx::cdiv(len, split);
         split = ivx::cdiv(len, seg);
         void *part;
-        if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * sizeof(float) * split + 64, &part))) return rc;
+        if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * sizeof(float) * split * (fast ? 2 : 1) + (fast ? (size_t)npix * 4 + 256 : 64), &part)))
+            return rc;
+        if (fast) {
+            uint32_t *list = (uint32_t *)((float *)part + 2 * split * npix), *nlist = list + npix;
+            IVX_HIP(hipMemsetAsync(nlist, 0, 4, st));
+            if (axis == 0)
+                hipLaunchKernelGGL((k_fcm_max_walk<0, true>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+                                   (float *)part, status);
+            else
+                hipLaunchKernelGGL((k_fcm_max_walk<1, true>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+                                   (float *)part, status);
+            IVX_LAUNCH_CHECK();
+            return decide_and_fix((float *)part, npix, (int)split, list, nlist);
+        }
         if (axis == 0)
-            hipLaunchKernelGGL(k_fcm_max_walk<0>, dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+            hipLaunchKernelGGL((k_fcm_max_walk<0, false>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
                                (float *)part, status);
         else
-            hipLaunchKernelGGL(k_fcm_max_walk<1>, dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+            hipLaunchKernelGGL((k_fcm_max_walk<1, false>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
                                (float *)part, status);
         IVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_fcm_max_combine, dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st, (const float *)part, npix,

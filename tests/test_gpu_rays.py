@@ -225,3 +225,39 @@ def test_device_powf_is_the_host_libms_powf_bit_for_bit(ivxlib, oracle):
     assert np.array_equal(got.view(np.uint32), res[L.lib().ivx_powf_variant()].view(np.uint32))
     other = res[1 - L.lib().ivx_powf_variant()]
     assert (other.view(np.uint32)[~nan] != want.view(np.uint32)[~nan]).sum() <= 4  # (~3 in 10^9 differ between the builds)
+
+
+def test_fast_power_of_the_contour_maxip_stays_inside_its_bound(ivxlib, oracle):
+    """The contour MaxIP folds bounds from the transcendental unit (v_log_f32 / v_exp_f32) and takes glibc's powf only for the
+    pixels whose bounds leave an integer open (k_fcm_max_decide / k_fcm_fix): the bound must hold -- |fast - libm's powf| <=
+    rel * fast (+ a flush-to-zero allowance far below one count) for bases in [0, 1] and exponents in (0, 64], 8 M inputs
+    with the edges (0, 1, the float below 1, 2^-24, exponents 2, 0.5, 64)."""
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceBuffer, c64
+    n = 1 << 23
+    rng = np.random.default_rng(17)
+    x = rng.random(n, dtype=np.float32)
+    x[: n // 4] = (1.0 - rng.random(n // 4) ** 4).astype(np.float32)          # crowded towards 1 (flat regions of the ray)
+    x[n // 4: n // 2] = (rng.random(n // 4) ** 6).astype(np.float32)           # and towards 0
+    y = rng.uniform(0.01, 64.0, n).astype(np.float32)
+    y[::3] = rng.choice(np.array([0.5, 1.5, 2.0, 3.0, 3.3, 8.0, 64.0], np.float32), len(y[::3]))
+    x[(x > 0) & (x < 2.0 ** -24)] = 2.0 ** -24  # (1 - |d / gm| is 0 or at least one ulp of 1: the kernel never sees less)
+    x[:8] = [0.0, 1.0, np.nextafter(np.float32(1), np.float32(0)), 2.0 ** -24, 0.5, 2.0 ** -20, 0.999, 0.25]
+    want = oracle.powf_array(x, y).astype(np.float64)
+    dx_, dy_, do_ = DeviceBuffer(n * 4), DeviceBuffer(n * 4), DeviceBuffer(n * 4)
+    dx_.upload(x)
+    dy_.upload(y)
+    out = {}
+    for variant in (2, 3):
+        L.check(L.lib().ivx_dev_powf(dx_.ptr, dy_.ptr, do_.ptr, c64(n), variant, None))
+        L.synchronize()
+        out[variant] = do_.download((n,), np.float32).astype(np.float64)
+    fast, rel = out[2], out[3]
+    err = np.abs(fast - want)
+    assert np.isfinite(fast).all() and np.isfinite(rel).all()
+    assert (err <= rel * fast + 1e-37).all(), (int((err > rel * fast + 1e-37).sum()), float((err / np.maximum(fast, 1e-300)).max()))
+    # and the margin the bound keeps (a factor of four was the design): the worst observed error against the bound
+    ok = (fast > 1e-30) & (rel > 0)
+    used = err[ok] / (rel[ok] * fast[ok])
+    print("fast power: worst error / bound = %.3f" % float(used.max()))
+    assert used.max() < 0.6
