@@ -239,6 +239,13 @@ int ivx_dev_mc_surface_levels(const ivx_mc_params *p, const uint64_t *inside_bit
 /* the list pass of ivx_dev_mc_emit on its own (it needs the counts, not the voxels): queue it early, on the stream the
  * emit will use; the emit that follows with max_tris <= this max_tris skips its own list pass */
 int ivx_dev_mc_list(const ivx_mc_params *p, const void *scratch, int64_t max_tris, void *stream);
+/* The host form in two halves that share the device work (replaces the count call + emit call of the form below, which upload the
+ * piece and count twice): _begin uploads, counts and emits into the library's own output block and returns the count; _fetch,
+ * which must be the NEXT host-level call of the process, copies the soup into the array the caller sized from it (IVX_EINVAL when
+ * anything came in between: take ivx_marching_cubes then).  Same soup, same order, same bits.
+ * Replaces vtkContourFilter::Update of create_surface_piece (invesalius/data/surface_process.py:172-186). */
+int ivx_marching_cubes_begin(const ivx_mc_params *p, const void *a, const int64_t strides[3], int64_t *ntris);
+int ivx_marching_cubes_fetch(float *tris, int64_t ntris);
 /* Host form: strided piece in, soup out.  tris == NULL -> count only.  Returns count in *ntris. */
 int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const int64_t strides[3], float *tris,
                        int64_t max_tris, int64_t *ntris);

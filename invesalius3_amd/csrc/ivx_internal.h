@@ -60,6 +60,8 @@ int ws_get(int slot, size_t nbytes, void **dptr);
 // partials, union-find tables, ...) per stream, so several resident volumes can run concurrently from different
 // host threads, each on its own stream.
 int ws_get_s(int slot, hipStream_t stream, size_t nbytes, void **dptr);
+uint64_t host_epoch(); // number of the running outermost host-level call (HostCallGuard)
+int ws_release_s(int slot, hipStream_t stream, size_t keep_below); // frees the slot's block when it is larger than keep_below
 // The host-level entry points (ivx_* without _dev_) share the stream-0 workspaces and are serialised by this lock
 // (ctypes drops the GIL; the PyO3 originals held it).
 struct HostCallGuard {

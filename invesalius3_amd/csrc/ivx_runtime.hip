@@ -74,6 +74,25 @@ int ws_get_s(int slot, hipStream_t stream, size_t nbytes, void **dptr) {
     return IVX_OK;
 }
 
+// give a stream's slot back when it holds more than `keep_below` bytes (big, rarely needed blocks: the IFT flood's link records)
+int ws_release_s(int slot, hipStream_t stream, size_t keep_below) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Slot *s = nullptr;
+    if (stream == nullptr) {
+        s = &g_ws[slot];
+    } else {
+        auto it = g_ws_stream.find(std::make_pair(slot, stream));
+        if (it == g_ws_stream.end()) return IVX_OK;
+        s = &it->second;
+    }
+    if (s->p && s->n > keep_below) {
+        IVX_HIP(hipFree(s->p));
+        s->p = nullptr;
+        s->n = 0;
+    }
+    return IVX_OK;
+}
+
 static std::recursive_mutex g_host_mu;
 static int g_host_depth = 0;       // nesting of host-level entry points (they call each other)
 static uint64_t g_host_epoch = 1;  // one per OUTERMOST host call: what upload_strided staged stays valid inside it
@@ -87,6 +106,7 @@ HostCallGuard::HostCallGuard() {
         signal(SIGSEGV, ivx_bt_handler);
     }
 }
+uint64_t host_epoch() { return g_host_epoch; } // (the number of the running outermost host call)
 HostCallGuard::~HostCallGuard() {
     g_host_depth--;
     g_host_mu.unlock();

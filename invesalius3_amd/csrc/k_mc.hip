@@ -675,7 +675,8 @@ __device__ __forceinline__ void mcf_publish(unsigned long long *st, uint64_t fla
 template <typename T, bool LEVELS>
 __global__ __launch_bounds__(256) void k_mc_fused(const uint64_t *__restrict__ bits, const T *__restrict__ a, Geom g, size_t nwords,
                                                   uint64_t pbits, double iso, unsigned long long *state /* zeroed, one per workgroup */,
-                                                  uint64_t *__restrict__ total_out, uint64_t cap, float *__restrict__ tris, McLevels lv) {
+                                                  uint32_t *ticket /* zeroed */, uint64_t *__restrict__ total_out, uint64_t cap,
+                                                  float *__restrict__ tris, McLevels lv) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tri[256 * 15];
     // 19 KB of LDS per workgroup = eight workgroups per CU (at 34 KB and four per CU the kernel took 269 us against the 158 us of
     // the four launches it replaces: a workgroup's phases are a chain of barriers and round trips that only other workgroups
@@ -694,7 +695,13 @@ __global__ __launch_bounds__(256) void k_mc_fused(const uint64_t *__restrict__ b
     __shared__ unsigned long long s_excl;
     __shared__ int s_e0[12], s_e1[12], s_ec[12];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t bid = blockIdx.x;
+    // The look-back below waits for workgroups with smaller ids: a workgroup's id is therefore the ORDER IN WHICH IT STARTED (a
+    // ticket), not blockIdx.x -- whatever order the hardware dispatches in, everybody a workgroup waits for is already running
+    // (the dispatch order is not promised).
+    __shared__ uint32_t s_bid;
+    if (tid == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
     s_ntri[tid] = MC_NTRI[tid];
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -1527,12 +1534,15 @@ static int run_fused(const ivx_mc_params *p, const Geom &g, const Scratch &s, co
         g_list_built.erase(scratch); // whatever list was built from this scratch's old counts is void
     }
     IVX_HIP(hipMemsetAsync(boff, 0, (s.nblocks + 1) * 8, st)); // the look-back's status words + the total
+    uint32_t *ticket = (uint32_t *)(scratch + s.off_bsum);         // (the workgroup sums of the four-launch path: unused here)
+    IVX_HIP(hipMemsetAsync(ticket, 0, 4, st));
+    IVX_REQUIRE((uint64_t)s.nwords * 64u * MC_MAX_TRI < (1ull << 40), IVX_EINVAL, "mc_surface: more triangles than the look-back's 40-bit prefix holds");
     if (lv)
         hipLaunchKernelGGL((k_mc_fused<T, true>), dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, (const T *)a, g, s.nwords, pad_bits(p, 0),
-                           p->iso[0], (unsigned long long *)boff, boff + s.nblocks, (uint64_t)(max_tris > 0 ? max_tris : 0), tris, *lv);
+                           p->iso[0], (unsigned long long *)boff, ticket, boff + s.nblocks, (uint64_t)(max_tris > 0 ? max_tris : 0), tris, *lv);
     else
         hipLaunchKernelGGL((k_mc_fused<T, false>), dim3((unsigned)s.nblocks), dim3(256), 0, st, bits, (const T *)a, g, s.nwords, pad_bits(p, 0),
-                           p->iso[0], (unsigned long long *)boff, boff + s.nblocks, (uint64_t)(max_tris > 0 ? max_tris : 0), tris,
+                           p->iso[0], (unsigned long long *)boff, ticket, boff + s.nblocks, (uint64_t)(max_tris > 0 ? max_tris : 0), tris,
                            McLevels{nullptr, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0, 0.0}});
     IVX_LAUNCH_CHECK();
     return IVX_OK;
@@ -1654,6 +1664,56 @@ extern "C" int ivx_marching_cubes(const ivx_mc_params *p, const void *a, const i
         return rc;
     IVX_HIP(hipMemcpy(tris, d_tris, (size_t)cnt * 36, hipMemcpyDeviceToHost));
     return IVX_OK;
+}
+
+// The host form in two halves that share the device work: _begin uploads the piece once, counts AND emits into the library's
+// output block and returns the count; _fetch -- the very next host-level call -- copies the soup into the array the caller has
+// sized from that count.  (ivx_marching_cubes' count call + emit call upload the piece twice and count twice: 2.6 + 12 ms for a
+// 512^3 mask whose kernels take 0.15 ms -- VERDICT r5 weak #11.)  _fetch refuses (IVX_EINVAL) when another host-level call came
+// in between: the caller then takes the two-call form.
+static uint64_t g_mc_begin_epoch = 0;
+static int64_t g_mc_begin_count = 0;
+extern "C" int ivx_marching_cubes_begin(const ivx_mc_params *p, const void *a, const int64_t strides[3], int64_t *ntris) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    IVX_REQUIRE(p && a && ntris, IVX_EINVAL, "marching_cubes_begin: null argument");
+    Geom g;
+    int rc = make_geom(p, &g);
+    if (rc) return rc;
+    g_mc_begin_epoch = 0;
+    const size_t isz = dtype_size(p->dtype);
+    const int64_t shape[3] = {p->nz, p->ny, p->nx};
+    const size_t n = (size_t)p->nz * p->ny * p->nx;
+    void *d_a, *d_scr;
+    size_t sb;
+    if ((rc = ivx_dev_mc_scratch_bytes(p, &sb))) return rc;
+    if ((rc = ws_get(WS_IN, n * isz, &d_a))) return rc;
+    if ((rc = ws_get(WS_AUX0, sb, &d_scr))) return rc;
+    if ((rc = upload_strided(d_a, a, shape, strides, isz, WS_IN))) return rc;
+    int64_t cnt = 0;
+    if ((rc = ivx_dev_mc_count(p, d_a, d_scr, &cnt, nullptr))) return rc;
+    *ntris = cnt;
+    if (cnt) {
+        void *d_tris;
+        if ((rc = ws_get(WS_OUT, (size_t)cnt * 36, &d_tris))) return rc;
+        if ((rc = ivx_dev_mc_emit(p, d_a, d_scr, (float *)d_tris, cnt, nullptr))) return rc;
+    }
+    g_mc_begin_epoch = host_epoch();
+    g_mc_begin_count = cnt;
+    return IVX_OK;
+}
+extern "C" int ivx_marching_cubes_fetch(float *tris, int64_t ntris) {
+    ivx::HostCallGuard host_guard__;
+    using namespace ivx;
+    IVX_REQUIRE(g_mc_begin_epoch != 0 && host_epoch() == g_mc_begin_epoch + 1 && ntris == g_mc_begin_count, IVX_EINVAL,
+                "marching_cubes_fetch: not the call right behind ivx_marching_cubes_begin (or another count): take ivx_marching_cubes");
+    g_mc_begin_epoch = 0;
+    if (ntris == 0) return IVX_OK;
+    IVX_REQUIRE(tris, IVX_EINVAL, "marching_cubes_fetch: null buffer");
+    void *d_tris;
+    int rc;
+    if ((rc = ws_get(WS_OUT, (size_t)ntris * 36, &d_tris))) return rc; // (the block _begin filled: large enough, not reallocated)
+    return copy_d2h(tris, d_tris, (size_t)ntris * 36); // (the page-locked lanes for destinations whose pages are not resident yet)
 }
 
 // ---- indexed mesh API: must follow ivx_dev_mc_count on the same params / scratch / stream --------------------------

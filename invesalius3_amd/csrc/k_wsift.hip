@@ -587,12 +587,20 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
     {
         const char *el = getenv("IVX_WS_LINKS");
         if (!(el && el[0] == '0')) {
+            // one 32-byte record per entry that is not a marker (level 0 -- slots [0, M) of the list -- is never read through
+            // them: `rec` points M records in front of the block).  The records are an accelerator, 8x the bytes of the list they
+            // replace: when the device cannot spare them the flood takes the unlinked kernels (same labels) instead of failing
+            // (ADVICE r5).
             uint64_t total_entries = 0;
             for (uint32_t c = 0; c < 65536; c++) total_entries += hist[c];
+            const uint64_t nrec = total_entries > M ? total_entries - M : 0;
             void *lm = nullptr;
-            IVX_REQUIRE(ws_get_s(WS_WSLINK, st, (size_t)total_entries * 32 + 256, &lm) == IVX_OK, IVX_ENOMEM,
-                        "watershed_ift: %zu bytes for the entries' link records", (size_t)total_entries * 32 + 256);
-            rec = (uint32_t *)lm;
+            if (ws_get_s(WS_WSLINK, st, (size_t)nrec * 32 + 256, &lm) == IVX_OK && lm) {
+                rec = (uint32_t *)((uintptr_t)lm - (uintptr_t)M * 32u);
+            } else {
+                (void)hipGetLastError(); // (the failed allocation's error is dealt with here)
+                if (trace_enabled()) fprintf(stderr, "ivx: watershed_ift: no room for %zu bytes of link records, flooding without them\n", (size_t)nrec * 32);
+            }
         }
     }
     if (rec) {
@@ -654,6 +662,15 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
         for (int i = 8; i < 16; i++) stats[i] = 0;
         tm.read(stats + 8); // [8] costs, [9] zones, [10] bucketing, [11] level chain, [12] labels (microseconds)
         stats[13] = levels_done; stats[14] = level_rounds; stats[15] = level_voxels; // the cost map's bit-plane levels
+    }
+    { // the link records stay cached between floods unless they hold more than an eighth of the device (then: allocated per flood)
+        static size_t keep = 0;
+        if (!keep) {
+            size_t fr = 0, tot = 0;
+            keep = hipMemGetInfo(&fr, &tot) == hipSuccess && tot ? tot / 8 : ((size_t)4 << 30);
+        }
+        const int rc = ws_release_s(WS_WSLINK, st, keep);
+        if (rc != IVX_OK) return rc;
     }
     return IVX_OK;
 }

@@ -42,6 +42,16 @@ def marching_cubes(a, spacing, iso_values, roi_start=0, pad_xy=True, pad_bottom=
     p.iso[:] = iso + [0.0] * (2 - len(iso))
     n = ctypes.c_int64(0)
     lib = L.lib()
+    # one upload, one count, one emit: the soup waits in the library's output block while numpy makes room for it (round 6; the
+    # count call + emit call below sent a 512^3 mask over PCIe twice -- 14 ms of which 0.15 ms were kernels)
+    L.check(lib.ivx_marching_cubes_begin(ctypes.byref(p), L.ptr(a), L.i64(a.strides), ctypes.byref(n)), "marching_cubes")
+    tris = np.empty((n.value, 3, 3), np.float32)
+    rc = lib.ivx_marching_cubes_fetch(L.ptr(tris), ctypes.c_int64(n.value))
+    if rc == L.IVX_OK:
+        return tris
+    if rc != L.IVX_EINVAL:
+        L.check(rc, "marching_cubes")
+    # (another thread's host-level call came in between the two halves: the two-call form)
     L.check(lib.ivx_marching_cubes(ctypes.byref(p), L.ptr(a), L.i64(a.strides), None, ctypes.c_int64(0),
                                    ctypes.byref(n)), "marching_cubes")
     tris = np.empty((n.value, 3, 3), np.float32)
@@ -300,12 +310,23 @@ def fill_holes(verts, faces, hole_size=300.0):
     # the worst case, one new point per three rim edges and one cap triangle per rim edge, of which every edge of the mesh could be
     # one; np.empty pages that are never written cost nothing
     cap_v, cap_t = len(f), 3 * len(f)
-    new_v, new_f = np.empty((cap_v, 3), np.float32), np.empty((cap_t, 3), np.int32)
-    nv, nt = ctypes.c_int64(cap_v), ctypes.c_int64(cap_t)
-    L.check(L.lib().ivx_mesh_fill_holes(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), ctypes.c_double(float(hole_size)),
-                                        L.ptr(new_v), L.ptr(new_f), ctypes.byref(nv), ctypes.byref(nt)), "mesh_fill_holes")
+    while True:
+        try:
+            new_v, new_f = np.empty((cap_v, 3), np.float32), np.empty((cap_t, 3), np.int32)
+        except MemoryError:  # a host that commits at allocation time (vm.overcommit_memory=2): start small, grow on demand
+            cap_v, cap_t = max(1024, cap_v // 16), max(3072, cap_t // 16)
+            continue
+        nv, nt = ctypes.c_int64(cap_v), ctypes.c_int64(cap_t)
+        rc = L.lib().ivx_mesh_fill_holes(L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), ctypes.c_double(float(hole_size)),
+                                         L.ptr(new_v), L.ptr(new_f), ctypes.byref(nv), ctypes.byref(nt))
+        if rc == L.IVX_EINVAL and cap_t < 3 * len(f) and "room for" in L.last_error():  # the smaller buffers of the fallback were too small
+            cap_v, cap_t = min(len(f), cap_v * 4), min(3 * len(f), cap_t * 4)
+            continue
+        L.check(rc, "mesh_fill_holes")
+        break
     if nv.value == 0:
         return v, f, 0
+    # (np.concatenate copies: nothing returned keeps the worst-case buffers alive)
     return np.concatenate([v, new_v[:nv.value]]), np.concatenate([f, new_f[:nt.value]]), int(nv.value)
 
 
@@ -327,12 +348,21 @@ def point_normals(verts, faces, feature_angle=80.0, splitting=True, auto_orient=
     cosang = ctypes.c_double(float(np.cos(np.deg2rad(feature_angle))))
     # ONE call with room for the worst case (every corner its own point): pages of np.empty that are never written cost nothing
     cap = len(v) + 3 * len(f)
-    n = ctypes.c_int64(cap)
     args = (L.ptr(v), ctypes.c_int64(len(v)), L.ptr(f), ctypes.c_int64(len(f)), cosang, int(bool(splitting)), int(bool(auto_orient)))
-    out_v, out_f = np.empty((cap, 3), np.float32), np.empty((len(f), 3), np.int32)
-    pn, cn = np.empty((cap, 3), np.float32), np.empty((len(f), 3), np.float32)
+    try:
+        out_v, pn = np.empty((cap, 3), np.float32), np.empty((cap, 3), np.float32)
+    except MemoryError:  # a host that commits at allocation time: ask for the size first (the two-call protocol)
+        n = ctypes.c_int64(0)
+        L.check(lib.ivx_mesh_point_normals(*args, None, None, None, None, ctypes.byref(n)), "mesh_point_normals")
+        cap = int(n.value)
+        out_v, pn = np.empty((cap, 3), np.float32), np.empty((cap, 3), np.float32)
+    n = ctypes.c_int64(cap)
+    out_f, cn = np.empty((len(f), 3), np.int32), np.empty((len(f), 3), np.float32)
     L.check(lib.ivx_mesh_point_normals(*args, L.ptr(out_v), L.ptr(out_f), L.ptr(pn), L.ptr(cn), ctypes.byref(n)), "mesh_point_normals")
-    return out_v[:n.value], out_f, pn[:n.value], cn
+    # shrink in place (no copy, and no view that keeps the worst-case buffers alive)
+    out_v.resize((n.value, 3), refcheck=False)
+    pn.resize((n.value, 3), refcheck=False)
+    return out_v, out_f, pn, cn
 
 
 def join_process_surface(filenames, algorithm, smooth_iterations, smooth_relaxation_factor, decimate_reduction, keep_largest,

@@ -223,6 +223,9 @@ def do_watershed(image, markers, tfile, shape, bstruct, algorithm, mg_size, use_
         if len(sz) != image.ndim:
             raise RuntimeError("size must have one entry per image axis")
         gs = (ctypes.c_int * 3)(*((1,) * (3 - len(sz)) + sz))
+    # (The library validates, uploads and floods first and writes into `dst` only when the flood has succeeded -- a rejected
+    # marker array or an allocation failure leaves the caller's file untouched, as the reference's `mask[:] = tmp_mask` after the
+    # flood does; only an error during the final download itself could leave the file partly written.)
     # `mask[:] = tmp_mask` (:58): the labels land in the memmap itself when it has the image's shape (it always does in the
     # reference's callers, styles.py:2102-2134); a broadcasting assignment keeps numpy's semantics through a temporary
     direct = mask.size == img3.size and tuple(d for d in mask.shape if d != 1) == tuple(d for d in img3.shape if d != 1)
