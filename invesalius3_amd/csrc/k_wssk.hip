@@ -1070,17 +1070,41 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
                 const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
                 if ((zm >> k) & 1u) root[k] = comp[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)];
             }
-            sk_offer_plateau_wide<CONN>(g, tau, pm, v, t + GEN1, sg, next, st);
-            if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(1) }
+            // the offers to the plateau neighbours AND to the basins' roots in flight together (round 6: the basins' atomics used to
+            // be issued behind the plateau offers' returns -- a second dependent round trip per round, 2 us of its 12), then the
+            // returns: pushes for the plateau voxels stamped first, the count of basins stamped first
+            unsigned long long old[27], oldr[27];
+            const unsigned long long nt = t + GEN1;
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                old[k] = 0ull;
+                if (!has_off<CONN>(g.smask, k)) continue;
+                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                if ((pm >> k) & 1u) old[k] = atomicMin(&tau[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)], nt);
+            }
             uint32_t last = ENTRY;
 #pragma unroll
             for (int k = 0; k < 27; k++) {
+                oldr[k] = 0ull;
                 if (!has_off<CONN>(g.smask, k)) continue;
                 if (root[k] == ENTRY || root[k] == last) continue; // (most neighbours of one voxel share a basin)
                 last = root[k];
-                stamped += atomicMin(&tau[root[k]], t) == TINF;
+                oldr[k] = atomicMin(&tau[root[k]], t);
             }
-            if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(2) }
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                if (!has_off<CONN>(g.smask, k)) continue;
+                const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+                if (!__ballot((pm >> k) & 1u)) continue; // (wave-uniform)
+                stage_push(old[k] == TINF, (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx), sg, next, &st->n_next);
+            }
+            if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(1) }
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                if (!has_off<CONN>(g.smask, k)) continue;
+                stamped += oldr[k] == TINF;
+            }
+            if (SK_TICKS && tr) { SK_TICK(2) }
         } else {
             unsigned long long tb = TINF;
             if (act) tb = ld64(&tau[comp[v]]);
