@@ -1198,12 +1198,14 @@ def run_surface_tail(args, job):
     soup = vol.marching_cubes(download=True)
     # host-level calls (arrays in, arrays out: upload + kernels + download), on the largest region like the reference's pipeline
     kv, kf = ov.download((largest[0], 3), np.float32), of.download((largest[1], 3), np.int32)
-    t = time.perf_counter()
-    fv, ff, nholes = sp.fill_holes(kv, kf, 300.0)
-    t_fill = (time.perf_counter() - t) * 1e3
-    t = time.perf_counter()
-    pv, pf, pn, cn = sp.point_normals(fv, ff, 80.0, True, True)
-    t_pn = (time.perf_counter() - t) * 1e3
+    t_fill = t_pn = None
+    for _ in range(2):  # (the second call: the first one sizes the library's workspace blocks -- hipMalloc of a few hundred MB)
+        t = time.perf_counter()
+        fv, ff, nholes = sp.fill_holes(kv, kf, 300.0)
+        t_fill = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
+        pv, pf, pn, cn = sp.point_normals(fv, ff, 80.0, True, True)
+        t_pn = (time.perf_counter() - t) * 1e3
     # parity: what the indexed mesh must be (the soup, bit for bit) and what the numbers must add up to (float64 numpy)
     ok_soup = None
     if soup is not None:
@@ -1227,7 +1229,7 @@ def run_surface_tail(args, job):
                                   "normals as host calls on the largest region" % (n, nt, nv), "parallelism": "single GPU"},
            "stage_ms": {k: round(v, 4) for k, v in stage.items()},
            "host_call_ms": {"fill_holes": round(t_fill, 2), "point_normals": round(t_pn, 2),
-                            "note": "arrays in, arrays out: upload + kernels + download of %d triangles (PCIe inclusive)" % len(kf)},
+                            "note": "arrays in, arrays out: upload + kernels + download of %d triangles (PCIe inclusive), second call" % len(kf)},
            "triangles": int(nt), "points": int(nv), "regions": int(largest[2]), "largest_region_triangles": int(largest[1]),
            "holes_filled": int(nholes), "points_after_splitting": int(len(pv)), "volume_area": vol_area,
            "roofline": roofline("indexed mesh (k_mc_count + k_mci_count + k_mci_vertices_levels + k_mci_faces)", alg["indexed_mesh"],

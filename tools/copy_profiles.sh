@@ -17,5 +17,18 @@ for f in bench_watershed_512 bench_watershed_sk_512 bench_watershed_1024 bench_w
 for f in bench_strong_1gpu bench_host_512 bench_mc_one_launch bench_watershed_512_nolinks; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
 [ -f $O/gpu_tests.txt ] && cp $O/gpu_tests.txt $P/${R}_gpu_tests.txt
 [ -f $O/force_slab.json ] && cp $O/force_slab.json $P/${R}_force_slab.json
-for k in slab_kt mip_kt stitch_kt; do f=$(find $O -name "${k}_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_${k}_kernel_stats.csv; done
+for f in bench_surface_tail bench_mesh_512 bench_edit_512; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
+#  a host-call file made from other sources than the tree's is not a family member: refuse it
+if [ -f $O/bench_host_512.json ]; then
+  python3 - $O/bench_host_512.json <<'PY' || { echo "bench_host_512.json was not made from these sources: not copied"; rm -f $P/${R}_bench_host_512.json; }
+import hashlib, json, os, sys
+h = hashlib.sha256()
+for d in ("invesalius3_amd/csrc", "invesalius3_amd"):
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".py")):
+            h.update(open(os.path.join(d, f), "rb").read())
+sys.exit(0 if json.load(open(sys.argv[1])).get("sources_sha16") == h.hexdigest()[:16] else 1)
+PY
+fi
+for k in slab_kt mip_kt stitch_kt tail_kt; do f=$(find $O -name "${k}_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_${k}_kernel_stats.csv; done
 echo "copied $O -> $P/${R}_*  (re-run 'python bench.py' afterwards for a line that quotes the new pmc_traffic.json)"
