@@ -85,7 +85,9 @@ struct SkState {
     // the working workgroups add to
     unsigned long long pctl;
     uint32_t ticks[16]; // IVX_WS_TRACE: workgroup 0's time per part of a round, summed over the flood (wall_clock64 ticks of 10 ns)
-    uint32_t pad2[14];
+    uint32_t joined;    // k_sk_level<.., LOCAL>: workgroups that found themselves on the chosen XCD (their ids: the order they joined in)
+    uint32_t arrived;   //                        workgroups of the launch that have looked (all of them: `joined` is final then)
+    uint32_t pad2[12];
 };
 static_assert(sizeof(SkState) == 256 && offsetof(SkState, pctl) == 128, "ctl is 8-byte aligned, pctl starts a 128-byte line");
 
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__r
     if (i == 0) { // the level's frontier loop starts from list 0, phase A
         st->done = 0; st->gen = gbase; st->n_in = cnt;
         st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
         st->ctl = sk_ctl(seq, 0, 0, cnt); // the first round of this level is the host's launch number `seq`
         st->pctl = sk_pctl(0, 0, 0, 0, cnt); // (the resident launch counts its rounds from 0)
     }
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void k_sk_split_assign(const unsigned long lon
         const uint32_t cnt = cnt_e + cnt_l;
         st->done = 0; st->gen = gbase; st->n_in = cnt;
         st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
         st->ctl = sk_ctl(seq, 0, 0, cnt);
         st->pctl = sk_pctl(0, 0, 0, 0, cnt);
     }
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(G0_T) void k_sk_gen0(WsGeom g, const uint16_t *__re
     if (chunk == 0 && tid == 0) { // the level's frontier loop starts from list 0, phase A (as k_sk_assign)
         st->done = 0; st->gen = gbase; st->n_in = cnt;
         st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
         st->ctl = sk_ctl(seq, 0, 0, cnt);
         st->pctl = sk_pctl(0, 0, 0, 0, cnt);
     }
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(256) void k_sk_assign_ranked(const unsigned long lo
     if (i == 0 && pos_off == 0) {
         st->done = 0; st->gen = gbase; st->n_in = total;
         st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
         st->ctl = sk_ctl(seq, 0, 0, total);
         st->pctl = sk_pctl(0, 0, 0, 0, total);
     }
@@ -859,6 +861,27 @@ struct SkStage {
     volatile uint32_t n[4];
 };
 
+// LOCAL (k_sk_level on ONE XCD, see there): what crosses workgroups is written with workgroup-scope operations -- performed in
+// the XCD's L2, where the line STAYS -- instead of agent-scope ones (write-through to the fabric, line dropped); loads keep the
+// agent-scope form (L1 bypassed, served by the L2) either way.
+template <bool LOCAL> __device__ __forceinline__ uint32_t sk_add32(uint32_t *p, uint32_t v) {
+    if constexpr (LOCAL) return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LOCAL> __device__ __forceinline__ unsigned long long sk_min64(unsigned long long *p, unsigned long long v) {
+    if constexpr (LOCAL) return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LOCAL> __device__ __forceinline__ void sk_store32(uint32_t *p, uint32_t v) {
+    if constexpr (LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LOCAL> __device__ __forceinline__ void sk_store64(unsigned long long *p, unsigned long long v) {
+    if constexpr (LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool LOCAL = false>
 __device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, uint32_t *glist, uint32_t *gcnt) {
     const unsigned long long b = __ballot(want);
     if (!b) return;
@@ -869,24 +892,25 @@ __device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, u
     if (lane == leader) {
         base = sg.n[wv];
         if (base + n <= WB_CAP) sg.n[wv] = base + n;
-        else base = 0x80000000u | atomicAdd(gcnt, n); // no room (rare): straight to the global list
+        else base = 0x80000000u | sk_add32<LOCAL>(gcnt, n); // no room (rare): straight to the global list
     }
     base = __shfl(base, leader, 64);
     if (!want) return;
-    if (base & 0x80000000u) __hip_atomic_store(&glist[(base & 0x7FFFFFFFu) + rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (base & 0x80000000u) sk_store32<LOCAL>(&glist[(base & 0x7FFFFFFFu) + rank], v);
     else sg.buf[wv][base + rank] = v;
 }
 
 // all lanes of the wave are here
+template <bool LOCAL = false>
 __device__ __forceinline__ void stage_flush(SkStage &sg, uint32_t *glist, uint32_t *gcnt) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t n = sg.n[wv];
     if (!n) return;
     uint32_t off = 0;
-    if (lane == 0) off = atomicAdd(gcnt, n);
+    if (lane == 0) off = sk_add32<LOCAL>(gcnt, n);
     off = __shfl(off, 0, 64);
-    // (agent-scope stores: inside the resident launch the next round's readers sit on other XCDs, behind other L2s)
-    for (uint32_t j = lane; j < n; j += 64) __hip_atomic_store(&glist[off + j], sg.buf[wv][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (agent-scope stores: inside the resident launch the next round's readers sit on other XCDs, behind other L2s -- unless LOCAL)
+    for (uint32_t j = lane; j < n; j += 64) sk_store32<LOCAL>(&glist[off + j], sg.buf[wv][j]);
     if (lane == 0) sg.n[wv] = 0;
 }
 
@@ -1005,7 +1029,7 @@ __device__ __forceinline__ void st32(uint32_t *p, uint32_t v) { __hip_atomic_sto
 
 // the offers of one voxel with every neighbour in flight at once (the loop over the set bits in sk_offer_plateau is a chain of
 // dependent round trips, one per neighbour; inside the resident launch a round IS its chain of round trips)
-template <int CONN>
+template <int CONN, bool LOCAL = false>
 __device__ __forceinline__ void sk_offer_plateau_wide(const WsGeom &g, unsigned long long *tau, uint32_t pm, uint32_t v, unsigned long long nt,
                                                       SkStage &sg, uint32_t *next, SkState *st) {
     unsigned long long old[27];
@@ -1014,14 +1038,14 @@ __device__ __forceinline__ void sk_offer_plateau_wide(const WsGeom &g, unsigned 
         old[k] = 0ull;
         if (!has_off<CONN>(g.smask, k)) continue;
         const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-        if ((pm >> k) & 1u) old[k] = atomicMin(&tau[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)], nt);
+        if ((pm >> k) & 1u) old[k] = sk_min64<LOCAL>(&tau[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)], nt);
     }
 #pragma unroll
     for (int k = 0; k < 27; k++) {
         if (!has_off<CONN>(g.smask, k)) continue;
         const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
         if (!__ballot((pm >> k) & 1u)) continue; // (wave-uniform)
-        stage_push(old[k] == TINF, (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx), sg, next, &st->n_next);
+        stage_push<LOCAL>(old[k] == TINF, (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx), sg, next, &st->n_next);
     }
 }
 
@@ -1034,7 +1058,7 @@ __device__ __forceinline__ void sk_offer_plateau_wide(const WsGeom &g, unsigned 
 constexpr uint32_t SK_SOLO_MAX = 256; // list entries up to which ONE workgroup takes the round without a hand-over (one pass)
 
 // one round's share of a workgroup: list entries wg * 256 + k * nactive * 256 (the whole workgroup is here)
-template <int CONN>
+template <int CONN, bool LOCAL>
 __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
                                                const uint32_t *__restrict__ comp, unsigned long long *tau, const SkLists &L,
                                                const uint32_t *dlist, uint32_t ndl, SkState *st, SkStage &sg, uint32_t phase,
@@ -1080,7 +1104,7 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
                 old[k] = 0ull;
                 if (!has_off<CONN>(g.smask, k)) continue;
                 const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-                if ((pm >> k) & 1u) old[k] = atomicMin(&tau[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)], nt);
+                if ((pm >> k) & 1u) old[k] = sk_min64<LOCAL>(&tau[(uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx)], nt);
             }
             uint32_t last = ENTRY;
 #pragma unroll
@@ -1089,14 +1113,14 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
                 if (!has_off<CONN>(g.smask, k)) continue;
                 if (root[k] == ENTRY || root[k] == last) continue; // (most neighbours of one voxel share a basin)
                 last = root[k];
-                oldr[k] = atomicMin(&tau[root[k]], t);
+                oldr[k] = sk_min64<LOCAL>(&tau[root[k]], t);
             }
 #pragma unroll
             for (int k = 0; k < 27; k++) {
                 if (!has_off<CONN>(g.smask, k)) continue;
                 const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
                 if (!__ballot((pm >> k) & 1u)) continue; // (wave-uniform)
-                stage_push(old[k] == TINF, (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx), sg, next, &st->n_next);
+                stage_push<LOCAL>(old[k] == TINF, (uint32_t)((int64_t)v + dz * g.hw + dy * g.w + dx), sg, next, &st->n_next);
             }
             if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(1) }
 #pragma unroll
@@ -1110,13 +1134,13 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
             if (act) tb = ld64(&tau[comp[v]]);
             act = act && (uint32_t)(tb >> 32) == gen;
             if (SK_TICKS && tr) { SK_TICK(0) }
-            sk_offer_plateau_wide<CONN>(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
+            sk_offer_plateau_wide<CONN, LOCAL>(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
             if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(1) }
         }
-        stage_flush(sg, next, &st->n_next);
+        stage_flush<LOCAL>(sg, next, &st->n_next);
         if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(3) }
     }
-    if (stamped) atomicAdd(&st->n_stamped, stamped);
+    if (stamped) sk_add32<LOCAL>(&st->n_stamped, stamped);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0); // this wave's stores and atomics have been acknowledged
     __syncthreads();
@@ -1135,19 +1159,57 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
 // A round's time is its chain of dependent DRAM-latency accesses (~1.5 us each, agent-scope or not: pmask / zmask / comp are
 // random reads of 0.5 GB arrays) -- voxel -> masks and stamp -> basin roots -> atomics, twice per generation with the relay
 // -- and 1 742 generations times that chain is the level chain's floor; who runs the round hardly matters.
-template <int CONN>
+// LOCAL (round 6): the level's rounds on ONE XCD.  A round is a chain of dependent accesses to the stamps, the lists and the
+// counters; at agent scope each of them is a trip over the fabric (the writer's L2 drops the line: the next reader misses too).
+// The workgroups that find themselves on XCD 0 (HW_REG_XCC_ID, read at run time -- which workgroup lands where is not promised,
+// so nobody assumes it) share one L2: between them a workgroup-scope atomic IS coherent (atomics execute in the L2, loads
+// bypass the L1), and the level's working set stays in that L2 from round to round.  The others leave at once.  The launch
+// is eight times as wide so that an eighth of it is enough; kernel boundaries make the result visible to everybody else.
+// MEASURED (512^3, opt-in IVX_SK_LOCAL=1, same labels): level chain 44.6 - 46.8 ms against 39.1 with the rounds spread over all
+// eight XCDs at agent scope -- 32 compute units and one L2's atomic unit serve the mid-sized rounds more slowly than the fabric
+// trips cost.  Kept as an A/B, not the default.
+template <int CONN, bool LOCAL>
 __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
                                                   const uint32_t *__restrict__ comp, unsigned long long *tau, SkLists L,
                                                   const uint32_t *dlist, uint32_t ndl, uint32_t per_wg, uint32_t solo_max, SkState *st) {
     __shared__ SkStage sg;
     __shared__ unsigned long long s_ctl;
     __shared__ uint32_t s_last, s_next[4]; // s_next: phase, list, entries, 1 = level exhausted
+    uint32_t my_wg = blockIdx.x, n_wg = gridDim.x;
+    if (LOCAL) {
+        __shared__ uint32_t s_id[2];
+        if (threadIdx.x == 0) {
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const bool mine = (xcc & 7u) == 0u;
+            uint32_t id = 0xFFFFFFFFu, n = 0;
+            if (mine) id = __hip_atomic_fetch_add(&st->joined, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (returned: performed)
+            __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine) {
+                for (uint32_t spins = 0; ld32(&st->arrived) < gridDim.x; spins++) {
+                    if (spins > SK_SPIN_LIMIT) { // (a workgroup of the launch never started: give up cleanly)
+                        st32(&st->done, 3u);
+                        id = 0xFFFFFFFFu;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                n = ld32(&st->joined);
+            }
+            s_id[0] = id;
+            s_id[1] = n;
+        }
+        __syncthreads();
+        if (s_id[0] == 0xFFFFFFFFu) return;
+        my_wg = s_id[0];
+        n_wg = s_id[1];
+    }
     const uint32_t gen0 = ld32(&st->gen); // (k_sk_assign's launch wrote it)
     uint32_t want = 0;                    // sequence number of the next word this workgroup has not seen
     for (;;) {
         if (threadIdx.x == 0) {
             unsigned long long c;
-            const unsigned long long tp0 = SK_TICKS && blockIdx.x == 0 ? wall_clock64() : 0ull;
+            const unsigned long long tp0 = SK_TICKS && my_wg == 0 ? wall_clock64() : 0ull;
             for (uint32_t spins = 0;; spins++) {
                 c = __hip_atomic_load(&st->pctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t sq = (uint32_t)(c >> 54);
@@ -1160,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
                 }
                 __builtin_amdgcn_s_sleep(SK_POLL_SLEEP);
             }
-            if (SK_TICKS && blockIdx.x == 0) atomicAdd(&st->ticks[12], (uint32_t)(wall_clock64() - tp0)); // waiting for the round's word
+            if (SK_TICKS && my_wg == 0) atomicAdd(&st->ticks[12], (uint32_t)(wall_clock64() - tp0)); // waiting for the round's word
             s_ctl = c;
         }
         __syncthreads();
@@ -1172,29 +1234,29 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
         uint32_t cum = (uint32_t)(ctl >> 34) & PGEN_MAX; // generations begun since the level's first word
         uint32_t gen = gen0 + cum;
         const uint32_t n_in = phase ? ndl : n_front;
-        const uint32_t nactive = min((uint32_t)gridDim.x, (n_in + per_wg - 1u) / per_wg);
-        if (blockIdx.x < nactive) {
-            sk_level_round<CONN>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, blockIdx.x, nactive);
-            const unsigned long long tt0 = SK_TICKS && blockIdx.x == 0 && threadIdx.x == 0 ? wall_clock64() : 0ull;
-            if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1u) == nactive - 1;
+        const uint32_t nactive = min(n_wg, (n_in + per_wg - 1u) / per_wg);
+        if (my_wg < nactive) {
+            sk_level_round<CONN, LOCAL>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, my_wg, nactive);
+            const unsigned long long tt0 = SK_TICKS && my_wg == 0 && threadIdx.x == 0 ? wall_clock64() : 0ull;
+            if (threadIdx.x == 0) s_last = sk_add32<LOCAL>(&st->ticket, 1u) == nactive - 1;
             __syncthreads();
-            if (SK_TICKS && blockIdx.x == 0 && threadIdx.x == 0) {
+            if (SK_TICKS && my_wg == 0 && threadIdx.x == 0) {
                 atomicAdd(&st->ticks[13], (uint32_t)(wall_clock64() - tt0)); // the ticket
                 atomicAdd(&st->ticks[14], 1u);                                // rounds workgroup 0 took part in
             }
             if (s_last) { // (the whole workgroup)
-                if (threadIdx.x == 0) st32(&st->ticket, 0u);
+                if (threadIdx.x == 0) sk_store32<LOCAL>(&st->ticket, 0u);
                 for (;;) {
                     if (threadIdx.x == 0) {
                         const uint32_t nst = ld32(&st->n_stamped), nnx = ld32(&st->n_next);
-                        atomicAdd(&st->rounds, 1u);
-                        st32(&st->n_stamped, 0u);
+                        sk_add32<LOCAL>(&st->rounds, 1u);
+                        sk_store32<LOCAL>(&st->n_stamped, 0u);
                         if (phase == 0 && nst) { // basins were stamped: they relay before the generation advances
-                            atomicAdd(&st->brounds, 1u);
+                            sk_add32<LOCAL>(&st->brounds, 1u);
                             s_next[0] = 1u; s_next[1] = in_sel; s_next[2] = n_front; s_next[3] = 0u;
                         } else if (nnx) { // next generation
-                            st32(&st->n_next, 0u);
-                            atomicAdd(&st->gens, 1u);
+                            sk_store32<LOCAL>(&st->n_next, 0u);
+                            sk_add32<LOCAL>(&st->gens, 1u);
                             s_next[0] = 0u; s_next[1] = in_sel ^ 1u; s_next[2] = nnx; s_next[3] = 0u;
                         } else {
                             s_next[3] = 1u;
@@ -1212,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
                         cum++;
                     }
                     if (!solo) break;
-                    sk_level_round<CONN>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, 0u, 1u);
+                    sk_level_round<CONN, LOCAL>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, 0u, 1u);
                 }
                 if (threadIdx.x == 0) {
                     unsigned long long nctl;
@@ -1228,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
                         nctl = sk_pctl(want, cum, in_sel, phase, n_front);
                     }
                     __builtin_amdgcn_s_waitcnt(0);
-                    __hip_atomic_store(&st->pctl, nctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sk_store64<LOCAL>(&st->pctl, nctl);
                 }
             }
         }
@@ -1835,6 +1897,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const uint32_t per_wg = epb && atoi(epb) >= 32 ? (uint32_t)atoi(epb) : 256u; // (round 6: 1024 -> 256 = one pass per workgroup, 49.8 -> 44.7 ms of level chain at 512^3)
     const char *eso = getenv("IVX_SK_SOLO"); // most list entries one workgroup takes alone inside a resident launch (0: never; A/B)
     const uint32_t solo_max = eso ? (uint32_t)atoi(eso) : SK_SOLO_MAX;
+    const char *elo = getenv("IVX_SK_LOCAL"), *elw = getenv("IVX_SK_LOCAL_WGS"); // the level's rounds on one XCD (k_sk_level<.., LOCAL>); A/B
+    const bool level_local = elo && elo[0] == '1';
+    const int64_t local_wgs = elw && atoi(elw) >= 1 ? std::min(atoi(elw), 128) : 128; // workgroups wanted on that XCD (32 CUs; 256 -- a launch of 2 048 -- never got all its workgroups started beside the side stream)
     const char *erc = getenv("IVX_SK_RES_PER_CU");
     const int64_t res_per_cu = erc && atoi(erc) >= 1 && atoi(erc) <= 4 ? atoi(erc) : 1;
     uint32_t start = 0, dstart = 0, roff = 0, gbase = 1, seq = 0;
@@ -2060,8 +2125,14 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             const uint32_t lvl_per_wg = per_wg; // (round 6: one pass per workgroup here too -- 512 entries measured 136.7 ms of level chain at 1024^3, 256: 131.6)
             const int64_t lvl_res = wide ? 2 : res_per_cu;
             const unsigned nres = (unsigned)std::min<int64_t>(std::max<int64_t>(cdiv(2 * (int64_t)std::max(cnt, ndl), lvl_per_wg), 8), lvl_res * std::max(ncu, 8));
-            WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_level<CC>, dim3(nres), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists,
-                                                      b.dlist + dstart, ndl, lvl_per_wg, solo_max, b.st));
+            if (level_local) { // the rounds on one XCD: an eighth of an eight times wider launch
+                const unsigned want_wgs = (unsigned)std::min<int64_t>(std::max<int64_t>(cdiv(2 * (int64_t)std::max(cnt, ndl), lvl_per_wg), 1), local_wgs);
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_level<CC, true>), dim3(8 * want_wgs), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau,
+                                                          lists, b.dlist + dstart, ndl, lvl_per_wg, solo_max, b.st));
+            } else {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_level<CC, false>), dim3(nres), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists,
+                                                          b.dlist + dstart, ndl, lvl_per_wg, solo_max, b.st));
+            }
             IVX_LAUNCH_CHECK();
             gknown = false;
             if (trace) {
