@@ -256,12 +256,12 @@ def test_cost_levels_on_the_region_growing_engine(ivxlib, oracle, monkeypatch, c
                                  {"IVX_SK_SORT": "merge", "IVX_SK_CHUNK": "32"}, {"IVX_SK_SORT": "fused"},
                                  {"IVX_SK_SORT": "fused", "IVX_SK_CHUNK": "64"}, {"IVX_SK_SPLIT": "0"},
                                  {"IVX_SK_SPLIT": "0", "IVX_SK_CHUNK": "64"}, {"IVX_SK_LATE_MAX": "0"},
-                                 {"IVX_SK_LATE_MAX": "0", "IVX_SK_CHUNK": "32"}])
+                                 {"IVX_SK_LATE_MAX": "0", "IVX_SK_CHUNK": "32"}, {"IVX_SK_LOCAL": "1"}])
 def test_generation0_sorts(ivxlib, oracle, monkeypatch, env):
     """A level's generation 0 -- keys, sort, stamps -- on the library-free paths: chunk sort in LDS + pairwise ranks (the
     default), chunk sort + merge passes (levels of more than 128 chunks), and everything in one launch behind a device-wide
     barrier (opt-in); with the early part sorted on the side stream beside the level below and the late part ranked by
-    brute force (the default) and as one list (IVX_SK_SPLIT=0); every level forced off the one-workgroup path and chunks
+    brute force (the default) and as one list (IVX_SK_SPLIT=0); with a level's rounds on one XCD (IVX_SK_LOCAL=1); every level forced off the one-workgroup path and chunks
     short enough that a small volume has dozens of them: labels == the serial flood, generations and the tied-marker
     count == the default path's."""
     import warnings
