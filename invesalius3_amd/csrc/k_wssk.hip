@@ -1361,11 +1361,14 @@ __device__ __forceinline__ bool sk_plateau_eval(unsigned long long *s, uint32_t 
 template <int CONN>
 __global__ __launch_bounds__(256) void k_sk_plateau_relax(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
                                                           unsigned long long *tau, const uint32_t *__restrict__ list, uint8_t *dirty,
-                                                          uint32_t c, SkState *st) {
+                                                          uint32_t c, SkState *st, const uint32_t *__restrict__ nlist, uint32_t offset) {
     __shared__ unsigned long long s[NCELL];
     __shared__ uint32_t s_act[TY][TX];
     __shared__ uint32_t s_ev2, s_gmax;
-    const int64_t tile = list[blockIdx.x];
+    // (the grid is sized from the PREVIOUS round's list while the host is still reading this round's length: workgroups beyond
+    // the list return at once, a longer list gets a second launch behind `offset`)
+    if (blockIdx.x + offset >= *nlist) return;
+    const int64_t tile = list[blockIdx.x + offset];
     int z0, y0, x0;
     tile_origin(g, tile, z0, y0, x0);
     constexpr int PER = (NCELL + 255) / 256;
@@ -2088,6 +2091,11 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         if (tile_level) {
             hipLaunchKernelGGL(k_sk_mark_tiles, dim3(gb), dim3(256), 0, st, g, b.lists[0], cnt, b.dirty);
             IVX_LAUNCH_CHECK();
+            // Rounds of dirty tiles.  The host never stands between two rounds' kernels: a round's relaxation is launched with a grid
+            // guessed from the previous round's list (1.5 x + 64: the wave front grows slowly) BEFORE the host has read how long this
+            // round's list is -- the read then overlaps the kernel (110 us), and a list longer than the guess gets a second launch
+            // behind it.  (Rounds 1 - 5: list length read first, 20 us of host round trip per round, 61 / 125 rounds per flood.)
+            uint32_t guess = 0;
             for (;;) {
                 IVX_HIP(hipMemsetAsync(&b.wst->nlist, 0, 4, st));
                 hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, b.dirty, b.tlist, b.wst);
@@ -2095,12 +2103,21 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
                 uint32_t mseq = 0, nl = 0;
                 int rc = mailbox_publish(&b.wst->nlist, 1, st, &mseq);
                 if (rc != IVX_OK) return rc;
+                if (guess) {
+                    WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(guess), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c, b.st,
+                                                              &b.wst->nlist, 0u));
+                    IVX_LAUNCH_CHECK();
+                }
                 rc = mailbox_wait(mseq, st, &nl, 1);
                 if (rc != IVX_OK) return rc;
-                if (!nl) break;
+                if (!nl) break; // (a guessed launch of this round found an empty list and returned)
                 ntile_rounds++;
-                WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(nl), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c, b.st));
-                IVX_LAUNCH_CHECK();
+                if (nl > guess) {
+                    WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(nl - guess), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c,
+                                                              b.st, &b.wst->nlist, guess));
+                    IVX_LAUNCH_CHECK();
+                }
+                guess = (uint32_t)std::min<int64_t>(g.ntiles, (int64_t)nl + nl / 2 + 64);
             }
             uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
             int rc = mailbox_publish(&b.st->done, 4, st, &mseq);
