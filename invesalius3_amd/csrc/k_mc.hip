@@ -387,7 +387,24 @@ __global__ __launch_bounds__(1024) void k_mc_scan(const uint32_t *__restrict__ b
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t base = (size_t)blockIdx.x * (1024 * PER);
     uint64_t pre = 0;
-    for (size_t i = threadIdx.x; i < base; i += 1024) pre += bsum[i];
+    { // (base is a multiple of 16 384: whole 16-byte groups, four independent loads in flight per lane and trip)
+        const uint4 *b4 = reinterpret_cast<const uint4 *>(bsum);
+        const size_t n4 = base / 4;
+        uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        size_t i = threadIdx.x;
+        for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+            const uint4 a = b4[i], b = b4[i + 1024], c = b4[i + 2048], d = b4[i + 3072];
+            p0 += (uint64_t)a.x + a.y + a.z + a.w;
+            p1 += (uint64_t)b.x + b.y + b.z + b.w;
+            p2 += (uint64_t)c.x + c.y + c.z + c.w;
+            p3 += (uint64_t)d.x + d.y + d.z + d.w;
+        }
+        for (; i < n4; i += 1024) {
+            const uint4 a = b4[i];
+            p0 += (uint64_t)a.x + a.y + a.z + a.w;
+        }
+        pre = p0 + p1 + p2 + p3;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
     if (lane == 0) s_wave[wv] = pre;
