@@ -27,19 +27,23 @@
 //
 // Pipeline (one stream, no CPU arithmetic):
 //   1. k_ws_relax<SK>  the cost map by chaotic relaxation over dirty 16x16x8 tiles (shared with the IFT flood);
-//   2. k_sk_classify   generation-0 flags, drained voxels (I < C) and their same-level drained neighbours; union-find
-//                      (k_ws_runs / k_ws_union / k_ws_flatten) makes every drained basin one set whose time stamp lives at
-//                      its root; k_ws_bucket: generation 0 and the drained voxels, each bucketed by level;
-//   3. per non-empty level, ascending: k_sk_gen0 -- ONE launch: keys (marker: raster index; other: smallest T among
-//      lower-C neighbours) -> sorted (every workgroup sorts a chunk in LDS, then ranks its keys against every other
-//      chunk behind one device-wide barrier) -> T, run labels, first frontier -- then k_sk_round until the level is
-//      exhausted (levels of more than 2^20 generation-0 voxels: k_sk_keys -> k_sk_sort_chunks -> k_sk_merge_pass x log2
-//      -> k_sk_assign).  A
-//      generation is at most two launches: A -- the frontier stamps its unstamped neighbours of value c with the next
+//   2. k_sk_classify   generation-0 flags (EARLY: some neighbour lies below the level underneath -- the key is final one level
+//                      early; LATE: all lower neighbours sit in the level right underneath), drained voxels (I < C) and their
+//                      same-level drained neighbours; union-find makes every drained basin one set whose time stamp lives at
+//                      its root; generation 0 bucketed by (level, late), the drained voxels by level;
+//   3. per non-empty level, ascending:
+//        generation 0 -- keys (marker: raster index; other: smallest T among lower-C neighbours), sorted, stamped (T, run
+//        labels, first frontier) -- by our own kernels, no library: k_sk_keys -> k_sk_sort_chunks (bitonic in LDS) ->
+//        k_sk_rank_pairs (pairwise ranks) | k_sk_merge_pass (lists of more than 128 chunks) -> k_sk_assign_ranked.  The EARLY
+//        part of a level is sorted on a SIDE STREAM while the level underneath floods; behind that flood only the late part
+//        is keyed and ONE launch stamps everything (k_sk_split_assign: late pairs ranked by brute force in LDS).
+//        k_sk_gen0 (the whole of it in one launch behind a device-wide barrier) is an opt-in that measured slower.
+//        Then the level's rounds in ONE resident launch (k_sk_level: a round boundary is a hand-over through a polled control
+//        word; IVX_SK_PERSIST=0: k_sk_round launches in batches).  A
+//      generation is at most two rounds: A -- the frontier stamps its unstamped neighbours of value c with the next
 //      generation and offers its own stamp to the basins it touches (atomicMin at the root); B -- only if a basin was
 //      stamped: the level's drained voxels whose basin carries this generation's stamp hand it, one generation later, to
-//      their unstamped neighbours of value c.  The last workgroup of a launch sets up the next one; the host queues
-//      launches in batches and reads one mailbox line per batch.  Two shortcuts: a RUN of consecutive small levels is
+//      their unstamped neighbours of value c.  Two shortcuts: a RUN of consecutive small levels is
 //      taken by one workgroup in one launch (k_sk_levels_small: keys, LDS sort, stamps, generations behind barriers);
 //      a basin-free level that is not small (the zero plateau of a windowed gradient) is relaxed tile-wise in LDS
 //      (k_sk_plateau_relax: its stamps are a fixed point any relaxation order reaches).
@@ -196,34 +200,6 @@ __global__ __launch_bounds__(256) void k_sk_keys(WsGeom g, const uint16_t *__res
     }
     key[i] = K;
     val[i] = p;
-}
-
-// sorted generation 0 -> time stamps (G = gbase, R = roff + position), the runs' labels, the first frontier
-template <typename MT>
-__global__ __launch_bounds__(256) void k_sk_assign(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
-                                                   const MT *__restrict__ mk, unsigned long long *tau, int32_t *runlabel,
-                                                   uint32_t *__restrict__ front, uint32_t cnt, uint32_t roff, uint32_t gbase, uint32_t seq,
-                                                   SkState *st) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    // gbase 0: the level follows another one of the same chain on the device (nobody writes gnext during this launch)
-    if (gbase == 0) gbase = __hip_atomic_load(&st->gnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i == 0) { // the level's frontier loop starts from list 0, phase A
-        st->done = 0; st->gen = gbase; st->n_in = cnt;
-        st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
-        st->ctl = sk_ctl(seq, 0, 0, cnt); // the first round of this level is the host's launch number `seq`
-        st->pctl = sk_pctl(0, 0, 0, 0, cnt); // (the resident launch counts its rounds from 0)
-    }
-    if (i >= cnt) return;
-    const uint32_t p = val[i];
-    const unsigned long long K = key[i];
-    const int m = (int)mk[p];
-    // a run's label: its marker's, or the label of the run its parent belongs to (an earlier level: final)
-    const int32_t l = m ? (int32_t)m : (K == TINF ? 0 : runlabel[(uint32_t)(K & 0xFFFFFFFFull)]); // (TINF cannot happen: no wild read if it does)
-    runlabel[roff + i] = l;
-    tau[p] = ((unsigned long long)gbase << 32) | (unsigned long long)(roff + i);
-    front[i] = p;
-    if (m && i > 0 && (int)mk[val[i - 1]] != m) atomicAdd(&st->mixed, 1u); // markers sort first: val[i-1] is one too
 }
 
 __device__ __forceinline__ bool sk_pair_less(unsigned long long ka, uint32_t va, unsigned long long kb, uint32_t vb) {
@@ -1021,7 +997,6 @@ __global__ __launch_bounds__(256) void k_sk_round(WsGeom g, const uint32_t *__re
 // agent-scope atomic access (sc1 on gfx950: served at the point all XCDs share), so a round boundary needs no L2 write-back /
 // invalidate: a workgroup waits for its own stores (s_waitcnt) and signs the ticket.  (With __threadfence() pairs instead,
 // every round paid the write-back of eight L2s: 36 us per round, measured -- four times a launch.)
-constexpr uint32_t SEQ_DONE = 0x3FFFFFFFu;
 constexpr uint32_t SK_SPIN_LIMIT = 1u << 22; // polls of ~0.5 us: a lost hand-over ends the launch with done = 3, it never hangs
 
 __device__ __forceinline__ uint32_t ld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
