@@ -228,29 +228,38 @@ __global__ __launch_bounds__(1024) void k_sk_prevlevel(const uint32_t *__restric
     }
 }
 
-// generation 0 bucketed by (level, late): bucket 2 c holds the voxels of level c whose key is final one level early (markers
-// among them), bucket 2 c + 1 the late ones -- a level's list is one stretch, early part first.  (k_ws_bucket's scheme.)
-constexpr int BK2_LB = 8192;
+// generation 0 bucketed by (level, late) -- bucket 2 c holds the voxels of level c whose key is final one level early (markers
+// among them), bucket 2 c + 1 the late ones: a level's list is one stretch, early part first -- and, in the same pass, the drained
+// voxels by level (buckets 131072 + c: their stretches follow generation 0's in the same list).  k_ws_bucket's scheme (LDS
+// counters for the low levels, their return values ARE the slots), one read of kind[] and C[] instead of two (round 6).
+constexpr int BK2_LB = 8192, BK3_D0 = 131072, BK3_N = 196608;
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void k_sk_bucket2(int64_t n, const uint16_t *__restrict__ C, const uint8_t *__restrict__ kind,
+__global__ __launch_bounds__(256) void k_sk_bucket3(int64_t n, const uint16_t *__restrict__ C, const uint8_t *__restrict__ kind,
                                                     uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist) {
     __shared__ uint32_t sh[BK2_LB];
+    __shared__ uint32_t shd[BK_LB];
     for (int i = threadIdx.x; i < BK2_LB; i += 256) sh[i] = 0;
+    for (int i = threadIdx.x; i < BK_LB; i += 256) shd[i] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
     for (int pass = 0; pass < (SCATTER ? 2 : 1); pass++) {
         for (int j = 0; j < BK_CH; j++) {
             const int64_t p = b0 + (int64_t)j * 256 + threadIdx.x;
             const uint8_t kd = p < n ? kind[p] : (uint8_t)0;
-            if (kd != KIND_GEN0 && kd != KIND_GEN0_LATE) continue;
-            const uint32_t bk = 2u * C[p] + (kd == KIND_GEN0_LATE ? 1u : 0u);
-            if (bk < (uint32_t)BK2_LB) {
-                const uint32_t off = atomicAdd(&sh[bk], 1u);
-                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
-            } else if (!SCATTER || pass == 1) {
-                const uint32_t off = atomicAdd(&hist_or_cursor[bk], 1u);
-                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
+            if (!kd) continue;
+            const uint32_t c = C[p];
+            uint32_t off;
+            if (kd == KIND_DRAINED) {
+                if (c < (uint32_t)BK_LB) off = atomicAdd(&shd[c], 1u);
+                else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[BK3_D0 + c], 1u);
+                else continue;
+            } else {
+                const uint32_t bk = 2u * c + (kd == KIND_GEN0_LATE ? 1u : 0u);
+                if (bk < (uint32_t)BK2_LB) off = atomicAdd(&sh[bk], 1u);
+                else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[bk], 1u);
+                else continue;
             }
+            if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
         }
         __syncthreads();
         if (pass == 0) {
@@ -259,6 +268,13 @@ __global__ __launch_bounds__(256) void k_sk_bucket2(int64_t n, const uint16_t *_
                 if (v) {
                     const uint32_t base = atomicAdd(&hist_or_cursor[i], v);
                     if (SCATTER) sh[i] = base;
+                }
+            }
+            for (int i = threadIdx.x; i < BK_LB; i += 256) {
+                const uint32_t v = shd[i];
+                if (v) {
+                    const uint32_t base = atomicAdd(&hist_or_cursor[BK3_D0 + i], v);
+                    if (SCATTER) shd[i] = base;
                 }
             }
             __syncthreads();
@@ -1607,14 +1623,14 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->comp = (uint32_t *)take((size_t)g.n * 4);
     b->zmask = (uint32_t *)take((size_t)g.n * 4);
     b->pmask = (uint32_t *)take((size_t)g.n * 4);
-    b->dlist = (uint32_t *)take((size_t)g.n * 4);
+    b->dlist = nullptr; // (set once generation 0 has been counted: the drained voxels share elist, behind generation 0)
     b->elist = (uint32_t *)take((size_t)g.n * 4);
     for (int i = 0; i < 2; i++) b->lists[i] = (uint32_t *)take((size_t)g.n * 4);
-    b->hist = (uint32_t *)take(131072 * 4); // (level, late) buckets
-    b->cursor = (uint32_t *)take(131072 * 4);
+    b->hist = (uint32_t *)take((size_t)BK3_N * 4); // (level, late) buckets of generation 0, then the drained voxels' levels
+    b->cursor = (uint32_t *)take((size_t)BK3_N * 4);
     b->prevl = (uint16_t *)take(65536 * 2);
-    b->dhist = (uint32_t *)take(65536 * 4);
-    b->dcursor = (uint32_t *)take(65536 * 4);
+    b->dhist = b->hist ? b->hist + BK3_D0 : nullptr;
+    b->dcursor = b->cursor ? b->cursor + BK3_D0 : nullptr;
     b->lhist = (uint32_t *)take(65536 * 4);
     b->mbits = (uint32_t *)take(2048 * 4);
     b->bcount = (uint32_t *)take((size_t)(nblk + 1) * 4);
@@ -1731,28 +1747,16 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         const int rc = ws_zone_union(g, conn, b.zmask, b.comp, st);
         if (rc != IVX_OK) return rc;
     }
-    IVX_HIP(hipMemsetAsync(b.hist, 0, 131072 * 4, st));
-    IVX_HIP(hipMemsetAsync(b.dhist, 0, 65536 * 4, st));
-    std::vector<uint32_t> hist2(131072), dhist(65536);
-    { // generation 0 -> elist, a level's early part then its late part (bucket 2 c, 2 c + 1)
-        hipLaunchKernelGGL(k_sk_bucket2<false>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.hist, b.elist);
+    IVX_HIP(hipMemsetAsync(b.hist, 0, (size_t)BK3_N * 4, st));
+    std::vector<uint32_t> hist3(BK3_N), dhist(65536);
+    { // generation 0 (a level's early part, then its late part) and, behind all of it, the drained voxels: ONE list, two passes
+        hipLaunchKernelGGL(k_sk_bucket3<false>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.hist, b.elist);
         IVX_LAUNCH_CHECK();
-        IVX_HIP(hipMemcpyAsync(hist2.data(), b.hist, 131072 * 4, hipMemcpyDeviceToHost, st));
-        IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, 131072 * 4, hipMemcpyDeviceToDevice, st));
-        const int rc = scan_u32_exclusive(b.cursor, 131072, b.bsum, b.total, st);
+        IVX_HIP(hipMemcpyAsync(hist3.data(), b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToHost, st));
+        IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToDevice, st));
+        const int rc = scan_u32_exclusive(b.cursor, BK3_N, b.bsum, b.total, st);
         if (rc != IVX_OK) return rc;
-        hipLaunchKernelGGL(k_sk_bucket2<true>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.cursor, b.elist);
-        IVX_LAUNCH_CHECK();
-    }
-    { // drained voxels -> dlist
-        const SkKindPred pred{b.kind, KIND_DRAINED};
-        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, b.dhist, b.dlist);
-        IVX_LAUNCH_CHECK();
-        IVX_HIP(hipMemcpyAsync(dhist.data(), b.dhist, 65536 * 4, hipMemcpyDeviceToHost, st));
-        IVX_HIP(hipMemcpyAsync(b.dcursor, b.dhist, 65536 * 4, hipMemcpyDeviceToDevice, st));
-        const int rc = scan_u32_exclusive(b.dcursor, 65536, b.bsum, b.total, st);
-        if (rc != IVX_OK) return rc;
-        hipLaunchKernelGGL((k_ws_bucket<SkKindPred, true>), dim3(gbk), dim3(256), 0, st, g.n, b.C, pred, b.dcursor, b.dlist);
+        hipLaunchKernelGGL(k_sk_bucket3<true>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.cursor, b.elist);
         IVX_LAUNCH_CHECK();
     }
     std::vector<uint32_t> mbits(2048); // levels that hold markers
@@ -1761,10 +1765,14 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipStreamSynchronize(st)); // the histograms are on the host now
     std::vector<uint32_t> hist(65536), hist_l(65536); // generation 0 per level: all of it, its late part
+    uint64_t ngen0_all = 0;
     for (uint32_t c = 0; c < 65536; c++) {
-        hist[c] = hist2[2 * c] + hist2[2 * c + 1];
-        hist_l[c] = hist2[2 * c + 1];
+        hist[c] = hist3[2 * c] + hist3[2 * c + 1];
+        hist_l[c] = hist3[2 * c + 1];
+        dhist[c] = hist3[BK3_D0 + c];
+        ngen0_all += hist[c];
     }
+    b.dlist = b.elist + ngen0_all; // (the drained voxels' stretches follow generation 0's in the one list)
     uint64_t ngen0 = 0;
     uint32_t maxcnt = 0;
     for (uint32_t c = 0; c < 65535; c++) { // (65535 = never reached: no generation 0 there)
@@ -1904,7 +1912,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const char *senv = getenv("IVX_SK_SMALL"); // 0: never take the one-workgroup path (A/B measurements)
     const bool small_on = !(senv && senv[0] == '0');
     auto is_small = [&](uint32_t c) { return small_on && hist[c] <= (uint32_t)SMALL_GEN0 && lhist[c] <= SMALL_TOTAL; };
-    SkSmallArgs sa{b.C, I, b.comp, b.pmask, b.zmask, b.elist, b.dlist, b.hist, b.cursor, b.dhist, b.dcursor, b.tau, b.runlabel,
+    SkSmallArgs sa{b.C, I, b.comp, b.pmask, b.zmask, b.elist, /* dcursor holds positions in the one list: */ b.elist, b.hist, b.cursor, b.dhist, b.dcursor, b.tau, b.runlabel,
                    b.lists[0], b.lists[1], b.st};
     static const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
     const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
