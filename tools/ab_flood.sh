@@ -1,7 +1,6 @@
-# A/B of the region-growing engine's knobs on the bench step (each run its own process: the knobs are read once)
+# the bench step and the same step past the cache (each run its own process)
 run() { timeout 300 python bench.py --no-others --no-cpu $X < /dev/null 2>/dev/null | python -c "
 import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['ms_per_step'], j.get('stage_ms'), j.get('region_grow_rounds'))"; }
-X=""; echo default; run
-X="--config watershed --size 512"; echo ift512; run
-X="--config watershed_sk --size 512"; echo sk512; run
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['ms_per_step'], j.get('stage_ms'), j['roofline'].get('per_stage_frac'))"; }
+X=""; echo 512; run; run
+X="--size 1024 --hbm-synth"; echo 1024; run
