@@ -75,7 +75,8 @@ int ivx_memcpy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
 /* the sharded flood's vote words (invesalius3_amd/parallel.py, slab_region_grow; no counterpart upstream -- the reference has no
  * multi-GPU code): votes[0] = what ivx_comm_exchange_vote all-reduces, votes[1] = the words this rank's last OR gained.
  * _set: both words by a one-thread kernel; _read: both words to the host through the pinned mailbox (no stream
- * synchronisation), after which votes[0] <- votes[1] on the device -- staged for the next round's all-reduce */
+ * synchronisation), after which votes[0] <- votes[1] and votes[1] <- 0 on the device -- staged for the next round's all-reduce and
+ * for ivx_dev_flood_or_planes_acc */
 int ivx_dev_vote_set(int32_t *votes, int32_t v0, int32_t v1, void *stream);
 int ivx_dev_vote_read(int32_t *votes, int32_t out[2], void *stream);
 /* page-locked host memory (hipHostMalloc): arrays kept there cross PCIe at the link's rate instead of through the runtime's
@@ -505,6 +506,10 @@ int ivx_dev_flood_or_planes(const ivx_flood_plan *p, const uint64_t *cand, uint6
 /* the same with NO read-back: the count is left in the caller's DEVICE word, where ivx_comm_exchange_vote's all-reduce
  * reads it in the next round */
 int ivx_dev_flood_or_planes_dev(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
+                                const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch,
+                                uint32_t *changed_dev, void *stream);
+/* the same, the count ADDED to the caller's device word (ivx_dev_vote_read leaves it at zero: no fill per round) */
+int ivx_dev_flood_or_planes_acc(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
                                 const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch,
                                 uint32_t *changed_dev, void *stream);
 /* out[v] = fill where reached (uint8 out), or data[v] = fill (in-place form, dtype of data) */

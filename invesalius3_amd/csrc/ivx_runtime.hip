@@ -521,6 +521,7 @@ __global__ void k_vote_publish(int32_t *v, uint32_t *mb, uint32_t seq) {
     mb[0] = (uint32_t)a;
     mb[1] = (uint32_t)b;
     v[0] = b;
+    v[1] = 0; // (ivx_dev_flood_or_planes_acc adds the next round's gains to it)
     __threadfence_system();
     __hip_atomic_store(&mb[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -2618,9 +2618,21 @@ extern "C" int ivx_dev_flood_or_plane(const ivx_flood_plan *p, const uint64_t *c
 // The same, without any read-back: the number of words that gained bits is left in the caller's DEVICE word (overwritten),
 // where the next exchange's all-reduce picks it up (ivx_comm_exchange_vote): a sharded region-growing round is
 // enqueue-only up to its single host read.
+static int or_planes_dev_impl(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a, const uint64_t *plane_a,
+                              int64_t z_b, const uint64_t *plane_b, void *scratch_, uint32_t *changed_dev, void *stream, bool zero);
 extern "C" int ivx_dev_flood_or_planes_dev(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
                                            const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch_,
                                            uint32_t *changed_dev, void *stream) {
+    return or_planes_dev_impl(p, cand, reached, z_a, plane_a, z_b, plane_b, scratch_, changed_dev, stream, true);
+}
+// ... ADDED to the caller's device word (which ivx_dev_vote_read left at zero): no 4-byte fill in front of every round
+extern "C" int ivx_dev_flood_or_planes_acc(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a,
+                                           const uint64_t *plane_a, int64_t z_b, const uint64_t *plane_b, void *scratch_,
+                                           uint32_t *changed_dev, void *stream) {
+    return or_planes_dev_impl(p, cand, reached, z_a, plane_a, z_b, plane_b, scratch_, changed_dev, stream, false);
+}
+static int or_planes_dev_impl(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, int64_t z_a, const uint64_t *plane_a,
+                              int64_t z_b, const uint64_t *plane_b, void *scratch_, uint32_t *changed_dev, void *stream, bool zero) {
     Tiles t;
     int rc = make_tiles(p, &t);
     if (rc) return rc;
@@ -2628,7 +2640,7 @@ extern "C" int ivx_dev_flood_or_planes_dev(const ivx_flood_plan *p, const uint64
     const int64_t nw = t.dy * t.wx;
     IVX_REQUIRE(changed_dev, IVX_EINVAL, "flood: null counter");
     hipStream_t st = ivx::S(stream);
-    IVX_HIP(hipMemsetAsync(changed_dev, 0, 4, st));
+    if (zero) IVX_HIP(hipMemsetAsync(changed_dev, 0, 4, st));
     if (!nw || (!plane_a && !plane_b)) return IVX_OK;
     uint8_t *dirty = (uint8_t *)((char *)scratch_ + s.off_dirty0);
     const int64_t zs[2] = {z_a, z_b};

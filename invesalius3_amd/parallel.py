@@ -227,7 +227,7 @@ def _make_slab_volume():
 
         def _seed_votes(self):
             """before round 1: "something happened" = the seeds -- already staged for the first all-reduce"""
-            L.check(L.lib().ivx_dev_vote_set(self._votes.ptr, 1, 1, self.stream), "vote_set")
+            L.check(L.lib().ivx_dev_vote_set(self._votes.ptr, 1, 0, self.stream), "vote_set")  # votes[1]: or_planes adds to it
 
         def stage_vote(self):
             """(nothing to queue: read_votes leaves votes[0] <- votes[1] behind on the device, _seed_votes sets both words.
@@ -236,7 +236,7 @@ def _make_slab_volume():
         def or_planes(self):
             pd = self._recv[0].ptr if self.lay.hb else None
             pu = self._recv[1].ptr if self.lay.ht else None
-            L.check(L.lib().ivx_dev_flood_or_planes_dev(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr, c64(0), pd,
+            L.check(L.lib().ivx_dev_flood_or_planes_acc(ctypes.byref(self.plan), self._cand.ptr, self.reached.ptr, c64(0), pd,
                                                         c64(self.lay.local_dz - 1), pu, self.flood_scratch.ptr,
                                                         self._votes.at(4), self.stream), "flood_or_planes")
 
