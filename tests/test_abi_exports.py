@@ -51,6 +51,8 @@ def test_product_never_imports_oracle():
                             r"CDLL\([^)]*oracle|dlopen\([^)]*oracle|#\s*include\s*[<\"][^>\"]*oracle|libivx_oracle)")
     bad_torch = re.compile(r"^\s*(from|import)\s+torch\b")
     bad_cpu_lib = re.compile(r"^\s*(from|import)\s+(scipy|skimage|sklearn|vtk|vtkmodules)\b")  # no third-party CPU arithmetic either
+    # ... and no device library kernels either: every kernel of libivx.so is in csrc/ (round 6 removed the last one, rocPRIM's radix sort)
+    bad_gpu_lib = re.compile(r"#\s*include\s*[<\"](rocprim|hipcub|thrust|rocthrust|cub|hipblas|rocblas|miopen|ck|ck_tile)[/.]")
     seen = 0
     for dirpath, dirs, files in os.walk(pkg):
         dirs[:] = [d for d in dirs if d not in ("build", "__pycache__")]
@@ -62,6 +64,7 @@ def test_product_never_imports_oracle():
                 assert not bad_oracle.search(line), "%s:%d reaches into oracle/: %s" % (f, n, line.strip())
                 assert not bad_torch.search(line), "%s:%d imports torch: %s" % (f, n, line.strip())
                 assert not bad_cpu_lib.search(line), "%s:%d imports a CPU library: %s" % (f, n, line.strip())
+                assert not bad_gpu_lib.search(line), "%s:%d includes a device library: %s" % (f, n, line.strip())
     assert seen > 20
     # build.py links only the package's own objects
     assert "oracle" not in open(os.path.join(pkg, "build.py")).read()
