@@ -84,7 +84,11 @@ struct SkState {
     // what a workgroup needs to decide whether it takes part in a launch, in ONE word (read with one atomic load):
     // bits 0..31 entries of the frontier, 32 phase, 33 which list, 34..63 sequence number of the launch it describes
     unsigned long long ctl;
-    uint32_t pad1[16];
+    // k_sk_level's ticket (round 6): bits 48.. workgroups of the running round that have finished, 32..47 how many of them
+    // stamped a basin for the first time, 0..31 list entries they appended -- the workgroup that closes the round learns all three
+    // from the ONE returning atomic that tells it it is the last (before: ticket, then a dependent trip for the two counters)
+    unsigned long long tick64;
+    uint32_t pad1[14];
     // the resident launch (k_sk_level) polls its control word from every workgroup: a line of its own, away from the counters
     // the working workgroups add to
     unsigned long long pctl;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256) void k_sk_split_assign(const unsigned long lon
         const uint32_t cnt = cnt_e + cnt_l;
         st->done = 0; st->gen = gbase; st->n_in = cnt;
         st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->tick64 = 0; st->joined = 0; st->arrived = 0;
         st->ctl = sk_ctl(seq, 0, 0, cnt);
         st->pctl = sk_pctl(0, 0, 0, 0, cnt);
     }
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(G0_T) void k_sk_gen0(WsGeom g, const uint16_t *__re
     if (chunk == 0 && tid == 0) { // the level's frontier loop starts from list 0, phase A (as k_sk_assign)
         st->done = 0; st->gen = gbase; st->n_in = cnt;
         st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->tick64 = 0; st->joined = 0; st->arrived = 0;
         st->ctl = sk_ctl(seq, 0, 0, cnt);
         st->pctl = sk_pctl(0, 0, 0, 0, cnt);
     }
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(256) void k_sk_assign_ranked(const unsigned long lo
     if (i == 0 && pos_off == 0) {
         st->done = 0; st->gen = gbase; st->n_in = total;
         st->phase = 0; st->in_sel = 0;
-        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->joined = 0; st->arrived = 0;
+        st->n_next = 0; st->n_stamped = 0; st->ticket = 0; st->tick64 = 0; st->joined = 0; st->arrived = 0;
         st->ctl = sk_ctl(seq, 0, 0, total);
         st->pctl = sk_pctl(0, 0, 0, 0, total);
     }
@@ -851,6 +855,7 @@ constexpr int WB_CAP = 1024;
 struct SkStage {
     volatile uint32_t buf[4][WB_CAP];
     volatile uint32_t n[4];
+    uint32_t pushed, stamped; // what this workgroup appended / stamped in the running round (k_sk_level's ticket carries them)
 };
 
 // LOCAL (k_sk_level on ONE XCD, see there): what crosses workgroups is written with workgroup-scope operations -- performed in
@@ -863,6 +868,10 @@ template <bool LOCAL> __device__ __forceinline__ uint32_t sk_add32(uint32_t *p, 
 template <bool LOCAL> __device__ __forceinline__ unsigned long long sk_min64(unsigned long long *p, unsigned long long v) {
     if constexpr (LOCAL) return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LOCAL> __device__ __forceinline__ unsigned long long sk_add64(unsigned long long *p, unsigned long long v) {
+    if constexpr (LOCAL) return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool LOCAL> __device__ __forceinline__ void sk_store32(uint32_t *p, uint32_t v) {
     if constexpr (LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -884,7 +893,10 @@ __device__ __forceinline__ void stage_push(bool want, uint32_t v, SkStage &sg, u
     if (lane == leader) {
         base = sg.n[wv];
         if (base + n <= WB_CAP) sg.n[wv] = base + n;
-        else base = 0x80000000u | sk_add32<LOCAL>(gcnt, n); // no room (rare): straight to the global list
+        else {
+            base = 0x80000000u | sk_add32<LOCAL>(gcnt, n); // no room (rare): straight to the global list
+            atomicAdd(&sg.pushed, n);
+        }
     }
     base = __shfl(base, leader, 64);
     if (!want) return;
@@ -899,7 +911,10 @@ __device__ __forceinline__ void stage_flush(SkStage &sg, uint32_t *glist, uint32
     const uint32_t n = sg.n[wv];
     if (!n) return;
     uint32_t off = 0;
-    if (lane == 0) off = sk_add32<LOCAL>(gcnt, n);
+    if (lane == 0) {
+        off = sk_add32<LOCAL>(gcnt, n);
+        atomicAdd(&sg.pushed, n);
+    }
     off = __shfl(off, 0, 64);
     // (agent-scope stores: inside the resident launch the next round's readers sit on other XCDs, behind other L2s -- unless LOCAL)
     for (uint32_t j = lane; j < n; j += 64) sk_store32<LOCAL>(&glist[off + j], sg.buf[wv][j]);
@@ -1059,6 +1074,7 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
     uint32_t *next = L.l[in_sel ^ 1u];
     const uint32_t stride = nactive * 256;
     if (threadIdx.x < 4) sg.n[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { sg.pushed = 0; sg.stamped = 0; }
     __syncthreads();
     const bool tr = SK_TICKS && wg == 0 && threadIdx.x == 0;
     unsigned long long tk = tr ? wall_clock64() : 0ull;
@@ -1131,7 +1147,7 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
         stage_flush<LOCAL>(sg, next, &st->n_next);
         if (SK_TICKS && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SK_TICK(3) }
     }
-    if (stamped) sk_add32<LOCAL>(&st->n_stamped, stamped);
+    if (stamped) atomicAdd(&sg.stamped, stamped); // (LDS: the ticket carries it)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0); // this wave's stores and atomics have been acknowledged
     __syncthreads();
@@ -1165,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
                                                   const uint32_t *dlist, uint32_t ndl, uint32_t per_wg, uint32_t solo_max, SkState *st) {
     __shared__ SkStage sg;
     __shared__ unsigned long long s_ctl;
-    __shared__ uint32_t s_last, s_next[4]; // s_next: phase, list, entries, 1 = level exhausted
+    __shared__ uint32_t s_last, s_next[4], s_tot[2], s_keep; // s_next: phase, list, entries, 1 = level exhausted
     uint32_t my_wg = blockIdx.x, n_wg = gridDim.x;
     if (LOCAL) {
         __shared__ uint32_t s_id[2];
@@ -1229,28 +1245,40 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
         if (my_wg < nactive) {
             sk_level_round<CONN, LOCAL>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, my_wg, nactive);
             const unsigned long long tt0 = SK_TICKS && my_wg == 0 && threadIdx.x == 0 ? wall_clock64() : 0ull;
-            if (threadIdx.x == 0) s_last = sk_add32<LOCAL>(&st->ticket, 1u) == nactive - 1;
+            if (threadIdx.x == 0) {
+                const uint32_t mine_p = sg.pushed, mine_s = sg.stamped ? 1u : 0u;
+                const unsigned long long old = sk_add64<LOCAL>(&st->tick64, (1ull << 48) | ((unsigned long long)mine_s << 32) | mine_p);
+                s_last = (uint32_t)(old >> 48) == nactive - 1;
+                s_tot[0] = (uint32_t)old + mine_p;                       // list entries the whole round appended
+                s_tot[1] = ((uint32_t)(old >> 32) & 0xFFFFu) + mine_s;   // workgroups of it that stamped a basin
+            }
             __syncthreads();
             if (SK_TICKS && my_wg == 0 && threadIdx.x == 0) {
                 atomicAdd(&st->ticks[13], (uint32_t)(wall_clock64() - tt0)); // the ticket
                 atomicAdd(&st->ticks[14], 1u);                                // rounds workgroup 0 took part in
             }
             if (s_last) { // (the whole workgroup)
-                if (threadIdx.x == 0) sk_store32<LOCAL>(&st->ticket, 0u);
-                for (;;) {
+                // The ticket's low word counts the entries appended in this GENERATION (round A and, if there is one, its relay B append
+                // to the same list): it is carried into a relay and cleared when the generation advances -- s_keep is what the word has
+                // to hold when the next hand-over round starts.
+                for (bool first = true;; first = false) {
                     if (threadIdx.x == 0) {
-                        const uint32_t nst = ld32(&st->n_stamped), nnx = ld32(&st->n_next);
+                        // (the round just closed: the ticket's totals; a round of the solo stretch: this workgroup's own counts)
+                        const uint32_t nst = first ? s_tot[1] : (sg.stamped ? 1u : 0u);
+                        const uint32_t nnx = first ? s_tot[0] : s_keep + sg.pushed;
                         sk_add32<LOCAL>(&st->rounds, 1u);
-                        sk_store32<LOCAL>(&st->n_stamped, 0u);
                         if (phase == 0 && nst) { // basins were stamped: they relay before the generation advances
                             sk_add32<LOCAL>(&st->brounds, 1u);
                             s_next[0] = 1u; s_next[1] = in_sel; s_next[2] = n_front; s_next[3] = 0u;
+                            s_keep = nnx;
                         } else if (nnx) { // next generation
                             sk_store32<LOCAL>(&st->n_next, 0u);
                             sk_add32<LOCAL>(&st->gens, 1u);
                             s_next[0] = 0u; s_next[1] = in_sel ^ 1u; s_next[2] = nnx; s_next[3] = 0u;
+                            s_keep = 0u;
                         } else {
                             s_next[3] = 1u;
+                            s_keep = 0u;
                         }
                         __builtin_amdgcn_s_waitcnt(0);
                     }
@@ -1280,6 +1308,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
                     } else {
                         nctl = sk_pctl(want, cum, in_sel, phase, n_front);
                     }
+                    sk_store64<LOCAL>(&st->tick64, (unsigned long long)s_keep); // (no arrivals yet; a relay continues its generation's count)
                     __builtin_amdgcn_s_waitcnt(0);
                     sk_store64<LOCAL>(&st->pctl, nctl);
                 }
