@@ -239,7 +239,8 @@ __global__ __launch_bounds__(1024) void k_sk_prevlevel(const uint32_t *__restric
 constexpr int BK2_LB = 8192, BK3_D0 = 131072, BK3_N = 196608;
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_sk_bucket3(int64_t n, const uint16_t *__restrict__ C, const uint8_t *__restrict__ kind,
-                                                    uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist) {
+                                                    uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist,
+                                                    const uint32_t *__restrict__ comp, uint32_t *__restrict__ droot) {
     __shared__ uint32_t sh[BK2_LB];
     __shared__ uint32_t shd[BK_LB];
     for (int i = threadIdx.x; i < BK2_LB; i += 256) sh[i] = 0;
@@ -263,7 +264,10 @@ __global__ __launch_bounds__(256) void k_sk_bucket3(int64_t n, const uint16_t *_
                 else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[bk], 1u);
                 else continue;
             }
-            if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
+            if (SCATTER && pass == 1) {
+                elist[off] = (uint32_t)p;
+                if (kd == KIND_DRAINED && droot) droot[off] = comp[p]; // (its basin's root: a relay round reads it with the list)
+            }
         }
         __syncthreads();
         if (pass == 0) {
@@ -1067,7 +1071,8 @@ constexpr uint32_t SK_SOLO_MAX = 256; // list entries up to which ONE workgroup 
 template <int CONN, bool LOCAL>
 __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
                                                const uint32_t *__restrict__ comp, unsigned long long *tau, const SkLists &L,
-                                               const uint32_t *dlist, uint32_t ndl, SkState *st, SkStage &sg, uint32_t phase,
+                                               const uint32_t *dlist, const uint32_t *__restrict__ droot, uint32_t ndl, SkState *st, SkStage &sg,
+                                               uint32_t phase,
                                                uint32_t in_sel, uint32_t n_front, uint32_t gen, uint32_t wg, uint32_t nactive) {
     const uint32_t n_in = phase ? ndl : n_front;
     const uint32_t *in = phase ? dlist : L.l[in_sel];
@@ -1138,7 +1143,7 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
             if (SK_TICKS && tr) { SK_TICK(2) }
         } else {
             unsigned long long tb = TINF;
-            if (act) tb = ld64(&tau[comp[v]]);
+            if (act) tb = ld64(&tau[droot[i]]); // (the root travels with the list: no gather into comp[] on the relay's critical path)
             act = act && (uint32_t)(tb >> 32) == gen;
             if (SK_TICKS && tr) { SK_TICK(0) }
             sk_offer_plateau_wide<CONN, LOCAL>(g, tau, act ? pmask[v] : 0u, v, tb + GEN1, sg, next, st);
@@ -1178,7 +1183,8 @@ __device__ __forceinline__ void sk_level_round(const WsGeom &g, const uint32_t *
 template <int CONN, bool LOCAL>
 __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__restrict__ pmask, const uint32_t *__restrict__ zmask,
                                                   const uint32_t *__restrict__ comp, unsigned long long *tau, SkLists L,
-                                                  const uint32_t *dlist, uint32_t ndl, uint32_t per_wg, uint32_t solo_max, SkState *st) {
+                                                  const uint32_t *dlist, const uint32_t *__restrict__ droot, uint32_t ndl, uint32_t per_wg,
+                                                  uint32_t solo_max, SkState *st) {
     __shared__ SkStage sg;
     __shared__ unsigned long long s_ctl;
     __shared__ uint32_t s_last, s_next[4], s_tot[2], s_keep; // s_next: phase, list, entries, 1 = level exhausted
@@ -1243,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
         const uint32_t n_in = phase ? ndl : n_front;
         const uint32_t nactive = min(n_wg, (n_in + per_wg - 1u) / per_wg);
         if (my_wg < nactive) {
-            sk_level_round<CONN, LOCAL>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, my_wg, nactive);
+            sk_level_round<CONN, LOCAL>(g, pmask, zmask, comp, tau, L, dlist, droot, ndl, st, sg, phase, in_sel, n_front, gen, my_wg, nactive);
             const unsigned long long tt0 = SK_TICKS && my_wg == 0 && threadIdx.x == 0 ? wall_clock64() : 0ull;
             if (threadIdx.x == 0) {
                 const uint32_t mine_p = sg.pushed, mine_s = sg.stamped ? 1u : 0u;
@@ -1293,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_sk_level(WsGeom g, const uint32_t *__re
                         cum++;
                     }
                     if (!solo) break;
-                    sk_level_round<CONN, LOCAL>(g, pmask, zmask, comp, tau, L, dlist, ndl, st, sg, phase, in_sel, n_front, gen, 0u, 1u);
+                    sk_level_round<CONN, LOCAL>(g, pmask, zmask, comp, tau, L, dlist, droot, ndl, st, sg, phase, in_sel, n_front, gen, 0u, 1u);
                 }
                 if (threadIdx.x == 0) {
                     unsigned long long nctl;
@@ -1633,7 +1639,7 @@ struct SkBufs {
     uint8_t *kind, *dirty, *pending;
     unsigned long long *tau, *ekey[2];
     SkSortBufs sort[2];
-    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *lists[2], *eval[2], *hist, *cursor, *dhist, *dcursor, *lhist, *mbits, *bcount, *bsum, *tlist, *total;
+    uint32_t *comp, *zmask, *pmask, *elist, *dlist, *droot, *lists[2], *eval[2], *hist, *cursor, *dhist, *dcursor, *lhist, *mbits, *bcount, *bsum, *tlist, *total;
     int32_t *runlabel;
     WsState *wst;
     SkState *st;
@@ -1653,6 +1659,7 @@ static void sk_layout(const WsGeom &g, char *base, SkBufs *b) {
     b->zmask = (uint32_t *)take((size_t)g.n * 4);
     b->pmask = (uint32_t *)take((size_t)g.n * 4);
     b->dlist = nullptr; // (set once generation 0 has been counted: the drained voxels share elist, behind generation 0)
+    b->droot = (uint32_t *)take((size_t)g.n * 4); // the drained entries' basin roots, slot for slot beside elist
     b->elist = (uint32_t *)take((size_t)g.n * 4);
     for (int i = 0; i < 2; i++) b->lists[i] = (uint32_t *)take((size_t)g.n * 4);
     b->hist = (uint32_t *)take((size_t)BK3_N * 4); // (level, late) buckets of generation 0, then the drained voxels' levels
@@ -1779,13 +1786,13 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_HIP(hipMemsetAsync(b.hist, 0, (size_t)BK3_N * 4, st));
     std::vector<uint32_t> hist3(BK3_N), dhist(65536);
     { // generation 0 (a level's early part, then its late part) and, behind all of it, the drained voxels: ONE list, two passes
-        hipLaunchKernelGGL(k_sk_bucket3<false>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.hist, b.elist);
+        hipLaunchKernelGGL(k_sk_bucket3<false>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.hist, b.elist, b.comp, (uint32_t *)nullptr);
         IVX_LAUNCH_CHECK();
         IVX_HIP(hipMemcpyAsync(hist3.data(), b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToHost, st));
         IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToDevice, st));
         const int rc = scan_u32_exclusive(b.cursor, BK3_N, b.bsum, b.total, st);
         if (rc != IVX_OK) return rc;
-        hipLaunchKernelGGL(k_sk_bucket3<true>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.cursor, b.elist);
+        hipLaunchKernelGGL(k_sk_bucket3<true>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.cursor, b.elist, b.comp, b.droot);
         IVX_LAUNCH_CHECK();
     }
     std::vector<uint32_t> mbits(2048); // levels that hold markers
@@ -1802,6 +1809,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         ngen0_all += hist[c];
     }
     b.dlist = b.elist + ngen0_all; // (the drained voxels' stretches follow generation 0's in the one list)
+    const uint32_t *droot_d = b.droot + ngen0_all;
     uint64_t ngen0 = 0;
     uint32_t maxcnt = 0;
     for (uint32_t c = 0; c < 65535; c++) { // (65535 = never reached: no generation 0 there)
@@ -2157,10 +2165,10 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             if (level_local) { // the rounds on one XCD: an eighth of an eight times wider launch
                 const unsigned want_wgs = (unsigned)std::min<int64_t>(std::max<int64_t>(cdiv(2 * (int64_t)std::max(cnt, ndl), lvl_per_wg), 1), local_wgs);
                 WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_level<CC, true>), dim3(8 * want_wgs), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau,
-                                                          lists, b.dlist + dstart, ndl, lvl_per_wg, solo_max, b.st));
+                                                          lists, b.dlist + dstart, droot_d + dstart, ndl, lvl_per_wg, solo_max, b.st));
             } else {
                 WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_level<CC, false>), dim3(nres), dim3(256), 0, st, g, b.pmask, b.zmask, b.comp, b.tau, lists,
-                                                          b.dlist + dstart, ndl, lvl_per_wg, solo_max, b.st));
+                                                          b.dlist + dstart, droot_d + dstart, ndl, lvl_per_wg, solo_max, b.st));
             }
             IVX_LAUNCH_CHECK();
             gknown = false;
