@@ -159,8 +159,12 @@ int ivx_dev_rays_z_slab(int kind, int dtype, const void *vol, int64_t dz, int64_
  * against libm on 1.5e9 inputs) in the build this machine's glibc selects -- ivx_powf_variant(): 1 = the FMA build x86-64 glibc
  * runs on CPUs with FMA + AVX2, 0 = the plain build (override: IVX_POWF_VARIANT=fma|plain). */
 int ivx_powf_variant(void);
-/* out[i] = powf(x[i], y[i]) as the contour MIP computes it (device float arrays; variant 1 / 0 as above, -1 = this machine's) */
+/* out[i] = powf(x[i], y[i]) as the contour MIP computes it (device float arrays; variant 1 / 0 as above, -1 = this machine's).
+ * Probes of the fused MaxIP's fast power (tests): 2 / 3 = its value and its relative bound. */
 int ivx_dev_powf(const float *x, const float *y, float *out, int64_t n, int variant, void *stream);
+/* (tests) the bounds the fused contour MaxIP folds for one voxel: d = the wrapped int16 difference along the ray, other = the two
+ * across it (int16 pair in a word), n = the exponent in [1, 64]; the reference's float32 value must lie in [lo, hi]. */
+int ivx_dev_fcm_bounds(const int32_t *d, const uint32_t *other, float n, float *lo, float *hi, int64_t count, void *stream);
 int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
                        void *tmp /* same dtype/shape */, int *status, void *stream);
 /* fast_countour_mip_internal with tmip == 0 (invesalius_rs/src/mips.rs:237-247: tmp = contour volume, out = fold_axis max):

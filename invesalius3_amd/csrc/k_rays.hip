@@ -505,6 +505,43 @@ __device__ __forceinline__ void fcm_value_fast(int16_t xm, int16_t xp, int16_t y
     }
 }
 
+// Exponent 1 (the GUI's default): v = gm * (1 - |d| / gm) IS gm - |d| up to rounding, and with D = the wrapped int16 differences
+// (g = D / 2) that is (sqrt(D0^2 + D1^2 + D2^2) - |Dray|) / 2.  The fold keeps t = v_sqrt_f32(S) - |Dray| (S exact in 32 bits:
+// three squares of at most 2^30; the unit's root is good to 1 ulp) and the ray's largest S; the pixel's bounds are
+// max(t) / 2 -+ sqrt(max S) / 2 * 2^-20 (k_fcm_max_decide).  Why that holds, with gm and v the real values: the reference's float
+// sequence gives gm (1 + a) * (base + b) * (1 + r) with |a| <= 2.5 * 2^-24 (squares and sums rounded, correctly rounded root),
+// |b| <= 2^-22 (quotient 3.5 * 2^-24, 1 - q half an ulp of 1), |r| <= 2^-24: within gm * 2^-22 + v * 3.5 * 2^-24 of gm - |d|; this
+// one (S rounded once, the unit's root, one subtraction) within gm * 1.25 * 2^-23 + v * 2^-24 -- together, v <= gm, at most
+// 0.69 * gm * 2^-20 for the voxel, and the ray's largest gm bounds every voxel's.  ~16 instructions a voxel instead of ~45 with the
+// correctly rounded root and quotient (the exponent-1 fold was ALU-bound at 0.17 of the roofline); tests/test_gpu_rays.py checks
+// the bound on 8 M gradients (worst observed: 0.2 of it).
+__device__ __forceinline__ void fcm_lin_fold(int dray, int da, int db, float *t_max, uint32_t *s_max) {
+    const uint32_t S = (uint32_t)(dray * dray) + (uint32_t)(da * da) + (uint32_t)(db * db);
+    const float t = __builtin_amdgcn_sqrtf((float)S) - fabsf((float)dray);
+    *t_max = t > *t_max ? t : *t_max;
+    *s_max = S > *s_max ? S : *s_max;
+}
+
+// Exponents >= 1 other than 1: the same integer S, the unit's reciprocal root for both gm and the quotient, fcm_pow_fast for the
+// power.  Against the reference's float sequence: base within 2^-21 (2^-22 each side of the real 1 - |d| / gm: see above; here
+// the quotient is |D| * v_rsq_f32(S), 1.75 * 2^-23 relative, and 1 - q half an ulp), and for x, y in [0, 1], n >= 1,
+// |x^n - y^n| <= n |x - y|: the power within n * 2^-21 + the fast power's own bound; gm (S * rsq / 2) within 2.5 * 2^-23 relative.
+// Bounds: v (1 -+ (rel + 2^-21)) -+ gm * n * 2^-21.  ~35 instructions a voxel against ~80 with the correctly rounded root and
+// quotient in front of the same fast power.
+__device__ __forceinline__ void fcm_pow_fold(int dray, int da, int db, float n, float *lo_max, float *hi_max) {
+    const uint32_t S = (uint32_t)(dray * dray) + (uint32_t)(da * da) + (uint32_t)(db * db);
+    const float Sf = (float)S;
+    const float r = __builtin_amdgcn_rsqf(Sf);
+    const float gm2 = S ? Sf * r : 0.0f; // sqrt(S) = 2 gm
+    const float base = S ? 1.0f - fabsf((float)dray) * r : 0.0f;
+    float rel;
+    const float v = 0.5f * gm2 * fcm_pow_fast(base, n, &rel);
+    const float e = v * (rel + 4.76837158203125e-7f) + gm2 * (n * 2.384185791015625e-7f); // gm * n * 2^-21 = gm2 * n * 2^-22
+    const float lo = v - e, hi = v + e;
+    *lo_max = lo > *lo_max ? lo : *lo_max;
+    *hi_max = hi > *hi_max ? hi : *hi_max;
+}
+
 __device__ __forceinline__ float fcm_value(int16_t xm, int16_t xp, int16_t ym, int16_t yp, int16_t zm, int16_t zp, float n,
                                            int axis, int pmode, const PowTabs *pt) {
     const float g0 = fd_sub<int16_t>(xp, xm) / (2.0f * 1.0f);
@@ -523,10 +560,10 @@ __device__ __forceinline__ float fcm_value(int16_t xm, int16_t xp, int16_t ym, i
 
 // FAST: fcm_value_fast's bounds folded instead of the exact value -- two partial planes per segment (lower, upper; the upper ones
 // behind all the lower ones), decided or handed to k_fcm_fix by k_fcm_max_combine
-template <int AXIS, bool FAST>
+template <int AXIS, int FAST> // FAST 0: exact; 1: bounds of the power; 2: exponent 1 (fcm_lin_fold); 3: exponents >= 1 (fcm_pow_fold)
 __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx,
                                                       float n, int pmode, int64_t seg, float *__restrict__ partial,
-                                                      int *__restrict__ status) {
+                                                      int *__restrict__ status, uint32_t *nlist) {
     __shared__ PowTabs s_pt;
     if (!FAST) fcm_pow_setup(&s_pt);
     const PowTabs *pt = &s_pt;
@@ -534,6 +571,7 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
     const int64_t cpr = sx / 8;
     const int64_t nr = AXIS == 0 ? sy : sz, len = AXIS == 0 ? sz : sy;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (FAST && nlist && t == 0 && blockIdx.y == 0) *nlist = 0; // (k_fcm_max_decide's list starts empty: it runs behind this kernel)
     if (t >= nr * cpr) return;
     const int64_t r = t / cpr, x0 = (t - r * cpr) * 8;
     const int64_t l0 = (int64_t)blockIdx.y * seg, l1 = l0 + seg < len ? l0 + seg : len;
@@ -546,7 +584,10 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
     rshort8_t prev = ld(col + (l0 == 0 ? 0 : l0 - 1) * sl), cur = ld(col + l0 * sl);
     float acc[8], acc_hi[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) acc[e] = acc_hi[e] = -INFINITY;
+    for (int e = 0; e < 8; e++) {
+        acc[e] = -INFINITY;
+        acc_hi[e] = FAST == 2 ? 0.0f : -INFINITY; // (FAST == 2: the bits of the largest S, an unsigned integer)
+    }
     bool bad = false;
 #pragma unroll 2
     for (int64_t l = l0; l < l1; l++) {
@@ -556,10 +597,25 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
         const int16_t *row = col + l * sl - x0;
         const int16_t left = x0 == 0 ? (int16_t)cur[0] : row[x0 - 1];
         const int16_t right = x0 + 8 == sx ? (int16_t)cur[7] : row[x0 + 8];
+        rshort8_t dx8, da8, dl8; // FAST >= 2: the three differences of the whole chunk, wrapping in 16 bits like the reference's T
+        if (FAST >= 2) {
+            rshort8_t xm8 = __builtin_shufflevector(cur, cur, 0, 0, 1, 2, 3, 4, 5, 6), xp8 = __builtin_shufflevector(cur, cur, 1, 2, 3, 4, 5, 6, 7, 7);
+            xm8[0] = left;
+            xp8[7] = right;
+            dx8 = xp8 - xm8;
+            da8 = ap - am;
+            dl8 = next - prev;
+        }
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int16_t xm = e == 0 ? left : (int16_t)cur[e - 1], xp = e == 7 ? right : (int16_t)cur[e + 1];
-            if (FAST) {
+            if (FAST == 2) { // (the ray runs along prev -> next for both axes)
+                uint32_t sm = __float_as_uint(acc_hi[e]);
+                fcm_lin_fold((int)dl8[e], (int)dx8[e], (int)da8[e], &acc[e], &sm);
+                acc_hi[e] = __uint_as_float(sm);
+            } else if (FAST == 3) {
+                fcm_pow_fold((int)dl8[e], (int)dx8[e], (int)da8[e], n, &acc[e], &acc_hi[e]);
+            } else if (FAST) {
                 float lo, hi;
                 if (AXIS == 0) fcm_value_fast(xm, xp, (int16_t)am[e], (int16_t)ap[e], (int16_t)prev[e], (int16_t)next[e], n, 0, &lo, &hi);
                 else fcm_value_fast(xm, xp, (int16_t)prev[e], (int16_t)next[e], (int16_t)am[e], (int16_t)ap[e], n, 1, &lo, &hi);
@@ -586,13 +642,14 @@ __global__ __launch_bounds__(256) void k_fcm_max_walk(const int16_t *__restrict_
     }
 }
 
-template <bool FAST> // FAST: the bounds' two planes (partial: lower then upper, one segment) instead of the pixel
+template <int FAST> // FAST (1 / 2 as above): the bounds' two planes (partial: lower then upper, one segment) instead of the pixel
 __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx, float n,
                                                       int pmode, int16_t *__restrict__ out, float *__restrict__ partial,
-                                                      int *__restrict__ status) {
+                                                      int *__restrict__ status, uint32_t *nlist) {
     __shared__ PowTabs s_pt;
     if (!FAST) fcm_pow_setup(&s_pt);
     const PowTabs *pt = &s_pt;
+    if (FAST && nlist && blockIdx.x == 0 && threadIdx.x == 0) *nlist = 0;
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= sz * sy) return;
@@ -603,6 +660,7 @@ __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict_
     const int16_t *rym = img + (z * sy + py) * sx, *ryp = img + (z * sy + fy) * sx;
     const int16_t *rzm = img + (pz * sy + y) * sx, *rzp = img + (fz * sy + y) * sx;
     float acc = -INFINITY, acc_hi = -INFINITY;
+    uint32_t acc_s = 0; // (FAST == 2: the largest S)
     bool bad = false;
     for (int64_t x0 = (int64_t)lane * 8; x0 < sx; x0 += 512) {
         const rshort8_t c = *reinterpret_cast<const rshort8_t *>(row + x0);
@@ -610,10 +668,15 @@ __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict_
         const rshort8_t zm = *reinterpret_cast<const rshort8_t *>(rzm + x0), zp = *reinterpret_cast<const rshort8_t *>(rzp + x0);
         const int16_t left = x0 == 0 ? (int16_t)c[0] : row[x0 - 1];
         const int16_t right = x0 + 8 == sx ? (int16_t)c[7] : row[x0 + 8];
+        const rshort8_t dy8 = yp - ym, dz8 = zp - zm;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int16_t xm = e == 0 ? left : (int16_t)c[e - 1], xp = e == 7 ? right : (int16_t)c[e + 1];
-            if (FAST) {
+            if (FAST == 2) { // (the ray runs along x)
+                fcm_lin_fold((int)(int16_t)((uint16_t)xp - (uint16_t)xm), (int)dy8[e], (int)dz8[e], &acc, &acc_s);
+            } else if (FAST == 3) {
+                fcm_pow_fold((int)(int16_t)((uint16_t)xp - (uint16_t)xm), (int)dy8[e], (int)dz8[e], n, &acc, &acc_hi);
+            } else if (FAST) {
                 float lo, hi;
                 fcm_value_fast(xm, xp, (int16_t)ym[e], (int16_t)yp[e], (int16_t)zm[e], (int16_t)zp[e], n, 2, &lo, &hi);
                 acc = lo > acc ? lo : acc;
@@ -629,7 +692,10 @@ __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict_
     for (int o = 32; o > 0; o >>= 1) {
         const float b = __shfl_xor(acc, o, 64);
         acc = b > acc ? b : acc;
-        if (FAST) {
+        if (FAST == 2) {
+            const uint32_t bs = (uint32_t)__shfl_xor((int)acc_s, o, 64);
+            acc_s = bs > acc_s ? bs : acc_s;
+        } else if (FAST) {
             const float bh = __shfl_xor(acc_hi, o, 64);
             acc_hi = bh > acc_hi ? bh : acc_hi;
         }
@@ -638,7 +704,7 @@ __global__ __launch_bounds__(256) void k_fcm_max_rows(const int16_t *__restrict_
     if (lane == 0) {
         if (FAST) {
             partial[ray] = acc;
-            partial[sz * sy + ray] = acc_hi;
+            partial[sz * sy + ray] = FAST == 2 ? __uint_as_float(acc_s) : acc_hi;
         } else {
             out[ray] = (int16_t)acc; // (sx >= 8 here, so acc is a real value; out of range only with `bad` set)
         }
@@ -659,39 +725,74 @@ __global__ __launch_bounds__(256) void k_fcm_max_combine(const float *__restrict
 
 // FAST fold: partial = `split` planes of lower bounds, then `split` planes of upper bounds.  A pixel whose bounds truncate to the
 // same integer is decided; the others (an integer inside the interval: a few in a thousand) go on a list for k_fcm_fix.
-__global__ __launch_bounds__(256) void k_fcm_max_decide(const float *__restrict__ partial, int64_t npix, int split, int16_t *__restrict__ out,
-                                                        uint32_t *__restrict__ list, uint32_t *nlist) {
+// lin (exponent 1): the first planes hold max t, the second ones the bits of max S (fcm_lin_fold): bounds max t / 2 -+ sqrt(max S) / 2 * 2^-20.
+__global__ __launch_bounds__(256) void k_fcm_max_decide(const float *__restrict__ partial, int64_t npix, int split, int lin,
+                                                        int16_t *__restrict__ out, uint32_t *__restrict__ list, uint32_t *nlist) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
-    float lo = partial[i], hi = partial[(int64_t)split * npix + i];
-    for (int s = 1; s < split; s++) {
-        const float a = partial[(int64_t)s * npix + i], b = partial[(int64_t)(split + s) * npix + i];
-        lo = a > lo ? a : lo;
-        hi = b > hi ? b : hi;
+    float lo = partial[i], hi = partial[(int64_t)split * npix + i], e_lin = 0.0f;
+    if (lin) {
+        uint32_t sm = __float_as_uint(hi);
+        for (int s = 1; s < split; s++) {
+            const float a = partial[(int64_t)s * npix + i];
+            const uint32_t b = __float_as_uint(partial[(int64_t)(split + s) * npix + i]);
+            lo = a > lo ? a : lo;
+            sm = b > sm ? b : sm;
+        }
+        const float v = 0.5f * lo, e = sqrtf((float)sm) * 4.76837158203125e-7f; // 2^-21 = 2^-20 / 2
+        lo = v - e;
+        hi = v + e;
+        e_lin = e;
+    } else {
+        for (int s = 1; s < split; s++) {
+            const float a = partial[(int64_t)s * npix + i], b = partial[(int64_t)(split + s) * npix + i];
+            lo = a > lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
     }
     // (values are >= 0; anything near the top of int16 goes to the exact fold, which also owns the out-of-range report)
     if (hi < 32766.0f && (int32_t)lo == (int32_t)hi) {
         out[i] = (int16_t)lo;
     } else {
+        // only the segments whose upper bound reaches the pixel's lower bound can hold the maximum: the exact pass walks those
+        // (one or two of 8 / 16: its scattered loads, not its arithmetic, are what it costs)
+        uint32_t m = 0;
+        if (!(hi < 32766.0f)) {
+            m = 0xFFFFFFFFu;
+        } else {
+            for (int s = 0; s < split; s++) { // (lin: the ray's largest S bounds every segment's)
+                const float hs = lin ? 0.5f * partial[(int64_t)s * npix + i] + e_lin : partial[(int64_t)(split + s) * npix + i];
+                if (hs >= lo) m |= 1u << s;
+            }
+        }
         out[i] = 0;
-        list[atomicAdd(nlist, 1u)] = (uint32_t)i;
+        const uint32_t k = atomicAdd(nlist, 1u);
+        list[2 * k] = (uint32_t)i;
+        list[2 * k + 1] = m;
     }
 }
 
-// the undecided pixels, exactly: one wave per pixel, lanes along the ray, glibc's powf for every voxel of it
+// the undecided pixels, exactly: one workgroup per pixel, lanes along the ray (a 512-voxel ray is two dependent rounds of seven
+// loads, not eight), the reference's float sequence -- glibc's powf, correctly rounded root and quotient -- for every voxel of it
 __global__ __launch_bounds__(256) void k_fcm_fix(const int16_t *__restrict__ img, int64_t sz, int64_t sy, int64_t sx, float n, int axis,
-                                                 int pmode, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist,
+                                                 int pmode, int64_t seg, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist,
                                                  int16_t *__restrict__ out, int *__restrict__ status) {
     __shared__ PowTabs s_pt;
-    fcm_pow_setup(&s_pt);
-    const int lane = threadIdx.x & 63;
-    const uint32_t nl = *nlist, nwaves = gridDim.x * 4u;
+    __shared__ float s_acc[4];
+    const uint32_t nl = *nlist;
+    if (blockIdx.x >= nl) return; // (whole workgroups: a few hundred pixels of 2^18 are open, most of the grid leaves here)
+    const uint2 first = reinterpret_cast<const uint2 *>(list)[blockIdx.x];
+    if (pmode != 1) fcm_pow_setup(&s_pt); // (exponent 1 takes no table)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t len = axis == 0 ? sz : axis == 1 ? sy : sx, nc = axis == 2 ? sy : sx;
-    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nl; w += nwaves) {
-        const int64_t i = list[w], r = i / nc, c = i - r * nc; // pixel (r, c): axis 0 -> (y, x), 1 -> (z, x), 2 -> (z, y)
+    for (uint32_t w = blockIdx.x; w < nl; w += gridDim.x) {
+        const uint2 ent = w == blockIdx.x ? first : reinterpret_cast<const uint2 *>(list)[w]; // (pixel, the segments of its ray still open)
+        const int64_t i = ent.x, r = i / nc, c = i - r * nc; // pixel (r, c): axis 0 -> (y, x), 1 -> (z, x), 2 -> (z, y)
         float acc = -INFINITY;
         bool bad = false;
-        for (int64_t l = lane; l < len; l += 64) {
+#pragma unroll 2
+        for (int64_t l = threadIdx.x; l < len; l += 256) {
+            if (!((ent.y >> (uint32_t)(l / seg)) & 1u)) continue;
             const int64_t z = axis == 0 ? l : r, y = axis == 0 ? r : axis == 1 ? l : c, x = axis == 2 ? l : c;
             const float v = fcm_voxel_exact(img, sz, sy, sx, z, y, x, n, axis, pmode, &s_pt);
             bad |= !(v > -32769.0f && v < 32768.0f);
@@ -703,7 +804,14 @@ __global__ __launch_bounds__(256) void k_fcm_fix(const int16_t *__restrict__ img
             acc = b > acc ? b : acc;
         }
         if (bad) atomicMin(status, IVX_EDOM);
-        if (lane == 0) out[i] = (int16_t)acc;
+        if (lane == 0) s_acc[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = s_acc[0];
+            for (int k = 1; k < 4; k++) m = s_acc[k] > m ? s_acc[k] : m;
+            out[i] = (int16_t)m;
+        }
+        __syncthreads();
     }
 }
 
@@ -852,6 +960,35 @@ extern "C" int ivx_dev_powf(const float *x, const float *y, float *out, int64_t 
     return IVX_OK;
 }
 
+// one voxel's bounds as the fused contour MaxIP folds them (tests): the wrapped int16 differences along the ray (d) and across it
+// (two int16 in a word), the exponent (1: fcm_lin_fold with k_fcm_max_decide's bound for that voxel alone; > 1: fcm_pow_fold)
+__global__ __launch_bounds__(256) void k_fcm_bounds_probe(const int32_t *__restrict__ d, const uint32_t *__restrict__ other, float n,
+                                                          float *__restrict__ lo, float *__restrict__ hi, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int da = (int)(int16_t)(other[i] & 0xFFFFu), db = (int)(int16_t)(other[i] >> 16);
+    if (n == 1.0f) {
+        float t = -INFINITY;
+        uint32_t sm = 0;
+        fcm_lin_fold(d[i], da, db, &t, &sm);
+        const float e = sqrtf((float)sm) * 4.76837158203125e-7f;
+        lo[i] = 0.5f * t - e;
+        hi[i] = 0.5f * t + e;
+    } else {
+        float l = -INFINITY, h = -INFINITY;
+        fcm_pow_fold(d[i], da, db, n, &l, &h);
+        lo[i] = l;
+        hi[i] = h;
+    }
+}
+extern "C" int ivx_dev_fcm_bounds(const int32_t *d, const uint32_t *other, float n, float *lo, float *hi, int64_t count, void *stream) {
+    IVX_REQUIRE(count >= 0 && n >= 1.0f && n <= 64.0f && (count == 0 || (d && other && lo && hi)), IVX_EINVAL, "fcm_bounds: bad arguments");
+    if (count == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_fcm_bounds_probe, dim3((unsigned)ivx::cdiv(count, 256)), dim3(256), 0, ivx::S(stream), d, other, n, lo, hi, count);
+    IVX_LAUNCH_CHECK();
+    return IVX_OK;
+}
+
 extern "C" int ivx_dev_fcm_volume(int dtype, const void *vol, int64_t dz, int64_t dy, int64_t dx, float n, int axis,
                                   void *tmp, int *status, void *stream) {
     hipStream_t st = ivx::S(stream);
@@ -891,65 +1028,68 @@ extern "C" int ivx_dev_fcm_maxip(int dtype, const void *vol, int64_t dz, int64_t
     if (fused_ok && dtype == IVX_I16 && dx % 8 == 0 && (((uintptr_t)vol) & 15) == 0) {
         const int pmode = fcm_pmode(n);
         const int16_t *img = (const int16_t *)vol;
-        // exponents other than 1: the fold on bounds from the transcendental unit, glibc's powf only for the pixels the bounds leave
-        // open (IVX_FCM_FAST=0: glibc's powf for every voxel, as in round 5 -- A/B, tests)
+        // the fold on bounds from the transcendental unit, the exact value (glibc's powf, correctly rounded root and quotient) only
+        // for the pixels the bounds leave open (IVX_FCM_FAST=0: glibc's powf for every voxel, as in round 5 -- A/B, tests)
         static const bool fast_ok = []() { const char *e = getenv("IVX_FCM_FAST"); return !(e && e[0] == '0'); }();
-        const bool fast = fast_ok && pmode != 1 && n > 0.0f && n <= 64.0f;
-        auto decide_and_fix = [&](float *part, int64_t npix, int split, uint32_t *list, uint32_t *nlist) -> int {
+        const bool lin = fast_ok && pmode == 1; // exponent 1: bounds from the unit's root and reciprocal (fcm_value_fast<true>)
+        const bool fast = lin || (fast_ok && n > 0.0f && n <= 64.0f);
+        const bool unit = !lin && fast && n >= 1.0f; // the unit's root in front of the fast power (fcm_pow_fold)
+        auto decide_and_fix = [&](float *part, int64_t npix, int split, int64_t seg, uint32_t *list, uint32_t *nlist) -> int {
             hipLaunchKernelGGL(k_fcm_max_decide, dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st, (const float *)part, npix, split,
-                               (int16_t *)out, list, nlist);
+                               lin ? 1 : 0, (int16_t *)out, list, nlist);
             IVX_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_fcm_fix, dim3(1024), dim3(256), 0, st, img, dz, dy, dx, n, axis, pmode, (const uint32_t *)list,
+            hipLaunchKernelGGL(k_fcm_fix, dim3(2048), dim3(256), 0, st, img, dz, dy, dx, n, axis, pmode, seg, (const uint32_t *)list,
                                (const uint32_t *)nlist, (int16_t *)out, status);
             IVX_LAUNCH_CHECK();
+            static const bool debug = getenv("IVX_FCM_DEBUG") != nullptr; // (tools/probe_fcm_fix.py: how many pixels the bounds left open)
+            if (debug) { uint32_t h = 0; hipStreamSynchronize(st); hipMemcpy(&h, nlist, 4, hipMemcpyDeviceToHost); fprintf(stderr, "fcm undecided %u of %lld (lin %d)\n", h, (long long)npix, (int)lin); }
             return IVX_OK;
         };
         if (axis == 2) {
             if (!fast) {
-                hipLaunchKernelGGL(k_fcm_max_rows<false>, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,
-                                   (int16_t *)out, (float *)nullptr, status);
+                hipLaunchKernelGGL(k_fcm_max_rows<0>, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,
+                                   (int16_t *)out, (float *)nullptr, status, (uint32_t *)nullptr);
                 IVX_LAUNCH_CHECK();
                 return IVX_OK;
             }
             const int64_t npix = dz * dy;
             void *part;
-            if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * 12 + 256, &part))) return rc;
-            uint32_t *list = (uint32_t *)((float *)part + 2 * npix), *nlist = list + npix;
-            IVX_HIP(hipMemsetAsync(nlist, 0, 4, st));
-            hipLaunchKernelGGL(k_fcm_max_rows<true>, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx, n, pmode,
-                               (int16_t *)out, (float *)part, status);
+            if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * 16 + 256, &part))) return rc;
+            uint32_t *list = (uint32_t *)((float *)part + 2 * npix), *nlist = list + 2 * npix; // (list: pixel, open segments)
+            hipLaunchKernelGGL(lin ? k_fcm_max_rows<2> : unit ? k_fcm_max_rows<3> : k_fcm_max_rows<1>, dim3((unsigned)ivx::cdiv(dz * dy, 4)), dim3(256), 0, st, img, dz, dy, dx,
+                               n, pmode, (int16_t *)out, (float *)part, status, nlist);
             IVX_LAUNCH_CHECK();
-            return decide_and_fix((float *)part, npix, 1, list, nlist);
+            return decide_and_fix((float *)part, npix, 1, dx, list, nlist);
         }
         const int64_t nr = axis == 0 ? dy : dz, len = axis == 0 ? dz : dy, npix = nr * dx;
         const int64_t nblk = ivx::cdiv(nr * (dx / 8), 256);
         // segments of the ray: enough workgroups to fill the chip, each long enough to amortise its two window chunks
-        int64_t split = ivx::cdiv(2048, nblk);
+        // (the exponent-1 fold is light enough for its partial planes to show: 8 segments at 512^3 measured 0.113 ms against 0.120 with 16;
+        // the power folds want the 16: 0.253 against 0.276)
+        static const int64_t wg_env = []() { const char *e = getenv("IVX_FCM_WGS"); return (int64_t)(e && atoi(e) > 0 ? atoi(e) : 0); }();
+        int64_t split = ivx::cdiv(wg_env ? wg_env : lin ? 1024 : 2048, nblk);
         if (split > len / 32) split = len / 32;
+        if (split > 32) split = 32; // (k_fcm_max_decide names the open segments in one word)
         if (split < 1) split = 1;
         const int64_t seg = ivx::cdiv(len, split);
         split = ivx::cdiv(len, seg);
         void *part;
-        if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * sizeof(float) * split * (fast ? 2 : 1) + (fast ? (size_t)npix * 4 + 256 : 64), &part)))
+        if ((rc = ivx::ws_get_s(ivx::WS_AUX3, st, (size_t)npix * sizeof(float) * split * (fast ? 2 : 1) + (fast ? (size_t)npix * 8 + 256 : 64), &part)))
             return rc;
         if (fast) {
-            uint32_t *list = (uint32_t *)((float *)part + 2 * split * npix), *nlist = list + npix;
-            IVX_HIP(hipMemsetAsync(nlist, 0, 4, st));
-            if (axis == 0)
-                hipLaunchKernelGGL((k_fcm_max_walk<0, true>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
-                                   (float *)part, status);
-            else
-                hipLaunchKernelGGL((k_fcm_max_walk<1, true>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
-                                   (float *)part, status);
+            uint32_t *list = (uint32_t *)((float *)part + 2 * split * npix), *nlist = list + 2 * npix;
+            auto walk = axis == 0 ? (lin ? k_fcm_max_walk<0, 2> : unit ? k_fcm_max_walk<0, 3> : k_fcm_max_walk<0, 1>)
+                                  : (lin ? k_fcm_max_walk<1, 2> : unit ? k_fcm_max_walk<1, 3> : k_fcm_max_walk<1, 1>);
+            hipLaunchKernelGGL(walk, dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg, (float *)part, status, nlist);
             IVX_LAUNCH_CHECK();
-            return decide_and_fix((float *)part, npix, (int)split, list, nlist);
+            return decide_and_fix((float *)part, npix, (int)split, seg, list, nlist);
         }
         if (axis == 0)
-            hipLaunchKernelGGL((k_fcm_max_walk<0, false>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
-                               (float *)part, status);
+            hipLaunchKernelGGL((k_fcm_max_walk<0, 0>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+                               (float *)part, status, (uint32_t *)nullptr);
         else
-            hipLaunchKernelGGL((k_fcm_max_walk<1, false>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
-                               (float *)part, status);
+            hipLaunchKernelGGL((k_fcm_max_walk<1, 0>), dim3((unsigned)nblk, (unsigned)split), dim3(256), 0, st, img, dz, dy, dx, n, pmode, seg,
+                               (float *)part, status, (uint32_t *)nullptr);
         IVX_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_fcm_max_combine, dim3((unsigned)ivx::cdiv(npix, 256)), dim3(256), 0, st, (const float *)part, npix,
                            (int)split, (int16_t *)out);

@@ -261,3 +261,46 @@ def test_fast_power_of_the_contour_maxip_stays_inside_its_bound(ivxlib, oracle):
     used = err[ok] / (rel[ok] * fast[ok])
     print("fast power: worst error / bound = %.3f" % float(used.max()))
     assert used.max() < 0.6
+
+
+@pytest.mark.parametrize("n", [1.0, 2.0, 1.5, 3.3, 8.0, 64.0])
+def test_contour_bounds_from_the_unit_hold_the_reference_value(ivxlib, oracle, n):
+    """Exponents >= 1 fold bounds built on the wrapped int16 differences D: S = D0^2 + D1^2 + D2^2 exact in 32 bits, then
+    v_sqrt_f32(S) - |Dray| (exponent 1, the GUI's default) or v_rsq_f32(S) in front of the fast power (fcm_pow_fold), and take the
+    reference's float sequence (correctly rounded root and quotient, glibc's powf) only for the pixels the bounds leave open.
+    The bounds must hold that sequence's value (numpy's float32 sqrt and division are correctly rounded; the power is the host
+    libm's) for every difference an int16 volume can produce: 4 M draws with the edges (one axis only, equal axes, the largest)."""
+    import ctypes
+    from invesalius3_amd import _lib as L
+    from invesalius3_amd.device import DeviceBuffer, c64
+    cnt = 1 << 22
+    rng = np.random.default_rng(23)
+    scale = 2.0 ** rng.uniform(0, 15, (3, cnt))
+    D = np.clip(np.round(rng.uniform(-1, 1, (3, cnt)) * scale), -32768, 32767).astype(np.int32)
+    D[:, :6] = np.array([[1, 0, 0], [32767, 32767, 32767], [-32768, -32768, -32768], [6, 8, 0], [0, 0, 15], [1, 32767, 0]], np.int32).T
+    D[1:, 6:cnt // 16] = 0            # the ray along the only gradient: base 0
+    D[0, cnt // 16:cnt // 8] = 0      # ... and across it: base 1
+    D[:, cnt // 8:cnt // 4] //= 256   # small gradients (flat tissue)
+    g = (D.astype(np.float32) / np.float32(2))
+    d = g[0]
+    s = ((d * d + g[1] * g[1]).astype(np.float32) + g[2] * g[2]).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        gm = np.sqrt(s)
+        base = np.where(s != 0, np.float32(1) - np.abs(d / gm), np.float32(0)).astype(np.float32)
+    power = base if n == 1.0 else oracle.powf_array(base, np.full(cnt, n, np.float32))
+    want = np.where(s != 0, gm * power, np.float32(0)).astype(np.float64)
+    other = ((D[1].astype(np.uint32) & 0xFFFF) | ((D[2].astype(np.uint32) & 0xFFFF) << 16)).astype(np.uint32)
+    dd, do, dlo, dhi = DeviceBuffer(cnt * 4), DeviceBuffer(cnt * 4), DeviceBuffer(cnt * 4), DeviceBuffer(cnt * 4)
+    dd.upload(np.ascontiguousarray(D[0]))
+    do.upload(other)
+    L.check(L.lib().ivx_dev_fcm_bounds(dd.ptr, do.ptr, ctypes.c_float(n), dlo.ptr, dhi.ptr, c64(cnt), None))
+    L.synchronize()
+    lo, hi = dlo.download((cnt,), np.float32).astype(np.float64), dhi.download((cnt,), np.float32).astype(np.float64)
+    assert np.isfinite(lo).all() and np.isfinite(hi).all()
+    bad = (want < lo) | (want > hi)
+    assert not bad.any(), (int(bad.sum()), D[:, bad][:, :4], want[bad][:4], lo[bad][:4], hi[bad][:4])
+    half = (hi - lo) / 2
+    ok = half > 0
+    used = np.abs(want - (hi + lo) / 2)[ok] / half[ok]
+    print("contour bounds, exponent %g: worst error / bound = %.3f, median half-width %.2e" % (n, float(used.max()), float(np.median(half[ok]))))
+    assert used.max() < 0.75  # (the analysis in k_rays.hip leaves a quarter in hand)
