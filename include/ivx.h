@@ -615,7 +615,8 @@ int ivx_watershed_merge(uint8_t *mask, const int64_t shape[3], const int64_t mas
  * ivx_dev_watershed_ift before its relaxation; needs dx % 64 == 0 and dy % 16 == 0 (IVX_EINVAL otherwise).
  * ivx_dev_sk_cost_levels: the same for the scikit-image branch's cost (largest image VALUE on the path, markers cost their own
  * value, lattice neighbours under `strct`): level c = what the markers of value <= c reach inside {image <= c}, on the
- * region-growing engine; stops after level 0 when that level holds < 5 % of the voxels (no plateau).  Needs dx % 64 == 0. */
+ * region-growing engine; stops after level 0 when that level holds < 5 % of the voxels (no plateau).  Needs dx % 64 == 0 and
+ * 16-byte aligned image and markers (IVX_EINVAL otherwise). */
 int ivx_dev_sk_cost_levels(const uint16_t *image, int mdtype, const void *markers, int64_t dz, int64_t dy, int64_t dx,
                            const uint8_t strct[27], uint16_t *C, int max_levels, double stop_frac, int *levels_done,
                            int64_t *reached, int64_t *rounds, void *stream);

@@ -289,9 +289,9 @@ template <int CONN, typename MT>
 __global__ __launch_bounds__(256) void k_ws_bucket_links(WsGeom g, const uint16_t *__restrict__ C, const uint32_t *__restrict__ comp,
                                                          const MT *__restrict__ mk, const uint32_t *__restrict__ pmask,
                                                          const uint32_t *__restrict__ zmask, uint32_t *__restrict__ cursor,
-                                                         uint32_t *__restrict__ rec) {
-    __shared__ uint32_t sh[BK_LB];
-    for (int i = threadIdx.x; i < BK_LB; i += 256) sh[i] = 0;
+                                                         uint32_t *__restrict__ rec, int lb) {
+    extern __shared__ uint32_t sh[]; // lb counters (k_ws_bucket: the host has the levels' histogram by now and asks for those that exist)
+    for (int i = threadIdx.x; i < lb; i += 256) sh[i] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
     for (int pass = 0; pass < 2; pass++) { // (the counting / placing scheme of k_ws_bucket<PRED, true>)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_ws_bucket_links(WsGeom g, const uint16_
             if (!e) continue;
             const uint32_t c = C[p];
             uint32_t off;
-            if (c < BK_LB) {
+            if (c < (uint32_t)lb) {
                 off = atomicAdd(&sh[c], 1u);
                 if (pass == 0) continue;
             } else {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_ws_bucket_links(WsGeom g, const uint16_
         }
         __syncthreads();
         if (pass == 0) {
-            for (int i = threadIdx.x; i < BK_LB; i += 256) {
+            for (int i = threadIdx.x; i < lb; i += 256) {
                 const uint32_t v = sh[i];
                 if (v) sh[i] = atomicAdd(&cursor[i], v);
             }
@@ -567,7 +567,7 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
 
     tm.mark(st);
     // ---- 3. entries by level -------------------------------------------------------------------------------
-    hipLaunchKernelGGL((k_ws_bucket<WsEntryPred<MT>, false>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g.n, b.C, WsEntryPred<MT>{b.comp, mk}, b.hist, b.elist);
+    hipLaunchKernelGGL((k_ws_bucket<WsEntryPred<MT>, false>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), (size_t)BK_LB * 4, st, g.n, b.C, WsEntryPred<MT>{b.comp, mk}, b.hist, b.elist, BK_LB);
     IVX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ws_set_hist0, dim3(1), dim3(1), 0, st, b.hist, M);
     std::vector<uint32_t> hist(65536);
@@ -603,11 +603,14 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
             }
         }
     }
+    int bk_lb = 64; // LDS counters of the placing pass: the levels that have entries (whole 64s, BK_LB at most)
+    for (uint32_t c = 0; c < 65536; c++)
+        if (hist[c]) bk_lb = (int)std::min<uint32_t>((c + 64u) & ~63u, (uint32_t)BK_LB);
     if (rec) {
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_bucket_links<CC, MT>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g, b.C, b.comp,
-                                                  mk, b.pmask, b.zmask, b.cursor, rec));
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_bucket_links<CC, MT>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), (size_t)bk_lb * 4, st, g, b.C,
+                                                  b.comp, mk, b.pmask, b.zmask, b.cursor, rec, bk_lb));
     } else {
-        hipLaunchKernelGGL((k_ws_bucket<WsEntryPred<MT>, true>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), 0, st, g.n, b.C, WsEntryPred<MT>{b.comp, mk}, b.cursor, b.elist);
+        hipLaunchKernelGGL((k_ws_bucket<WsEntryPred<MT>, true>), dim3((unsigned)cdiv(g.n, 256 * BK_CH)), dim3(256), (size_t)bk_lb * 4, st, g.n, b.C, WsEntryPred<MT>{b.comp, mk}, b.cursor, b.elist, bk_lb);
     }
     IVX_LAUNCH_CHECK();
 

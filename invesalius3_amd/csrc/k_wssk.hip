@@ -236,15 +236,17 @@ __global__ __launch_bounds__(1024) void k_sk_prevlevel(const uint32_t *__restric
 // among them), bucket 2 c + 1 the late ones: a level's list is one stretch, early part first -- and, in the same pass, the drained
 // voxels by level (buckets 131072 + c: their stretches follow generation 0's in the same list).  k_ws_bucket's scheme (LDS
 // counters for the low levels, their return values ARE the slots), one read of kind[] and C[] instead of two (round 6).
-constexpr int BK2_LB = 8192, BK3_D0 = 131072, BK3_N = 196608;
+constexpr int BK3_D0 = 131072, BK3_N = 196608;
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_sk_bucket3(int64_t n, const uint16_t *__restrict__ C, const uint8_t *__restrict__ kind,
                                                     uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist,
-                                                    const uint32_t *__restrict__ comp, uint32_t *__restrict__ droot) {
-    __shared__ uint32_t sh[BK2_LB];
-    __shared__ uint32_t shd[BK_LB];
-    for (int i = threadIdx.x; i < BK2_LB; i += 256) sh[i] = 0;
-    for (int i = threadIdx.x; i < BK_LB; i += 256) shd[i] = 0;
+                                                    const uint32_t *__restrict__ comp, uint32_t *__restrict__ droot, int lb) {
+    // counters in LDS for the levels below lb (dynamic, 3 lb words: 2 lb for generation 0's buckets, lb for the drained; lb <= BK_LB,
+    // sized by the host from the image's largest value -- with all 4096 levels, 48 KB a workgroup, three workgroups shared a compute
+    // unit and cleared / flushed 12 288 counters per 16 384 voxels: 10 ms of a 1024^3 flood for 3 GB)
+    extern __shared__ uint32_t sh[];
+    uint32_t *shd = sh + 2 * lb;
+    for (int i = threadIdx.x; i < 3 * lb; i += 256) sh[i] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
     for (int pass = 0; pass < (SCATTER ? 2 : 1); pass++) {
@@ -255,12 +257,12 @@ __global__ __launch_bounds__(256) void k_sk_bucket3(int64_t n, const uint16_t *_
             const uint32_t c = C[p];
             uint32_t off;
             if (kd == KIND_DRAINED) {
-                if (c < (uint32_t)BK_LB) off = atomicAdd(&shd[c], 1u);
+                if (c < (uint32_t)lb) off = atomicAdd(&shd[c], 1u);
                 else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[BK3_D0 + c], 1u);
                 else continue;
             } else {
                 const uint32_t bk = 2u * c + (kd == KIND_GEN0_LATE ? 1u : 0u);
-                if (bk < (uint32_t)BK2_LB) off = atomicAdd(&sh[bk], 1u);
+                if (bk < (uint32_t)(2 * lb)) off = atomicAdd(&sh[bk], 1u);
                 else if (!SCATTER || pass == 1) off = atomicAdd(&hist_or_cursor[bk], 1u);
                 else continue;
             }
@@ -271,14 +273,14 @@ __global__ __launch_bounds__(256) void k_sk_bucket3(int64_t n, const uint16_t *_
         }
         __syncthreads();
         if (pass == 0) {
-            for (int i = threadIdx.x; i < BK2_LB; i += 256) {
+            for (int i = threadIdx.x; i < 2 * lb; i += 256) {
                 const uint32_t v = sh[i];
                 if (v) {
                     const uint32_t base = atomicAdd(&hist_or_cursor[i], v);
                     if (SCATTER) sh[i] = base;
                 }
             }
-            for (int i = threadIdx.x; i < BK_LB; i += 256) {
+            for (int i = threadIdx.x; i < lb; i += 256) {
                 const uint32_t v = shd[i];
                 if (v) {
                     const uint32_t base = atomicAdd(&hist_or_cursor[BK3_D0 + i], v);
@@ -1750,7 +1752,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         const int lv_max = e1 ? atoi(e1) : 3;          // (512^3, windowed: cost map 9.7 ms without, 7.6 with one level, 5.7 with three)
         const double lv_frac = e2 ? atof(e2) : 0.99;
         const int64_t lv_min = e3 ? atoll(e3) : ((int64_t)1 << 21);
-        if (lv_max > 0 && g.w % 64 == 0 && g.n >= lv_min) {
+        if (lv_max > 0 && g.w % 64 == 0 && g.n >= lv_min && (((uintptr_t)I | (uintptr_t)mk) & 15) == 0) {
             uint8_t s27[27];
             for (int k = 0; k < 27; k++) s27[k] = (uint8_t)(k == 13 || ((g.smask >> k) & 1u));
             int levels_done = 0;
@@ -1770,7 +1772,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const unsigned gbk = (unsigned)cdiv(g.n, 256 * BK_CH);
     std::vector<uint32_t> lhist(65536); // voxels per level (a level that holds much of the volume is relaxed tile-wise)
     IVX_HIP(hipMemsetAsync(b.lhist, 0, 65536 * 4, st));
-    hipLaunchKernelGGL((k_ws_bucket<SkLevelPred, false>), dim3(gbk), dim3(256), 0, st, g.n, b.C, SkLevelPred{}, b.lhist, b.elist);
+    // LDS counters of the bucket passes: the levels that exist (no cost is above the image's largest value), whole 64s, BK_LB at most
+    const int bk_lb = (int)std::min<uint32_t>(((hw.imax + 1u) + 63u) & ~63u, (uint32_t)BK_LB);
+    hipLaunchKernelGGL((k_ws_bucket<SkLevelPred, false>), dim3(gbk), dim3(256), (size_t)bk_lb * 4, st, g.n, b.C, SkLevelPred{}, b.lhist, b.elist, bk_lb);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipMemcpyAsync(lhist.data(), b.lhist, 65536 * 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(k_sk_prevlevel, dim3(1), dim3(1024), 0, st, b.lhist, b.prevl);
@@ -1786,13 +1790,13 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_HIP(hipMemsetAsync(b.hist, 0, (size_t)BK3_N * 4, st));
     std::vector<uint32_t> hist3(BK3_N), dhist(65536);
     { // generation 0 (a level's early part, then its late part) and, behind all of it, the drained voxels: ONE list, two passes
-        hipLaunchKernelGGL(k_sk_bucket3<false>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.hist, b.elist, b.comp, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_sk_bucket3<false>, dim3(gbk), dim3(256), (size_t)bk_lb * 12, st, g.n, b.C, b.kind, b.hist, b.elist, b.comp, (uint32_t *)nullptr, bk_lb);
         IVX_LAUNCH_CHECK();
         IVX_HIP(hipMemcpyAsync(hist3.data(), b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToHost, st));
         IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToDevice, st));
         const int rc = scan_u32_exclusive(b.cursor, BK3_N, b.bsum, b.total, st);
         if (rc != IVX_OK) return rc;
-        hipLaunchKernelGGL(k_sk_bucket3<true>, dim3(gbk), dim3(256), 0, st, g.n, b.C, b.kind, b.cursor, b.elist, b.comp, b.droot);
+        hipLaunchKernelGGL(k_sk_bucket3<true>, dim3(gbk), dim3(256), (size_t)bk_lb * 12, st, g.n, b.C, b.kind, b.cursor, b.elist, b.comp, b.droot, bk_lb);
         IVX_LAUNCH_CHECK();
     }
     std::vector<uint32_t> mbits(2048); // levels that hold markers
@@ -2118,7 +2122,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             uint32_t guess = 0;
             for (;;) {
                 IVX_HIP(hipMemsetAsync(&b.wst->nlist, 0, 4, st));
-                hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, b.dirty, b.tlist, b.wst);
+                hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256 * BL_PER)), dim3(256), 0, st, g.ntiles, b.dirty, b.tlist, b.wst);
                 IVX_LAUNCH_CHECK();
                 uint32_t mseq = 0, nl = 0;
                 int rc = mailbox_publish(&b.wst->nlist, 1, st, &mseq);

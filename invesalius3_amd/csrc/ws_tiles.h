@@ -37,7 +37,7 @@ struct WsState {
     uint32_t base;     // next free time stamp
     uint32_t overflow; // time stamps ran out of the table
     uint32_t neg;      // a negative marker was seen
-    uint32_t pad0;
+    uint32_t imax;     // (scikit-image branch) largest image value: no cost is above it
     uint32_t nlist;    // dirty tiles of the next round            } read by the host
     uint32_t minrej;   // smallest cost refused by the gate so far } after every round
     uint32_t assigned; // voxels that have a finite cost           } (one mailbox message)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ws_init(WsGeom g, const MT *__restrict_
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * 2048;
-    uint32_t mine = 0;
+    uint32_t mine = 0, vmax = 0;
     bool neg = false;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_ws_init(WsGeom g, const MT *__restrict_
         const int m = (int)mk[p];
         C[p] = m ? (SK ? I[p] : (uint16_t)0) : (uint16_t)CINF; // a marker's cost is final from the start
         if (SK && I[p] == (uint16_t)CINF) st->overflow = 1;       // 65535 is the "never reached" cost
+        if (SK) vmax = max(vmax, (uint32_t)I[p]);
         if (m) {
             mine++;
             neg |= m < 0;
@@ -183,6 +184,11 @@ __global__ __launch_bounds__(256) void k_ws_init(WsGeom g, const MT *__restrict_
     }
     if (mine) atomicAdd(&s_cnt, mine);
     if (neg) st->neg = 1;
+    if (SK) { // (the bucket passes size their LDS counters by it)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, o, 64));
+        if ((threadIdx.x & 63) == 0 && vmax > __hip_atomic_load(&st->imax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->imax, vmax);
+    }
     __syncthreads();
     if (threadIdx.x == 0) bcount[blockIdx.x] = s_cnt;
 }
@@ -225,19 +231,50 @@ __global__ __launch_bounds__(256) void k_ws_fill_used(uint32_t *used, uint32_t m
     used[w] = (w == nw - 1 && (m & 31)) ? ((1u << (m & 31)) - 1u) : 0xFFFFFFFFu;
 }
 
+// dirty flags -> list.  Lane = 16 tiles (one 16-byte load), one atomic per workgroup: at 1024^3 (2^19 tiles) the lane-per-tile
+// form with an atomic per wave took 26 us a round, 170 rounds a flood.
+constexpr int BL_PER = 16;
 __global__ __launch_bounds__(256) void k_ws_build_list(int64_t ntiles, uint8_t *__restrict__ dirty, uint32_t *__restrict__ list,
                                                        WsState *st) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool d = t < ntiles && dirty[t];
-    const unsigned long long b = __ballot(d);
-    if (!b) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t off = 0;
-    if (lane == 0) off = atomicAdd(&st->nlist, (uint32_t)__popcll(b));
-    off = __shfl(off, 0, 64);
-    if (d) {
-        list[off + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)t;
-        dirty[t] = 0;
+    __shared__ uint32_t s_wave[4], s_base;
+    const int64_t t0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BL_PER;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t m = 0; // which of my 16 tiles are dirty
+    if (t0 + BL_PER <= ntiles) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(dirty + t0);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) m |= ((w[k] >> (8 * b)) & 0xFFu ? 1u : 0u) << (4 * k + b);
+        if (m) *reinterpret_cast<uint4 *>(dirty + t0) = make_uint4(0, 0, 0, 0);
+    } else {
+        for (int k = 0; k < BL_PER; k++)
+            if (t0 + k < ntiles && dirty[t0 + k]) {
+                m |= 1u << k;
+                dirty[t0 + k] = 0;
+            }
+    }
+    const uint32_t cnt = (uint32_t)__popc(m);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = tot ? atomicAdd(&st->nlist, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t off = s_base + inc - cnt;
+    for (int q = 0; q < wv; q++) off += s_wave[q];
+    while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1;
+        list[off++] = (uint32_t)(t0 + k);
     }
 }
 
@@ -430,33 +467,56 @@ constexpr int BK_LB = 4096, BK_CH = 64;
 // PRED: device functor, pred(p) = "voxel p goes into its level's list"
 template <typename PRED, bool SCATTER>
 __global__ __launch_bounds__(256) void k_ws_bucket(int64_t n, const uint16_t *__restrict__ C, PRED pred,
-                                                   uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist) {
-    __shared__ uint32_t sh[BK_LB];
-    for (int i = threadIdx.x; i < BK_LB; i += 256) sh[i] = 0;
+                                                   uint32_t *__restrict__ hist_or_cursor, uint32_t *__restrict__ elist, int lb) {
+    // lb counters in LDS (dynamic, lb * 4 bytes: BK_LB at most -- a caller that knows its highest level asks for fewer: 16 KB of LDS
+    // a workgroup and 4096 counters to clear and flush per 16 384 voxels are most of the pass when the levels end at 255)
+    extern __shared__ uint32_t sh[];
+    for (int i = threadIdx.x; i < lb; i += 256) sh[i] = 0;
     __syncthreads();
     const int64_t b0 = (int64_t)blockIdx.x * (256 * BK_CH);
     // One LDS atomic per voxel that goes into a list: the hardware serialises lanes that hit the same counter inside the
     // instruction, and its return value IS the voxel's slot.  (Before: a match-any loop per wave -- shuffle, ballot, one LDS
     // atomic by a leader lane per distinct level among the wave's voxels, ~20 - 30 dependent iterations on a noise volume --
     // which made these streaming passes 5 - 10x slower than their bytes: 2.2 + 0.8 ms at 512^3 for 0.9 GB.)
+    // (Round 6: a wave whose voxels all sit on ONE level -- the inside of a plateau, most of a windowed gradient -- takes one atomic
+    // for the wave instead of 64 serialised ones on the same counter: the passes over a 1024^3 volume were 3 - 6 ms each for 3 GB.)
+    const int lane = threadIdx.x & 63;
     for (int pass = 0; pass < (SCATTER ? 2 : 1); pass++) {
         for (int j = 0; j < BK_CH; j++) {
             const int64_t p = b0 + (int64_t)j * 256 + threadIdx.x;
             const bool e = p < n && pred(p);
-            if (!e) continue;
-            const uint32_t c = C[p];
-            if (c < BK_LB) {
-                const uint32_t off = atomicAdd(&sh[c], 1u);
-                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
-            } else if (!SCATTER || pass == 1) {
-                const uint32_t off = atomicAdd(&hist_or_cursor[c], 1u);
-                if (SCATTER && pass == 1) elist[off] = (uint32_t)p;
+            const uint32_t c = e ? (uint32_t)C[p] : 0xFFFFFFFFu;
+            const unsigned long long act = __ballot(e);
+            if (!act) continue;
+            const int lead = __builtin_ctzll(act);
+            const uint32_t c0 = (uint32_t)__shfl((int)c, lead, 64);
+            uint32_t off = 0;
+            bool have = false;
+            if (__ballot(c == c0) == act) {
+                uint32_t base = 0;
+                if (c0 < (uint32_t)lb) {
+                    if (lane == lead) base = atomicAdd(&sh[c0], (uint32_t)__popcll(act));
+                    have = e;
+                } else if (!SCATTER || pass == 1) {
+                    if (lane == lead) base = atomicAdd(&hist_or_cursor[c0], (uint32_t)__popcll(act));
+                    have = e;
+                }
+                off = (uint32_t)__shfl((int)base, lead, 64) + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+            } else if (e) {
+                if (c < (uint32_t)lb) {
+                    off = atomicAdd(&sh[c], 1u);
+                    have = true;
+                } else if (!SCATTER || pass == 1) {
+                    off = atomicAdd(&hist_or_cursor[c], 1u);
+                    have = true;
+                }
             }
+            if (have && SCATTER && pass == 1) elist[off] = (uint32_t)p;
         }
         __syncthreads();
         if (pass == 0) {
             // flush the counts (histogram) / turn them into this workgroup's base offsets (scatter)
-            for (int i = threadIdx.x; i < BK_LB; i += 256) {
+            for (int i = threadIdx.x; i < lb; i += 256) {
                 const uint32_t v = sh[i];
                 if (v) {
                     const uint32_t base = atomicAdd(&hist_or_cursor[i], v);
@@ -738,7 +798,7 @@ static int ws_cost_rounds(const WsGeom &g, int conn, const uint16_t *I, uint16_t
     uint32_t theta = gate ? 0u : CINF;
     for (;;) {
         IVX_HIP(hipMemsetAsync(&wst->nlist, 0, 4, st));
-        hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256)), dim3(256), 0, st, g.ntiles, dirty, list, wst);
+        hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256 * BL_PER)), dim3(256), 0, st, g.ntiles, dirty, list, wst);
         IVX_LAUNCH_CHECK();
         uint32_t seq = 0, msg[3] = {0, 0, 0};
         int rc = mailbox_publish(&wst->nlist, 3, st, &seq);

@@ -42,6 +42,35 @@ def test_mida_u8_and_f64(ivxlib, oracle, axis):
 
 
 @pytest.mark.parametrize("axis", [0, 1, 2])
+def test_mida_windows_at_their_edges(ivxlib, oracle, axis):
+    """get_opacity's ramp at its corners: windows of width 0 and 1, odd widths (half-integer edges), negative widths, wide windows,
+    a window at the top and at the bottom of int16, samples at both ends of the type -- same bits as the oracle's, all three axes."""
+    from invesalius3_amd import invesalius_rs as mips
+    img = synth_volume((24, 40, 72), seed=53)
+    img[::3, ::5, ::7] = 32767
+    img[1::3, 1::5, 1::7] = -32768
+    for wl, ww in ((0, 0), (100, 1), (101, 7), (5, 20000), (40, -50), (-1000, 8190), (-1000, 8191), (-1000, 8192), (300, 4094), (300, 4095),
+                   (300, 4096), (32000, 3), (-32768, 2), (32767, 32767)):
+        _same_mida(mips, oracle, img, axis, wl, ww)
+    u = ((img.astype(np.int32) + 1024) // 9).clip(0, 255).astype(np.uint8)
+    for wl, ww in ((128, 255), (3, 1), (0, 0), (255, 2), (60, 81)):
+        _same_mida(mips, oracle, u, axis, wl, ww)
+
+
+def _same_mida(mips, oracle, img, axis, wl, ww):
+    """Same bits -- or, where the reference panics (a width of 0 divides 0 by 0 and NumCast refuses the NaN), the same refusal."""
+    g, r = _out(img, axis), _out(img, axis)
+    try:
+        oracle.mida(img, axis, wl, ww, r)
+    except Exception as e:  # noqa: BLE001 (whatever the restatement raises for the reference's panic)
+        with pytest.raises(type(e)):
+            mips.mida(img, axis, wl, ww, g)
+        return
+    mips.mida(img, axis, wl, ww, g)
+    assert np.array_equal(g, r), (wl, ww)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
 def test_lmip(ivxlib, oracle, axis):
     from invesalius3_amd import invesalius_rs as mips
     img = synth_volume((33, 45, 150), seed=53)
