@@ -548,8 +548,10 @@ static int ws_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, uin
             const int rc = ivx_dev_ws_cost_levels(I, sizeof(MT) == 2 ? IVX_I16 : IVX_I8, mk, g.d, g.h, g.w, b.C, lv_max, lv_frac,
                                                   &levels_done, &level_voxels, &level_rounds, st);
             if (rc != IVX_OK) return rc;
-            // every tile looks once: the pockets, and anything the levels left for it
-            IVX_HIP(hipMemsetAsync(b.dirty, 1, (size_t)g.ntiles, st));
+            // the pockets, and anything the levels left: the tiles that hold a voxel without a cost (the levels' costs are final)
+            IVX_HIP(hipMemsetAsync(b.dirty, 0, (size_t)g.ntiles, st));
+            hipLaunchKernelGGL(k_ws_mark_open_tiles, dim3((unsigned)cdiv(g.n / 8, 256)), dim3(256), 0, st, g, b.C, b.dirty);
+            IVX_LAUNCH_CHECK();
         }
         const int rc = ws_cost_rounds<false>(g, conn, I, b.C, b.list, b.dirty, b.pending, b.st, st, &rounds, &visits);
         if (rc != IVX_OK) return rc;

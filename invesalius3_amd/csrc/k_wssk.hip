@@ -1760,7 +1760,16 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             const int rc = ivx_dev_sk_cost_levels(I, sizeof(MT) == 2 ? IVX_I16 : IVX_I8, mk, g.d, g.h, g.w, s27, b.C, lv_max, lv_frac,
                                                   &levels_done, &lvox, &lrounds, st);
             if (rc != IVX_OK) return rc;
-            IVX_HIP(hipMemsetAsync(b.dirty, 1, (size_t)g.ntiles, st)); // every tile looks once
+            // the levels' costs are final: only tiles that still hold a voxel without a cost have work (IVX_SK_RELAX_ALL=1: every tile
+            // looks once, as in rounds 2 - 5 -- A/B)
+            static const bool relax_all = []() { const char *e = getenv("IVX_SK_RELAX_ALL"); return e && e[0] == '1'; }();
+            if (relax_all) {
+                IVX_HIP(hipMemsetAsync(b.dirty, 1, (size_t)g.ntiles, st));
+            } else {
+                IVX_HIP(hipMemsetAsync(b.dirty, 0, (size_t)g.ntiles, st));
+                hipLaunchKernelGGL(k_ws_mark_open_tiles, dim3((unsigned)cdiv(g.n / 8, 256)), dim3(256), 0, st, g, b.C, b.dirty);
+                IVX_LAUNCH_CHECK();
+            }
         }
         const int rc = ws_cost_rounds<true>(g, conn, I, b.C, b.tlist, b.dirty, b.pending, b.wst, st, &rounds, &visits);
         if (rc != IVX_OK) return rc;

@@ -231,6 +231,22 @@ __global__ __launch_bounds__(256) void k_ws_fill_used(uint32_t *used, uint32_t m
     used[w] = (w == nw - 1 && (m & 31)) ? ((1u << (m & 31)) - 1u) : 0xFFFFFFFFu;
 }
 
+// The tiles that hold a voxel without a cost yet (CINF): behind the level floods -- whose costs are final -- the relaxation has
+// nothing to do anywhere else, and "every tile looks once" was a pass of 3 240-cell stagings over a volume that is 95 % done
+// (first round 0.83 ms at 512^3, 6.6 ms at 1024^3).  Lane = 8 voxels of a row (rows are whole 64s on this path).
+__global__ __launch_bounds__(256) void k_ws_mark_open_tiles(WsGeom g, const uint16_t *__restrict__ C, uint8_t *__restrict__ dirty) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n / 8) return;
+    const uint4 v = reinterpret_cast<const uint4 *>(C)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    bool open = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) open |= (w[k] & 0xFFFFu) == CINF || (w[k] >> 16) == CINF;
+    if (!open) return;
+    const int64_t p = i * 8, z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
+    dirty[((z / TZ) * g.nty + y / TY) * g.ntx + x / TX] = 1;
+}
+
 // dirty flags -> list.  Lane = 16 tiles (one 16-byte load), one atomic per workgroup: at 1024^3 (2^19 tiles) the lane-per-tile
 // form with an atomic per wave took 26 us a round, 170 rounds a flood.
 constexpr int BL_PER = 16;

@@ -71,6 +71,21 @@ def test_morphological_gradient_matches_scipy(ivxlib, oracle, size):
         assert np.array_equal(wp.cost_image(sl, False, 0, 0, 3), ndimage.morphological_gradient((sl - sl.min()).astype("uint16"), 3))
 
 
+@pytest.mark.parametrize("shape", [(70, 21, 40), (33, 8, 8), (4, 5, 16), (3, 9, 24), (1, 7, 8)])
+def test_morphological_gradient_3_over_slice_segments(ivxlib, oracle, shape, monkeypatch):
+    """The 3x3x3 gradient walks along z in segments of 32 slices with three slices' in-slice extrema in registers (k_misc.hip):
+    segment seams, a ragged last segment, volumes thinner than the window, both kernels (IVX_MG_WALK is read once per process:
+    the other one is reached through thin volumes) == scipy's morphological_gradient bit for bit."""
+    from invesalius3_amd import watershed_process as wp
+    img = synth_volume(shape, seed=64)
+    img[::7, ::3, ::5] = 3000
+    img[3::11, 1::4, 2::9] = -1000
+    base = (img - img.min()).astype("uint16")
+    assert np.array_equal(wp.cost_image(img, False, 0, 0, 3), ndimage.morphological_gradient(base, 3))
+    lut = oracle.get_LUT_value(img, 600, 200).astype("uint16")
+    assert np.array_equal(wp.cost_image(img, True, 200, 600, 3), ndimage.morphological_gradient(lut, 3))
+
+
 @pytest.mark.parametrize("overwrite", [False, True])
 def test_watershed_merge_rule(ivxlib, oracle, overwrite):
     from invesalius3_amd import watershed_process as wp
