@@ -97,6 +97,7 @@ int ccl_run(const ivx_flood_plan *p, const uint64_t *cand, uint64_t *reached, co
 // (~5 us instead of ~40 us).  Falls back to hipStreamSynchronize if the word does not arrive in time.
 int mailbox_publish(const void *dsrc, int ndwords, hipStream_t st, uint32_t *seq_out);
 int mailbox_wait(uint32_t seq, hipStream_t st, uint32_t *out, int ndwords);
+int mailbox_reserve(uint32_t **slot_out, uint32_t *seq_out); // for a kernel that publishes by itself (see ivx_runtime.hip)
 int vote_publish(int32_t *votes, hipStream_t st, uint32_t *seq_out); // { votes[0], votes[1] } -> mailbox, then votes[0] <- votes[1]
 // Progress line: 64 B of pinned, host-coherent memory per stream that the kernels of a running chain store to directly
 // (no publishing kernel) while the host polls it.  Every call hands out a fresh 8-bit tag (never 0) for bits 63..56 of

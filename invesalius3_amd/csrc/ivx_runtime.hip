@@ -507,6 +507,22 @@ int mailbox_publish(const void *dsrc, int ndwords, hipStream_t st, uint32_t *seq
     return IVX_OK;
 }
 
+// a slot and a sequence number for a kernel that publishes by itself (dwords 0 .. n-1, a system-scope fence, then the sequence
+// number into dword 63 with release semantics at system scope -- what k_mailbox_publish does): saves the publishing launch
+int mailbox_reserve(uint32_t **slot_out, uint32_t *seq_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_mb) {
+        void *p = nullptr;
+        IVX_HIP(hipHostMalloc(&p, 64 * 64 * 4, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(p, 0, 64 * 64 * 4);
+        g_mb = (uint32_t *)p;
+    }
+    *seq_out = ++g_mb_seq;
+    if (*seq_out == 0) *seq_out = ++g_mb_seq;
+    *slot_out = g_mb + (size_t)(*seq_out & 63u) * 64;
+    return IVX_OK;
+}
+
 // the sharded flood's vote (parallel.py, slab_region_grow): two device words { everybody's votes of the last round, my new count }.
 // Setting them and reading them used to be two memsets, a 4-byte device copy and a synchronising 8-byte download per round --
 // 16 us each as copy-engine calls; here: one-thread kernels and the mailbox (no stream synchronisation).

@@ -1743,6 +1743,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         if (stats) memset(stats, 0, 16 * sizeof(int64_t));
         return IVX_OK;
     }
+    const uint32_t nlev = std::min<uint32_t>(hw.imax + 2u, 65536u); // levels that can hold voxels: 0 .. the image's largest value
     int64_t rounds = 0, visits = 0;
     {
         // The levels that hold the bulk of the volume first, as ordinary region-growing floods (ivx_dev_sk_cost_levels):
@@ -1785,7 +1786,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const int bk_lb = (int)std::min<uint32_t>(((hw.imax + 1u) + 63u) & ~63u, (uint32_t)BK_LB);
     hipLaunchKernelGGL((k_ws_bucket<SkLevelPred, false>), dim3(gbk), dim3(256), (size_t)bk_lb * 4, st, g.n, b.C, SkLevelPred{}, b.lhist, b.elist, bk_lb);
     IVX_LAUNCH_CHECK();
-    IVX_HIP(hipMemcpyAsync(lhist.data(), b.lhist, 65536 * 4, hipMemcpyDeviceToHost, st));
+    IVX_HIP(hipMemcpyAsync(lhist.data(), b.lhist, (size_t)nlev * 4, hipMemcpyDeviceToHost, st)); // (only the levels the image has)
     hipLaunchKernelGGL(k_sk_prevlevel, dim3(1), dim3(1024), 0, st, b.lhist, b.prevl);
     IVX_LAUNCH_CHECK();
     IVX_HIP(hipMemsetAsync(b.mbits, 0, 2048 * 4, st));
@@ -1801,7 +1802,9 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     { // generation 0 (a level's early part, then its late part) and, behind all of it, the drained voxels: ONE list, two passes
         hipLaunchKernelGGL(k_sk_bucket3<false>, dim3(gbk), dim3(256), (size_t)bk_lb * 12, st, g.n, b.C, b.kind, b.hist, b.elist, b.comp, (uint32_t *)nullptr, bk_lb);
         IVX_LAUNCH_CHECK();
-        IVX_HIP(hipMemcpyAsync(hist3.data(), b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToHost, st));
+        // (the buckets that can be used: 2 c + late and BK3_D0 + c for the levels the image has -- not 786 KB of zeros)
+        IVX_HIP(hipMemcpyAsync(hist3.data(), b.hist, (size_t)nlev * 8, hipMemcpyDeviceToHost, st));
+        IVX_HIP(hipMemcpyAsync(hist3.data() + BK3_D0, b.hist + BK3_D0, (size_t)nlev * 4, hipMemcpyDeviceToHost, st));
         IVX_HIP(hipMemcpyAsync(b.cursor, b.hist, (size_t)BK3_N * 4, hipMemcpyDeviceToDevice, st));
         const int rc = scan_u32_exclusive(b.cursor, BK3_N, b.bsum, b.total, st);
         if (rc != IVX_OK) return rc;
@@ -1815,7 +1818,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     IVX_HIP(hipStreamSynchronize(st)); // the histograms are on the host now
     std::vector<uint32_t> hist(65536), hist_l(65536); // generation 0 per level: all of it, its late part
     uint64_t ngen0_all = 0;
-    for (uint32_t c = 0; c < 65536; c++) {
+    for (uint32_t c = 0; c < nlev; c++) {
         hist[c] = hist3[2 * c] + hist3[2 * c + 1];
         hist_l[c] = hist3[2 * c + 1];
         dhist[c] = hist3[BK3_D0 + c];
@@ -2129,16 +2132,15 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             // round's list is -- the read then overlaps the kernel (110 us), and a list longer than the guess gets a second launch
             // behind it.  (Rounds 1 - 5: list length read first, 20 us of host round trip per round, 61 / 125 rounds per flood.)
             uint32_t guess = 0;
+            int parity = 0; // (both list counters are zero between two loops: a loop ends on an empty list, which cleared the other one)
             for (;;) {
-                IVX_HIP(hipMemsetAsync(&b.wst->nlist, 0, 4, st));
-                hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256 * BL_PER)), dim3(256), 0, st, g.ntiles, b.dirty, b.tlist, b.wst);
-                IVX_LAUNCH_CHECK();
-                uint32_t mseq = 0, nl = 0;
-                int rc = mailbox_publish(&b.wst->nlist, 1, st, &mseq);
+                uint32_t mseq = 0, nl = 0, *cur = nullptr;
+                int rc = ws_build_list_publish(g.ntiles, b.dirty, b.tlist, b.wst, parity, st, &mseq, &cur); // (list, count and mailbox in one launch)
                 if (rc != IVX_OK) return rc;
+                parity ^= 1;
                 if (guess) {
                     WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(guess), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c, b.st,
-                                                              &b.wst->nlist, 0u));
+                                                              cur, 0u));
                     IVX_LAUNCH_CHECK();
                 }
                 rc = mailbox_wait(mseq, st, &nl, 1);
@@ -2147,7 +2149,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
                 ntile_rounds++;
                 if (nl > guess) {
                     WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(nl - guess), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c,
-                                                              b.st, &b.wst->nlist, guess));
+                                                              b.st, cur, guess));
                     IVX_LAUNCH_CHECK();
                 }
                 guess = (uint32_t)std::min<int64_t>(g.ntiles, (int64_t)nl + nl / 2 + 64);

@@ -42,6 +42,8 @@ struct WsState {
     uint32_t minrej;   // smallest cost refused by the gate so far } after every round
     uint32_t assigned; // voxels that have a finite cost           } (one mailbox message)
     uint32_t sweeps;   // LDS sweeps over all tile visits (statistics)
+    uint32_t nlist_b;  // the list length of every other round (k_ws_build_list: a round counts into one and clears the other)
+    uint32_t ticket;   // workgroups of k_ws_build_list that are done (the last one publishes)
 };
 
 template <int CONN> __device__ __forceinline__ bool has_off(uint32_t smask, int k) {
@@ -250,8 +252,11 @@ __global__ __launch_bounds__(256) void k_ws_mark_open_tiles(WsGeom g, const uint
 // dirty flags -> list.  Lane = 16 tiles (one 16-byte load), one atomic per workgroup: at 1024^3 (2^19 tiles) the lane-per-tile
 // form with an atomic per wave took 26 us a round, 170 rounds a flood.
 constexpr int BL_PER = 16;
+// With a mailbox slot (round 6): the launch also does what a 4-byte fill in front of it and a publishing kernel behind it did --
+// the round counts into `cur`, the last workgroup to finish (a ticket) clears `other` for the next round and writes
+// { length, minrej, assigned } to the host's mailbox itself: one launch per round instead of three (~10 us, 40 - 180 rounds a flood).
 __global__ __launch_bounds__(256) void k_ws_build_list(int64_t ntiles, uint8_t *__restrict__ dirty, uint32_t *__restrict__ list,
-                                                       WsState *st) {
+                                                       WsState *st, uint32_t *cur, uint32_t *other, uint32_t *mb, uint32_t seq) {
     __shared__ uint32_t s_wave[4], s_base;
     const int64_t t0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BL_PER;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256) void k_ws_build_list(int64_t ntiles, uint8_t *
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        s_base = tot ? atomicAdd(&st->nlist, tot) : 0u;
+        s_base = tot ? atomicAdd(cur, tot) : 0u;
     }
     __syncthreads();
     uint32_t off = s_base + inc - cnt;
@@ -292,6 +297,30 @@ __global__ __launch_bounds__(256) void k_ws_build_list(int64_t ntiles, uint8_t *
         m &= m - 1;
         list[off++] = (uint32_t)(t0 + k);
     }
+    if (!mb) return;
+    __threadfence(); // (this workgroup's count is in before its ticket)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+        st->ticket = 0;
+        *other = 0;
+        mb[0] = __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mb[1] = __hip_atomic_load(&st->minrej, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mb[2] = __hip_atomic_load(&st->assigned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __hip_atomic_store(&mb[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// one round's list, counted into the counter of the round's parity and published by the launch itself
+static int ws_build_list_publish(int64_t ntiles, uint8_t *dirty, uint32_t *list, WsState *wst, int parity, hipStream_t st, uint32_t *seq_out,
+                                 uint32_t **cur_out) {
+    uint32_t *slot = nullptr;
+    const int rc = mailbox_reserve(&slot, seq_out);
+    if (rc != IVX_OK) return rc;
+    uint32_t *cur = parity ? &wst->nlist_b : &wst->nlist, *other = parity ? &wst->nlist : &wst->nlist_b;
+    hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(ntiles, 256 * BL_PER)), dim3(256), 0, st, ntiles, dirty, list, wst, cur, other, slot, *seq_out);
+    IVX_LAUNCH_CHECK();
+    *cur_out = cur;
+    return IVX_OK;
 }
 
 // one visit of a dirty tile: relax to the local fix-point, write the changed costs back, wake the tiles that read them.
@@ -347,13 +376,15 @@ __device__ __forceinline__ bool ws_eval(uint32_t *s, uint32_t (*s_act)[TX], uint
 template <int CONN, bool SK>
 __global__ __launch_bounds__(256) void k_ws_relax(WsGeom g, const uint16_t *__restrict__ I, uint16_t *C,
                                                   const uint32_t *__restrict__ list, uint8_t *dirty, uint8_t *pending,
-                                                  WsState *st, uint32_t theta_flags) {
+                                                  WsState *st, uint32_t theta_flags, uint32_t offset, const uint32_t *nlist) {
     __shared__ uint32_t s[NCELL];
     __shared__ uint32_t s_act[TY][TX], s_chg[TY][TX];
     __shared__ uint16_t s_queue[CONN == 6 ? 2 : TX * TY * TZ]; // (the 6-neighbour form never pools)
     __shared__ uint32_t s_qn[2];
     __shared__ uint32_t s_new, s_rej, s_ev2;
-    const int64_t tile = list[blockIdx.x];
+    // (the grid may be a guess made before the host knew the list's length -- ws_cost_rounds: workgroups beyond the list leave)
+    if (blockIdx.x + offset >= *nlist) return;
+    const int64_t tile = list[blockIdx.x + offset];
     const uint32_t theta = theta_flags & 0xFFFFu; // bit 31 of the argument: collect the sweep statistic
     int z0, y0, x0;
     tile_origin(g, tile, z0, y0, x0);
@@ -812,9 +843,44 @@ static int ws_cost_rounds(const WsGeom &g, int conn, const uint16_t *I, uint16_t
     const bool gate = gate_env && gate_env[0] == '1'; // measured slower on the noise phantom (more rounds AND more visits): opt-in
     const bool trace = getenv("IVX_WS_TRACE") != nullptr;
     uint32_t theta = gate ? 0u : CINF;
+    // Without the gate the host never stands between two rounds' kernels (round 6, as for the plateau rounds of the scikit-image
+    // branch): a round's relaxation is launched on a grid guessed from the previous round's list (1.5 x + 64: the lists shrink
+    // from round to round) BEFORE the host has read this round's length; a longer list gets a second launch behind it.
+    static const bool ahead = []() { const char *e = getenv("IVX_WS_AHEAD"); return !(e && e[0] == '0'); }(); // (0: the list length is read before the launch -- A/B)
+    if (!gate && ahead) {
+        uint32_t guess = 0;
+        int parity = 0; // (both list counters are zero here, and again when the loop ends on an empty list)
+        for (;;) {
+            uint32_t seq = 0, msg[3] = {0, 0, 0}, *cur = nullptr;
+            int rc = ws_build_list_publish(g.ntiles, dirty, list, wst, parity, st, &seq, &cur);
+            if (rc != IVX_OK) return rc;
+            parity ^= 1;
+            if (guess) {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_relax<CC, SK>), dim3(guess), dim3(256), 0, st, g, I, C, list, dirty, pending, wst, CINF | (trace ? 0x80000000u : 0u), 0u, cur));
+                IVX_LAUNCH_CHECK();
+            }
+            rc = mailbox_wait(seq, st, msg, 3);
+            if (rc != IVX_OK) return rc;
+            const uint32_t nl = msg[0];
+            if (trace) fprintf(stderr, "ws round %lld tiles %u (guessed grid %u) assigned %u\n", (long long)rounds, nl, guess, msg[2]);
+            if (nl == 0) break; // nothing is refused without a gate: this is the fix-point
+            rounds++;
+            visits += nl;
+            if (nl > guess) {
+                WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_relax<CC, SK>), dim3(nl - guess), dim3(256), 0, st, g, I, C, list, dirty, pending, wst, CINF | (trace ? 0x80000000u : 0u), guess, cur));
+                IVX_LAUNCH_CHECK();
+            }
+            guess = (uint32_t)std::min<int64_t>(g.ntiles, (int64_t)nl + nl / 2 + 64);
+            IVX_REQUIRE(rounds < 1000000, IVX_EHIP, "watershed: relaxation does not terminate");
+        }
+        *rounds_out = rounds;
+        *visits_out = visits;
+        return IVX_OK;
+    }
     for (;;) {
         IVX_HIP(hipMemsetAsync(&wst->nlist, 0, 4, st));
-        hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256 * BL_PER)), dim3(256), 0, st, g.ntiles, dirty, list, wst);
+        hipLaunchKernelGGL(k_ws_build_list, dim3((unsigned)cdiv(g.ntiles, 256 * BL_PER)), dim3(256), 0, st, g.ntiles, dirty, list, wst, &wst->nlist,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
         IVX_LAUNCH_CHECK();
         uint32_t seq = 0, msg[3] = {0, 0, 0};
         int rc = mailbox_publish(&wst->nlist, 3, st, &seq);
@@ -833,7 +899,7 @@ static int ws_cost_rounds(const WsGeom &g, int conn, const uint16_t *I, uint16_t
         }
         rounds++;
         visits += nl;
-        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_relax<CC, SK>), dim3(nl), dim3(256), 0, st, g, I, C, list, dirty, pending, wst, theta | (trace ? 0x80000000u : 0u)));
+        WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_ws_relax<CC, SK>), dim3(nl), dim3(256), 0, st, g, I, C, list, dirty, pending, wst, theta | (trace ? 0x80000000u : 0u), 0u, &wst->nlist));
         IVX_LAUNCH_CHECK();
         IVX_REQUIRE(rounds < 1000000, IVX_EHIP, "watershed: relaxation does not terminate");
     }
