@@ -1386,10 +1386,38 @@ __device__ __forceinline__ bool sk_plateau_eval(unsigned long long *s, uint32_t 
     return true;
 }
 
+// The voxels AT the level's value (C == c and I == c) as a bit plane, linear voxel index = bit index: the tile-wise relaxation below
+// stages 3 240 cells per tile visit, and reading C and I for each of them (68-byte rows out of 128-byte lines) was more than
+// half of the bytes a visit moved -- 16 GB per flood, a burst of ~260 MB at the head of every round.  Lane = 8 voxels.
+__global__ __launch_bounds__(256) void k_sk_level_plane(const uint16_t *__restrict__ C, const uint16_t *__restrict__ I, int64_t n, uint32_t c,
+                                                        unsigned long long *__restrict__ P) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; // chunk of 8 voxels; whole words: the grid covers ceil(n / 64) * 8 chunks
+    uint32_t bits = 0;
+    if (i * 8 + 8 <= n) {
+        uint16_t vc[8], vi[8];
+        *reinterpret_cast<uint4 *>(vc) = reinterpret_cast<const uint4 *>(C)[i];
+        *reinterpret_cast<uint4 *>(vi) = reinterpret_cast<const uint4 *>(I)[i];
+#pragma unroll
+        for (int e = 0; e < 8; e++) bits |= ((uint32_t)vc[e] == c && (uint32_t)vi[e] == c ? 1u : 0u) << e;
+    } else {
+        for (int e = 0; e < 8; e++)
+            if (i * 8 + e < n) bits |= ((uint32_t)C[i * 8 + e] == c && (uint32_t)I[i * 8 + e] == c ? 1u : 0u) << e;
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long w = (unsigned long long)bits << (8 * (lane & 7));
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)w, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(w >> 32), o, 64);
+        w |= ((unsigned long long)hi << 32) | lo;
+    }
+    if ((lane & 7) == 0 && i * 8 < n) P[i >> 3] = w;
+}
+
 template <int CONN>
 __global__ __launch_bounds__(256) void k_sk_plateau_relax(WsGeom g, const uint16_t *__restrict__ I, const uint16_t *__restrict__ C,
                                                           unsigned long long *tau, const uint32_t *__restrict__ list, uint8_t *dirty,
-                                                          uint32_t c, SkState *st, const uint32_t *__restrict__ nlist, uint32_t offset) {
+                                                          uint32_t c, SkState *st, const uint32_t *__restrict__ nlist, uint32_t offset,
+                                                          const unsigned long long *__restrict__ P) {
     __shared__ unsigned long long s[NCELL];
     __shared__ uint32_t s_act[TY][TX];
     __shared__ uint32_t s_ev2, s_gmax;
@@ -1409,7 +1437,8 @@ __global__ __launch_bounds__(256) void k_sk_plateau_relax(WsGeom g, const uint16
         unsigned long long v = TNM;
         if ((uint64_t)xx < (uint64_t)g.w && (uint64_t)yy < (uint64_t)g.h && (uint64_t)zz < (uint64_t)g.d) {
             const int64_t Lx = zz * g.hw + yy * g.w + xx;
-            if ((uint32_t)C[Lx] == c && (uint32_t)I[Lx] == c) v = tau[Lx];
+            const bool at = P ? (P[Lx >> 6] >> (Lx & 63)) & 1ull : (uint32_t)C[Lx] == c && (uint32_t)I[Lx] == c;
+            if (at) v = tau[Lx];
         }
         s[ce] = v;
     }
@@ -2127,6 +2156,14 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         if (tile_level) {
             hipLaunchKernelGGL(k_sk_mark_tiles, dim3(gb), dim3(256), 0, st, g, b.lists[0], cnt, b.dirty);
             IVX_LAUNCH_CHECK();
+            // the level's voxels as a bit plane (in kind[]'s bytes: nobody reads those after the buckets); IVX_SK_PLANE=0: C and I per cell
+            static const bool plane_on = []() { const char *e = getenv("IVX_SK_PLANE"); return !(e && e[0] == '0'); }();
+            const unsigned long long *P = nullptr;
+            if (plane_on && (((uintptr_t)I | (uintptr_t)b.C) & 15) == 0) {
+                hipLaunchKernelGGL(k_sk_level_plane, dim3((unsigned)cdiv(cdiv(g.n, 64) * 8, 256)), dim3(256), 0, st, b.C, I, g.n, c, (unsigned long long *)b.kind);
+                IVX_LAUNCH_CHECK();
+                P = (const unsigned long long *)b.kind;
+            }
             // Rounds of dirty tiles.  The host never stands between two rounds' kernels: a round's relaxation is launched with a grid
             // guessed from the previous round's list (1.5 x + 64: the wave front grows slowly) BEFORE the host has read how long this
             // round's list is -- the read then overlaps the kernel (110 us), and a list longer than the guess gets a second launch
@@ -2140,7 +2177,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
                 parity ^= 1;
                 if (guess) {
                     WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(guess), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c, b.st,
-                                                              cur, 0u));
+                                                              cur, 0u, P));
                     IVX_LAUNCH_CHECK();
                 }
                 rc = mailbox_wait(mseq, st, &nl, 1);
@@ -2149,7 +2186,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
                 ntile_rounds++;
                 if (nl > guess) {
                     WS_CONN_SWITCH(conn, hipLaunchKernelGGL(k_sk_plateau_relax<CC>, dim3(nl - guess), dim3(256), 0, st, g, I, b.C, b.tau, b.tlist, b.dirty, c,
-                                                              b.st, cur, guess));
+                                                              b.st, cur, guess, P));
                     IVX_LAUNCH_CHECK();
                 }
                 guess = (uint32_t)std::min<int64_t>(g.ntiles, (int64_t)nl + nl / 2 + 64);
