@@ -1508,6 +1508,8 @@ constexpr int SMALL_GEN0 = 4096;        // generation-0 voxels of a level that s
 constexpr uint32_t SMALL_TOTAL = 32768; // voxels of a level one workgroup still walks
 
 struct SkSmallArgs {
+    const uint32_t *rec; // 32-byte key records of the run's entries (k_sk_small_recs), or nullptr
+    uint32_t run_start;  // position in elist of the run's first entry
     const uint16_t *C, *I;
     const uint32_t *comp, *pmask, *zmask, *elist, *dlist;
     const uint32_t *hist, *cursor, *dhist, *dcursor; // counts and (after the scatter pass) segment ENDS per level
@@ -1516,6 +1518,58 @@ struct SkSmallArgs {
     uint32_t *list0, *list1;
     SkState *st;
 };
+
+// Key records for a run of small levels (6 neighbours): a generation-0 voxel's key is the smallest stamp among its neighbours of
+// lower cost, read from tau[] at the neighbour or at its basin's root.  WHERE to read is settled before the flood starts -- list
+// entry -> marker? -> the neighbours' costs -> their values and roots: three dependent round trips that the run's ONE workgroup made
+// for every level (1.07 of its 2.2 ms at 512^3, measured by phase) -- so all the run's entries get a 32-byte record up front, by as
+// many workgroups as it takes: { voxel, six places in tau (NONE: no such neighbour), marker }.  The run then reads the record and
+// gathers the stamps: two round trips per level.
+template <typename MT>
+__global__ __launch_bounds__(256) void k_sk_small_recs(WsGeom g, const uint16_t *__restrict__ C, const MT *__restrict__ mk, const uint16_t *__restrict__ I,
+                                                       const uint32_t *__restrict__ comp, const uint32_t *__restrict__ el, uint32_t n,
+                                                       uint32_t *__restrict__ rec) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = el[i];
+    uint32_t a[6] = {NONE, NONE, NONE, NONE, NONE, NONE};
+    const bool marker = mk[p] != 0;
+    if (!marker) {
+        const uint32_t c = C[p];
+        const int64_t z = p / g.hw, r = p - z * g.hw, y = r / g.w, x = r - y * g.w;
+        const int64_t off[6] = {-g.hw, -g.w, -1, 1, g.w, g.hw};
+        const bool ok[6] = {z > 0, y > 0, x > 0, x + 1 < g.w, y + 1 < g.h, z + 1 < g.d};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if (!ok[k]) continue;
+            const int64_t q = (int64_t)p + off[k];
+            const uint32_t qc = C[q];
+            if (qc < c) a[k] = (uint32_t)I[q] < qc ? comp[q] : (uint32_t)q; // (a drained voxel's stamp is its basin's)
+        }
+    }
+    uint4 *r4 = reinterpret_cast<uint4 *>(rec + 8 * (size_t)i);
+    r4[0] = make_uint4(p, a[0], a[1], a[2]);
+    r4[1] = make_uint4(a[3], a[4], a[5], marker ? 1u : 0u);
+}
+
+// keys from such records (a level's late part: its records are made beside the level below, on the side stream)
+__global__ __launch_bounds__(256) void k_sk_keys_rec(const uint32_t *__restrict__ rec, const unsigned long long *tau,
+                                                     unsigned long long *__restrict__ key, uint32_t *__restrict__ val, uint32_t cnt) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    const uint4 *r4 = reinterpret_cast<const uint4 *>(rec + 8 * (size_t)i);
+    const uint4 r0 = r4[0], r1 = r4[1];
+    unsigned long long K = r0.x;
+    if (!r1.w) {
+        K = TINF;
+        const uint32_t ad[6] = {r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (ad[k] != NONE) K = min(K, ld64(&tau[ad[k]]));
+    }
+    key[i] = K;
+    val[i] = r0.x;
+}
 
 template <typename MT>
 __global__ __launch_bounds__(1024) void k_sk_levels_small(WsGeom g, SkSmallArgs a, const MT *__restrict__ mk, uint32_t c_lo, uint32_t c_hi,
@@ -1536,7 +1590,19 @@ __global__ __launch_bounds__(1024) void k_sk_levels_small(WsGeom g, SkSmallArgs 
         for (uint32_t i = tid; i < n2; i += 1024) {
             unsigned long long K = TINF;
             uint32_t p = 0;
-            if (i < cnt) {
+            if (i < cnt && a.rec) { // (the places to read were found before the run: k_sk_small_recs)
+                const uint4 *r4 = reinterpret_cast<const uint4 *>(a.rec + 8 * ((size_t)(el - a.elist) - a.run_start + i));
+                const uint4 r0 = r4[0], r1 = r4[1];
+                p = r0.x;
+                K = p;
+                if (!r1.w) {
+                    K = TINF;
+                    const uint32_t ad[6] = {r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+                        if (ad[k] != NONE) K = min(K, ld64(&a.tau[ad[k]]));
+                }
+            } else if (i < cnt) {
                 p = el[i];
                 K = p;
                 if (mk[p] == 0) {
@@ -1994,7 +2060,7 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     const char *senv = getenv("IVX_SK_SMALL"); // 0: never take the one-workgroup path (A/B measurements)
     const bool small_on = !(senv && senv[0] == '0');
     auto is_small = [&](uint32_t c) { return small_on && hist[c] <= (uint32_t)SMALL_GEN0 && lhist[c] <= SMALL_TOTAL; };
-    SkSmallArgs sa{b.C, I, b.comp, b.pmask, b.zmask, b.elist, /* dcursor holds positions in the one list: */ b.elist, b.hist, b.cursor, b.dhist, b.dcursor, b.tau, b.runlabel,
+    SkSmallArgs sa{nullptr, 0u, b.C, I, b.comp, b.pmask, b.zmask, b.elist, /* dcursor holds positions in the one list: */ b.elist, b.hist, b.cursor, b.dhist, b.dcursor, b.tau, b.runlabel,
                    b.lists[0], b.lists[1], b.st};
     static const char *tenv = getenv("IVX_SK_TILE_LEVEL"); // voxels from which a basin-free level is relaxed tile-wise (A/B; 0 = never)
     const uint64_t tile_min = tenv ? (uint64_t)atoll(tenv) : ((uint64_t)1 << 16);
@@ -2019,6 +2085,13 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
     uint32_t early_of = 0xFFFFFFFFu, early_cnt = 0; // the level whose early part is (being) sorted on the side stream, in set early_set
     int early_set = 0, next_set = 0;
     int64_t nsplit = 0;
+    // key records of a level's late part, two sets like the early parts' (6 neighbours; at the end of kind[]'s bytes, which nobody
+    // reads after the buckets; IVX_SK_LATE_RECS=0: the late keys chase the neighbours themselves)
+    static const bool late_recs_on = []() { const char *e = getenv("IVX_SK_LATE_RECS"); return !(e && e[0] == '0'); }();
+    const size_t late_rec_bytes = ((size_t)late_max * 32 + 255) & ~(size_t)255;
+    uint32_t *late_recs[2] = {nullptr, nullptr};
+    if (late_recs_on && split_on && conn == 6 && (size_t)g.n >= (size_t)g.n / 8 + 1024 + 2 * late_rec_bytes + ((size_t)1 << 22))
+        for (int q = 0; q < 2; q++) late_recs[q] = (uint32_t *)(b.kind + (((size_t)g.n - (size_t)(2 - q) * late_rec_bytes) & ~(size_t)255));
     // the early part of the level that follows c, if that level is a candidate: called before c's own work is queued
     auto queue_early_after = [&](uint32_t c) -> int {
         if (!split_on) return IVX_OK;
@@ -2039,6 +2112,11 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
         hipLaunchKernelGGL(k_sk_scatter_sorted, dim3((unsigned)cdiv(ce, 256)), dim3(256), 0, side.stream, so.key, so.val, so.part, so.shares, so.ch,
                            b.ekey[next_set], b.eval[next_set], ce);
         IVX_LAUNCH_CHECK();
+        if (late_recs[next_set] && hist_l[cn] && hist_l[cn] <= late_max) { // the late part's key records (k_sk_small_recs), for the chain's k_sk_keys_rec
+            hipLaunchKernelGGL(k_sk_small_recs<MT>, dim3((unsigned)cdiv(hist_l[cn], 256)), dim3(256), 0, side.stream, g, b.C, mk, I, b.comp,
+                               b.elist + sn + ce, hist_l[cn], late_recs[next_set]);
+            IVX_LAUNCH_CHECK();
+        }
         IVX_HIP(hipEventRecord(side.early[next_set], side.stream));
         early_of = cn;
         early_cnt = ce;
@@ -2065,7 +2143,18 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
                 esum += hist[q];
                 dsum += dhist[q];
             }
-            hipLaunchKernelGGL(k_sk_levels_small<MT>, dim3(1), dim3(1024), 0, st, g, sa, mk, c, c_hi, gbase, roff);
+            // key records of the run's entries (6 neighbours; in kind[]'s bytes behind the level plane's: nobody reads those any more)
+            static const bool recs_on = []() { const char *e = getenv("IVX_SK_SMALL_RECS"); return !(e && e[0] == '0'); }();
+            SkSmallArgs sr = sa;
+            const size_t rec_off = ((size_t)g.n / 8 + 511) & ~(size_t)255;
+            if (recs_on && conn == 6 && esum && rec_off + (size_t)esum * 32 + 2 * late_rec_bytes + 512 <= (size_t)g.n) {
+                uint32_t *rec = (uint32_t *)(b.kind + rec_off);
+                hipLaunchKernelGGL(k_sk_small_recs<MT>, dim3((unsigned)cdiv(esum, 256)), dim3(256), 0, st, g, b.C, mk, I, b.comp, b.elist + start, esum, rec);
+                IVX_LAUNCH_CHECK();
+                sr.rec = rec;
+                sr.run_start = start;
+            }
+            hipLaunchKernelGGL(k_sk_levels_small<MT>, dim3(1), dim3(1024), 0, st, g, sr, mk, c, c_hi, gbase, roff);
             IVX_LAUNCH_CHECK();
             uint32_t mseq = 0, msg[4] = {0, 0, 0, 0};
             int rc = mailbox_publish(&b.st->done, 4, st, &mseq);
@@ -2111,12 +2200,16 @@ static int sk_run(const WsGeom &g, const uint16_t *I, const MT *mk, MT *out, int
             const uint32_t ce = my_early_cnt, cl = cnt - ce;
             nsplit++;
             if (cl <= late_max) { // late keys, then every stamp in one launch (the late pairs ranked by brute force in LDS)
-                if (cl) {
+                IVX_HIP(hipStreamWaitEvent(st, side.early[my_early_set], 0)); // (long since: the side stream worked beside the level below)
+                if (cl && late_recs[my_early_set]) {
+                    hipLaunchKernelGGL(k_sk_keys_rec, dim3((unsigned)cdiv(cl, 256)), dim3(256), 0, st, late_recs[my_early_set], b.tau, b.sort[0].key_a,
+                                       b.sort[0].val_a, cl);
+                    IVX_LAUNCH_CHECK();
+                } else if (cl) {
                     WS_CONN_SWITCH(conn, hipLaunchKernelGGL((k_sk_keys<CC, MT>), dim3((unsigned)cdiv(cl, 256)), dim3(256), 0, st, g, b.C, mk, I, b.comp,
                                                               b.tau, b.elist + start + ce, b.sort[0].key_a, b.sort[0].val_a, cl, c));
                     IVX_LAUNCH_CHECK();
                 }
-                IVX_HIP(hipStreamWaitEvent(st, side.early[my_early_set], 0));
                 const unsigned nwg = (unsigned)(cdiv(ce, 256) + cdiv(cl, LATE_PER_WG));
                 hipLaunchKernelGGL(k_sk_split_assign<MT>, dim3(nwg), dim3(256), (size_t)cl * 12, st, b.ekey[my_early_set], b.eval[my_early_set], ce,
                                    b.sort[0].key_a, b.sort[0].val_a, cl, mk, b.tau, b.runlabel, b.lists[0], roff, g0_gbase, g0_seq, b.st);
