@@ -333,9 +333,25 @@ __global__ __launch_bounds__(256) void k_sk_split_assign(const unsigned long lon
     } else {
         unsigned long long *s_k = s_dyn;
         uint32_t *s_v = (uint32_t *)(s_dyn + cnt_l);
-        for (uint32_t i = tid; i < cnt_l; i += 256) {
-            s_k[i] = lkey[i];
-            s_v[i] = lvl[i];
+        // (eight pairs per lane in flight: one round trip per 2 048 late pairs -- the plain loop made one per 256, six in a row for
+        // a typical late part, in front of everything else this workgroup does)
+        for (uint32_t i0 = tid; i0 < cnt_l; i0 += 8u * 256u) {
+            unsigned long long rk[8];
+            uint32_t rv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t i = i0 + (uint32_t)q * 256u;
+                rk[q] = i < cnt_l ? lkey[i] : 0ull;
+                rv[q] = i < cnt_l ? lvl[i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t i = i0 + (uint32_t)q * 256u;
+                if (i < cnt_l) {
+                    s_k[i] = rk[q];
+                    s_v[i] = rv[q];
+                }
+            }
         }
         __syncthreads();
         const uint32_t j = (blockIdx.x - nwe) * LATE_PER_WG + tid / LATE_SPLIT, part = tid % LATE_SPLIT;
